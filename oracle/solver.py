@@ -1,0 +1,297 @@
+"""Banded / tensor solvers of rustpde ``src/solver`` -- CPU oracle (test infrastructure).
+
+Restates, lane-vectorised in NumPy:
+  Fdma          ``src/solver/fdma.rs:33-118``      (4-diagonal solve, offsets -2,0,+2,+4)
+  MatVecFdma    ``src/solver/matvec.rs:177-228``   (banded mat-vec, the B2 preconditioner)
+  Sdma          ``src/solver/sdma.rs:21-46``       (diagonal solve)
+  HholtzAdi     ``src/solver/hholtz_adi.rs:48-76,149-169``
+  FdmaTensor    ``src/solver/fdma_tensor.rs:106-154``
+  Poisson       ``src/solver/poisson.rs:54-94,195-236``
+  eig / inv     ``src/solver/utils.rs:67-107``
+All lane routines are written for axis 0 of a 2-D array (axis 1 = batch).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as _la
+
+from .bases import Base, Space2, FOURIER_R2C, _axis0
+
+
+# --------------------------------------------------------------------------- Fdma
+def fdma_sweep(low, dia, up1, up2):
+    """Forward elimination of the bands, ``fdma.rs:73-82``.  Arrays are indexed as in the
+    reference (``low[i-2] = a[i, i-2]``, ``up1[i] = a[i, i+2]``, ``up2[i] = a[i, i+4]``);
+    a trailing batch dimension is allowed (one matrix per batch entry)."""
+    low, dia, up1, up2 = (np.array(b, dtype=np.float64, copy=True) for b in (low, dia, up1, up2))
+    n = dia.shape[0]
+    for i in range(2, n):
+        low[i - 2] = low[i - 2] / dia[i - 2]
+        dia[i] = dia[i] - low[i - 2] * up1[i - 2]
+        if i < n - 2:
+            up1[i] = up1[i] - low[i - 2] * up2[i - 2]
+    return low, dia, up1, up2
+
+
+def fdma_solve0(bands, x):
+    """``Fdma::fdma`` (``fdma.rs:101-118``) along axis 0 of ``x`` (n, batch) with swept bands.
+    Bands are either 1-D (same matrix for all lanes) or (len, batch)."""
+    low, dia, up1, up2 = bands
+    if low.ndim == 1:
+        low, dia, up1, up2 = (b[:, None] for b in (low, dia, up1, up2))
+    x = np.array(x, copy=True)
+    n = x.shape[0]
+    for i in range(2, n):
+        x[i] = x[i] - x[i - 2] * low[i - 2]
+    x[n - 1] = x[n - 1] / dia[n - 1]
+    x[n - 2] = x[n - 2] / dia[n - 2]
+    x[n - 3] = (x[n - 3] - x[n - 1] * up1[n - 3]) / dia[n - 3]
+    x[n - 4] = (x[n - 4] - x[n - 2] * up1[n - 4]) / dia[n - 4]
+    for i in range(n - 5, -1, -1):
+        x[i] = (x[i] - x[i + 2] * up1[i] - x[i + 4] * up2[i]) / dia[i]
+    return x
+
+
+class Fdma:
+    """Four-diagonal matrix (offsets -2, 0, +2, +4) given by row-indexed bands of length n
+    (``low[r] = a[r, r-2]``, ``up1[r] = a[r, r+2]``, ``up2[r] = a[r, r+4]``; out of range = 0)."""
+
+    def __init__(self, low, dia, up1, up2, sweep=True):
+        n = len(dia)
+        self.n = n
+        self.raw = (np.asarray(low, float)[2:].copy(), np.asarray(dia, float).copy(),
+                    np.asarray(up1, float)[: n - 2].copy(), np.asarray(up2, float)[: n - 4].copy())
+        self.swept = fdma_sweep(*self.raw) if sweep else None
+
+    def solve(self, x, axis):
+        assert self.swept is not None, "Fdma: Forward sweep must be performed before solve!"
+        assert x.shape[axis] == self.n, "Fdma: dimension mismatch"
+        return _axis0(lambda y: fdma_solve0(self.swept, y), x, axis)
+
+
+# --------------------------------------------------------------------------- MatVecFdma
+class MatVecFdma:
+    """Banded mat-vec with an (m x n) matrix holding offsets 0, +2, +4 (``matvec.rs:177-228``)."""
+
+    def __init__(self, dia, up1, up2, n_in):
+        self.m = len(dia)
+        self.n = n_in
+        m = self.m
+        self.dia = np.asarray(dia, float)
+        self.up1 = np.where(np.arange(m) < m - 2, up1, 0.0)
+        self.up2 = np.where(np.arange(m) < m - 4, up2, 0.0)
+
+    def _apply0(self, x):
+        m = self.m
+        out = x[:m] * self.dia[:, None]
+        out[: m - 2] += x[2:m] * self.up1[: m - 2, None]
+        out[: m - 4] += x[4:m] * self.up2[: m - 4, None]
+        return out
+
+    def apply(self, x, axis):
+        assert x.shape[axis] == self.n
+        return _axis0(self._apply0, x, axis)
+
+
+# --------------------------------------------------------------------------- Sdma
+class Sdma:
+    def __init__(self, dia):
+        self.dia = np.asarray(dia, float)
+        self.n = len(dia)
+
+    def solve(self, x, axis):
+        shape = [1, 1]
+        shape[axis] = self.n
+        return x / self.dia.reshape(shape)
+
+
+# --------------------------------------------------------------------------- ingredients
+def ingredients_for_hholtz(base: Base):
+    """``field.rs:195-216``: band forms of (mat_a, mat_b, precond)."""
+    if base.kind == FOURIER_R2C:
+        k = base.wavenumbers()
+        return ("diag", np.ones(base.m)), ("diag", -(k ** 2)), None
+    if not base.is_composite:
+        raise NotImplementedError("solver ingredients for the orthonormal Chebyshev base "
+                                  "are not on the Navier2D path")
+    mat_a, mat_b = base.hholtz_bands()
+    return ("band", mat_a), ("band", mat_b), base.pinv_bands()
+
+
+# --------------------------------------------------------------------------- HholtzAdi
+class HholtzAdi:
+    """(I - c D2) vhat = A f, ADI-factored per axis   (``hholtz_adi.rs:48-76``)."""
+
+    def __init__(self, space: Space2, c):
+        self.solver = []
+        self.matvec = []
+        for axis, ci in enumerate(c):
+            base = space.bases[axis]
+            (ka, a), (_, b), precond = ingredients_for_hholtz(base)
+            if ka == "diag":
+                self.solver.append(Sdma(a - b * ci))
+                self.matvec.append(None)
+            else:
+                a_low, a_dia, a_up1, a_up2 = a
+                b_dia, b_up1 = b
+                self.solver.append(Fdma(a_low, a_dia - b_dia * ci, a_up1 - b_up1 * ci, a_up2))
+                self.matvec.append(MatVecFdma(*precond, n_in=base.n))
+
+    def solve(self, inp):
+        rhs = inp
+        for axis in (0, 1):
+            if self.matvec[axis] is not None:
+                rhs = self.matvec[axis].apply(rhs, axis)
+        out = self.solver[0].solve(rhs, 0)
+        return self.solver[1].solve(out, 1)
+
+
+class HholtzAdi1:
+    """1-D variant (``hholtz_adi.rs:78-118``), used by the reference's known-answer test."""
+
+    def __init__(self, base: Base, c):
+        self._h = HholtzAdi.__new__(HholtzAdi)
+        (ka, a), (_, b), precond = ingredients_for_hholtz(base)
+        a_low, a_dia, a_up1, a_up2 = a
+        b_dia, b_up1 = b
+        self.solver = Fdma(a_low, a_dia - b_dia * c, a_up1 - b_up1 * c, a_up2)
+        self.matvec = MatVecFdma(*precond, n_in=base.n)
+
+    def solve(self, b):
+        return self.solver.solve(self.matvec.apply(np.asarray(b, float)[:, None], 0), 0)[:, 0]
+
+
+# --------------------------------------------------------------------------- eig helpers
+def eig_sorted(xmat):
+    """``utils.rs:67-99``: real parts of LAPACK dgeev, sorted largest -> smallest, plus inverse."""
+    lam, q = _la.eig(xmat)
+    lam = lam.real
+    q = q.real
+    perm = np.argsort(lam, kind="stable")[::-1]
+    lam = lam[perm]
+    q = np.ascontiguousarray(q[:, perm])
+    return lam, q, _la.inv(q)
+
+
+def band_to_dense(low, dia, up1, up2):
+    n = len(dia)
+    a = np.zeros((n, n))
+    for r in range(n):
+        a[r, r] = dia[r]
+        if r >= 2:
+            a[r, r - 2] = low[r]
+        if r + 2 < n:
+            a[r, r + 2] = up1[r]
+        if r + 4 < n:
+            a[r, r + 4] = up2[r]
+    return a
+
+
+def eigen_decomposition_x(a_bands, c_bands, mode="full"):
+    """Diagonalise inv(C) A along the inner axis (``fdma_tensor.rs:123-127``).
+
+    mode="full"   : exactly the reference (one dense dgeev of the (m x m) matrix).
+    mode="parity" : even and odd coefficients decouple (all bands have even offsets);
+                    diagonalise the two blocks separately.  Same discrete operator, same
+                    solution up to round-off; 4x cheaper and immune to LAPACK mixing
+                    near-degenerate even/odd pairs.
+    Returns lam (m), fwd = Q^-1 C^-1 (m x m), bwd = Q (m x m)."""
+    a = band_to_dense(*a_bands)
+    c = band_to_dense(*c_bands)
+    m = a.shape[0]
+    if mode == "full":
+        cinv = _la.inv(c)
+        lam, q, qinv = eig_sorted(cinv @ a)
+        return lam, qinv @ cinv, q
+    lam = np.zeros(m)
+    fwd = np.zeros((m, m))
+    bwd = np.zeros((m, m))
+    pos = 0
+    blocks = []
+    for par in (0, 1):
+        idx = np.arange(par, m, 2)
+        cinv = _la.inv(c[np.ix_(idx, idx)])
+        l, q, qinv = eig_sorted(cinv @ a[np.ix_(idx, idx)])
+        blocks.append((idx, l, q, qinv @ cinv))
+    # interleave the two spectra into one descending list (as a full sort would)
+    all_l = np.concatenate([b[1] for b in blocks])
+    owner = np.concatenate([np.full(len(b[1]), p) for p, b in enumerate(blocks)])
+    local = np.concatenate([np.arange(len(b[1])) for b in blocks])
+    perm = np.argsort(all_l, kind="stable")[::-1]
+    for pos, j in enumerate(perm):
+        idx, l, q, f = blocks[owner[j]]
+        lam[pos] = l[local[j]]
+        bwd[idx, pos] = q[:, local[j]]
+        fwd[pos, idx] = f[local[j], :]
+    return lam, fwd, bwd
+
+
+# --------------------------------------------------------------------------- Poisson
+class Poisson:
+    """c D2 vhat = A f via eigen-decomposition in x and banded row solves in y
+    (``poisson.rs:54-94,195-236``; tensor data ``fdma_tensor.rs:74-154``)."""
+
+    def __init__(self, space: Space2, c, eig_mode="full", eig_override=None):
+        b0, b1 = space.bases
+        self.matvec = []
+        ing = []
+        for axis, ci in enumerate(c):
+            base = space.bases[axis]
+            (ka, a), (_, b), precond = ingredients_for_hholtz(base)
+            self.matvec.append(None if precond is None else MatVecFdma(*precond, n_in=base.n))
+            if ka == "diag":
+                ing.append(("diag", a, b * ci))
+            else:
+                b_dia, b_up1 = b
+                z = np.zeros_like(b_dia)
+                ing.append(("band", a, (z, b_dia * ci, b_up1 * ci, z)))  # (mass, laplacian)
+        # inner axis (0)
+        kind0, mass0, lap0 = ing[0]
+        if kind0 == "diag":
+            self.lam = lap0.copy()
+            self.fwd = self.bwd = None
+        elif eig_override is not None:
+            self.lam, self.fwd, self.bwd = (np.array(x, copy=True) for x in eig_override)
+        else:
+            self.lam, self.fwd, self.bwd = eigen_decomposition_x(lap0, mass0, eig_mode)
+        # outermost axis (1): raw (unswept) bands of A_y = laplacian, C_y = mass
+        kind1, mass1, lap1 = ing[1]
+        assert kind1 == "band"
+        self.fdma_a = Fdma(*lap1, sweep=False)
+        self.fdma_c = Fdma(*mass1, sweep=False)
+        self.alpha = 0.0
+        # singularity fix, poisson.rs:84-87 (shifts the WHOLE eigenvalue vector)
+        if abs(self.lam[0]) < 1e-10:
+            self.lam = self.lam - 1e-10
+
+    def row_bands(self):
+        """Swept bands of A_y + lam_i C_y for every x-row i: arrays (len, nrows)."""
+        l = (self.lam + self.alpha)[None, :]
+        raw = [a[:, None] + c[:, None] * l for a, c in zip(self.fdma_a.raw, self.fdma_c.raw)]
+        return fdma_sweep(*raw)
+
+    def solve(self, inp):
+        rhs = inp
+        for axis in (0, 1):
+            if self.matvec[axis] is not None:
+                rhs = self.matvec[axis].apply(rhs, axis)
+        out = self.fwd @ rhs if self.fwd is not None else rhs
+        # rows i of `out` are lanes along y; batch them: (ny_m, nx_m)
+        out = np.ascontiguousarray(fdma_solve0(self.row_bands(), np.ascontiguousarray(out.T)).T)
+        if self.bwd is not None:
+            out = self.bwd @ out
+        return out
+
+
+class Poisson1:
+    """1-D variant (``poisson.rs:96-140``; ``fdma_tensor.rs:148-152``: A swept once, alpha = 0)."""
+
+    def __init__(self, base: Base, c):
+        (ka, a), (_, b), precond = ingredients_for_hholtz(base)
+        b_dia, b_up1 = b
+        z = np.zeros_like(b_dia)
+        self.solver = Fdma(z, b_dia * c, b_up1 * c, z)
+        self.matvec = MatVecFdma(*precond, n_in=base.n)
+
+    def solve(self, b):
+        return self.solver.solve(self.matvec.apply(np.asarray(b, float)[:, None], 0), 0)[:, 0]
