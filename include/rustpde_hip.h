@@ -1,0 +1,113 @@
+/* rustpde_hip.h -- C ABI of the MI355X-native Navier2D time-step engine (librustpde_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of preiter93/rustpde-mpi: a Rust host keeps
+ * `Navier2D::new_confined / new_periodic`, `integrate()` and its HDF5 callbacks and forwards
+ * the per-step work to these symbols (binding sketch in INTEGRATION.md).  The reference has no
+ * FFI of its own (no `extern "C"` anywhere in src/); each entry point below names the Rust item
+ * it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero code on failure; the message of the
+ *     last failure on the calling thread is returned by rpde_last_error().  Nothing unwinds
+ *     across the boundary.
+ *   - handles are opaque; one host thread per handle; each handle owns one HIP stream.
+ *   - arrays are caller-owned, row-major f64; complex spectral arrays are interleaved (re, im)
+ *     pairs, bit-compatible with num_complex::Complex<f64>.  Host buffers are only touched
+ *     during the call.
+ *   - physical arrays have shape (nx, ny); spectral arrays have the shape of the reference's
+ *     `vhat` of that field (query with rpde_navier2d_spectral_shape).
+ */
+#ifndef RUSTPDE_HIP_H
+#define RUSTPDE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rpde_navier2d rpde_navier2d;   /* Navier2D<f64|Complex<f64>, Space2>  src/navier_stokes/navier.rs:49-89 */
+typedef struct rpde_space2 rpde_space2;       /* funspace Space2<B0,B1>              src/bases.rs:11-19, src/field.rs:59-72 */
+typedef struct rpde_hholtz_adi rpde_hholtz_adi; /* HholtzAdi<f64,2>                  src/solver/hholtz_adi.rs:31-39 */
+typedef struct rpde_poisson rpde_poisson;     /* Poisson<f64,2>                      src/solver/poisson.rs:33-40 */
+
+/* base kinds (funspace BaseKind, used at src/field.rs:172-179) */
+enum { RPDE_CHEBYSHEV = 0, RPDE_CHEB_DIRICHLET = 1, RPDE_CHEB_NEUMANN = 2, RPDE_FOURIER_R2C = 3 };
+enum { RPDE_PHYSICAL = 0, RPDE_SPECTRAL = 1 };
+
+const char* rpde_last_error(void);
+const char* rpde_version(void);
+/* 1 when the library was built for the GPU (HIP, gfx950); the test-only host emulation build reports 0 */
+int rpde_is_device_build(void);
+int rpde_device_count(int* count);
+
+/* ---- engine level: what `impl Integrate for Navier2D` does ----------------------------------- */
+/* Navier2D::new_confined(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes/navier.rs:215-308 */
+int rpde_navier2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                  const char* bc, int device, rpde_navier2d** out);
+/* Navier2D::new_periodic(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes/navier.rs:336-428 */
+int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                  const char* bc, int device, rpde_navier2d** out);
+int rpde_navier2d_destroy(rpde_navier2d* h);
+/* set_velocity / set_temperature / init_random / reset_time  src/navier_stokes/navier.rs:161-187 */
+int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n);
+int rpde_navier2d_set_temperature(rpde_navier2d* h, double amp, double m, double n);
+int rpde_navier2d_init_random(rpde_navier2d* h, double amp, uint64_t seed);
+int rpde_navier2d_reset_time(rpde_navier2d* h);
+/* field access: name in {"velx","vely","temp","pres","pseu"} = the public Field2 members
+ * (navier.rs:52-62); space RPDE_PHYSICAL = `.v` (after backward()), RPDE_SPECTRAL = `.vhat`   */
+int rpde_navier2d_spectral_shape(rpde_navier2d* h, const char* name, int* rows, int* cols, int* is_complex);
+int rpde_navier2d_set_field(rpde_navier2d* h, const char* name, int space, const double* data, size_t len);
+int rpde_navier2d_get_field(rpde_navier2d* h, const char* name, int space, double* data, size_t len);
+int rpde_navier2d_get_grid(rpde_navier2d* h, int axis, double* x, size_t len);   /* Field2::x, field.rs:69 */
+/* n x Integrate::update()                                    src/navier_stokes/navier.rs:438-466 */
+int rpde_navier2d_update(rpde_navier2d* h, int nsteps);
+/* device time of the last rpde_navier2d_update call, HIP events on the engine's stream */
+int rpde_navier2d_last_update_ms(rpde_navier2d* h, double* ms);
+/* Integrate::get_time / get_dt                               src/navier_stokes/navier.rs:468-474 */
+int rpde_navier2d_time(rpde_navier2d* h, double* t);
+int rpde_navier2d_dt(rpde_navier2d* h, double* dt);
+/* params map ("ra","pr","nu","ka")                           src/navier_stokes/navier.rs:229-233 */
+int rpde_navier2d_param(rpde_navier2d* h, const char* key, double* value);
+/* Integrate::exit(): 1 when ||div|| is NaN                   src/navier_stokes/navier.rs:482-489 */
+int rpde_navier2d_exit(rpde_navier2d* h, int* flag);
+/* DivNorm::div_norm                                          src/navier_stokes/navier_eq.rs:33-51 */
+int rpde_navier2d_div_norm(rpde_navier2d* h, double* value);
+/* integrate(&mut pde, max_time, None) without callbacks      src/lib.rs:187-219 ; returns steps taken */
+int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps);
+
+/* ---- operator level: funspace Space2 methods as called by rustpde ---------------------------- */
+/* Space2::new(&base0(n0), &base1(n1)); base1 must be a Chebyshev-family base                     */
+int rpde_space2_create(int kind0, int n0, int kind1, int n1, int device, rpde_space2** out);
+int rpde_space2_destroy(rpde_space2* s);
+/* shapes in elements; which: 0 physical, 1 spectral (vhat), 2 orthonormal                         */
+int rpde_space2_shape(rpde_space2* s, int which, int* rows, int* cols, int* is_complex);
+/* forward_inplace_par / backward_inplace_par                 src/field.rs:103-110                */
+int rpde_space2_forward(rpde_space2* s, const double* v, size_t nv, double* vhat, size_t nvhat);
+int rpde_space2_backward(rpde_space2* s, const double* vhat, size_t nvhat, double* v, size_t nv);
+/* to_ortho_par / from_ortho                                  src/field.rs:113-123                */
+int rpde_space2_to_ortho(rpde_space2* s, const double* vhat, size_t nvhat, double* out, size_t nout);
+int rpde_space2_from_ortho(rpde_space2* s, const double* in, size_t nin, double* vhat, size_t nvhat);
+/* gradient_par(vhat, [d0,d1], Some([s0,s1])); pass s0 = s1 = 1 for `None`   src/field.rs:127-129 */
+int rpde_space2_gradient(rpde_space2* s, const double* vhat, size_t nvhat, int d0, int d1,
+                         double s0, double s1, double* out, size_t nout);
+
+/* HholtzAdi::new(&field, [c0, c1]) / Solve::solve            src/solver/hholtz_adi.rs:48-76,149-169 */
+int rpde_hholtz_adi_create(rpde_space2* s, double c0, double c1, rpde_hholtz_adi** out);
+int rpde_hholtz_adi_solve(rpde_hholtz_adi* hs, const double* in_ortho, size_t nin, double* out, size_t nout);
+int rpde_hholtz_adi_destroy(rpde_hholtz_adi* hs);
+/* Poisson::new(&field, [c0, c1]) / Solve::solve              src/solver/poisson.rs:54-94,195-236 */
+int rpde_poisson_create(rpde_space2* s, double c0, double c1, rpde_poisson** out);
+int rpde_poisson_solve(rpde_poisson* ps, const double* in_ortho, size_t nin, double* out, size_t nout);
+int rpde_poisson_destroy(rpde_poisson* ps);
+
+/* pencil transposes (single device: LDS-tiled kernel).  out[c][r] = in[r][c]; elem = 1 | 2        *
+ * funspace Decomp2d::transpose_x_to_y / transpose_y_to_x     src/field_mpi.rs:456-477             */
+int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, int device);
+/* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
+ * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
+int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

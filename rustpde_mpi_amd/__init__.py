@@ -1,0 +1,329 @@
+"""rustpde_mpi_amd -- host-side mirror of rustpde's Navier2D interface over the HIP engine.
+
+The reference is a compiled Rust crate; its Rust toolchain is not available in this image, so
+the host side above the C ABI (include/rustpde_hip.h) is this thin Python mirror (used by the
+tests and bench.py) plus the C++ engine inside the library.  Names, argument meaning and error
+behaviour follow the reference:
+
+    Navier2D.new_confined(nx, ny, ra, pr, dt, aspect, bc)    src/navier_stokes/navier.rs:215-308
+    Navier2D.new_periodic(nx, ny, ra, pr, dt, aspect, bc)    src/navier_stokes/navier.rs:336-428
+    .update() .get_time() .get_dt() .exit()                  trait Integrate, src/lib.rs:167-178
+    integrate(pde, max_time, save_intervall)                 src/lib.rs:187-219
+    .set_velocity .set_temperature .init_random .reset_time  src/navier_stokes/navier.rs:161-187
+    .velx .vely .temp .pres .pseu (each with .v / .vhat / .x)  navier.rs:52-62, field.rs:59-72
+    Space2 / HholtzAdi / Poisson                             funspace Space2, src/solver/*.rs
+
+Where the reference panics (unknown bc, shape mismatch) this raises RpdeError.  The HIP library
+is mandatory: importing works everywhere, but the first use raises if
+rustpde_mpi_amd/librustpde_hip.so has not been built -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._capi import Lib, RpdeError, as_f64, ptr
+
+__all__ = ["Navier2D", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
+           "chebyshev", "cheb_dirichlet", "cheb_neumann", "fourier_r2c", "LIB_PATH"]
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
+_lib = None
+
+
+def lib() -> Lib:
+    """The in-tree HIP library (loaded on first use; raises RpdeError if it is missing)."""
+    global _lib
+    if _lib is None:
+        _lib = Lib(LIB_PATH)
+        if not _lib.is_device_build:
+            raise RpdeError(f"{LIB_PATH} is not a HIP build")
+    return _lib
+
+
+PHYSICAL, SPECTRAL = 0, 1
+CHEBYSHEV, CHEB_DIRICHLET, CHEB_NEUMANN, FOURIER_R2C = 0, 1, 2, 3
+
+
+def chebyshev(n): return (CHEBYSHEV, n)
+def cheb_dirichlet(n): return (CHEB_DIRICHLET, n)
+def cheb_neumann(n): return (CHEB_NEUMANN, n)
+def fourier_r2c(n): return (FOURIER_R2C, n)
+
+
+class _FieldView:
+    """`Field2` members of the reference's Navier2D: `.v` (physical), `.vhat` (spectral), `.x`."""
+
+    def __init__(self, nav: "Navier2D", name: str):
+        self._nav, self._name = nav, name
+
+    def _shape(self):
+        r, c, z = C.c_int(), C.c_int(), C.c_int()
+        self._nav._lib.call("rpde_navier2d_spectral_shape", self._nav._h, self._name.encode(),
+                            C.byref(r), C.byref(c), C.byref(z))
+        return r.value, c.value, bool(z.value)
+
+    @property
+    def v(self):
+        out = np.empty((self._nav.nx, self._nav.ny))
+        self._nav._lib.call("rpde_navier2d_get_field", self._nav._h, self._name.encode(), PHYSICAL,
+                            ptr(out), out.size)
+        return out
+
+    @v.setter
+    def v(self, value):
+        a = as_f64(value)
+        if a.shape != (self._nav.nx, self._nav.ny):
+            raise RpdeError(f"physical field must have shape {(self._nav.nx, self._nav.ny)}")
+        self._nav._lib.call("rpde_navier2d_set_field", self._nav._h, self._name.encode(), PHYSICAL,
+                            ptr(a), a.size)
+
+    @property
+    def vhat(self):
+        r, c, z = self._shape()
+        out = np.empty((r, c * (2 if z else 1)))
+        self._nav._lib.call("rpde_navier2d_get_field", self._nav._h, self._name.encode(), SPECTRAL,
+                            ptr(out), out.size)
+        return out.view(np.complex128) if z else out
+
+    @vhat.setter
+    def vhat(self, value):
+        r, c, z = self._shape()
+        a = as_f64(np.asarray(value, dtype=np.complex128 if z else np.float64))
+        if a.shape != (r, c * (2 if z else 1)):
+            raise RpdeError(f"spectral field {self._name} must have shape {(r, c)}")
+        self._nav._lib.call("rpde_navier2d_set_field", self._nav._h, self._name.encode(), SPECTRAL,
+                            ptr(a), a.size)
+
+    @property
+    def x(self):
+        out = []
+        for axis, n in enumerate((self._nav.nx, self._nav.ny)):
+            g = np.empty(n)
+            self._nav._lib.call("rpde_navier2d_get_grid", self._nav._h, axis, ptr(g), g.size)
+            out.append(g)
+        return out
+
+
+class Navier2D:
+    """Device-resident `Navier2D` (2-D Rayleigh-Benard convection, f64)."""
+
+    def __init__(self, handle, nx, ny, periodic, library):
+        self._h, self.nx, self.ny, self.periodic, self._lib = handle, nx, ny, periodic, library
+        for name in ("velx", "vely", "temp", "pres", "pseu"):
+            setattr(self, name, _FieldView(self, name))
+
+    @classmethod
+    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic):
+        library = library or lib()
+        h = C.c_void_p()
+        library.call(fn, int(nx), int(ny), float(ra), float(pr), float(dt), float(aspect),
+                     str(bc).encode(), int(device), C.byref(h))
+        return cls(h, int(nx), int(ny), periodic, library)
+
+    @classmethod
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+        return cls._new("rpde_navier2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device,
+                        library, False)
+
+    @classmethod
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+        return cls._new("rpde_navier2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device,
+                        library, True)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.call("rpde_navier2d_destroy", self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- initial conditions
+    def set_velocity(self, amp, m, n):
+        self._lib.call("rpde_navier2d_set_velocity", self._h, float(amp), float(m), float(n))
+
+    def set_temperature(self, amp, m, n):
+        self._lib.call("rpde_navier2d_set_temperature", self._h, float(amp), float(m), float(n))
+
+    def init_random(self, amp, seed=0):
+        self._lib.call("rpde_navier2d_init_random", self._h, float(amp), int(seed))
+
+    def reset_time(self):
+        self._lib.call("rpde_navier2d_reset_time", self._h)
+
+    # ---- trait Integrate
+    def update(self, nsteps: int = 1):
+        self._lib.call("rpde_navier2d_update", self._h, int(nsteps))
+
+    def get_time(self):
+        t = C.c_double()
+        self._lib.call("rpde_navier2d_time", self._h, C.byref(t))
+        return t.value
+
+    def get_dt(self):
+        t = C.c_double()
+        self._lib.call("rpde_navier2d_dt", self._h, C.byref(t))
+        return t.value
+
+    def exit(self):
+        f = C.c_int()
+        self._lib.call("rpde_navier2d_exit", self._h, C.byref(f))
+        return bool(f.value)
+
+    def callback(self):
+        """I/O callback of the reference (HDF5 snapshot + info.txt); host-side, not part of the
+        accelerated path."""
+
+    # ---- extras
+    def div_norm(self):
+        v = C.c_double()
+        self._lib.call("rpde_navier2d_div_norm", self._h, C.byref(v))
+        return v.value
+
+    def last_update_ms(self):
+        v = C.c_double()
+        self._lib.call("rpde_navier2d_last_update_ms", self._h, C.byref(v))
+        return v.value
+
+    @property
+    def params(self):
+        out = {}
+        for k in ("ra", "pr", "nu", "ka"):
+            v = C.c_double()
+            self._lib.call("rpde_navier2d_param", self._h, k.encode(), C.byref(v))
+            out[k] = v.value
+        return out
+
+    def physical_fields(self):
+        return {k: getattr(self, k).v for k in ("velx", "vely", "temp", "pres")}
+
+    def integrate(self, max_time, exit_check_every=1):
+        n = C.c_long()
+        self._lib.call("rpde_navier2d_integrate", self._h, float(max_time), int(exit_check_every),
+                       C.byref(n))
+        return n.value
+
+
+MAX_TIMESTEP = 10_000_000
+
+
+def integrate(pde, max_time, save_intervall=None):
+    """`rustpde::integrate` (src/lib.rs:187-219): update / callback / break tests."""
+    timestep = 0
+    eps_dt = pde.get_dt() * 1e-4
+    while True:
+        pde.update()
+        timestep += 1
+        if save_intervall is not None:
+            t = pde.get_time()
+            if (t + eps_dt) % save_intervall < pde.get_dt() / 2.0:
+                pde.callback()
+        if pde.get_time() + eps_dt >= max_time:
+            break
+        if timestep >= MAX_TIMESTEP:
+            break
+        if pde.exit():
+            break
+    return timestep
+
+
+# ------------------------------------------------------------------------------------------------
+class Space2:
+    """funspace `Space2::new(&base0, &base1)` on the device (operator-level C ABI)."""
+
+    def __init__(self, base0, base1, device=0, library=None):
+        self._lib = library or lib()
+        self._h = C.c_void_p()
+        self._lib.call("rpde_space2_create", base0[0], base0[1], base1[0], base1[1], int(device),
+                       C.byref(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.call("rpde_space2_destroy", self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def shape(self, which):
+        r, c, z = C.c_int(), C.c_int(), C.c_int()
+        self._lib.call("rpde_space2_shape", self._h, {"physical": 0, "spectral": 1, "ortho": 2}[which],
+                       C.byref(r), C.byref(c), C.byref(z))
+        return r.value, c.value, bool(z.value)
+
+    def _out(self, which):
+        r, c, z = self.shape(which)
+        return np.empty((r, c * (2 if z else 1))), z
+
+    def _run(self, fn, a, which_out, *extra):
+        a = as_f64(a)
+        out, z = self._out(which_out)
+        self._lib.call(fn, self._h, ptr(a), a.size, *extra, ptr(out), out.size)
+        return out.view(np.complex128) if z else out
+
+    def forward(self, v): return self._run("rpde_space2_forward", v, "spectral")
+    def backward(self, vhat): return self._run("rpde_space2_backward", vhat, "physical")
+    def to_ortho(self, vhat): return self._run("rpde_space2_to_ortho", vhat, "ortho")
+    def from_ortho(self, c): return self._run("rpde_space2_from_ortho", c, "spectral")
+
+    def gradient(self, vhat, deriv, scale=None):
+        s = scale or (1.0, 1.0)
+        return self._run("rpde_space2_gradient", vhat, "ortho", int(deriv[0]), int(deriv[1]),
+                         float(s[0]), float(s[1]))
+
+
+class _Solver:
+    _create = _solve = _destroy = ""
+
+    def __init__(self, space: Space2, c):
+        self._space, self._lib = space, space._lib
+        self._h = C.c_void_p()
+        self._lib.call(self._create, space._h, float(c[0]), float(c[1]), C.byref(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.call(self._destroy, self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def solve(self, rhs_ortho):
+        a = as_f64(rhs_ortho)
+        out, z = self._space._out("spectral")
+        self._lib.call(self._solve, self._h, ptr(a), a.size, ptr(out), out.size)
+        return out.view(np.complex128) if z else out
+
+
+class HholtzAdi(_Solver):
+    """`HholtzAdi::new(&field, [c0, c1])` + `solve` (src/solver/hholtz_adi.rs:48-76,149-169)."""
+    _create, _solve, _destroy = "rpde_hholtz_adi_create", "rpde_hholtz_adi_solve", "rpde_hholtz_adi_destroy"
+
+
+class Poisson(_Solver):
+    """`Poisson::new(&field, [c0, c1])` + `solve` (src/solver/poisson.rs:54-94,195-236)."""
+    _create, _solve, _destroy = "rpde_poisson_create", "rpde_poisson_solve", "rpde_poisson_destroy"
+
+
+def transpose(a, device=0, library=None):
+    library = library or lib()
+    a = np.asarray(a)
+    z = np.iscomplexobj(a)
+    f = as_f64(a)
+    rows, cols = a.shape
+    out = np.empty((cols, rows * (2 if z else 1)))
+    library.call("rpde_transpose", ptr(f), rows, cols, 2 if z else 1, ptr(out), int(device))
+    return out.view(np.complex128) if z else out
+
+
+def gemm(a, b, transb=False, device=0, library=None):
+    library = library or lib()
+    a, b = as_f64(a), as_f64(b)
+    M, K = a.shape
+    N = b.shape[0] if transb else b.shape[1]
+    out = np.empty((M, N))
+    library.call("rpde_gemm", M, N, K, ptr(a), ptr(b), 1 if transb else 0, ptr(out), int(device))
+    return out

@@ -1,0 +1,67 @@
+"""Build the HIP library in-tree: rustpde_mpi_amd/librustpde_hip.so (gfx950 only).
+
+    python -m rustpde_mpi_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects are cached under rustpde_mpi_amd/csrc/build/ and
+rebuilt when a source or header is newer.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "librustpde_hip.so")
+SOURCES = ["kernels.cc", "hostmath.cc", "ops.cc", "engine.cc", "capi.cc"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _newest_header():
+    t = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith(".h"):
+                t = max(t, os.path.getmtime(os.path.join(root, f)))
+    return t
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
+    hdr_t = _newest_header()
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(bdir, src.replace(".cc", ".o"))
+        objs.append(obj)
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t)):
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+               "-Wno-unused-result", "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if (force or not os.path.exists(OUT)
+            or os.path.getmtime(OUT) < max(os.path.getmtime(o) for o in objs)):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

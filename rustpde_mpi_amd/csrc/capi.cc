@@ -1,0 +1,361 @@
+// extern "C" boundary (include/rustpde_hip.h).  Exceptions never cross it.
+#include "../../include/rustpde_hip.h"
+
+#include <cmath>
+#include <string>
+
+#include "engine.h"
+
+using namespace rpde;
+
+static thread_local std::string g_err;
+
+struct rpde_navier2d { Navier2DEngine* e; int device; };
+struct rpde_space2 { Space2Ops* sp; Stream st; int device; };
+struct rpde_hholtz_adi { HholtzAdiOp* op; rpde_space2* s; };
+struct rpde_poisson { PoissonOp* op; rpde_space2* s; };
+
+static void select_device(int device) {
+#ifndef RPDE_EMU
+  RPDE_HIP(hipSetDevice(device));
+#else
+  (void)device;
+#endif
+}
+
+#define RPDE_TRY(...)                                      \
+  try {                                                    \
+    __VA_ARGS__;                                           \
+    return 0;                                              \
+  } catch (const std::exception& ex) {                     \
+    g_err = ex.what();                                     \
+    return 1;                                              \
+  } catch (...) {                                          \
+    g_err = "unknown error";                               \
+    return 2;                                              \
+  }
+
+#define RPDE_CHECK_HANDLE(h) RPDE_REQUIRE((h) != nullptr, "null handle")
+
+extern "C" {
+
+const char* rpde_last_error(void) { return g_err.c_str(); }
+const char* rpde_version(void) {
+#ifdef RPDE_EMU
+  return "rustpde_hip 0.1 (host emulation build: tests only)";
+#else
+  return "rustpde_hip 0.1 (HIP gfx950)";
+#endif
+}
+int rpde_is_device_build(void) {
+#ifdef RPDE_EMU
+  return 0;
+#else
+  return 1;
+#endif
+}
+int rpde_device_count(int* count) {
+  RPDE_TRY({
+    RPDE_REQUIRE(count, "null pointer");
+#ifdef RPDE_EMU
+    *count = 0;
+#else
+    RPDE_HIP(hipGetDeviceCount(count));
+#endif
+  })
+}
+
+static int create_engine(int nx, int ny, double ra, double pr, double dt, double aspect,
+                         const char* bc, int device, bool periodic, rpde_navier2d** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out && bc, "null pointer");
+    select_device(device);
+    auto* h = new rpde_navier2d{nullptr, device};
+    try {
+      h->e = new Navier2DEngine(nx, ny, ra, pr, dt, aspect, bc, periodic);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  })
+}
+int rpde_navier2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                  const char* bc, int device, rpde_navier2d** out) {
+  return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, false, out);
+}
+int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                  const char* bc, int device, rpde_navier2d** out) {
+  return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, true, out);
+}
+int rpde_navier2d_destroy(rpde_navier2d* h) {
+  RPDE_TRY({
+    if (h) { select_device(h->device); delete h->e; delete h; }
+  })
+}
+int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_velocity(amp, m, n); })
+}
+int rpde_navier2d_set_temperature(rpde_navier2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_temperature(amp, m, n); })
+}
+int rpde_navier2d_init_random(rpde_navier2d* h, double amp, uint64_t seed) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->init_random(amp, seed); })
+}
+int rpde_navier2d_reset_time(rpde_navier2d* h) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); h->e->reset_time(); })
+}
+int rpde_navier2d_spectral_shape(rpde_navier2d* h, const char* name, int* rows, int* cols, int* is_complex) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && rows && cols && is_complex, "null pointer");
+    int e = 1;
+    h->e->spectral_shape(name, rows, cols, &e);
+    *is_complex = e == 2;
+  })
+}
+int rpde_navier2d_set_field(rpde_navier2d* h, const char* name, int space, const double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->set_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->set_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_navier2d_get_field(rpde_navier2d* h, const char* name, int space, double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->get_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->get_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_navier2d_get_grid(rpde_navier2d* h, int axis, double* x, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(x && (axis == 0 || axis == 1), "bad argument");
+    h->e->grid(axis, x, len);
+  })
+}
+int rpde_navier2d_update(rpde_navier2d* h, int nsteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->update(nsteps); })
+}
+int rpde_navier2d_last_update_ms(rpde_navier2d* h, double* ms) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(ms, "null pointer"); *ms = h->e->last_update_ms(); })
+}
+int rpde_navier2d_time(rpde_navier2d* h, double* t) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(t, "null pointer"); *t = h->e->time(); })
+}
+int rpde_navier2d_dt(rpde_navier2d* h, double* dt) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(dt, "null pointer"); *dt = h->e->dt(); })
+}
+int rpde_navier2d_param(rpde_navier2d* h, const char* key, double* value) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(key && value, "null pointer"); *value = h->e->param(key); })
+}
+int rpde_navier2d_exit(rpde_navier2d* h, int* flag) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(flag, "null pointer");
+    select_device(h->device);
+    *flag = h->e->exit() ? 1 : 0;
+  })
+}
+int rpde_navier2d_div_norm(rpde_navier2d* h, double* value) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(value, "null pointer");
+    select_device(h->device);
+    *value = h->e->div_norm();
+  })
+}
+int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    select_device(h->device);
+    // src/lib.rs:187-219 without the I/O callback; the NaN guard (which costs two gradients in
+    // the reference, every step) is evaluated every `exit_check_every` steps (>= 1)
+    const long kMaxTimestep = 10000000;
+    const int every = exit_check_every < 1 ? 1 : exit_check_every;
+    const double eps_dt = h->e->dt() * 1e-4;
+    long n = 0;
+    for (;;) {
+      h->e->update(1);
+      ++n;
+      if (h->e->time() + eps_dt >= max_time) break;
+      if (n >= kMaxTimestep) break;
+      if (n % every == 0 && h->e->exit()) break;
+    }
+    if (steps) *steps = n;
+  })
+}
+
+// ------------------------------------------------------------------------------------------
+int rpde_space2_create(int kind0, int n0, int kind1, int n1, int device, rpde_space2** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out, "null pointer");
+    RPDE_REQUIRE(kind0 >= 0 && kind0 <= 3 && kind1 >= 0 && kind1 <= 2, "unknown base kind");
+    select_device(device);
+    auto* s = new rpde_space2{nullptr, Stream{}, device};
+    try {
+      s->sp = new Space2Ops(make_base((BaseKind)kind0, n0), make_base((BaseKind)kind1, n1));
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    *out = s;
+  })
+}
+int rpde_space2_destroy(rpde_space2* s) {
+  RPDE_TRY({ if (s) { select_device(s->device); delete s->sp; delete s; } })
+}
+static void shape_of(Space2Ops& sp, int which, int* r, int* c, int* e) {
+  switch (which) {
+    case 0: *r = sp.phys_rows(); *c = sp.phys_cols(); *e = 1; break;
+    case 1: *r = sp.spec_rows(); *c = sp.spec_cols(); *e = sp.elem(); break;
+    case 2: *r = sp.ortho_rows(); *c = sp.ortho_cols(); *e = sp.elem(); break;
+    default: fail("shape selector must be 0 (physical), 1 (spectral) or 2 (orthonormal)");
+  }
+}
+int rpde_space2_shape(rpde_space2* s, int which, int* rows, int* cols, int* is_complex) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s);
+    RPDE_REQUIRE(rows && cols && is_complex, "null pointer");
+    int e = 1;
+    shape_of(*s->sp, which, rows, cols, &e);
+    *is_complex = e == 2;
+  })
+}
+
+}  // extern "C"
+namespace {
+// host array -> Arr2 of a given shape selector, with length check
+Arr2 upload_shape(Space2Ops& sp, int which, const double* h, size_t n, const char* what) {
+  int r, c, e;
+  shape_of(sp, which, &r, &c, &e);
+  RPDE_REQUIRE(h != nullptr, "null pointer");
+  RPDE_REQUIRE(n == (size_t)r * c * e, std::string(what) + ": array length does not match the space");
+  Arr2 a(r, c, e);
+  dev_upload2d(a.p(), a.ld, h, r, (long)c * e);
+  return a;
+}
+Arr2 alloc_shape(Space2Ops& sp, int which, const double* h, size_t n, const char* what) {
+  int r, c, e;
+  shape_of(sp, which, &r, &c, &e);
+  RPDE_REQUIRE(h != nullptr, "null pointer");
+  RPDE_REQUIRE(n == (size_t)r * c * e, std::string(what) + ": array length does not match the space");
+  return Arr2(r, c, e);
+}
+void download(const Arr2& a, double* h) { dev_download2d(h, a.p(), a.ld, a.rows, (long)a.cols * a.elem); }
+}  // namespace
+extern "C" {
+
+int rpde_space2_forward(rpde_space2* s, const double* v, size_t nv, double* vhat, size_t nvhat) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); select_device(s->device);
+    Arr2 a = upload_shape(*s->sp, 0, v, nv, "forward input");
+    Arr2 b = alloc_shape(*s->sp, 1, vhat, nvhat, "forward output");
+    s->sp->forward(a, b, s->st); dev_sync(s->st); download(b, vhat);
+  })
+}
+int rpde_space2_backward(rpde_space2* s, const double* vhat, size_t nvhat, double* v, size_t nv) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); select_device(s->device);
+    Arr2 a = upload_shape(*s->sp, 1, vhat, nvhat, "backward input");
+    Arr2 b = alloc_shape(*s->sp, 0, v, nv, "backward output");
+    s->sp->backward(a, b, s->st); dev_sync(s->st); download(b, v);
+  })
+}
+int rpde_space2_to_ortho(rpde_space2* s, const double* vhat, size_t nvhat, double* out, size_t nout) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); select_device(s->device);
+    Arr2 a = upload_shape(*s->sp, 1, vhat, nvhat, "to_ortho input");
+    Arr2 b = alloc_shape(*s->sp, 2, out, nout, "to_ortho output");
+    s->sp->to_ortho(a, b, s->st); dev_sync(s->st); download(b, out);
+  })
+}
+int rpde_space2_from_ortho(rpde_space2* s, const double* in, size_t nin, double* vhat, size_t nvhat) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); select_device(s->device);
+    Arr2 a = upload_shape(*s->sp, 2, in, nin, "from_ortho input");
+    Arr2 b = alloc_shape(*s->sp, 1, vhat, nvhat, "from_ortho output");
+    s->sp->from_ortho(a, b, s->st); dev_sync(s->st); download(b, vhat);
+  })
+}
+int rpde_space2_gradient(rpde_space2* s, const double* vhat, size_t nvhat, int d0, int d1,
+                         double s0, double s1, double* out, size_t nout) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); select_device(s->device);
+    RPDE_REQUIRE(d0 >= 0 && d1 >= 0 && d0 <= 4 && d1 <= 4, "derivative order out of range");
+    Arr2 a = upload_shape(*s->sp, 1, vhat, nvhat, "gradient input");
+    Arr2 b = alloc_shape(*s->sp, 2, out, nout, "gradient output");
+    s->sp->gradient(a, d0, d1, s0, s1, b, s->st); dev_sync(s->st); download(b, out);
+  })
+}
+
+int rpde_hholtz_adi_create(rpde_space2* s, double c0, double c1, rpde_hholtz_adi** out) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); RPDE_REQUIRE(out, "null pointer"); select_device(s->device);
+    *out = new rpde_hholtz_adi{new HholtzAdiOp(*s->sp, c0, c1), s};
+  })
+}
+int rpde_hholtz_adi_solve(rpde_hholtz_adi* hs, const double* in, size_t nin, double* out, size_t nout) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(hs); select_device(hs->s->device);
+    Arr2 a = upload_shape(*hs->s->sp, 2, in, nin, "HholtzAdi input");
+    Arr2 b = alloc_shape(*hs->s->sp, 1, out, nout, "HholtzAdi output");
+    hs->op->solve(a, b, hs->s->st); dev_sync(hs->s->st); download(b, out);
+  })
+}
+int rpde_hholtz_adi_destroy(rpde_hholtz_adi* hs) {
+  RPDE_TRY({ if (hs) { delete hs->op; delete hs; } })
+}
+int rpde_poisson_create(rpde_space2* s, double c0, double c1, rpde_poisson** out) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); RPDE_REQUIRE(out, "null pointer"); select_device(s->device);
+    *out = new rpde_poisson{new PoissonOp(*s->sp, c0, c1), s};
+  })
+}
+int rpde_poisson_solve(rpde_poisson* ps, const double* in, size_t nin, double* out, size_t nout) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(ps); select_device(ps->s->device);
+    Arr2 a = upload_shape(*ps->s->sp, 2, in, nin, "Poisson input");
+    Arr2 b = alloc_shape(*ps->s->sp, 1, out, nout, "Poisson output");
+    ps->op->solve(a, b, ps->s->st); dev_sync(ps->s->st); download(b, out);
+  })
+}
+int rpde_poisson_destroy(rpde_poisson* ps) {
+  RPDE_TRY({ if (ps) { delete ps->op; delete ps; } })
+}
+
+int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, int device) {
+  RPDE_TRY({
+    RPDE_REQUIRE(in && out && rows > 0 && cols > 0 && (elem == 1 || elem == 2), "bad argument");
+    select_device(device);
+    Stream st;
+    Arr2 a(rows, cols, elem), b(cols, rows, elem);
+    dev_upload2d(a.p(), a.ld, in, rows, (long)cols * elem);
+    launch_transpose(a.p(), a.ld, b.p(), b.ld, rows, cols, elem, st);
+    dev_sync(st);
+    dev_download2d(out, b.p(), b.ld, cols, (long)rows * elem);
+  })
+}
+int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device) {
+  RPDE_TRY({
+    RPDE_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "bad argument");
+    select_device(device);
+    Stream st;
+    Arr2 A(M, K), B(transb ? N : K, transb ? K : N), C(M, N);
+    dev_upload2d(A.p(), A.ld, a, M, K);
+    dev_upload2d(B.p(), B.ld, b, B.rows, B.cols);
+    if (transb) launch_gemm_nt(M, N, K, A.p(), A.ld, B.p(), B.ld, C.p(), C.ld, st);
+    else launch_gemm_nn(M, N, K, A.p(), A.ld, B.p(), B.ld, C.p(), C.ld, st);
+    dev_sync(st);
+    dev_download2d(c, C.p(), C.ld, M, N);
+  })
+}
+
+}  // extern "C"

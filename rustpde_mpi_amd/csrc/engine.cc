@@ -1,0 +1,568 @@
+#include "engine.h"
+
+#include <chrono>
+#include <cmath>
+#include <random>
+
+namespace rpde {
+
+struct Navier2DEngine::Field {
+  std::string name;
+  Space2Ops* sp = nullptr;
+  DBuf* buf = nullptr;
+  bool yx = true;        // internal layout: YX (transposed) or canonical XY (pseu)
+  bool ortho = false;    // spectral shape = ortho shape (pres)
+};
+
+static double get_nu(double ra, double pr, double h) { return std::sqrt(pr / (ra / std::pow(h, 3.0))); }
+static double get_ka(double ra, double pr, double h) { return std::sqrt(1.0 / ((ra / std::pow(h, 3.0)) * pr)); }
+
+Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
+                               const std::string& bc, bool periodic)
+    : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
+  RPDE_REQUIRE(bc == "rbc", "Boundary condition type \"" + bc + "\" not recognized! (supported: \"rbc\")");
+  RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
+#ifndef RPDE_EMU
+  RPDE_HIP(hipStreamCreate(&st_.s));
+#endif
+  nu_ = get_nu(ra, pr, sy_ * 2.0);
+  ka_ = get_ka(ra, pr, sy_ * 2.0);
+  my_ = ny - 2;
+  if (periodic) { mx_ = nx / 2 + 1; kx_ = nx / 2 + 1; ex_ = 2; }
+  else { mx_ = nx - 2; kx_ = nx; ex_ = 1; }
+  const BaseKind bx_vel = periodic ? kFourierR2c : kChebDirichlet;
+  const BaseKind bx_tmp = periodic ? kFourierR2c : kChebNeumann;
+  const BaseKind bx_ort = periodic ? kFourierR2c : kChebyshev;
+  sp_vel_ = std::make_unique<Space2Ops>(make_base(bx_vel, nx), make_base(kChebDirichlet, ny));
+  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebDirichlet, ny));
+  sp_ortho_ = std::make_unique<Space2Ops>(make_base(bx_ort, nx), make_base(kChebyshev, ny));
+  sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
+  hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, dt * nu_ / (sx_ * sx_), dt * nu_ / (sy_ * sy_));
+  hh_temp_ = std::make_unique<HholtzAdiOp>(*sp_temp_, dt * ka_ / (sx_ * sx_), dt * ka_ / (sy_ * sy_));
+  pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_));
+
+  ldx_ = pitch(periodic ? nx + 2 : nx);
+  ldy_ = pitch((long)ny * ex_);
+  const size_t nyx = (size_t)ny * ldx_;
+  const size_t nxy = (size_t)nx * ldy_;
+  for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
+  for (auto& b : Y_) b.alloc(nyx);
+  for (auto& b : X_) b.alloc(nxy);
+  BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy);
+  red_.alloc(2);
+
+  auto mk = [&](const char* name, Space2Ops* sp, DBuf* buf, bool yx, bool ortho) {
+    auto f = std::make_unique<Field>();
+    f->name = name; f->sp = sp; f->buf = buf; f->yx = yx; f->ortho = ortho;
+    fields_[name] = std::move(f);
+  };
+  mk("velx", sp_vel_.get(), &U_, true, false);
+  mk("vely", sp_vel_.get(), &V_, true, false);
+  mk("temp", sp_temp_.get(), &T_, true, false);
+  mk("pres", sp_ortho_.get(), &P_, true, true);
+  mk("pseu", sp_pseu_.get(), &PS_, false, false);
+
+  // ---- boundary-condition lift (boundary_conditions.rs:18-36 / 143-161) and its constants
+  {
+    Space2Ops& so = *sp_ortho_;
+    const Vec y = base_coords(so.base(1));
+    const double x1 = y.front(), x2 = y.back(), y1 = 0.5, y2 = -0.5;
+    const double m = (y2 - y1) / (x2 - x1), n = (y1 * x2 - y2 * x1) / (x2 - x1);
+    Vec prof((size_t)nx * ny);
+    for (int i = 0; i < nx; ++i)
+      for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = m * y[j] + n;
+    Arr2 v(nx, ny, 1), vh(so.ortho_rows(), ny, ex_), g(so.ortho_rows(), ny, ex_), g2(so.ortho_rows(), ny, ex_);
+    dev_upload2d(v.p(), v.ld, prof.data(), nx, ny);
+    so.forward(v, vh, st_);
+    launch_transpose(vh.p(), vh.ld, TBC_.p, ldx_, vh.rows, vh.cols, ex_, st_);
+    // dt * ka * (d2/dx2 + d2/dy2) tempbc enters solve_temp (navier_eq.rs:214-218)
+    so.gradient(vh, 2, 0, sx_, sy_, g, st_);
+    so.gradient(vh, 0, 2, sx_, sy_, g2, st_);
+    {
+      ProgramBuilder pb(2, so.axis(1).slot_len, g.rows, ex_);
+      const int a = pb.arr(g.p(), g.ld, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(g2.p(), g2.ld, ex_, ex_ == 2 ? 1 : 0);
+      pb.load(0, a, ny); pb.load(0, b, ny, 1.0, true); pb.store(0, a, ny);
+      pb.run(st_);
+    }
+    launch_transpose(g.p(), g.ld, TBC2_.p, ldx_, g.rows, g.cols, ex_, st_);
+    // physical gradients of the lift for the temperature convection (navier_eq.rs:66-69)
+    Arr2 ph(nx, ny, 1);
+    so.gradient(vh, 1, 0, sx_, sy_, g, st_);
+    so.backward(g, ph, st_);
+    launch_transpose(ph.p(), ph.ld, Y_[0].p, ldx_, nx, ny, 1, st_);
+    launch_transpose(Y_[0].p, ldx_, BX_.p, ldy_, ny, nx, 1, st_);
+    so.gradient(vh, 0, 1, sx_, sy_, g, st_);
+    so.backward(g, ph, st_);
+    launch_transpose(ph.p(), ph.ld, Y_[0].p, ldx_, nx, ny, 1, st_);
+    launch_transpose(Y_[0].p, ldx_, BY_.p, ldy_, ny, nx, 1, st_);
+    dev_sync(st_);
+  }
+  if (periodic) build_periodic(); else build_confined();
+}
+
+Navier2DEngine::~Navier2DEngine() {
+#ifndef RPDE_EMU
+  if (st_.s) { (void)hipStreamSynchronize(st_.s); (void)hipStreamDestroy(st_.s); }
+#endif
+}
+
+double Navier2DEngine::param(const std::string& key) const {
+  if (key == "ra") return ra_;
+  if (key == "pr") return pr_;
+  if (key == "nu") return nu_;
+  if (key == "ka") return ka_;
+  fail("unknown parameter \"" + key + "\"");
+}
+
+void Navier2DEngine::grid(int axis, double* x, size_t len) const {
+  const Base& b = sp_vel_->base(axis);
+  RPDE_REQUIRE((int)len == b.n, "grid: wrong length");
+  const Vec c = base_coords(b);
+  const double sc = axis == 0 ? sx_ : sy_;
+  for (int i = 0; i < b.n; ++i) x[i] = c[i] * sc;
+}
+
+Navier2DEngine::Field& Navier2DEngine::field(const std::string& name) {
+  auto it = fields_.find(name);
+  RPDE_REQUIRE(it != fields_.end(), "unknown field \"" + name + "\" (velx, vely, temp, pres, pseu)");
+  return *it->second;
+}
+
+void Navier2DEngine::spectral_shape(const std::string& name, int* rows, int* cols, int* elem) {
+  Field& f = field(name);
+  *rows = f.ortho ? f.sp->ortho_rows() : f.sp->spec_rows();
+  *cols = f.ortho ? f.sp->ortho_cols() : f.sp->spec_cols();
+  *elem = f.sp->elem();
+}
+
+void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
+  int r, c, e;
+  spectral_shape(f.name, &r, &c, &e);
+  RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
+  if (f.yx) launch_transpose(f.buf->p, ldx_, out.p(), out.ld, c, r, e, st_);
+  else {  // XY with pitch ldy_: two transposes through scratch keep the kernel set small
+    launch_transpose(f.buf->p, ldy_, Y_[0].p, ldx_, r, c, e, st_);
+    launch_transpose(Y_[0].p, ldx_, out.p(), out.ld, c, r, e, st_);
+  }
+}
+
+void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
+  int r, c, e;
+  spectral_shape(f.name, &r, &c, &e);
+  RPDE_REQUIRE(in.rows == r && in.cols == c && in.elem == e, "internal: canonical shape");
+  if (f.yx) launch_transpose(in.p(), in.ld, f.buf->p, ldx_, r, c, e, st_);
+  else {
+    launch_transpose(in.p(), in.ld, Y_[0].p, ldx_, r, c, e, st_);
+    launch_transpose(Y_[0].p, ldx_, f.buf->p, ldy_, c, r, e, st_);
+  }
+  if (f.name == "pres") refresh_gy();
+}
+
+void Navier2DEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
+  Field& f = field(name);
+  int r, c, e;
+  spectral_shape(name, &r, &c, &e);
+  RPDE_REQUIRE(len == (size_t)r * c * e, "set_field: wrong length for the spectral shape of " + name);
+  Arr2 a(r, c, e);
+  dev_upload2d(a.p(), a.ld, host, r, (long)c * e);
+  canonical_to_state(a, f);
+  dev_sync(st_);
+}
+
+void Navier2DEngine::get_field_spectral(const std::string& name, double* host, size_t len) {
+  Field& f = field(name);
+  int r, c, e;
+  spectral_shape(name, &r, &c, &e);
+  RPDE_REQUIRE(len == (size_t)r * c * e, "get_field: wrong length for the spectral shape of " + name);
+  Arr2 a(r, c, e);
+  state_to_canonical(f, a);
+  dev_sync(st_);
+  dev_download2d(host, a.p(), a.ld, r, (long)c * e);
+}
+
+void Navier2DEngine::set_field_physical(const std::string& name, const double* host, size_t len) {
+  Field& f = field(name);
+  RPDE_REQUIRE(len == (size_t)nx_ * ny_, "set_field: physical arrays are nx*ny doubles");
+  int r, c, e;
+  spectral_shape(name, &r, &c, &e);
+  Arr2 v(nx_, ny_, 1), vh(r, c, e);
+  dev_upload2d(v.p(), v.ld, host, nx_, ny_);
+  f.sp->forward(v, vh, st_);
+  canonical_to_state(vh, f);
+  dev_sync(st_);
+}
+
+void Navier2DEngine::get_field_physical(const std::string& name, double* host, size_t len) {
+  Field& f = field(name);
+  RPDE_REQUIRE(len == (size_t)nx_ * ny_, "get_field: physical arrays are nx*ny doubles");
+  int r, c, e;
+  spectral_shape(name, &r, &c, &e);
+  Arr2 v(nx_, ny_, 1), vh(r, c, e);
+  state_to_canonical(f, vh);
+  f.sp->backward(vh, v, st_);
+  dev_sync(st_);
+  dev_download2d(host, v.p(), v.ld, nx_, ny_);
+}
+
+static void sincos_field(const Base& b0, const Base& b1, double sx, double sy, double amp, double m,
+                         double n, bool sin_cos, Vec& out) {
+  // functions.rs:85-126: coordinates normalised by x[last] - x[0] (not exactly periodic for Fourier)
+  Vec x = base_coords(b0), y = base_coords(b1);
+  for (double& v : x) v *= sx;
+  for (double& v : y) v *= sy;
+  const double x0 = x.front(), xl = x.back() - x.front(), y0 = y.front(), yl = y.back() - y.front();
+  out.resize(x.size() * y.size());
+  for (size_t i = 0; i < x.size(); ++i)
+    for (size_t j = 0; j < y.size(); ++j) {
+      const double xa = M_PI * m * ((x[i] - x0) / xl), ya = M_PI * n * ((y[j] - y0) / yl);
+      out[i * y.size() + j] = sin_cos ? amp * std::sin(xa) * std::cos(ya) : amp * std::cos(xa) * std::sin(ya);
+    }
+}
+
+void Navier2DEngine::set_velocity(double amp, double m, double n) {
+  Vec v;
+  sincos_field(sp_vel_->base(0), sp_vel_->base(1), sx_, sy_, amp, m, n, true, v);
+  set_field_physical("velx", v.data(), v.size());
+  sincos_field(sp_vel_->base(0), sp_vel_->base(1), sx_, sy_, -amp, m, n, false, v);
+  set_field_physical("vely", v.data(), v.size());
+}
+
+void Navier2DEngine::set_temperature(double amp, double m, double n) {
+  Vec v;
+  sincos_field(sp_temp_->base(0), sp_temp_->base(1), sx_, sy_, -amp, m, n, false, v);
+  set_field_physical("temp", v.data(), v.size());
+}
+
+void Navier2DEngine::init_random(double amp, unsigned long long seed) {
+  // navier.rs:173-182: uniform(-amp, amp) on temp, velx, vely (the reference's RNG is unseeded;
+  // parity runs should pass explicit arrays through set_field_physical instead)
+  std::mt19937_64 rng(seed);
+  std::uniform_real_distribution<double> dist(-amp, amp);
+  Vec v((size_t)nx_ * ny_);
+  for (const char* nm : {"temp", "velx", "vely"}) {
+    for (double& x : v) x = dist(rng);
+    set_field_physical(nm, v.data(), v.size());
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+void Navier2DEngine::add_line(const ProgramBuilder& pb, const char* tag) {
+  Launch l;
+  l.type = Launch::kLine;
+  l.pg = pb.pg;
+  l.tag = tag;
+  step_.push_back(l);
+}
+void Navier2DEngine::add_transpose(const double* in, long ldi, double* out, long ldo, int rows,
+                                   int cols, int elem, const char* tag) {
+  Launch l;
+  l.type = Launch::kTranspose;
+  l.in = in; l.ldi = ldi; l.out = out; l.ldo = ldo; l.rows = rows; l.cols = cols; l.elem = elem;
+  l.tag = tag;
+  step_.push_back(l);
+}
+void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, long lda,
+                              const double* B, long ldb, double* C, long ldc, const char* tag) {
+  Launch l;
+  l.type = nn ? Launch::kGemmNN : Launch::kGemmNT;
+  l.in = A; l.ldi = lda; l.b = B; l.ldb = ldb; l.out = C; l.ldo = ldc; l.M = M; l.N = N; l.K = K;
+  l.tag = tag;
+  step_.push_back(l);
+}
+void Navier2DEngine::run_launch(const Launch& l) {
+  switch (l.type) {
+    case Launch::kLine: launch_line_program(l.pg, st_); break;
+    case Launch::kTranspose: launch_transpose(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, st_); break;
+    case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
+    case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
+    case Launch::kSetElem: launch_set_element(l.out, 0, 0.0, st_); break;
+  }
+}
+
+void Navier2DEngine::update(int nsteps) {
+  RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
+#ifndef RPDE_EMU
+  hipEvent_t e0, e1;
+  RPDE_HIP(hipEventCreate(&e0));
+  RPDE_HIP(hipEventCreate(&e1));
+  RPDE_HIP(hipEventRecord(e0, st_.s));
+#else
+  auto t0 = std::chrono::steady_clock::now();
+#endif
+  for (int s = 0; s < nsteps; ++s) {
+    for (const Launch& l : step_) run_launch(l);
+    time_ += dt_;
+  }
+#ifndef RPDE_EMU
+  RPDE_HIP(hipEventRecord(e1, st_.s));
+  RPDE_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RPDE_HIP(hipEventElapsedTime(&ms, e0, e1));
+  last_ms_ = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+#else
+  last_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#endif
+}
+
+double Navier2DEngine::div_norm() {
+  // div = d/dx velx + d/dy vely in the orthonormal space (navier_eq.rs:19-24), through the
+  // generic operators (diagnostic path, not part of the step)
+  Space2Ops& sv = *sp_vel_;
+  Arr2 u(sv.spec_rows(), sv.spec_cols(), ex_), g1(sv.ortho_rows(), sv.ortho_cols(), ex_),
+      g2(sv.ortho_rows(), sv.ortho_cols(), ex_);
+  state_to_canonical(field("velx"), u);
+  sv.gradient(u, 1, 0, sx_, sy_, g1, st_);
+  state_to_canonical(field("vely"), u);
+  sv.gradient(u, 0, 1, sx_, sy_, g2, st_);
+  ProgramBuilder pb(2, sv.axis(1).slot_len, g1.rows, ex_);
+  const int a = pb.arr(g1.p(), g1.ld, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(g2.p(), g2.ld, ex_, ex_ == 2 ? 1 : 0);
+  pb.load(0, a, ny_); pb.load(0, b, ny_, 1.0, true); pb.store(0, a, ny_);
+  pb.run(st_);
+  launch_sumsq(g1.p(), g1.ld, g1.rows, g1.cols * ex_, red_.p, st_);
+  dev_sync(st_);
+  double h[2];
+  dev_download(h, red_.p, sizeof(h));
+  if (h[1] > 0) return std::nan("");
+  return std::sqrt(h[0]);
+}
+
+bool Navier2DEngine::exit() { return std::isnan(div_norm()); }
+
+// d/dy of the pressure in YX layout, used by the vely right-hand side (navier_eq.rs:195)
+void Navier2DEngine::refresh_gy() {
+  const int rows_x = sp_ortho_->ortho_rows();
+  launch_transpose(P_.p, ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, st_);
+  ProgramBuilder pb(2, sp_ortho_->axis(1).slot_len, rows_x, ex_);
+  pb.set_fft(sp_ortho_->axis(1));
+  const int a = pb.arr(X_[0].p, ldy_, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(X_[1].p, ldy_, ex_, ex_ == 2 ? 1 : 0);
+  pb.load(0, a, ny_); pb.cdiff(0, 0, ny_, 1.0 / sy_); pb.store(0, b, ny_);
+  pb.run(st_);
+  launch_transpose(X_[1].p, ldy_, GY_.p, ldx_, rows_x, ny_, ex_, st_);
+}
+
+// ==========================================================================================
+// confined step: Chebyshev x Chebyshev
+void Navier2DEngine::build_confined() {
+  step_.clear();
+  const int nx = nx_, ny = ny_, mx = mx_, my = my_;
+  AxisTables& xD = sp_vel_->axis(0);   // Dirichlet(nx)
+  AxisTables& xN = sp_temp_->axis(0);  // Neumann(nx)
+  AxisTables& yD = sp_vel_->axis(1);   // Dirichlet(ny)
+  AxisTables& yN = sp_pseu_->axis(1);  // Neumann(ny)
+  const int slx = xD.slot_len, sly = yD.slot_len;
+  const long ldx = ldx_, ldy = ldy_;
+  const double dt = dt_;
+  const int cut_x = nx * 2 / 3, cut_y = ny * 2 / 3;
+
+  // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
+  struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
+      {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
+  for (auto& f : s1) {
+    ProgramBuilder pb(4, slx, my);
+    pb.set_fft(*f.ax);
+    const int a = pb.arr(f.st->p, ldx), o0 = pb.arr(f.w0->p, ldx), o1 = pb.arr(f.w1->p, ldx);
+    pb.load(2, a, mx);
+    pb.to_ortho(2, *f.ax);
+    pb.cdiff(0, 2, nx, 1.0 / sx_);
+    pb.dct(2, nx, f.ax->bwd_pre.p, nullptr);
+    pb.store(2, o0, nx);
+    pb.axpby(2, 0, 1.0, 0, 0.0, nx);
+    pb.dct(2, nx, f.ax->bwd_pre.p, nullptr);
+    pb.store(2, o1, nx);
+    add_line(pb, "S1 x: state -> phys-x, d/dx");
+  }
+  // ---- T1: to XY
+  for (int k = 0; k < 6; ++k) add_transpose(Y_[k].p, ldx, X_[k].p, ldy, my, nx, 1, "T1");
+  // ---- S2: y-lines: physical products and forward y transform
+  auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {  // slot 2 <- physical line
+    const int a = pb.arr(src.p, ldy);
+    pb.load(2, a, my);
+    pb.to_ortho(2, yD);
+    if (deriv) pb.cdiff(2, 2, ny, 1.0 / sy_);
+    pb.dct(2, ny, yD.bwd_pre.p, nullptr);
+  };
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ], u = W0U, v = W0V
+    ProgramBuilder pb(4, sly, nx);
+    pb.set_fft(yD);
+    phys(pb, X_[0], false);                 // u
+    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
+    phys(pb, fx, false);                    // d/dx f  (x-derivative taken in S1)
+    if (bx) pb.load(2, pb.arr(bx->p, ldy), ny, 1.0, true);
+    pb.mul(1, 0, 2, ny);
+    phys(pb, X_[2], false);                 // v
+    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
+    phys(pb, f0, true);                     // d/dy f
+    if (by) pb.load(2, pb.arr(by->p, ldy), ny, 1.0, true);
+    pb.mul(1, 0, 2, ny, 1.0, true);
+    pb.axpby(2, 1, 1.0, 1, 0.0, ny);
+    pb.dct(2, ny, nullptr, yD.fwd_post.p);
+    pb.zero(2, cut_y, ny);
+    pb.store(2, pb.arr(out.p, ldy), ny);
+    add_line(pb, tag);
+  };
+  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
+  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
+  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
+  // ---- T2: conv terms to YX
+  for (int k = 0; k < 3; ++k) add_transpose(X_[6 + k].p, ldy, Y_[k].p, ldx, nx, ny, 1, "T2");
+  // ---- S3: x-lines: forward x transform, RHS assembly, x part of the ADI Helmholtz solve
+  auto rhs = [&](int which, const char* tag) {  // 0 velx, 1 vely, 2 temp
+    AxisTables& ax = which == 2 ? xN : xD;
+    DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
+    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+    ProgramBuilder pb(4, slx, ny);
+    pb.set_fft(ax);
+    pb.load(2, pb.arr(Y_[which].p, ldx), nx);
+    pb.dct(2, nx, nullptr, ax.fwd_post.p);
+    pb.zero(2, cut_x, nx);
+    pb.loadx(0, pb.arr(state.p, ldx), mx, my, yD.low.p);     // S_y (cross-line), Dirichlet in y
+    pb.to_ortho(0, ax);                                       // S_x
+    pb.axpby(0, 0, 1.0, 2, -dt, nx);
+    if (which == 0) {
+      pb.load(2, pb.arr(P_.p, ldx), nx);
+      pb.cdiff(2, 2, nx, 1.0 / sx_);
+      pb.axpby(0, 0, 1.0, 2, -dt, nx);
+    } else if (which == 1) {
+      pb.load(0, pb.arr(GY_.p, ldx), nx, -dt, true);
+      pb.loadx(2, pb.arr(T_.p, ldx), mx, my, yD.low.p);       // buoyancy: temp.to_ortho() + tempbc
+      pb.to_ortho(2, xN);
+      pb.load(2, pb.arr(TBC_.p, ldx), nx, 1.0, true);
+      pb.axpby(0, 0, 1.0, 2, dt, nx);
+    } else {
+      pb.load(0, pb.arr(TBC2_.p, ldx), nx, dt * ka_, true);
+    }
+    pb.pinv_matvec(0, ax);
+    pb.fdma_solve(0, mx, hh.fdma[0]);
+    pb.store(0, pb.arr(Y_[3 + which].p, ldx), mx);
+    add_line(pb, tag);
+  };
+  rhs(0, "S3 x: rhs + hholtz-x velx");
+  rhs(1, "S3 x: rhs + hholtz-x vely");
+  rhs(2, "S3 x: rhs + hholtz-x temp");
+  // ---- T3
+  for (int k = 0; k < 3; ++k) add_transpose(Y_[3 + k].p, ldx, X_[k].p, ldy, ny, mx, 1, "T3");
+  // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
+  for (int which = 0; which < 3; ++which) {
+    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+    ProgramBuilder pb(4, sly, mx);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[which].p, ldy), ny);
+    pb.pinv_matvec(0, yD);
+    pb.fdma_solve(0, my, hh.fdma[1]);
+    pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
+    if (which == 1) {
+      pb.zero(0, my, sly);
+      pb.to_ortho(0, yD);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.store(0, pb.arr(X_[6].p, ldy), ny);
+    }
+    add_line(pb, "S4 y: hholtz-y");
+  }
+  // ---- T4: new (uncorrected) state back to YX
+  add_transpose(X_[3].p, ldy, U_.p, ldx, mx, my, 1, "T4");
+  add_transpose(X_[4].p, ldy, V_.p, ldx, mx, my, 1, "T4");
+  add_transpose(X_[5].p, ldy, T_.p, ldx, mx, my, 1, "T4");
+  add_transpose(X_[6].p, ldy, Y_[0].p, ldx, mx, ny, 1, "T4");
+  // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
+  PoissonOp& po = *pois_;
+  {
+    ProgramBuilder pb(4, slx, ny);
+    pb.set_fft(xD);
+    pb.loadx(0, pb.arr(U_.p, ldx), mx, my, yD.low.p);
+    pb.to_ortho(0, xD);
+    pb.cdiff(0, 0, nx, 1.0 / sx_);
+    pb.load(2, pb.arr(Y_[0].p, ldx), mx);
+    pb.to_ortho(2, xD);
+    pb.axpby(0, 0, 1.0, 2, 1.0, nx);
+    pb.store(0, pb.arr(DIV_.p, ldx), nx);
+    pb.pinv_matvec(0, xN);
+    pb.store(0, pb.arr(Y_[1].p, ldx), mx, 1.0, po.half);
+    add_line(pb, "S5 x: div + poisson precond-x");
+  }
+  // ---- G1: eigen-space transform along x (NT GEMM absorbs the YX -> XY transpose)
+  add_gemm(false, po.me, ny, po.me, po.fwd_e.p(), po.fwd_e.ld, Y_[1].p, ldx, X_[0].p, ldy, "G1 even");
+  add_gemm(false, po.mo, ny, po.mo, po.fwd_o.p(), po.fwd_o.ld, Y_[1].p + po.half, ldx,
+           X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
+  // ---- S6: y preconditioner + per-eigenvalue banded solves
+  {
+    ProgramBuilder pb(4, sly, mx);
+    pb.set_fft(yN);
+    pb.load(0, pb.arr(X_[0].p, ldy), ny);
+    pb.pinv_matvec(0, yN);
+    pb.fdma_solve(0, my, po.rows);
+    pb.store(0, pb.arr(X_[1].p, ldy), my);
+    add_line(pb, "S6 y: poisson rows");
+  }
+  // ---- G2: back to coefficient space (rows of one parity are 2 ldy apart)
+  add_gemm(true, po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy, "G2 even");
+  add_gemm(true, po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
+           PS_.p + ldy, 2 * ldy, "G2 odd");
+  {
+    Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.tag = "pseu[0,0]=0"; step_.push_back(l);
+  }
+  // ---- S7: y part of the velocity correction
+  {
+    ProgramBuilder pb(4, sly, mx);
+    pb.set_fft(yN);
+    pb.load(0, pb.arr(PS_.p, ldy), my);
+    pb.to_ortho(0, yN);
+    pb.cdiff(2, 0, ny, -1.0 / sy_);
+    pb.from_ortho(0, yD);
+    pb.store(0, pb.arr(X_[2].p, ldy), my);
+    pb.from_ortho(2, yD);
+    pb.store(2, pb.arr(X_[3].p, ldy), my);
+    add_line(pb, "S7 y: correction-y");
+  }
+  // ---- T5
+  add_transpose(X_[2].p, ldy, Y_[2].p, ldx, mx, my, 1, "T5");
+  add_transpose(X_[3].p, ldy, Y_[3].p, ldx, mx, my, 1, "T5");
+  add_transpose(PS_.p, ldy, Y_[4].p, ldx, mx, my, 1, "T5");
+  // ---- S8: x part of the velocity correction
+  {
+    ProgramBuilder pb(4, slx, my);
+    pb.set_fft(xD);
+    pb.load(0, pb.arr(Y_[2].p, ldx), mx);
+    pb.to_ortho(0, xN);
+    pb.cdiff(0, 0, nx, -1.0 / sx_);
+    pb.from_ortho(0, xD);
+    pb.load(0, pb.arr(U_.p, ldx), mx, 1.0, true);
+    pb.store(0, pb.arr(U_.p, ldx), mx);
+    pb.load(0, pb.arr(Y_[3].p, ldx), mx);
+    pb.to_ortho(0, xN);
+    pb.from_ortho(0, xD);
+    pb.load(0, pb.arr(V_.p, ldx), mx, 1.0, true);
+    pb.store(0, pb.arr(V_.p, ldx), mx);
+    add_line(pb, "S8 x: correction-x");
+  }
+  // ---- S9: pressure update
+  {
+    ProgramBuilder pb(4, slx, ny);
+    pb.set_fft(xN);
+    pb.loadx(0, pb.arr(Y_[4].p, ldx), mx, my, yN.low.p, 1.0 / dt);
+    pb.to_ortho(0, xN);
+    pb.load(0, pb.arr(DIV_.p, ldx), nx, -nu_, true);
+    pb.load(0, pb.arr(P_.p, ldx), nx, 1.0, true);
+    pb.store(0, pb.arr(P_.p, ldx), nx);
+    add_line(pb, "S9 x: pressure update");
+  }
+  // ---- T6 / S10 / T7: d/dy pres for the next step
+  add_transpose(P_.p, ldx, X_[0].p, ldy, ny, nx, 1, "T6");
+  {
+    ProgramBuilder pb(4, sly, nx);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[0].p, ldy), ny);
+    pb.cdiff(0, 0, ny, 1.0 / sy_);
+    pb.store(0, pb.arr(X_[1].p, ldy), ny);
+    add_line(pb, "S10 y: d/dy pres");
+  }
+  add_transpose(X_[1].p, ldy, GY_.p, ldx, nx, ny, 1, "T7");
+}
+
+void Navier2DEngine::build_periodic() {
+  fail("periodic engine not built yet");
+}
+
+}  // namespace rpde

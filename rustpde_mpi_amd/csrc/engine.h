@@ -1,0 +1,100 @@
+// Navier2D engine: device-resident mirror of rustpde's `Navier2D<T, S>` for 2-D Rayleigh-Benard
+// convection (src/navier_stokes/navier.rs:49-89, 215-308, 336-428, 438-466).  All fields stay in
+// HBM; `update(n)` runs n time steps as a fixed sequence of line programs (x-lines on "YX"
+// arrays, y-lines on "XY" arrays), transposes and, for the confined case, four f64 MFMA GEMMs
+// per step (the eigen-decomposition Poisson solve, src/solver/poisson.rs:195-236).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+
+#include "ops.h"
+
+namespace rpde {
+
+class Navier2DEngine {
+ public:
+  Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
+                 const std::string& bc, bool periodic);
+  ~Navier2DEngine();
+
+  // initial conditions (src/navier_stokes/navier.rs:161-182, functions.rs:85-126)
+  void set_velocity(double amp, double m, double n);
+  void set_temperature(double amp, double m, double n);
+  void init_random(double amp, unsigned long long seed);
+  void reset_time() { time_ = 0.0; }
+
+  // field access; name in {velx, vely, temp, pres, pseu}; physical arrays are (nx x ny) row-major
+  // f64, spectral arrays have the reference's `vhat` shape (complex interleaved when periodic)
+  void set_field_physical(const std::string& name, const double* host, size_t len);
+  void get_field_physical(const std::string& name, double* host, size_t len);
+  void set_field_spectral(const std::string& name, const double* host, size_t len);
+  void get_field_spectral(const std::string& name, double* host, size_t len);
+  void spectral_shape(const std::string& name, int* rows, int* cols, int* elem);
+
+  void update(int nsteps);           // n x Integrate::update
+  double div_norm();                 // ||div||_2 of the current velocity (navier_eq.rs:33-51)
+  bool exit();                       // NaN guard of Integrate::exit (navier.rs:482-489)
+  double time() const { return time_; }
+  double dt() const { return dt_; }
+  double param(const std::string& key) const;
+  double last_update_ms() const { return last_ms_; }
+  void grid(int axis, double* x, size_t len) const;
+  void sync() { dev_sync(st_); }
+  int nx() const { return nx_; }
+  int ny() const { return ny_; }
+  bool periodic() const { return periodic_; }
+
+  Stream st_;
+
+ private:
+  struct Field;   // per-field bookkeeping
+  void build_programs();
+  void step();
+  Field& field(const std::string& name);
+  void state_to_canonical(Field& f, Arr2& out);
+  void canonical_to_state(const Arr2& in, Field& f);
+  void refresh_gy();
+
+  int nx_, ny_, mx_, my_, kx_;   // kx_: x-modes of a spectral line (nx, or nx/2+1 complex)
+  bool periodic_;
+  double ra_, pr_, nu_, ka_, dt_, time_ = 0.0, sx_, sy_;
+  double last_ms_ = 0.0;
+  long ldx_, ldy_;               // pitches (doubles) of YX and XY work arrays
+  int ex_;                       // doubles per spectral x-entry (1 confined, 2 periodic)
+
+  std::unique_ptr<Space2Ops> sp_vel_, sp_temp_, sp_ortho_, sp_pseu_;
+  std::unique_ptr<HholtzAdiOp> hh_vel_, hh_temp_;
+  std::unique_ptr<PoissonOp> pois_;
+
+  // state + constants (YX layout: row = y index, contiguous x)
+  DBuf U_, V_, T_, P_, GY_, TBC_, TBC2_, DIV_;
+  DBuf Y_[6];
+  // XY layout work arrays (row = x index, contiguous y)
+  DBuf X_[9], BX_, BY_, PS_;
+  DBuf red_;                     // reduction scratch (2 doubles)
+  std::map<std::string, std::unique_ptr<Field>> fields_;
+
+  // the step as a list of launches
+  struct Launch {
+    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem } type;
+    Program pg;                  // kLine
+    const double* in = nullptr;  // transposes / gemm A
+    const double* b = nullptr;   // gemm B
+    double* out = nullptr;
+    long ldi = 0, ldb = 0, ldo = 0;
+    int rows = 0, cols = 0, elem = 1, M = 0, N = 0, K = 0;
+    const char* tag = "";
+  };
+  std::vector<Launch> step_;
+  void add_line(const ProgramBuilder& pb, const char* tag);
+  void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
+                     const char* tag);
+  void add_gemm(bool nn, int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                double* C, long ldc, const char* tag);
+  void build_confined();
+  void build_periodic();
+  void run_launch(const Launch& l);
+};
+
+}  // namespace rpde

@@ -1,0 +1,354 @@
+#include "hostmath.h"
+
+#include <dlfcn.h>
+#include <glob.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+
+#include "platform.h"
+
+namespace rpde {
+
+static const long double kPiL = 3.141592653589793238462643383279502884L;
+
+Base make_base(BaseKind kind, int n) {
+  Base b{kind, n, n};
+  if (kind == kChebDirichlet || kind == kChebNeumann) b.m = n - 2;
+  if (kind == kFourierR2c) {
+    RPDE_REQUIRE(n % 2 == 0, "fourier_r2c needs an even number of points");
+    b.m = n / 2 + 1;
+  }
+  RPDE_REQUIRE(n >= 5 || kind == kFourierR2c, "Chebyshev bases need n >= 5");
+  return b;
+}
+
+Vec base_coords(const Base& b) {
+  Vec x(b.n);
+  for (int j = 0; j < b.n; ++j)
+    x[j] = b.is_cheb() ? -std::cos(M_PI * (double)j / (double)(b.n - 1))
+                       : 2.0 * M_PI * (double)j / (double)b.n;
+  return x;
+}
+
+Vec base_dx(const Base& b, const Vec& x) {
+  const int n = b.n;
+  Vec dx(n);
+  if (!b.is_cheb()) {
+    std::fill(dx.begin(), dx.end(), x[2] - x[1]);
+    return dx;
+  }
+  for (int i = 0; i < n; ++i) {
+    const double l = (i == 0) ? x[0] : (x[i] + x[i - 1]) / 2.0;
+    const double r = (i == n - 1) ? x[n - 1] : (x[i + 1] + x[i]) / 2.0;
+    dx[i] = r - l;
+  }
+  return dx;
+}
+
+Vec stencil_low(const Base& b) {
+  RPDE_REQUIRE(b.is_composite(), "stencil of a non-composite base");
+  Vec low(b.m);
+  for (int k = 0; k < b.m; ++k) {
+    if (b.kind == kChebDirichlet) low[k] = -1.0;
+    else { const double r = (double)k / ((double)k + 2.0); low[k] = -(r * r); }
+  }
+  return low;
+}
+
+Vec cheb_fwd_post(int n) {
+  Vec f(n);
+  for (int k = 0; k < n; ++k) f[k] = ((k & 1) ? -1.0 : 1.0) / (double)(n - 1);
+  f[0] *= 0.5; f[n - 1] *= 0.5;
+  return f;
+}
+Vec cheb_bwd_pre(int n) {
+  Vec f(n);
+  for (int k = 0; k < n; ++k) f[k] = ((k & 1) ? -1.0 : 1.0) * 0.5;
+  f[0] *= 2.0; f[n - 1] *= 2.0;
+  return f;
+}
+
+Vec fft_twiddles(int nfft) {
+  Vec t(2 * (size_t)nfft);
+  for (int k = 0; k < nfft; ++k) {
+    const long double a = 2.0L * kPiL * (long double)k / (long double)nfft;
+    t[2 * k] = (double)cosl(a);
+    t[2 * k + 1] = (double)(-sinl(a));
+  }
+  return t;
+}
+Vec dct_split_twiddles(int N) {
+  Vec t(2 * (size_t)(N + 1));
+  for (int k = 0; k <= N; ++k) {
+    const long double a = kPiL * (long double)k / (long double)N;
+    t[2 * k] = (double)cosl(a);
+    t[2 * k + 1] = (double)sinl(a);
+  }
+  return t;
+}
+Vec rfft_split_twiddles(int nx) {
+  const int M = nx / 2;
+  Vec t(2 * (size_t)(M + 1));
+  for (int k = 0; k <= M; ++k) {
+    const long double a = 2.0L * kPiL * (long double)k / (long double)nx;
+    t[2 * k] = (double)cosl(a);
+    t[2 * k + 1] = (double)sinl(a);
+  }
+  return t;
+}
+Vec dct_direct_costab(int N) {
+  Vec t(2 * (size_t)N);
+  for (int m = 0; m < 2 * N; ++m) t[m] = (double)cosl(kPiL * (long double)m / (long double)N);
+  return t;
+}
+
+FromOrthoTables from_ortho_tables(const Base& b) {
+  RPDE_REQUIRE(b.is_composite(), "from_ortho of a non-composite base");
+  const int m = b.m;
+  const Vec low = stencil_low(b);
+  Vec main(m), off(std::max(0, m - 2));
+  for (int k = 0; k < m; ++k) main[k] = 1.0 + low[k] * low[k];
+  for (int k = 0; k + 2 < m; ++k) off[k] = 1.0 * low[k];
+  Vec w(m, 0.0), den(m, 0.0);
+  for (int i = 0; i < m; ++i) {
+    den[i] = (i >= 2) ? main[i] - off[i - 2] * w[i - 2] : main[i];
+    if (i < m - 2) w[i] = off[i] / den[i];
+  }
+  FromOrthoTables t;
+  t.t0.assign(m, 1.0);
+  t.t1 = low;
+  t.t2.assign(m, 0.0);
+  t.p_up.resize(m); t.q_up.assign(m, 0.0); t.q_dn.assign(m, 0.0);
+  for (int i = 0; i < m; ++i) {
+    t.p_up[i] = 1.0 / den[i];
+    if (i >= 2) t.q_up[i] = -off[i - 2] / den[i];
+    if (i < m - 2) t.q_dn[i] = -w[i];
+  }
+  return t;
+}
+
+Mv3Tables pinv_tables(const Base& b) {
+  RPDE_REQUIRE(b.is_cheb(), "pinv of a Fourier base");
+  const int n = b.n, m = n - 2;
+  Mv3Tables t;
+  t.t0.resize(m); t.t1.assign(m, 0.0); t.t2.assign(m, 0.0);
+  for (int r = 0; r < m; ++r) {
+    const double i = (double)(r + 2);
+    t.t0[r] = (r == 0) ? 0.25 : 1.0 / (4.0 * i * (i - 1.0));
+    if (r + 2 <= n - 3) t.t1[r] = -1.0 / (2.0 * (i * i - 1.0));
+    if (r + 2 <= n - 5) t.t2[r] = 1.0 / (4.0 * i * (i + 1.0));
+  }
+  return t;
+}
+
+Bands hholtz_mat_a(const Base& b) {
+  const int m = b.m;
+  const Mv3Tables p = pinv_tables(b);
+  const Vec low = stencil_low(b);
+  auto dia_at = [&](int k) { return k < m ? 1.0 : 0.0; };
+  auto low_at = [&](int k) { return k < m ? low[k] : 0.0; };
+  Bands a{Vec(m, 0.0), Vec(m), Vec(m), Vec(m)};
+  for (int r = 0; r < m; ++r) {
+    if (r >= 2) a.low[r] = p.t0[r] * low[r - 2];
+    a.dia[r] = p.t0[r] * 1.0 + p.t1[r] * low[r];
+    a.up1[r] = p.t1[r] * dia_at(r + 2) + p.t2[r] * low_at(r + 2);
+    a.up2[r] = p.t2[r] * dia_at(r + 4);
+  }
+  return a;
+}
+
+Bands hholtz_mat_b(const Base& b) {
+  const int m = b.m;
+  const Vec low = stencil_low(b);
+  Bands x{Vec(m, 0.0), low, Vec(m, 0.0), Vec(m, 0.0)};
+  for (int r = 0; r + 2 < m; ++r) x.up1[r] = 1.0;
+  return x;
+}
+
+Bands bands_axpy(const Bands& a, double c, const Bands& b) {
+  const size_t m = a.dia.size();
+  Bands r{Vec(m), Vec(m), Vec(m), Vec(m)};
+  for (size_t i = 0; i < m; ++i) {
+    r.low[i] = a.low[i] + c * b.low[i];
+    r.dia[i] = a.dia[i] + c * b.dia[i];
+    r.up1[i] = a.up1[i] + c * b.up1[i];
+    r.up2[i] = a.up2[i] + c * b.up2[i];
+  }
+  return r;
+}
+
+void fdma_sweep(Bands& mtx) {
+  // reference indexing: low_ref[i-2] = low[i]; see src/solver/fdma.rs:73-82
+  const int n = (int)mtx.dia.size();
+  for (int i = 2; i < n; ++i) {
+    mtx.low[i] = mtx.low[i] / mtx.dia[i - 2];
+    mtx.dia[i] = mtx.dia[i] - mtx.low[i] * mtx.up1[i - 2];
+    if (i < n - 2) mtx.up1[i] = mtx.up1[i] - mtx.low[i] * mtx.up2[i - 2];
+  }
+}
+
+FdmaTables fdma_tables(const Bands& s) {
+  const int n = (int)s.dia.size();
+  FdmaTables t{Vec(n, 0.0), Vec(n), Vec(n, 0.0), Vec(n, 0.0)};
+  for (int i = 0; i < n; ++i) {
+    if (i >= 2) t.q1[i] = -s.low[i];
+    t.p2[i] = 1.0 / s.dia[i];
+    if (i < n - 2) t.q2[i] = -s.up1[i] / s.dia[i];
+    if (i < n - 4) t.r2[i] = -s.up2[i] / s.dia[i];
+  }
+  return t;
+}
+
+// ------------------------------------------------------------------------------------- LAPACK
+namespace {
+using dgeev_t = void (*)(const char*, const char*, const int*, double*, const int*, double*,
+                         double*, double*, const int*, double*, const int*, double*, const int*,
+                         int*, size_t, size_t);
+using dgetrf_t = void (*)(const int*, const int*, double*, const int*, int*, int*);
+using dgetri_t = void (*)(const int*, double*, const int*, const int*, double*, const int*, int*);
+using dgemm_t = void (*)(const char*, const char*, const int*, const int*, const int*,
+                         const double*, const double*, const int*, const double*, const int*,
+                         const double*, double*, const int*, size_t, size_t);
+
+struct Lapack {
+  void* h = nullptr;
+  std::string path;
+  dgeev_t dgeev = nullptr;
+  dgetrf_t dgetrf = nullptr;
+  dgetri_t dgetri = nullptr;
+  dgemm_t dgemm = nullptr;
+};
+
+void* sym2(void* h, const char* a, const char* b) {
+  void* p = dlsym(h, a);
+  return p ? p : dlsym(h, b);
+}
+
+bool try_open(Lapack& L, const std::string& path) {
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) return false;
+  Lapack t;
+  t.h = h;
+  t.path = path;
+  t.dgeev = (dgeev_t)sym2(h, "scipy_dgeev_", "dgeev_");
+  t.dgetrf = (dgetrf_t)sym2(h, "scipy_dgetrf_", "dgetrf_");
+  t.dgetri = (dgetri_t)sym2(h, "scipy_dgetri_", "dgetri_");
+  t.dgemm = (dgemm_t)sym2(h, "scipy_dgemm_", "dgemm_");
+  if (t.dgeev && t.dgetrf && t.dgetri && t.dgemm) { L = t; return true; }
+  dlclose(h);
+  return false;
+}
+
+Lapack& lapack() {
+  static Lapack L;
+  if (L.h) return L;
+  std::vector<std::string> cand;
+  if (const char* e = std::getenv("RPDE_LAPACK_LIB")) cand.push_back(e);
+  const char* pats[] = {
+      "/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so",
+      "/usr/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so",
+      "/usr/local/lib/python3*/site-packages/scipy.libs/libscipy_openblas*.so",
+      "/opt/conda/lib/python3*/site-packages/scipy.libs/libscipy_openblas*.so",
+  };
+  for (const char* p : pats) {
+    glob_t g;
+    if (glob(p, 0, nullptr, &g) == 0)
+      for (size_t i = 0; i < g.gl_pathc; ++i) cand.push_back(g.gl_pathv[i]);
+    globfree(&g);
+  }
+  for (const char* s : {"libopenblas.so.0", "libopenblas.so", "liblapack.so.3", "liblapack.so"})
+    cand.push_back(s);
+  for (const auto& c : cand)
+    if (try_open(L, c)) return L;
+  fail("rustpde_hip: no LAPACK (dgeev/dgetrf/dgetri/dgemm) found for the Poisson eigen-"
+       "decomposition; set RPDE_LAPACK_LIB to an OpenBLAS/LAPACK shared library");
+}
+
+// column-major helpers
+void invert_cm(Lapack& L, Vec& a, int n) {
+  std::vector<int> ipiv(n);
+  int info = 0;
+  L.dgetrf(&n, &n, a.data(), &n, ipiv.data(), &info);
+  RPDE_REQUIRE(info == 0, "dgetrf failed");
+  int lwork = -1;
+  double wq = 0;
+  L.dgetri(&n, a.data(), &n, ipiv.data(), &wq, &lwork, &info);
+  lwork = (int)wq + 1;
+  Vec work(lwork);
+  L.dgetri(&n, a.data(), &n, ipiv.data(), work.data(), &lwork, &info);
+  RPDE_REQUIRE(info == 0, "dgetri failed");
+}
+Vec matmul_cm(Lapack& L, const Vec& a, const Vec& b, int n) {
+  Vec c((size_t)n * n);
+  const double one = 1.0, zero = 0.0;
+  L.dgemm("N", "N", &n, &n, &n, &one, a.data(), &n, b.data(), &n, &zero, c.data(), &n, 1, 1);
+  return c;
+}
+}  // namespace
+
+std::string lapack_library_path() { return lapack().path; }
+
+EigenX eigen_decomposition_parity(const Bands& a, const Bands& c) {
+  Lapack& L = lapack();
+  const int m = (int)a.dia.size();
+  EigenX out;
+  out.me = (m + 1) / 2;
+  out.mo = m / 2;
+  out.lam.resize(m);
+  out.fwd.resize((size_t)out.me * out.me + (size_t)out.mo * out.mo);
+  out.bwd.resize(out.fwd.size());
+  size_t moff = 0;
+  int loff = 0;
+  for (int par = 0; par < 2; ++par) {
+    const int mb = par == 0 ? out.me : out.mo;
+    auto dense_cm = [&](const Bands& bd) {
+      Vec d((size_t)mb * mb, 0.0);
+      for (int r = 0; r < mb; ++r) {
+        const int R = par + 2 * r;
+        auto put = [&](int cc, double v) { if (cc >= 0 && cc < mb) d[(size_t)cc * mb + r] = v; };
+        put(r - 1, bd.low[R]);
+        put(r, bd.dia[R]);
+        put(r + 1, bd.up1[R]);
+        put(r + 2, bd.up2[R]);
+      }
+      return d;
+    };
+    Vec cinv = dense_cm(c);
+    invert_cm(L, cinv, mb);
+    Vec x = matmul_cm(L, cinv, dense_cm(a), mb);
+    Vec wr(mb), wi(mb), vr((size_t)mb * mb);
+    int info = 0, lwork = -1, one = 1;
+    double wq = 0;
+    L.dgeev("N", "V", &mb, x.data(), &mb, wr.data(), wi.data(), nullptr, &one, vr.data(), &mb, &wq,
+            &lwork, &info, 1, 1);
+    lwork = (int)wq + 1;
+    Vec work(lwork);
+    L.dgeev("N", "V", &mb, x.data(), &mb, wr.data(), wi.data(), nullptr, &one, vr.data(), &mb,
+            work.data(), &lwork, &info, 1, 1);
+    RPDE_REQUIRE(info == 0, "dgeev failed");
+    std::vector<int> perm(mb);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int i, int j) { return wr[i] > wr[j]; });
+    Vec q((size_t)mb * mb);
+    for (int k = 0; k < mb; ++k)
+      std::copy(vr.begin() + (size_t)perm[k] * mb, vr.begin() + (size_t)(perm[k] + 1) * mb,
+                q.begin() + (size_t)k * mb);
+    Vec qinv = q;
+    invert_cm(L, qinv, mb);
+    Vec f = matmul_cm(L, qinv, cinv, mb);
+    for (int k = 0; k < mb; ++k) out.lam[loff + k] = wr[perm[k]];
+    for (int i = 0; i < mb; ++i)
+      for (int k = 0; k < mb; ++k) {
+        out.bwd[moff + (size_t)i * mb + k] = q[(size_t)k * mb + i];   // Q(i,k)
+        out.fwd[moff + (size_t)k * mb + i] = f[(size_t)i * mb + k];   // F(k,i)
+      }
+    moff += (size_t)mb * mb;
+    loff += mb;
+  }
+  return out;
+}
+
+}  // namespace rpde

@@ -1,0 +1,79 @@
+// Host-side (setup only) mathematics of the function spaces and solver matrices.
+// Everything here runs once at construction; results are uploaded as constant tables.
+//
+// Reference: funspace 0.3.0 bases/matrices as used by rustpde (call sites
+// src/field.rs:195-216), Fdma::sweep (src/solver/fdma.rs:73-82), HholtzAdi::new
+// (src/solver/hholtz_adi.rs:48-76), Poisson::new (src/solver/poisson.rs:54-94),
+// FdmaTensor::from_matrix (src/solver/fdma_tensor.rs:106-154), utils::eig/inv
+// (src/solver/utils.rs:67-107).
+#pragma once
+#include <string>
+#include <vector>
+
+namespace rpde {
+
+enum BaseKind : int { kChebyshev = 0, kChebDirichlet = 1, kChebNeumann = 2, kFourierR2c = 3 };
+
+using Vec = std::vector<double>;
+
+struct Base {
+  BaseKind kind;
+  int n;  // physical points
+  int m;  // spectral coefficients (complex count for Fourier)
+  bool is_cheb() const { return kind != kFourierR2c; }
+  bool is_composite() const { return kind == kChebDirichlet || kind == kChebNeumann; }
+  int n_ortho() const { return kind == kFourierR2c ? m : n; }
+};
+Base make_base(BaseKind kind, int n);
+
+Vec base_coords(const Base& b);                 // grid points (unscaled)
+Vec base_dx(const Base& b, const Vec& x);       // src/field.rs:135-163
+Vec stencil_low(const Base& b);                 // S[k+2,k]  (S[k,k] = 1), length m
+
+// DCT-I scaling tables for a Chebyshev line of n points (N = n-1)
+Vec cheb_fwd_post(int n);   // (-1)^k / N, halved at both ends
+Vec cheb_bwd_pre(int n);    // (-1)^k * (1/2 interior, 1 at the ends)
+
+// twiddles
+Vec fft_twiddles(int nfft);            // (cos, -sin)(2 pi k / nfft), k < nfft
+Vec dct_split_twiddles(int N);         // (cos, sin)(pi k / N), k <= N
+Vec rfft_split_twiddles(int nx);       // (cos, sin)(2 pi k / nx), k <= nx/2
+Vec dct_direct_costab(int N);          // cos(pi m / N), m < 2N
+
+// from_ortho as MV3 + ascending REC1 + descending REC1 (tables of length m, padded with zeros)
+struct FromOrthoTables {
+  Vec t0, t1, t2;   // rhs_k = t0 c_k + t1 c_{k+2}
+  Vec p_up, q_up;   // g_k = p b_k + q g_{k-2}
+  Vec q_dn;         // x_k = g_k + q x_{k+2}
+};
+FromOrthoTables from_ortho_tables(const Base& b);
+
+// B2 pseudo-inverse rows 2.. as MV3 tables (length m = n-2)
+struct Mv3Tables { Vec t0, t1, t2; };
+Mv3Tables pinv_tables(const Base& b);
+
+// four-diagonal matrix in row-indexed band form (length m each; out-of-range entries are 0)
+struct Bands { Vec low, dia, up1, up2; };
+Bands hholtz_mat_a(const Base& b);    // pinv . S
+Bands hholtz_mat_b(const Base& b);    // peye . S   (offsets 0, +2 only)
+Bands bands_axpy(const Bands& a, double c, const Bands& b);  // a + c b
+void fdma_sweep(Bands& m);            // in place, reference op order
+
+// solve tables for a swept Fdma: ascending REC1 (q1) then descending REC2 (p2, q2, r2)
+struct FdmaTables { Vec q1, p2, q2, r2; };
+FdmaTables fdma_tables(const Bands& swept);
+
+// dense helpers (row-major) + LAPACK (loaded at run time from the OpenBLAS that ships with SciPy,
+// the same library family the reference links: Cargo.toml:39,45-46)
+struct EigenX {
+  Vec lam;   // m eigenvalues; index order = [even-parity block | odd-parity block], each descending
+  Vec fwd;   // block-diagonal Q^-1 C^-1 : fwd_e (me x me) then fwd_o (mo x mo), row-major
+  Vec bwd;   // block-diagonal Q         : bwd_e (me x me) then bwd_o (mo x mo), row-major
+  int me, mo;
+};
+// Diagonalise inv(C) A per parity block (all bands have even offsets, so even and odd
+// coefficients decouple exactly).  Throws if LAPACK cannot be loaded.
+EigenX eigen_decomposition_parity(const Bands& a, const Bands& c);
+std::string lapack_library_path();
+
+}  // namespace rpde

@@ -1,0 +1,294 @@
+// Device kernels (gfx950) and their launchers.  With -DRPDE_EMU the same line-VM source is
+// compiled for the host (tests only, see platform.h); transposes/GEMM/reductions are then plain
+// loops that define the expected results of the HIP kernels.
+#include "kernels.h"
+
+#include <cmath>
+
+namespace rpde {
+
+// three compile-time configurations of the line kernel, selected by slot length
+using CfgS = LineCfg<64, 17, 2, 1024>;      // lines up to 1084 doubles
+using CfgM = LineCfg<128, 17, 1024, 2048>;  // lines up to 2172 doubles
+using CfgL = LineCfg<256, 17, 2048, 4096>;  // lines up to 4348 doubles
+
+#ifndef RPDE_EMU
+// =================================================================================== HIP build
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::T) void line_kernel(const Program pg) {
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
+  Blk blk{(int)blockIdx.x, (int)blockIdx.y, Cfg::T, rpde_lds};
+  run_line_program<Cfg>(blk, pg);
+}
+
+template <class Cfg>
+static void launch_cfg(const Program& pg, Stream& st) {
+  const size_t bytes = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kCarryLen) * sizeof(double);
+  RPDE_REQUIRE(bytes <= 160 * 1024, "line program needs more than 160 KiB of LDS");
+  static size_t configured = 0;
+  if (bytes > configured) {
+    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    configured = bytes;
+  }
+  dim3 grid(pg.nlines, pg.ncomp), block(Cfg::T);
+  hipLaunchKernelGGL(line_kernel<Cfg>, grid, block, bytes, st.s, pg);
+  RPDE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------- transpose
+template <class E, int TS>
+__global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ in, long ldi,
+                                                        E* __restrict__ out, long ldo, int rows,
+                                                        int cols) {
+  __shared__ E tile[TS][TS + 1];
+  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+  constexpr int RY = 256 / TS;
+  const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+#pragma unroll
+  for (int i = ty; i < TS; i += RY) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = in[(long)r * ldi + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = ty; i < TS; i += RY) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[(long)c * ldo + r] = tile[tx][i];
+  }
+}
+
+void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
+                      int elem, Stream& st) {
+  if (rows <= 0 || cols <= 0) return;
+  if (elem == 1) {
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    hipLaunchKernelGGL((transpose_kernel<double, 64>), grid, dim3(256), 0, st.s, in, ldi, out, ldo,
+                       rows, cols);
+  } else {
+    RPDE_REQUIRE(elem == 2 && ldi % 2 == 0 && ldo % 2 == 0, "complex transpose needs even pitches");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL((transpose_kernel<double2, 32>), grid, dim3(256), 0, st.s,
+                       reinterpret_cast<const double2*>(in), ldi / 2,
+                       reinterpret_cast<double2*>(out), ldo / 2, rows, cols);
+  }
+  RPDE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------- f64 MFMA GEMM
+// C (M x N) = A (M x K, k contiguous) * B, with B either (N x K, k contiguous)  [NN = false]
+// or (K x N, n contiguous) [NN = true].  128 x 128 x 16 block tile, 4 waves in a 2 x 2 grid,
+// each wave 4 x 4 tiles of v_mfma_f64_16x16x4_f64.  LDS layout [k/4][row][k%4] makes every
+// fragment read one contiguous 512-byte ds_read_b64 per wave (conflict free).
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+template <bool NN>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
+                                                       const double* __restrict__ A, long lda,
+                                                       const double* __restrict__ B, long ldb,
+                                                       double* __restrict__ C, long ldc) {
+  __shared__ __attribute__((aligned(16))) double As[4][128][4];
+  __shared__ __attribute__((aligned(16))) double Bs[4][128][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  dbl4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+
+  double ra[8], rb[8];
+  const int arow = tid >> 1, akk = (tid & 1) * 8;        // A (and B when !NN): row, first k
+  const int bk = tid >> 4, bnn = (tid & 15) * 8;          // B when NN: k, first n
+
+  auto gload = [&](int k0) {
+    {
+      const int r = m0 + arow;
+      const double* p = A + (long)r * lda + k0 + akk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ra[e] = (r < M && k0 + akk + e < K) ? p[e] : 0.0;
+    }
+    if constexpr (!NN) {
+      const int r = n0 + arow;
+      const double* p = B + (long)r * ldb + k0 + akk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[e] = (r < N && k0 + akk + e < K) ? p[e] : 0.0;
+    } else {
+      const int k = k0 + bk;
+      const double* p = B + (long)k * ldb + n0 + bnn;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[e] = (k < K && n0 + bnn + e < N) ? p[e] : 0.0;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) As[(akk + e) >> 2][arow][(akk + e) & 3] = ra[e];
+    if constexpr (!NN) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bs[(akk + e) >> 2][arow][(akk + e) & 3] = rb[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bs[bk >> 2][bnn + e][bk & 3] = rb[e];
+    }
+  };
+
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    lstore();
+    __syncthreads();
+    if (k0 + 16 < K) gload(k0 + 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[s][wm * 64 + i * 16 + l15][l4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[s][wn * 64 + j * 16 + l15][l4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r];
+      }
+    }
+}
+
+void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream& st) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C,
+                     ldc);
+  RPDE_HIP(hipGetLastError());
+}
+void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream& st) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C,
+                     ldc);
+  RPDE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------- small kernels
+__global__ void set_element_kernel(double* p, long idx, double v) { p[idx] = v; }
+void launch_set_element(double* p, long idx, double value, Stream& st) {
+  hipLaunchKernelGGL(set_element_kernel, dim3(1), dim3(1), 0, st.s, p, idx, value);
+  RPDE_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ a, long ld, int rows,
+                                                    int cols, double* out2) {
+  __shared__ double ssum[256];
+  __shared__ double snan[256];
+  double s = 0.0, nn = 0.0;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const double v = a[(long)r * ld + c];
+      if (v != v) nn += 1.0; else s += v * v;
+    }
+  ssum[threadIdx.x] = s; snan[threadIdx.x] = nn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; snan[threadIdx.x] += snan[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(&out2[0], ssum[0]); atomicAdd(&out2[1], snan[0]); }
+}
+void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream& st) {
+  RPDE_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(double), st.s));
+  const int grid = rows < 1024 ? rows : 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st.s, a, ld, rows, cols, out2);
+  RPDE_HIP(hipGetLastError());
+}
+
+#else
+// =================================================================================== EMU build
+template <class Cfg>
+static void launch_cfg(const Program& pg, Stream&) {
+  const size_t nd = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kCarryLen);
+  RPDE_REQUIRE(nd * sizeof(double) <= 160 * 1024, "line program needs more than 160 KiB of LDS");
+  std::vector<double> lds(nd);
+  for (int comp = 0; comp < pg.ncomp; ++comp)
+    for (int line = 0; line < pg.nlines; ++line) {
+      // poison the LDS like uninitialised hardware memory would be
+      std::fill(lds.begin(), lds.end(), std::nan(""));
+      Blk blk{line, comp, Cfg::T, lds.data()};
+      run_line_program<Cfg>(blk, pg);
+    }
+}
+
+void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
+                      int elem, Stream&) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c)
+      for (int e = 0; e < elem; ++e) out[(long)c * ldo + (long)r * elem + e] = in[(long)r * ldi + (long)c * elem + e];
+}
+void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream&) {
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      double s = 0.0;
+      for (int k = 0; k < K; ++k) s += A[(long)m * lda + k] * B[(long)n * ldb + k];
+      C[(long)m * ldc + n] = s;
+    }
+}
+void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream&) {
+  std::vector<double> row(N);
+  for (int m = 0; m < M; ++m) {
+    std::fill(row.begin(), row.end(), 0.0);
+    for (int k = 0; k < K; ++k) {
+      const double a = A[(long)m * lda + k];
+      const double* b = B + (long)k * ldb;
+      for (int n = 0; n < N; ++n) row[n] += a * b[n];
+    }
+    for (int n = 0; n < N; ++n) C[(long)m * ldc + n] = row[n];
+  }
+}
+void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
+void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream&) {
+  double s = 0.0, nn = 0.0;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const double v = a[(long)r * ld + c];
+      if (v != v) nn += 1.0; else s += v * v;
+    }
+  out2[0] = s; out2[1] = nn;
+}
+#endif
+
+// =================================================================================== common
+void launch_line_program(const Program& pg, Stream& st) {
+  RPDE_REQUIRE(pg.nops > 0 && pg.nops <= kMaxOps, "bad line program");
+  if (pg.nlines <= 0 || pg.ncomp <= 0) return;
+  const int sl = pg.slot_len;
+  auto fits = [&](int tmax, int fmin, int fmax) {
+    return sl <= tmax && (pg.fft_n == 0 || (pg.fft_n >= fmin && pg.fft_n <= fmax));
+  };
+  if (fits(CfgS::kMaxSlotLen, CfgS::FMIN, CfgS::FMAX)) launch_cfg<CfgS>(pg, st);
+  else if (fits(CfgM::kMaxSlotLen, CfgM::FMIN, CfgM::FMAX)) launch_cfg<CfgM>(pg, st);
+  else if (fits(CfgL::kMaxSlotLen, CfgL::FMIN, CfgL::FMAX)) launch_cfg<CfgL>(pg, st);
+  else fail("no line-kernel configuration for slot length " + std::to_string(sl) +
+            " / FFT length " + std::to_string(pg.fft_n) +
+            " (supported: Chebyshev n = 2^k + 1 <= 4097, Fourier nx = 2^k <= 4096, or any n <= 500"
+            " through the direct transform)");
+}
+
+}  // namespace rpde

@@ -1,0 +1,30 @@
+// Host-callable launchers of the device kernels (HIP build) or their host emulation (EMU build).
+#pragma once
+#include "line_vm.h"
+
+namespace rpde {
+
+// slot length (doubles) needed for lines of `maxlen` doubles (room for the +2/+4 stencil reads)
+inline int slot_len_for(int maxlen) { return (maxlen + 4 + 1) & ~1; }
+
+// run a line program: grid = (nlines, ncomp), one workgroup per line
+void launch_line_program(const Program& pg, Stream& st);
+
+// out[c * ldo + r] = in[r * ldi + c], r < rows, c < cols; elem = 1 (double) or 2 (interleaved complex)
+void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
+                      int elem, Stream& st);
+
+// C[m, n] = sum_k A[m, k] * B[n, k]   (A: M x K lda, B: N x K ldb, C: M x N ldc), f64
+void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream& st);
+// C[m, n] = sum_k A[m, k] * B[k, n]   (A: M x K lda, B: K x N ldb, C: M x N ldc), f64
+void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
+                    double* C, long ldc, Stream& st);
+
+// p[idx] = value (single element; used for pseu[0,0] = 0)
+void launch_set_element(double* p, long idx, double value, Stream& st);
+
+// sum of squares + NaN flag of a pitched 2-D array into out[0] (sum), out[1] (nan count)
+void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream& st);
+
+}  // namespace rpde

@@ -1,0 +1,430 @@
+#include "ops.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace rpde {
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+AxisTables::AxisTables(const Base& b) : base(b) {
+  if (b.is_cheb()) {
+    const int N = b.n - 1;
+    if (is_pow2(N) && N >= 2 && N <= 4096) {
+      fft_n = N;
+      tw.upload(fft_twiddles(N));
+      tw2.upload(dct_split_twiddles(N));
+    } else {
+      RPDE_REQUIRE(b.n <= 500, "Chebyshev sizes other than n = 2^k + 1 (<= 4097) are only "
+                               "supported up to n = 500 (direct transform)");
+      fft_n = 0;
+      tw2.upload(dct_direct_costab(N));
+    }
+    slot_len = slot_len_for(b.n);
+    fwd_post.upload(cheb_fwd_post(b.n));
+    bwd_pre.upload(cheb_bwd_pre(b.n));
+    Mv3Tables pv = pinv_tables(b);
+    pv0.upload(pv.t0); pv1.upload(pv.t1); pv2.upload(pv.t2);
+    if (b.is_composite()) {
+      low.upload(stencil_low(b));
+      FromOrthoTables f = from_ortho_tables(b);
+      fo_t0.upload(f.t0); fo_t1.upload(f.t1); fo_t2.upload(f.t2);
+      fo_pup.upload(f.p_up); fo_qup.upload(f.q_up); fo_qdn.upload(f.q_dn);
+    }
+  } else {
+    RPDE_REQUIRE(is_pow2(b.n) && b.n >= 4 && b.n <= 4096,
+                 "fourier_r2c needs nx = 2^k with 4 <= nx <= 4096 on one device");
+    fft_n = b.n / 2;
+    tw.upload(fft_twiddles(fft_n));
+    tw2.upload(rfft_split_twiddles(b.n));
+    slot_len = slot_len_for(b.n + 2);
+  }
+}
+
+FdmaDev upload_fdma(const FdmaTables& t) {
+  FdmaDev d;
+  d.n = (int)t.p2.size();
+  d.q1.upload(t.q1); d.p2.upload(t.p2); d.q2.upload(t.q2); d.r2.upload(t.r2);
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------
+ProgramBuilder::ProgramBuilder(int nslots, int slot_len, int nlines, int ncomp) {
+  pg.nslots = nslots;
+  pg.slot_len = slot_len;
+  pg.nlines = nlines;
+  pg.ncomp = ncomp;
+  pg.tw = pg.tw2 = 0;
+}
+void ProgramBuilder::set_fft(const AxisTables& ax) {
+  pg.fft_n = ax.fft_n;
+  pg.tw = ax.tw.p ? tab(ax.tw.p) : 0;
+  pg.tw2 = tab(ax.tw2.p);
+}
+int ProgramBuilder::arr(double* p, long ld, int es, long coff) {
+  for (int i = 0; i < narr_; ++i)
+    if (pg.arr[i].p == p && pg.arr[i].ld == ld && pg.arr[i].es == es && pg.arr[i].coff == coff) return i;
+  RPDE_REQUIRE(narr_ < kMaxArr, "too many arrays in a line program");
+  pg.arr[narr_] = ArrayRef{p, ld, coff, es, 0};
+  return narr_++;
+}
+int ProgramBuilder::tab(const double* t) {
+  RPDE_REQUIRE(t != nullptr, "null table");
+  for (int i = 0; i < ntab_; ++i)
+    if (pg.tabs[i] == t) return i;
+  RPDE_REQUIRE(ntab_ < kMaxTab, "too many tables in a line program");
+  pg.tabs[ntab_] = t;
+  return ntab_++;
+}
+Op& ProgramBuilder::push(int code) {
+  RPDE_REQUIRE(pg.nops < kMaxOps, "line program too long");
+  Op& o = pg.ops[pg.nops++];
+  o = Op{};
+  o.code = code;
+  o.tab = -1;
+  o.s0 = 1.0;
+  return o;
+}
+void ProgramBuilder::load(int d, int a, int n, double s0, bool acc) {
+  RPDE_REQUIRE(n <= pg.slot_len, "line longer than the slot");
+  Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = acc;
+}
+void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, double s0, bool acc) {
+  Op& o = push(OP_LOADX); o.d = d; o.arr = a; o.n = n; o.i1 = rows; o.tab = tab(lowtab); o.s0 = s0; o.acc = acc;
+}
+void ProgramBuilder::store(int a, int ar, int n, double s0, int half) {
+  Op& o = push(OP_STORE); o.a = a; o.arr = ar; o.n = n; o.s0 = s0; o.i0 = half > 0; o.i1 = half;
+}
+void ProgramBuilder::sten(int d, int a, int n_ortho, const double* low) {
+  Op& o = push(OP_STEN); o.d = d; o.a = a; o.n = n_ortho; o.tab = tab(low);
+}
+void ProgramBuilder::mv3(int d, int a, int n, const double* t0, const double* t1, const double* t2, long tabld) {
+  const int i0 = tab(t0), i1 = tab(t1), i2 = tab(t2);
+  RPDE_REQUIRE(i1 == i0 + 1 && i2 == i0 + 2, "mv3 tables must be registered consecutively");
+  Op& o = push(OP_MV3); o.d = d; o.a = a; o.n = n; o.tab = i0; o.tabld = tabld;
+}
+void ProgramBuilder::cdiff(int d, int a, int n, double scale) {
+  Op& o = push(OP_CDIFF); o.d = d; o.a = a; o.n = n; o.s0 = scale;
+}
+void ProgramBuilder::rec1(int d, int a, int n, const double* p, const double* q, int dir, long tabld) {
+  const int ip = p ? tab(p) : -1, iq = tab(q);
+  Op& o = push(OP_REC1); o.d = d; o.a = a; o.n = n; o.tab = ip; o.i0 = iq; o.i1 = dir; o.tabld = tabld;
+}
+void ProgramBuilder::rec2(int d, int a, int n, const double* p, const double* q, const double* r, long tabld) {
+  const int ip = p ? tab(p) : -1, iq = tab(q), ir = tab(r);
+  Op& o = push(OP_REC2); o.d = d; o.a = a; o.n = n; o.tab = ip; o.i0 = iq; o.i1 = ir; o.tabld = tabld;
+}
+void ProgramBuilder::dct(int d, int n, const double* pre, const double* post) {
+  RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
+  const int ipre = pre ? tab(pre) : -1, ipost = post ? tab(post) : -1;
+  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost;
+}
+void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {
+  Op& o = push(OP_MUL); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.acc = acc;
+}
+void ProgramBuilder::axpby(int d, int a, double s0, int b, double s1, int n) {
+  Op& o = push(OP_AXPBY); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.s1 = s1;
+}
+void ProgramBuilder::zero(int d, int from, int to) {
+  Op& o = push(OP_ZERO); o.d = d; o.i0 = from; o.i1 = to;
+}
+void ProgramBuilder::tabdiv(int d, int a, int n, const double* t, int shift) {
+  Op& o = push(OP_TABDIV); o.d = d; o.a = a; o.n = n; o.tab = tab(t); o.i0 = shift;
+}
+void ProgramBuilder::rfft_f(int d, int nx) { Op& o = push(OP_RFFT_F); o.d = d; o.n = nx; }
+void ProgramBuilder::rfft_b(int d, int nx) { Op& o = push(OP_RFFT_B); o.d = d; o.n = nx; }
+void ProgramBuilder::cik(int d, int a, int nc, double s0, int power) {
+  Op& o = push(OP_CIK); o.d = d; o.a = a; o.n = nc; o.s0 = s0; o.i0 = power;
+}
+void ProgramBuilder::to_ortho(int d, const AxisTables& ax) {
+  if (ax.base.is_composite()) sten(d, d, ax.base.n, ax.low.p);
+}
+void ProgramBuilder::from_ortho(int d, const AxisTables& ax) {
+  if (!ax.base.is_composite()) return;
+  const int m = ax.base.m;
+  mv3(d, d, m, ax.fo_t0.p, ax.fo_t1.p, ax.fo_t2.p);
+  rec1(d, d, m, ax.fo_pup.p, ax.fo_qup.p, +1);
+  rec1(d, d, m, nullptr, ax.fo_qdn.p, -1);
+}
+void ProgramBuilder::fdma_solve(int d, int n, const FdmaDev& f) {
+  rec1(d, d, n, nullptr, f.q1.p, +1, f.tabld);
+  rec2(d, d, n, f.p2.p, f.q2.p, f.r2.p, f.tabld);
+}
+void ProgramBuilder::pinv_matvec(int d, const AxisTables& ax) {
+  mv3(d, d, ax.base.n - 2, ax.pv0.p, ax.pv1.p, ax.pv2.p);
+}
+
+// ------------------------------------------------------------------------------------------
+Space2Ops::Space2Ops(const Base& b0, const Base& b1) {
+  RPDE_REQUIRE(b1.is_cheb(), "axis 1 must be a Chebyshev-family base");
+  ax_[0] = std::make_unique<AxisTables>(b0);
+  ax_[1] = std::make_unique<AxisTables>(b1);
+}
+
+void Space2Ops::run_lines(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
+                          double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st,
+                          int order, double scale, const FdmaDev* fd, const double* diag) {
+  // ncomp = 2: the lines are interleaved complex but the op is real (acts on re and im alike)
+  ProgramBuilder pb(2, ax.slot_len, nlines, ncomp);
+  pb.set_fft(ax);
+  const int es = ncomp, coff = ncomp == 2 ? 1 : 0;
+  const int ai = pb.arr(in, ldi, es, coff);
+  const int ao = pb.arr(out, ldo, es, coff);
+  const Base& b = ax.base;
+  pb.load(0, ai, len_in);
+  switch (kind) {
+    case kToOrtho: pb.to_ortho(0, ax); break;
+    case kFromOrtho: pb.from_ortho(0, ax); break;
+    case kForwardOrtho:
+    case kForward:
+      if (b.is_cheb()) {
+        pb.dct(0, b.n, nullptr, ax.fwd_post.p);
+        if (kind == kForward) pb.from_ortho(0, ax);
+      } else {
+        pb.rfft_f(0, b.n);
+      }
+      break;
+    case kBackwardOrtho:
+    case kBackward:
+      if (b.is_cheb()) {
+        if (kind == kBackward) pb.to_ortho(0, ax);
+        pb.dct(0, b.n, ax.bwd_pre.p, nullptr);
+      } else {
+        pb.rfft_b(0, b.n);
+      }
+      break;
+    case kDiff:
+      if (b.is_cheb()) {
+        pb.to_ortho(0, ax);
+        for (int o = 0; o < order; ++o) pb.cdiff(0, 0, b.n, 1.0 / scale);
+      } else {
+        if (order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order);
+      }
+      break;
+    case kPinvMatvec: pb.pinv_matvec(0, ax); break;
+    case kFdmaSolve: pb.fdma_solve(0, len_in, *fd); break;
+    case kDiagSolve: pb.tabdiv(0, 0, len_in, diag, b.is_cheb() ? 0 : 1); break;
+  }
+  pb.store(0, ao, len_out);
+  pb.run(st);
+}
+
+void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Stream& st, int order,
+                           double scale, const FdmaDev* fd, const double* diag) {
+  const AxisTables& ax = *ax_[axis];
+  const Base& b = ax.base;
+  // element counts along the axis, in and out, and element types
+  auto len_of = [&](bool input) -> int {
+    const int n = b.n, m = b.m, no = b.n_ortho();
+    switch (kind) {
+      case kToOrtho: return input ? m : no;
+      case kFromOrtho: return input ? no : m;
+      case kForwardOrtho: return input ? n : no;
+      case kForward: return input ? n : m;
+      case kBackwardOrtho: return input ? no : n;
+      case kBackward: return input ? m : n;
+      case kDiff: return input ? m : no;
+      case kPinvMatvec: return input ? n : n - 2;
+      case kFdmaSolve: case kDiagSolve: return m;
+    }
+    return 0;
+  };
+  const int li = len_of(true), lo = len_of(false);
+  if (axis == 1) {
+    RPDE_REQUIRE(in.cols == li && out.cols == lo && in.rows == out.rows && in.elem == out.elem,
+                 "shape mismatch in axis-1 operator");
+    run_lines(kind, ax, in.p(), in.ld, li, out.p(), out.ld, lo, in.rows, in.elem, st, order, scale,
+              fd, diag);
+    return;
+  }
+  // axis 0: transpose, run along the now contiguous axis, transpose back
+  const bool fourier = !b.is_cheb();
+  const bool real_to_cplx = fourier && (kind == kForwardOrtho || kind == kForward);
+  const bool cplx_to_real = fourier && (kind == kBackwardOrtho || kind == kBackward);
+  RPDE_REQUIRE(in.rows == li && out.rows == lo && in.cols == out.cols, "shape mismatch in axis-0 operator");
+  const int ncols = in.cols;
+  Arr2 tin(ncols, li, in.elem), tout(ncols, lo, out.elem);
+  launch_transpose(in.p(), in.ld, tin.p(), tin.ld, in.rows, in.cols, in.elem, st);
+  if (fourier) {
+    // lines are genuinely complex (or real <-> complex): one component, element stride 1
+    ProgramBuilder pb(2, ax.slot_len, ncols, 1);
+    pb.set_fft(ax);
+    const int ai = pb.arr(tin.p(), tin.ld), ao = pb.arr(tout.p(), tout.ld);
+    pb.load(0, ai, li * in.elem);
+    if (real_to_cplx) pb.rfft_f(0, b.n);
+    else if (cplx_to_real) pb.rfft_b(0, b.n);
+    else if (kind == kDiff) { if (order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order); }
+    else if (kind == kDiagSolve) pb.tabdiv(0, 0, 2 * b.m, diag, 1);
+    else if (kind == kToOrtho || kind == kFromOrtho) {}
+    else fail("operator not defined for a Fourier axis");
+    pb.store(0, ao, lo * out.elem);
+    pb.run(st);
+  } else {
+    RPDE_REQUIRE(in.elem == out.elem, "element type mismatch");
+    run_lines(kind, ax, tin.p(), tin.ld, li, tout.p(), tout.ld, lo, ncols, in.elem, st, order, scale,
+              fd, diag);
+  }
+  launch_transpose(tout.p(), tout.ld, out.p(), out.ld, tout.rows, tout.cols, out.elem, st);
+  dev_sync(st);  // temporaries are released on return
+}
+
+void Space2Ops::forward(const Arr2& v, Arr2& vhat, Stream& st) {
+  RPDE_REQUIRE(v.rows == phys_rows() && v.cols == phys_cols() && v.elem == 1, "forward: bad input shape");
+  RPDE_REQUIRE(vhat.rows == spec_rows() && vhat.cols == spec_cols() && vhat.elem == elem(),
+               "forward: bad output shape");
+  Arr2 t(phys_rows(), spec_cols(), 1);
+  apply_axis(kForward, 1, v, t, st);
+  apply_axis(kForward, 0, t, vhat, st);
+  dev_sync(st);
+}
+void Space2Ops::backward(const Arr2& vhat, Arr2& v, Stream& st) {
+  RPDE_REQUIRE(v.rows == phys_rows() && v.cols == phys_cols() && v.elem == 1, "backward: bad output shape");
+  RPDE_REQUIRE(vhat.rows == spec_rows() && vhat.cols == spec_cols() && vhat.elem == elem(),
+               "backward: bad input shape");
+  Arr2 t(phys_rows(), spec_cols(), 1);
+  apply_axis(kBackward, 0, vhat, t, st);
+  apply_axis(kBackward, 1, t, v, st);
+  dev_sync(st);
+}
+void Space2Ops::to_ortho(const Arr2& vhat, Arr2& out, Stream& st) {
+  RPDE_REQUIRE(out.rows == ortho_rows() && out.cols == ortho_cols() && out.elem == elem(),
+               "to_ortho: bad output shape");
+  Arr2 t(ortho_rows(), spec_cols(), elem());
+  apply_axis(kToOrtho, 0, vhat, t, st);
+  apply_axis(kToOrtho, 1, t, out, st);
+  dev_sync(st);
+}
+void Space2Ops::from_ortho(const Arr2& in, Arr2& vhat, Stream& st) {
+  RPDE_REQUIRE(in.rows == ortho_rows() && in.cols == ortho_cols() && in.elem == elem(),
+               "from_ortho: bad input shape");
+  Arr2 t(spec_rows(), ortho_cols(), elem());
+  apply_axis(kFromOrtho, 0, in, t, st);
+  apply_axis(kFromOrtho, 1, t, vhat, st);
+  dev_sync(st);
+}
+void Space2Ops::gradient(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& out, Stream& st) {
+  RPDE_REQUIRE(out.rows == ortho_rows() && out.cols == ortho_cols() && out.elem == elem(),
+               "gradient: bad output shape");
+  Arr2 t(ortho_rows(), spec_cols(), elem());
+  apply_axis(kDiff, 0, vhat, t, st, d0, s0);
+  apply_axis(kDiff, 1, t, out, st, d1, s1);
+  dev_sync(st);
+}
+
+// ------------------------------------------------------------------------------------------
+HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
+  const double c[2] = {c0, c1};
+  for (int axis = 0; axis < 2; ++axis) {
+    const Base& b = sp.base(axis);
+    if (b.is_cheb()) {
+      RPDE_REQUIRE(b.is_composite(), "HholtzAdi: orthonormal Chebyshev base is not supported");
+      Bands mtx = bands_axpy(hholtz_mat_a(b), -c[axis], hholtz_mat_b(b));
+      fdma_sweep(mtx);
+      fdma[axis] = upload_fdma(fdma_tables(mtx));
+    } else {
+      Vec d(b.m);
+      for (int k = 0; k < b.m; ++k) d[k] = 1.0 - (-(double)k * (double)k) * c[axis];
+      diag0.upload(d);
+    }
+  }
+}
+
+void HholtzAdiOp::solve(const Arr2& in, Arr2& out, Stream& st) {
+  const int e = sp.elem();
+  RPDE_REQUIRE(in.rows == sp.ortho_rows() && in.cols == sp.ortho_cols() && in.elem == e,
+               "HholtzAdi: input must have the orthonormal shape");
+  RPDE_REQUIRE(out.rows == sp.spec_rows() && out.cols == sp.spec_cols() && out.elem == e,
+               "HholtzAdi: output must have the composite shape");
+  const bool cheb0 = sp.base(0).is_cheb();
+  Arr2 t0(sp.spec_rows(), sp.ortho_cols(), e), t1(sp.spec_rows(), sp.spec_cols(), e),
+      t2(sp.spec_rows(), sp.spec_cols(), e);
+  const Arr2* cur = &in;
+  if (cheb0) { sp.apply_axis(Space2Ops::kPinvMatvec, 0, in, t0, st); cur = &t0; }
+  sp.apply_axis(Space2Ops::kPinvMatvec, 1, *cur, t1, st);
+  if (cheb0) sp.apply_axis(Space2Ops::kFdmaSolve, 0, t1, t2, st, 0, 1.0, &fdma[0]);
+  else sp.apply_axis(Space2Ops::kDiagSolve, 0, t1, t2, st, 0, 1.0, nullptr, diag0.p);
+  sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, out, st, 0, 1.0, &fdma[1]);
+  dev_sync(st);
+}
+
+// ------------------------------------------------------------------------------------------
+static Arr2 upload_dense(const double* src, int rows, int cols) {
+  Arr2 a(rows, cols, 1);
+  dev_upload2d(a.p(), a.ld, src, rows, cols);
+  return a;
+}
+
+PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
+  const Base& b0 = sp.base(0);
+  const Base& b1 = sp.base(1);
+  RPDE_REQUIRE(b1.is_composite(), "Poisson: axis 1 must be a composite Chebyshev base");
+  const int m0 = b0.m, m1 = b1.m;
+  if (b0.is_cheb()) {
+    RPDE_REQUIRE(b0.is_composite(), "Poisson: axis 0 must be composite Chebyshev or Fourier");
+    Bands ax = bands_axpy(Bands{Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0)}, c0,
+                          hholtz_mat_b(b0));
+    Bands cx = hholtz_mat_a(b0);
+    EigenX eg = eigen_decomposition_parity(ax, cx);
+    me = eg.me; mo = eg.mo;
+    lam = eg.lam;
+    fwd_e = upload_dense(eg.fwd.data(), me, me);
+    bwd_e = upload_dense(eg.bwd.data(), me, me);
+    fwd_o = upload_dense(eg.fwd.data() + (size_t)me * me, mo, mo);
+    bwd_o = upload_dense(eg.bwd.data() + (size_t)me * me, mo, mo);
+  } else {
+    lam.resize(m0);
+    for (int k = 0; k < m0; ++k) lam[k] = -((double)k * (double)k) * c0;
+  }
+  half = (me + 1) & ~1;
+  // singularity fix (src/solver/poisson.rs:84-87): lam[0] of the descending list is the largest
+  const double lmax = *std::max_element(lam.begin(), lam.end());
+  if (std::fabs(lmax) < 1e-10)
+    for (double& l : lam) l -= 1e-10;
+  // per-row factorised y systems (A_y + lam_r C_y)
+  const Bands ay = bands_axpy(Bands{Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0)}, c1,
+                              hholtz_mat_b(b1));
+  const Bands cy = hholtz_mat_a(b1);
+  const long ld = pitch(m1);
+  Vec q1((size_t)m0 * ld, 0.0), p2((size_t)m0 * ld, 0.0), q2((size_t)m0 * ld, 0.0), r2((size_t)m0 * ld, 0.0);
+  for (int r = 0; r < m0; ++r) {
+    Bands mtx = bands_axpy(ay, lam[r], cy);
+    fdma_sweep(mtx);
+    FdmaTables t = fdma_tables(mtx);
+    std::copy(t.q1.begin(), t.q1.end(), q1.begin() + (size_t)r * ld);
+    std::copy(t.p2.begin(), t.p2.end(), p2.begin() + (size_t)r * ld);
+    std::copy(t.q2.begin(), t.q2.end(), q2.begin() + (size_t)r * ld);
+    std::copy(t.r2.begin(), t.r2.end(), r2.begin() + (size_t)r * ld);
+  }
+  rows.n = m1;
+  rows.tabld = ld;
+  rows.q1.upload(q1); rows.p2.upload(p2); rows.q2.upload(q2); rows.r2.upload(r2);
+}
+
+void PoissonOp::solve(const Arr2& in, Arr2& out, Stream& st) {
+  const int e = sp.elem();
+  RPDE_REQUIRE(in.rows == sp.ortho_rows() && in.cols == sp.ortho_cols() && in.elem == e,
+               "Poisson: input must have the orthonormal shape");
+  RPDE_REQUIRE(out.rows == sp.spec_rows() && out.cols == sp.spec_cols() && out.elem == e,
+               "Poisson: output must have the composite shape");
+  const bool cheb0 = sp.base(0).is_cheb();
+  const int m0 = sp.spec_rows(), m1 = sp.spec_cols();
+  Arr2 t0(m0, sp.ortho_cols(), e), t1(m0, m1, e), t2(m0, m1, e), t3(m0, m1, e);
+  const Arr2* cur = &in;
+  if (cheb0) { sp.apply_axis(Space2Ops::kPinvMatvec, 0, in, t0, st); cur = &t0; }
+  sp.apply_axis(Space2Ops::kPinvMatvec, 1, *cur, t1, st);
+  if (cheb0) {
+    // ghat[k, :] = sum_i fwd[k, i] rhs[i, :]  per parity block (rows of one parity: stride 2 ld)
+    launch_gemm_nn(me, m1, me, fwd_e.p(), fwd_e.ld, t1.p(), 2 * t1.ld, t2.p(), t2.ld, st);
+    launch_gemm_nn(mo, m1, mo, fwd_o.p(), fwd_o.ld, t1.p() + t1.ld, 2 * t1.ld,
+                   t2.p() + (size_t)me * t2.ld, t2.ld, st);
+    sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, t3, st, 0, 1.0, &rows);
+    launch_gemm_nn(me, m1, me, bwd_e.p(), bwd_e.ld, t3.p(), t3.ld, out.p(), 2 * out.ld, st);
+    launch_gemm_nn(mo, m1, mo, bwd_o.p(), bwd_o.ld, t3.p() + (size_t)me * t3.ld, t3.ld,
+                   out.p() + out.ld, 2 * out.ld, st);
+  } else {
+    sp.apply_axis(Space2Ops::kFdmaSolve, 1, t1, out, st, 0, 1.0, &rows);
+  }
+  dev_sync(st);
+}
+
+}  // namespace rpde

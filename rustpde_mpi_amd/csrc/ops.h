@@ -1,0 +1,158 @@
+// Operator layer: device tables per basis, a builder for line programs, and the generic
+// (canonical row-major "XY" layout, like the reference's ndarray) spectral operators
+// forward / backward / to_ortho / from_ortho / gradient and the HholtzAdi / Poisson solvers.
+// The generic operators mirror funspace's Space2 methods one-to-one (src/field.rs:103-129) and
+// the `Solve` trait (src/solver.rs:59-82): out-of-place, shapes checked, errors thrown.
+// The fused time step (engine.cc) builds its own, longer programs from the same pieces.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "hostmath.h"
+#include "kernels.h"
+
+namespace rpde {
+
+inline long pitch(long n) { return (n + 15) & ~15L; }
+
+// device-resident tables of one 1-D basis
+struct AxisTables {
+  Base base{};
+  int fft_n = 0;       // complex FFT length (0: direct O(n^2) DCT)
+  int slot_len = 0;    // slot length for lines of this axis (doubles)
+  DBuf tw, tw2, fwd_post, bwd_pre;             // transforms
+  DBuf low;                                     // stencil (composite)
+  DBuf fo_t0, fo_t1, fo_t2, fo_pup, fo_qup, fo_qdn;  // from_ortho
+  DBuf pv0, pv1, pv2;                           // B2 pseudo-inverse rows (Chebyshev family)
+  explicit AxisTables(const Base& b);
+  int n_phys() const { return base.n; }
+  int n_ortho() const { return base.n_ortho(); }   // complex count for Fourier
+  int n_spec() const { return base.m; }
+  int ortho_doubles() const { return base.is_cheb() ? base.n : 2 * base.m; }
+  int spec_doubles() const { return base.is_cheb() ? base.m : 2 * base.m; }
+};
+
+// swept Fdma solve tables on device: constant (tabld = 0) or one row of tables per line
+struct FdmaDev {
+  DBuf q1, p2, q2, r2;
+  long tabld = 0;
+  int n = 0;
+};
+FdmaDev upload_fdma(const FdmaTables& t);
+
+// ------------------------------------------------------------------------------------------
+class ProgramBuilder {
+ public:
+  Program pg{};
+  ProgramBuilder(int nslots, int slot_len, int nlines, int ncomp = 1);
+  void set_fft(const AxisTables& ax);
+  int arr(double* p, long ld, int es = 1, long coff = 0);
+  int arr(const double* p, long ld, int es = 1, long coff = 0) {
+    return arr(const_cast<double*>(p), ld, es, coff);
+  }
+  int tab(const double* t);
+  // ops (slot indices d, a, b)
+  void load(int d, int arr, int n, double s0 = 1.0, bool acc = false);
+  void loadx(int d, int arr, int n, int rows, const double* lowtab, double s0 = 1.0, bool acc = false);
+  void store(int a, int arr, int n, double s0 = 1.0, int deinterleave_half = 0);
+  void sten(int d, int a, int n_ortho, const double* low);
+  void mv3(int d, int a, int n, const double* t0, const double* t1, const double* t2, long tabld = 0);
+  void cdiff(int d, int a, int n, double scale);
+  void rec1(int d, int a, int n, const double* p, const double* q, int dir, long tabld = 0);
+  void rec2(int d, int a, int n, const double* p, const double* q, const double* r, long tabld = 0);
+  void dct(int d, int n, const double* pre, const double* post);
+  void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
+  void axpby(int d, int a, double s0, int b, double s1, int n);
+  void zero(int d, int from, int to);
+  void tabdiv(int d, int a, int n, const double* t, int shift);
+  void rfft_f(int d, int nx);
+  void rfft_b(int d, int nx);
+  void cik(int d, int a, int ncomplex, double s0, int power);
+  // composites
+  void to_ortho(int d, const AxisTables& ax);                 // slot d: composite -> ortho (in place)
+  void from_ortho(int d, const AxisTables& ax);               // slot d: ortho -> composite (in place)
+  void fdma_solve(int d, int n, const FdmaDev& f);            // slot d in place
+  void pinv_matvec(int d, const AxisTables& ax);              // slot d: ortho (n) -> (n-2), in place
+  void run(Stream& st) { launch_line_program(pg, st); }
+
+ private:
+  Op& push(int code);
+  int narr_ = 0, ntab_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// a 2-D device array in canonical (XY) layout: rows x cols elements of `elem` doubles, pitch ld doubles
+struct Arr2 {
+  DBuf buf;
+  int rows = 0, cols = 0, elem = 1;
+  long ld = 0;
+  Arr2() = default;
+  Arr2(int r, int c, int e = 1) { alloc(r, c, e); }
+  void alloc(int r, int c, int e = 1) {
+    rows = r; cols = c; elem = e; ld = pitch((long)c * e);
+    buf.alloc((size_t)r * ld);
+  }
+  double* p() const { return buf.p; }
+  size_t bytes() const { return (size_t)rows * ld * sizeof(double); }
+};
+
+// funspace Space2<B0, B1> on device (canonical layout)
+class Space2Ops {
+ public:
+  Space2Ops(const Base& b0, const Base& b1);
+  const Base& base(int axis) const { return ax_[axis]->base; }
+  AxisTables& axis(int a) { return *ax_[a]; }
+  bool complex_spectral() const { return !ax_[0]->base.is_cheb(); }
+  int elem() const { return complex_spectral() ? 2 : 1; }
+  // shapes (rows, cols) in elements
+  int phys_rows() const { return ax_[0]->base.n; }
+  int phys_cols() const { return ax_[1]->base.n; }
+  int spec_rows() const { return ax_[0]->base.m; }
+  int spec_cols() const { return ax_[1]->base.m; }
+  int ortho_rows() const { return ax_[0]->base.n_ortho(); }
+  int ortho_cols() const { return ax_[1]->base.n; }
+
+  void forward(const Arr2& v, Arr2& vhat, Stream& st);
+  void backward(const Arr2& vhat, Arr2& v, Stream& st);
+  void to_ortho(const Arr2& vhat, Arr2& out, Stream& st);
+  void from_ortho(const Arr2& in, Arr2& vhat, Stream& st);
+  void gradient(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& out, Stream& st);
+
+  // single-axis building blocks on canonical arrays (axis 0 goes through a transposed copy)
+  enum Kind { kToOrtho, kFromOrtho, kForwardOrtho, kBackwardOrtho, kForward, kBackward, kDiff,
+              kPinvMatvec, kFdmaSolve, kDiagSolve };
+  void apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Stream& st, int order = 0,
+                  double scale = 1.0, const FdmaDev* fd = nullptr, const double* diag = nullptr);
+
+ private:
+  std::unique_ptr<AxisTables> ax_[2];
+  void run_lines(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
+                 double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st, int order,
+                 double scale, const FdmaDev* fd, const double* diag);
+};
+
+// HholtzAdi (src/solver/hholtz_adi.rs:48-76,149-169) on canonical arrays
+class HholtzAdiOp {
+ public:
+  HholtzAdiOp(Space2Ops& sp, double c0, double c1);
+  void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
+  FdmaDev fdma[2];      // Chebyshev axes
+  DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
+  Space2Ops& sp;
+};
+
+// Poisson (src/solver/poisson.rs:54-94,195-236) on canonical arrays
+class PoissonOp {
+ public:
+  PoissonOp(Space2Ops& sp, double c0, double c1);
+  void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
+  Space2Ops& sp;
+  // x direction
+  int me = 0, mo = 0, half = 0;  // parity block sizes; column offset of the odd block in split arrays
+  Vec lam;                       // eigenvalues (after the singularity shift), engine order
+  Arr2 fwd_e, fwd_o, bwd_e, bwd_o;
+  // y direction: per-x-row swept tables, row index = eigen index (confined) or wavenumber (periodic)
+  FdmaDev rows;
+};
+
+}  // namespace rpde

@@ -1,0 +1,177 @@
+// Platform layer: one kernel source, two builds.
+//
+//  * HIP build (product): hipcc --offload-arch=gfx950.  Kernels are __global__ functions, one
+//    workgroup per line, LDS = dynamic shared memory, phases separated by __syncthreads().
+//  * EMU build (tests only, -DRPDE_EMU, plain g++): the SAME kernel bodies are compiled for the
+//    host; a "phase" becomes a loop over thread ids and per-thread registers that live across a
+//    barrier become (T x K) arrays.  It exists so that the index arithmetic of every line
+//    program can be checked against the oracle without a GPU.  It is never built into, loaded
+//    by, or reachable from the product library (see tests/emu/README.md).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifndef RPDE_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+namespace rpde {
+
+// ---------------------------------------------------------------------------------------------
+// error handling (host)
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+[[noreturn]] inline void fail(const std::string& msg) { throw Error(msg); }
+#define RPDE_REQUIRE(cond, msg)                                                           \
+  do {                                                                                    \
+    if (!(cond)) ::rpde::fail(std::string(msg) + "  [" #cond "] " + __FILE__ + ":" +      \
+                              std::to_string(__LINE__));                                  \
+  } while (0)
+
+#ifndef RPDE_EMU
+#define RPDE_HIP(call)                                                                    \
+  do {                                                                                    \
+    hipError_t _e = (call);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      ::rpde::fail(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #call " "  \
+                   + __FILE__ + ":" + std::to_string(__LINE__));                          \
+  } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// device code markers and the phase / barrier / per-thread-register model
+#ifdef RPDE_EMU
+#define RPDE_HD
+#define RPDE_DEV
+struct Blk {          // one workgroup
+  int line;           // blockIdx.x
+  int comp;           // blockIdx.y
+  int T;              // blockDim.x
+  double* lds;        // base of the workgroup's LDS
+};
+#define RPDE_PHASE(blk, tid) for (int tid = 0; tid < (blk).T; ++tid)
+#define RPDE_SYNC(blk) ((void)0)
+#define RPDE_TLS(blk, type, name, K) std::vector<type> name##_st((size_t)(blk).T * (K)); const int name##_K = (K)
+#define RPDE_T(name) (&name##_st[(size_t)tid * name##_K])
+#else
+#define RPDE_HD __host__ __device__
+#define RPDE_DEV __device__ __forceinline__
+struct Blk {
+  int line, comp, T;
+  double* lds;
+};
+#define RPDE_PHASE(blk, tid) for (int tid = (int)threadIdx.x, _once = 1; _once; _once = 0)
+#define RPDE_SYNC(blk) __syncthreads()
+#define RPDE_TLS(blk, type, name, K) type name[K]
+#define RPDE_T(name) name
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// device memory + stream (host side)
+struct Stream {
+#ifdef RPDE_EMU
+  int dummy = 0;
+#else
+  hipStream_t s = nullptr;
+#endif
+};
+
+inline void* dev_alloc(size_t bytes) {
+#ifdef RPDE_EMU
+  void* p = std::calloc(bytes ? bytes : 1, 1);
+  RPDE_REQUIRE(p, "host allocation failed");
+  return p;
+#else
+  void* p = nullptr;
+  RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
+  RPDE_HIP(hipMemset(p, 0, bytes ? bytes : 8));
+  return p;
+#endif
+}
+inline void dev_free(void* p) {
+#ifdef RPDE_EMU
+  std::free(p);
+#else
+  if (p) (void)hipFree(p);
+#endif
+}
+inline void dev_upload(void* dst, const void* src, size_t bytes) {
+#ifdef RPDE_EMU
+  std::memcpy(dst, src, bytes);
+#else
+  RPDE_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+#endif
+}
+inline void dev_download(void* dst, const void* src, size_t bytes) {
+#ifdef RPDE_EMU
+  std::memcpy(dst, src, bytes);
+#else
+  RPDE_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+#endif
+}
+// pitched copies: `rows` rows of `cols` doubles; host is dense, device has leading dimension ld
+inline void dev_upload2d(double* dst, long ld, const double* src, long rows, long cols) {
+#ifdef RPDE_EMU
+  for (long r = 0; r < rows; ++r) std::memcpy(dst + r * ld, src + r * cols, cols * sizeof(double));
+#else
+  RPDE_HIP(hipMemcpy2D(dst, ld * sizeof(double), src, cols * sizeof(double), cols * sizeof(double),
+                       rows, hipMemcpyHostToDevice));
+#endif
+}
+inline void dev_download2d(double* dst, const double* src, long ld, long rows, long cols) {
+#ifdef RPDE_EMU
+  for (long r = 0; r < rows; ++r) std::memcpy(dst + r * cols, src + r * ld, cols * sizeof(double));
+#else
+  RPDE_HIP(hipMemcpy2D(dst, cols * sizeof(double), src, ld * sizeof(double), cols * sizeof(double),
+                       rows, hipMemcpyDeviceToHost));
+#endif
+}
+inline void dev_zero(void* p, size_t bytes, Stream& st) {
+#ifdef RPDE_EMU
+  (void)st;
+  std::memset(p, 0, bytes);
+#else
+  RPDE_HIP(hipMemsetAsync(p, 0, bytes, st.s));
+#endif
+}
+inline void dev_sync(Stream& st) {
+#ifdef RPDE_EMU
+  (void)st;
+#else
+  RPDE_HIP(hipStreamSynchronize(st.s));
+#endif
+}
+
+// owning device buffer of doubles
+struct DBuf {
+  double* p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  explicit DBuf(size_t count) { alloc(count); }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept {
+    if (this != &o) { dev_free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DBuf() { dev_free(p); }
+  void alloc(size_t count) {
+    dev_free(p);
+    n = count;
+    p = static_cast<double*>(dev_alloc(count * sizeof(double)));
+  }
+  void upload(const std::vector<double>& h) {
+    if (h.size() != n) alloc(h.size());
+    dev_upload(p, h.data(), h.size() * sizeof(double));
+  }
+};
+
+}  // namespace rpde

@@ -1,0 +1,68 @@
+"""CPU-side checks of the kernel sources through their host emulation build (tests/emu/README.md):
+line programs, tables, the fused step schedule -- against the oracle.  The GPU parity tests proper
+are in test_gpu_parity.py and run the same checks on the HIP library."""
+import numpy as np
+import pytest
+
+import rustpde_mpi_amd as R
+from tests import checks as K
+
+SPACES = [("cheb_dirichlet", 7, "cheb_dirichlet", 7), ("cheb_neumann", 17, "cheb_dirichlet", 33),
+          ("chebyshev", 33, "chebyshev", 17), ("cheb_dirichlet", 129, "cheb_neumann", 65),
+          ("fourier_r2c", 16, "cheb_dirichlet", 9), ("fourier_r2c", 64, "cheb_neumann", 33),
+          ("cheb_dirichlet", 10, "cheb_neumann", 300),   # direct (non power-of-two) transform
+          ("cheb_neumann", 9, "cheb_dirichlet", 1025), ("cheb_dirichlet", 2049, "cheb_dirichlet", 9),
+          ("cheb_dirichlet", 4097, "cheb_neumann", 9), ("fourier_r2c", 4096, "cheb_dirichlet", 9)]
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1", SPACES)
+def test_space_ops(emu_lib, k0, n0, k1, n1):
+    K.check_space_ops(emu_lib, k0, n0, k1, n1)
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1,c", [
+    ("cheb_dirichlet", 33, "cheb_dirichlet", 17, [1e-3, 2e-3]),
+    ("cheb_neumann", 65, "cheb_dirichlet", 129, [3e-5, 1e-5]),
+    ("cheb_neumann", 129, "cheb_neumann", 65, [1.0, 0.5]),
+    ("fourier_r2c", 64, "cheb_dirichlet", 33, [1e-3, 1e-3]),
+    ("fourier_r2c", 32, "cheb_neumann", 65, [1.0, 1.0])])
+def test_solvers(emu_lib, k0, n0, k1, n1, c):
+    K.check_solvers(emu_lib, k0, n0, k1, n1, c)
+
+
+def test_reference_known_answers(emu_lib):
+    K.check_reference_known_answers(emu_lib)
+
+
+@pytest.mark.parametrize("nx,ny,ra,dt,steps", [(17, 17, 1e4, 0.01, 5), (33, 33, 1e5, 0.01, 20),
+                                               (65, 33, 1e5, 0.01, 10), (33, 65, 1e5, 0.01, 10)])
+def test_confined_step(emu_lib, nx, ny, ra, dt, steps):
+    K.check_step_parity(emu_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
+
+
+def test_confined_step_aspect(emu_lib):
+    K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
+
+
+def test_errors_mirror_reference_panics(emu_lib):
+    with pytest.raises(R.RpdeError, match="not recognized"):
+        R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "xyz", library=emu_lib)
+    nav = R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib)
+    with pytest.raises(R.RpdeError):
+        nav.velx.v = np.zeros((3, 3))
+    sp = R.Space2(R.cheb_dirichlet(9), R.cheb_dirichlet(9), library=emu_lib)
+    with pytest.raises(R.RpdeError, match="length"):
+        sp.forward(np.zeros((4, 4)))
+
+
+def test_field_roundtrip_and_random_ic(emu_lib):
+    nav = R.Navier2D.new_confined(17, 33, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib)
+    rng = np.random.default_rng(3)
+    vh = rng.standard_normal((15, 31))
+    nav.temp.vhat = vh
+    assert K.rel(nav.temp.vhat, vh) < 1e-15
+    p = rng.standard_normal((17, 33))
+    nav.pres.vhat = p
+    assert K.rel(nav.pres.vhat, p) < 1e-15
+    nav.init_random(0.1, seed=7)
+    assert np.abs(nav.velx.v).max() < 0.2

@@ -1,0 +1,66 @@
+"""Parity tests proper: the HIP library on a real MI355X, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+import rustpde_mpi_amd as R
+from tests import checks as K
+from tests.test_emu_parity import SPACES
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_is_hip_build(hip_lib):
+    assert hip_lib.is_device_build and "gfx950" in hip_lib.version
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1", SPACES + [("cheb_dirichlet", 1025, "cheb_dirichlet", 1025),
+                                                  ("fourier_r2c", 1024, "cheb_neumann", 513)])
+def test_space_ops(hip_lib, k0, n0, k1, n1):
+    K.check_space_ops(hip_lib, k0, n0, k1, n1)
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1,c", [
+    ("cheb_dirichlet", 33, "cheb_dirichlet", 17, [1e-3, 2e-3]),
+    ("cheb_neumann", 65, "cheb_dirichlet", 129, [3e-5, 1e-5]),
+    ("cheb_neumann", 129, "cheb_neumann", 65, [1.0, 0.5]),
+    ("cheb_neumann", 513, "cheb_neumann", 257, [1.0, 1.0]),
+    ("fourier_r2c", 64, "cheb_dirichlet", 33, [1e-3, 1e-3]),
+    ("fourier_r2c", 32, "cheb_neumann", 65, [1.0, 1.0])])
+def test_solvers(hip_lib, k0, n0, k1, n1, c):
+    K.check_solvers(hip_lib, k0, n0, k1, n1, c)
+
+
+def test_reference_known_answers(hip_lib):
+    K.check_reference_known_answers(hip_lib)
+
+
+@pytest.mark.parametrize("M,N,K_,transb", [(128, 128, 16, True), (200, 333, 77, True), (257, 129, 255, False),
+                                          (64, 1000, 513, False), (1024, 1025, 1023, True)])
+def test_mfma_gemm(hip_lib, M, N, K_, transb):
+    """f64 MFMA GEMM (transpose-detecting: asymmetric random operands, ragged edges)."""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((M, K_))
+    b = rng.standard_normal((N, K_) if transb else (K_, N))
+    c = R.gemm(a, b, transb=transb, library=hip_lib)
+    ref = a @ (b.T if transb else b)
+    assert K.rel(c, ref) < 1e-13
+
+
+@pytest.mark.parametrize("rows,cols,cplx", [(64, 64, False), (129, 1025, False), (1000, 77, True), (33, 2049, True)])
+def test_transpose(hip_lib, rows, cols, cplx):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((rows, cols)) + (1j * rng.standard_normal((rows, cols)) if cplx else 0)
+    t = R.transpose(a, library=hip_lib)
+    assert np.array_equal(t, a.T)          # bit exact
+    assert np.array_equal(R.transpose(t, library=hip_lib), a)   # involution
+
+
+@pytest.mark.parametrize("nx,ny,ra,dt,steps", [(17, 17, 1e4, 0.01, 5), (33, 33, 1e5, 0.01, 20),
+                                               (65, 33, 1e5, 0.01, 10), (129, 129, 1e5, 0.01, 100)])
+def test_confined_step(hip_lib, nx, ny, ra, dt, steps):
+    """BASELINE.json configs[0] (129x129, Ra=1e5, dt=0.01, 100 steps) and smaller cases."""
+    K.check_step_parity(hip_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
+
+
+def test_confined_257(hip_lib):
+    K.check_step_parity(hip_lib, False, 257, 257, 1e6, 0.005, 40, check_at=[40])

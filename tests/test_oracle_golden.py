@@ -1,0 +1,156 @@
+"""The oracle against every known-answer vector / doc-test the reference holds for this path
+(SURVEY.md section 8c).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import bases as B, navier as N, solver as S
+from tests.checks import known_answers
+
+G = known_answers()
+TOL_REF = 1e-3  # the reference's own tolerance (approx_eq, src/solver/poisson.rs:253)
+
+
+def test_hholtz_adi_1d():
+    t = G["hholtz_adi_1d"]
+    x = S.HholtzAdi1(B.cheb_dirichlet(t["n"]), t["c"]).solve(t["b"])
+    assert np.abs(x - np.array(t["x"])).max() < 1e-8   # all printed digits
+    assert np.abs(x - np.array(t["x"])).max() < TOL_REF
+
+
+def test_hholtz_adi_2d():
+    t = G["hholtz_adi_2d"]
+    sp = B.Space2(B.cheb_dirichlet(7), B.cheb_dirichlet(7))
+    x = S.HholtzAdi(sp, t["c"]).solve(np.tile(np.array(t["b_row"], float), (7, 1)))
+    ref = np.array(t["x"])
+    assert np.abs(x - ref).max() < TOL_REF
+    assert np.abs(x - ref).max() < 5e-7 * 10  # 4 printed digits of 1e-3-sized entries
+
+
+def test_poisson_1d():
+    t = G["poisson_1d"]
+    x = S.Poisson1(B.cheb_dirichlet(t["n"]), t["c"]).solve(t["b"])
+    assert np.abs(x - np.array(t["x"])).max() < 1e-4  # printed to 4 decimals
+
+
+@pytest.mark.parametrize("mode", ["full", "parity"])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_poisson_2d(mode, cplx):
+    t = G["poisson_2d"]
+    sp = B.Space2(B.cheb_dirichlet(8), B.cheb_dirichlet(7))
+    b = np.tile(np.array(t["b_row"], float), (8, 1))
+    ref = np.array(t["x"])
+    if cplx:  # src/solver/poisson.rs:327-361
+        b = b * (1 + 1j)
+        ref = ref * (1 + 1j)
+    x = S.Poisson(sp, t["c"], eig_mode=mode).solve(b)
+    assert np.abs(x - ref).max() < TOL_REF
+    assert np.abs(x - ref).max() < 2e-6  # printed digits
+
+
+def test_analytic_roundtrips():
+    n = np.pi / 2
+    alpha = 1e-5
+    # hholtz_adi.rs:248-277
+    sp = B.Space2(B.cheb_dirichlet(16), B.cheb_dirichlet(7))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(n * x)[:, None] * np.cos(n * y)[None, :]
+    exp = f.v / (1 + alpha * n * n * 2)
+    f.forward(); f.vhat = S.HholtzAdi(sp, [alpha, alpha]).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+    # hholtz_adi.rs:279-308
+    sp = B.Space2(B.fourier_r2c(16), B.cheb_dirichlet(7))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(x)[:, None] * np.cos(n * y)[None, :]
+    exp = f.v / (1 + alpha * n * n + alpha)
+    f.forward(); f.vhat = S.HholtzAdi(sp, [alpha, alpha]).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+    # poisson.rs:363-393
+    sp = B.Space2(B.cheb_dirichlet(8), B.cheb_dirichlet(7))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(n * x)[:, None] * np.cos(n * y)[None, :]
+    exp = -f.v / (n * n * 2)
+    f.forward(); f.vhat = S.Poisson(sp, [1.0, 1.0]).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+    # poisson.rs:395-426
+    sp = B.Space2(B.fourier_r2c(16), B.cheb_dirichlet(7))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(2 * x)[:, None] * np.cos(n * y)[None, :]
+    exp = -f.v / (4 + n * n)
+    f.forward(); f.vhat = S.Poisson(sp, [1.0, 1.0]).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+
+
+def test_average_doc_test():
+    """src/field/average.rs:12-25, 38-51 pins node ordering and dx."""
+    t = G["average_doc_test"]
+    f = N.Field2(B.Space2(B.chebyshev(6), B.chebyshev(5)))
+    f.v = np.tile(np.arange(5.0), (6, 1))
+    assert np.allclose(f.average_axis(0), t["average_axis0"], atol=1e-14)
+    assert abs(f.average() - t["average"]) < 1e-14
+
+
+def test_band_forms_match_dense_matrices():
+    """Band forms used for large n == funspace's dense mass / laplace_inv products (field.rs:203-212)."""
+    for b in (B.cheb_dirichlet(12), B.cheb_neumann(13)):
+        s = b.mass_dense()
+        pinv = b.laplace_inv_eye_dense() @ b.laplace_inv_dense()
+        (al, ad, a1, a2), (bd, b1) = b.hholtz_bands()
+        assert np.allclose(S.band_to_dense(al, ad, a1, a2), pinv @ s, atol=1e-15)
+        z = np.zeros_like(bd)
+        assert np.allclose(S.band_to_dense(z, bd, b1, z), b.laplace_inv_eye_dense() @ s, atol=1e-15)
+        p0, p2, p4 = b.pinv_bands()
+        m = b.m
+        dense = np.zeros((m, b.n))
+        for r in range(m):
+            dense[r, r] = p0[r]; dense[r, r + 2] = p2[r]
+            if r + 4 < b.n: dense[r, r + 4] = p4[r]
+        assert np.allclose(dense, pinv, atol=1e-15)
+
+
+def test_differentiation_and_projection():
+    sp = B.Space2(B.chebyshev(33), B.chebyshev(24))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.sin(1.3 * x)[:, None] * np.cos(0.7 * y + 0.2)[None, :]
+    f.forward()
+    assert np.abs(sp.backward(sp.gradient(f.vhat, [1, 0])) - 1.3 * np.cos(1.3 * x)[:, None] * np.cos(0.7 * y + 0.2)[None, :]).max() < 1e-11
+    assert np.abs(sp.backward(sp.gradient(f.vhat, [0, 2])) + 0.49 * f.v).max() < 1e-9
+    for b0 in (B.cheb_dirichlet(17), B.cheb_neumann(17)):
+        s2 = B.Space2(b0, B.cheb_dirichlet(12))
+        a = np.random.default_rng(0).standard_normal((15, 10))
+        assert np.abs(s2.from_ortho(s2.to_ortho(a)) - a).max() < 1e-13
+        assert np.abs(s2.forward(s2.backward(a)) - a).max() < 1e-13
+
+
+def test_step_physics():
+    """From rest the pressure builds up the hydrostatic balance (velocities stay at the splitting-
+    error level); divergence stays small; Nu ~ 1 below the critical Ra."""
+    nav = N.Navier2D.new_confined(33, 33, 1e3, 1.0, 0.01, 1.0, "rbc")
+    for _ in range(5):
+        nav.update()
+    fields = nav.physical_fields()
+    assert np.abs(fields["velx"]).max() < 1e-3 and np.abs(fields["vely"]).max() < 1e-3
+    assert np.abs(fields["pres"]).max() > 1e-2
+    nav.set_velocity(0.2, 1, 1); nav.set_temperature(0.2, 1, 1)
+    nav.integrate(2.0)
+    assert nav.div_norm() < 1e-3
+    assert abs(nav.eval_nu() - 1.0) < 0.2
+    assert not nav.exit()
+
+
+def test_full_and_parity_eigenbases_agree_after_transient():
+    """Two valid eigen-decompositions of the same x operator: fields agree to round-off once the
+    incompatible initial condition has been projected out ('parity and conditioning')."""
+    a = N.Navier2D.new_confined(33, 33, 1e5, 1.0, 0.01, 1.0, "rbc", eig_mode="full")
+    b = N.Navier2D.new_confined(33, 33, 1e5, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    for z in (a, b):
+        z.set_velocity(0.2, 1, 1); z.set_temperature(0.2, 1, 1)
+        for _ in range(30):
+            z.update()
+    fa, fb = a.physical_fields(), b.physical_fields()
+    for k in fa:
+        assert np.linalg.norm(fa[k] - fb[k]) / np.linalg.norm(fa[k]) < 1e-11
