@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""bench.py -- timesteps/s of the 2-D Rayleigh-Benard step (f64) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 4097 --ny 4097] [--no-cpu-baseline]
+
+A "step" is one `Navier2D::update()` (src/navier_stokes/navier.rs:438-466 of the reference) on the
+confined 4097 x 4097 case (BASELINE.json: the configuration the >= 50 timesteps/s target is quoted
+on; it fits one GPU).  Inputs (the deterministic initial condition of examples/navier_rbc.rs) are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the pencil-sharded engine is not
+built yet, so every rank runs an independent replica of the same case and
+the line says so in config.parallelism -- it is a replica count, not a scaling claim.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (spec)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--nx", type=int, default=4097)
+    p.add_argument("--ny", type=int, default=4097)
+    p.add_argument("--ra", type=float, default=1e8)
+    p.add_argument("--dt", type=float, default=2e-4)
+    p.add_argument("--periodic", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--profile-steps", type=int, default=3)
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of rustpde, OpenBLAS path) timed on the host cores: a bounded
+    sample of the same workload."""
+    from oracle import navier as N
+    ctor = N.Navier2D.new_periodic if args.periodic else N.Navier2D.new_confined
+    t0 = time.perf_counter()
+    ora = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", eig_mode="parity")
+    ora.set_velocity(0.2, 1.0, 1.0)
+    ora.set_temperature(0.2, 1.0, 1.0)
+    setup = time.perf_counter() - t0
+    ora.update()  # warm-up (FFT plans, page faults)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        ora.update()
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{args.cpu_steps} steps of the same {args.nx}x{args.ny} case after 1 warm-up step "
+                      f"(NumPy/SciPy oracle, OpenBLAS dgemm + pocketfft, setup {setup:.1f}s not timed)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import rustpde_mpi_amd as R
+
+    ctor = R.Navier2D.new_periodic if args.periodic else R.Navier2D.new_confined
+    nav = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", device=local_rank)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    nav.update(args.warmup)
+    # which kernel dominates?  (per-launch HIP events, outside the timed region)
+    prof = nav.profile(args.profile_steps)
+    tot = sum(r["ms_total"] for r in prof)
+    dom = max(prof, key=lambda r: r["ms_total"])
+    nav.set_timed_tag(dom["tag"])
+
+    barrier()
+    t0 = time.perf_counter()
+    nav.update(args.steps)            # returns after the stream has drained (HIP events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = nav.last_update_ms()
+    tag_ms, tag_n = nav.get_timed()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    assert not nav.exit(), "NaN in the divergence after the timed run"
+    per_launch_ms = tag_ms / max(tag_n, 1)
+    if dom["flops"] > 0:
+        achieved = dom["flops"] / (per_launch_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": None}
+    else:
+        achieved = dom["bytes"] / (per_launch_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+    roof["kernel"] = dom["tag"]
+    roof["launches_timed"] = tag_n
+    roof["ms_per_launch"] = per_launch_ms
+    # per-phase view of one step (profile pass): time share and algorithmic throughput
+    phases = []
+    for r in sorted(prof, key=lambda r: -r["ms_total"])[:8]:
+        ms = r["ms_total"] / r["launches"]
+        phases.append({"kernel": r["tag"], "share": round(r["ms_total"] / tot, 4), "ms_per_launch": round(ms, 4),
+                       "GB/s": round(r["bytes"] / (ms * 1e-3) / 1e9, 1),
+                       "TFLOP/s": round(r["flops"] / (ms * 1e-3) / 1e12, 2)})
+    # transform pass of the reference op sequence: 13 two-dimensional transforms = 416 nx ny bytes
+    line_ms = sum(r["ms_total"] for r in prof if r["tag"].startswith(("S1", "S2", "S3"))) / args.profile_steps
+    out = {
+        "metric": "timesteps/sec (2D RBC, f64)",
+        "value": world * args.steps / elapsed,
+        "unit": "timesteps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "device_ms_per_step": dev_ms / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))",
+        "config": {"workload": f"Navier2D::new_{'periodic' if args.periodic else 'confined'} "
+                               f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect=1 bc=rbc",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas "
+                                  "(pencil sharding over RCCL not built yet)"},
+        "roofline": roof,
+        "phases": phases,
+        "transform_stage_ms_per_step": line_ms,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

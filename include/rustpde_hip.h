@@ -63,6 +63,12 @@ int rpde_navier2d_get_grid(rpde_navier2d* h, int axis, double* x, size_t len);  
 int rpde_navier2d_update(rpde_navier2d* h, int nsteps);
 /* device time of the last rpde_navier2d_update call, HIP events on the engine's stream */
 int rpde_navier2d_last_update_ms(rpde_navier2d* h, double* ms);
+/* measurement hooks (bench.py): per-launch HIP-event profile of `nsteps` steps as a text table   *
+ * "tag\tlaunches\tms_total\talgorithmic_bytes_per_launch\tflops_per_launch\n"; and live timing of *
+ * the launches whose tag contains `tag` inside rpde_navier2d_update (pass "" to switch it off)  */
+int rpde_navier2d_profile(rpde_navier2d* h, int nsteps, char* buf, size_t len);
+int rpde_navier2d_set_timed_tag(rpde_navier2d* h, const char* tag);
+int rpde_navier2d_get_timed(rpde_navier2d* h, double* ms_total, long* launches);
 /* Integrate::get_time / get_dt                               src/navier_stokes/navier.rs:468-474 */
 int rpde_navier2d_time(rpde_navier2d* h, double* t);
 int rpde_navier2d_dt(rpde_navier2d* h, double* dt);
@@ -106,6 +112,11 @@ int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, 
 /* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
  * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);
+
+/* micro-benchmark of one line-program shape (bench/tests only): LOAD + <what> + STORE on `nlines`  *
+ * Chebyshev-Dirichlet lines of n points; what in {copy, sten, mv3, cdiff, fromortho, fdma, dct,     *
+ * dct2, rfft}; returns the mean device time of one launch in ms (HIP events, `reps` launches)      */
+int rpde_microbench(const char* what, int n, int nlines, int reps, int device, double* ms);
 
 #ifdef __cplusplus
 }

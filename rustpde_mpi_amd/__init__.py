@@ -188,6 +188,25 @@ class Navier2D:
         self._lib.call("rpde_navier2d_last_update_ms", self._h, C.byref(v))
         return v.value
 
+    def profile(self, nsteps=1):
+        """Per-launch HIP-event profile: list of dicts (tag, launches, ms_total, bytes, flops)."""
+        buf = C.create_string_buffer(1 << 16)
+        self._lib.call("rpde_navier2d_profile", self._h, int(nsteps), buf, len(buf))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            tag, n, ms, by, fl = line.split("\t")
+            rows.append({"tag": tag, "launches": int(n), "ms_total": float(ms), "bytes": float(by),
+                         "flops": float(fl)})
+        return rows
+
+    def set_timed_tag(self, tag: str):
+        self._lib.call("rpde_navier2d_set_timed_tag", self._h, tag.encode())
+
+    def get_timed(self):
+        ms, n = C.c_double(), C.c_long()
+        self._lib.call("rpde_navier2d_get_timed", self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     @property
     def params(self):
         out = {}
@@ -327,3 +346,11 @@ def gemm(a, b, transb=False, device=0, library=None):
     out = np.empty((M, N))
     library.call("rpde_gemm", M, N, K, ptr(a), ptr(b), 1 if transb else 0, ptr(out), int(device))
     return out
+
+
+def microbench(what, n, nlines, reps=20, device=0, library=None):
+    """Mean device time (ms) of one launch of LOAD + <what> + STORE on `nlines` lines of n points."""
+    library = library or lib()
+    ms = C.c_double()
+    library.call("rpde_microbench", what.encode(), int(n), int(nlines), int(reps), int(device), C.byref(ms))
+    return ms.value

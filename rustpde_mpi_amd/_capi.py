@@ -37,6 +37,9 @@ SIGNATURES = {
     "rpde_navier2d_get_grid": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t]),
     "rpde_navier2d_update": (C.c_int, [_vp, C.c_int]),
     "rpde_navier2d_last_update_ms": (C.c_int, [_vp, _dp]),
+    "rpde_navier2d_profile": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_size_t]),
+    "rpde_navier2d_set_timed_tag": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_navier2d_get_timed": (C.c_int, [_vp, _dp, C.POINTER(C.c_long)]),
     "rpde_navier2d_time": (C.c_int, [_vp, _dp]),
     "rpde_navier2d_dt": (C.c_int, [_vp, _dp]),
     "rpde_navier2d_param": (C.c_int, [_vp, C.c_char_p, _dp]),
@@ -60,6 +63,7 @@ SIGNATURES = {
     "rpde_poisson_destroy": (C.c_int, [_vp]),
     "rpde_transpose": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, _dp, C.c_int]),
     "rpde_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]),
+    "rpde_microbench": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }
 
 

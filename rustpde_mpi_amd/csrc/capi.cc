@@ -2,6 +2,7 @@
 #include "../../include/rustpde_hip.h"
 
 #include <cmath>
+#include <cstring>
 #include <string>
 
 #include "engine.h"
@@ -146,6 +147,20 @@ int rpde_navier2d_update(rpde_navier2d* h, int nsteps) {
 }
 int rpde_navier2d_last_update_ms(rpde_navier2d* h, double* ms) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(ms, "null pointer"); *ms = h->e->last_update_ms(); })
+}
+int rpde_navier2d_profile(rpde_navier2d* h, int nsteps, char* buf, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(buf && len > 0, "null pointer"); select_device(h->device);
+    const std::string s = h->e->profile(nsteps);
+    RPDE_REQUIRE(s.size() + 1 <= len, "profile buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  })
+}
+int rpde_navier2d_set_timed_tag(rpde_navier2d* h, const char* tag) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(tag, "null pointer"); h->e->set_timed_tag(tag); })
+}
+int rpde_navier2d_get_timed(rpde_navier2d* h, double* ms_total, long* launches) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(ms_total && launches, "null pointer"); h->e->get_timed(ms_total, launches); })
 }
 int rpde_navier2d_time(rpde_navier2d* h, double* t) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(t, "null pointer"); *t = h->e->time(); })
@@ -355,6 +370,62 @@ int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb,
     else launch_gemm_nn(M, N, K, A.p(), A.ld, B.p(), B.ld, C.p(), C.ld, st);
     dev_sync(st);
     dev_download2d(c, C.p(), C.ld, M, N);
+  })
+}
+
+
+int rpde_microbench(const char* what, int n, int nlines, int reps, int device, double* ms) {
+  RPDE_TRY({
+    RPDE_REQUIRE(what && ms && n >= 5 && nlines > 0 && reps > 0, "bad argument");
+    select_device(device);
+    const std::string w = what;
+    Stream st;
+    const bool fourier = w == "rfft";
+    AxisTables ax(make_base(fourier ? kFourierR2c : kChebDirichlet, n));
+    const Base& b = ax.base;
+    Bands mtx = bands_axpy(hholtz_mat_a(make_base(kChebDirichlet, fourier ? 9 : n)), -1e-6,
+                           hholtz_mat_b(make_base(kChebDirichlet, fourier ? 9 : n)));
+    fdma_sweep(mtx);
+    FdmaDev fd = upload_fdma(fdma_tables(mtx));
+    const long ld = pitch(n + 2);
+    DBuf in((size_t)nlines * ld), out((size_t)nlines * ld);
+    {
+      Vec hbuf((size_t)nlines * ld);
+      for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
+      in.upload(hbuf);
+    }
+    ProgramBuilder pb(4, ax.slot_len, nlines, 1);
+    pb.set_fft(ax);
+    const int ai = pb.arr(in.p, ld), ao = pb.arr(out.p, ld);
+    const int m = b.m;
+    if (w == "copy") { pb.load(0, ai, n); }
+    else if (w == "sten") { pb.load(0, ai, m); pb.to_ortho(0, ax); }
+    else if (w == "mv3") { pb.load(0, ai, n); pb.pinv_matvec(0, ax); }
+    else if (w == "cdiff") { pb.load(0, ai, n); pb.cdiff(0, 0, n, 1.0); }
+    else if (w == "fromortho") { pb.load(0, ai, n); pb.from_ortho(0, ax); }
+    else if (w == "fdma") { pb.load(0, ai, m); pb.fdma_solve(0, m, fd); }
+    else if (w == "dct") { pb.load(0, ai, n); pb.dct(0, n, ax.bwd_pre.p, nullptr); }
+    else if (w == "dct2") { pb.load(0, ai, n); pb.dct(0, n, ax.bwd_pre.p, nullptr); pb.dct(0, n, nullptr, ax.fwd_post.p); }
+    else if (w == "rfft") { pb.load(0, ai, n); pb.rfft_f(0, n); pb.rfft_b(0, n); }
+    else fail("unknown microbench \"" + w + "\"");
+    pb.store(0, ao, fourier ? n : (w == "sten" ? n : m));
+    pb.run(st);  // warm-up
+    dev_sync(st);
+#ifndef RPDE_EMU
+    hipEvent_t e0, e1;
+    RPDE_HIP(hipEventCreate(&e0)); RPDE_HIP(hipEventCreate(&e1));
+    RPDE_HIP(hipEventRecord(e0, st.s));
+    for (int r = 0; r < reps; ++r) pb.run(st);
+    RPDE_HIP(hipEventRecord(e1, st.s));
+    RPDE_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    RPDE_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#else
+    for (int r = 0; r < reps; ++r) pb.run(st);
+    *ms = 0.0;
+#endif
   })
 }
 

@@ -251,6 +251,13 @@ void Navier2DEngine::add_line(const ProgramBuilder& pb, const char* tag) {
   l.type = Launch::kLine;
   l.pg = pb.pg;
   l.tag = tag;
+  for (int i = 0; i < l.pg.nops; ++i) {
+    const Op& o = l.pg.ops[i];
+    if (o.code == OP_LOAD || o.code == OP_LOADX || o.code == OP_STORE)
+      l.bytes += 8.0 * o.n * (double)l.pg.nlines * l.pg.ncomp;
+    if ((o.code == OP_REC1 || o.code == OP_REC2 || o.code == OP_MV3) && o.tabld != 0)
+      l.bytes += 8.0 * o.n * (double)l.pg.nlines * l.pg.ncomp * (o.code == OP_REC2 ? 3 : o.code == OP_MV3 ? 3 : 1);
+  }
   step_.push_back(l);
 }
 void Navier2DEngine::add_transpose(const double* in, long ldi, double* out, long ldo, int rows,
@@ -259,6 +266,7 @@ void Navier2DEngine::add_transpose(const double* in, long ldi, double* out, long
   l.type = Launch::kTranspose;
   l.in = in; l.ldi = ldi; l.out = out; l.ldo = ldo; l.rows = rows; l.cols = cols; l.elem = elem;
   l.tag = tag;
+  l.bytes = 16.0 * rows * (double)cols * elem;
   step_.push_back(l);
 }
 void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, long lda,
@@ -267,6 +275,8 @@ void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, lon
   l.type = nn ? Launch::kGemmNN : Launch::kGemmNT;
   l.in = A; l.ldi = lda; l.b = B; l.ldb = ldb; l.out = C; l.ldo = ldc; l.M = M; l.N = N; l.K = K;
   l.tag = tag;
+  l.flops = 2.0 * M * (double)N * K;
+  l.bytes = 8.0 * ((double)M * K + (double)N * K + (double)M * N);
   step_.push_back(l);
 }
 void Navier2DEngine::run_launch(const Launch& l) {
@@ -289,8 +299,25 @@ void Navier2DEngine::update(int nsteps) {
 #else
   auto t0 = std::chrono::steady_clock::now();
 #endif
+#ifndef RPDE_EMU
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+#endif
   for (int s = 0; s < nsteps; ++s) {
-    for (const Launch& l : step_) run_launch(l);
+    for (const Launch& l : step_) {
+#ifndef RPDE_EMU
+      const bool timed = !timed_tag_.empty() && std::string(l.tag).find(timed_tag_) != std::string::npos;
+      if (timed) {
+        hipEvent_t a, b;
+        RPDE_HIP(hipEventCreate(&a)); RPDE_HIP(hipEventCreate(&b));
+        RPDE_HIP(hipEventRecord(a, st_.s));
+        run_launch(l);
+        RPDE_HIP(hipEventRecord(b, st_.s));
+        tev.emplace_back(a, b);
+        continue;
+      }
+#endif
+      run_launch(l);
+    }
     time_ += dt_;
   }
 #ifndef RPDE_EMU
@@ -301,9 +328,69 @@ void Navier2DEngine::update(int nsteps) {
   last_ms_ = ms;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  for (auto& p : tev) {
+    float t = 0.f;
+    RPDE_HIP(hipEventElapsedTime(&t, p.first, p.second));
+    timed_ms_ += t; ++timed_count_;
+    (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+  }
 #else
   last_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 #endif
+}
+
+std::string Navier2DEngine::profile(int nsteps) {
+  struct Acc { long n = 0; double ms = 0, bytes = 0, flops = 0; };
+  std::vector<std::string> order;
+  std::map<std::string, Acc> acc;
+  for (int s = 0; s < nsteps; ++s) {
+#ifndef RPDE_EMU
+    std::vector<hipEvent_t> ev(step_.size() + 1);
+    for (auto& e : ev) RPDE_HIP(hipEventCreate(&e));
+    RPDE_HIP(hipEventRecord(ev[0], st_.s));
+    for (size_t i = 0; i < step_.size(); ++i) {
+      run_launch(step_[i]);
+      RPDE_HIP(hipEventRecord(ev[i + 1], st_.s));
+    }
+    RPDE_HIP(hipEventSynchronize(ev.back()));
+#endif
+    for (size_t i = 0; i < step_.size(); ++i) {
+      float t = 0.f;
+#ifndef RPDE_EMU
+      RPDE_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+#else
+      auto t0 = std::chrono::steady_clock::now();
+      run_launch(step_[i]);
+      t = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#endif
+      const std::string tag = step_[i].tag;
+      if (!acc.count(tag)) order.push_back(tag);
+      Acc& a = acc[tag];
+      a.n += 1; a.ms += t; a.bytes = step_[i].bytes; a.flops = step_[i].flops;
+    }
+#ifndef RPDE_EMU
+    for (auto& e : ev) (void)hipEventDestroy(e);
+#endif
+    time_ += dt_;
+  }
+  std::string out;
+  for (const auto& tag : order) {
+    const Acc& a = acc[tag];
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s\t%ld\t%.6f\t%.0f\t%.0f\n", tag.c_str(), a.n, a.ms, a.bytes, a.flops);
+    out += buf;
+  }
+  return out;
+}
+
+std::string Navier2DEngine::describe_step() const {
+  std::string out;
+  for (const Launch& l : step_) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\n", l.tag, l.bytes, l.flops);
+    out += buf;
+  }
+  return out;
 }
 
 double Navier2DEngine::div_norm() {
@@ -334,7 +421,7 @@ bool Navier2DEngine::exit() { return std::isnan(div_norm()); }
 void Navier2DEngine::refresh_gy() {
   const int rows_x = sp_ortho_->ortho_rows();
   launch_transpose(P_.p, ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, st_);
-  ProgramBuilder pb(2, sp_ortho_->axis(1).slot_len, rows_x, ex_);
+  ProgramBuilder pb(1, sp_ortho_->axis(1).slot_len, rows_x, ex_);
   pb.set_fft(sp_ortho_->axis(1));
   const int a = pb.arr(X_[0].p, ldy_, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(X_[1].p, ldy_, ex_, ex_ == 2 ? 1 : 0);
   pb.load(0, a, ny_); pb.cdiff(0, 0, ny_, 1.0 / sy_); pb.store(0, b, ny_);
@@ -360,18 +447,18 @@ void Navier2DEngine::build_confined() {
   struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
   for (auto& f : s1) {
-    ProgramBuilder pb(4, slx, my);
-    pb.set_fft(*f.ax);
-    const int a = pb.arr(f.st->p, ldx), o0 = pb.arr(f.w0->p, ldx), o1 = pb.arr(f.w1->p, ldx);
-    pb.load(2, a, mx);
-    pb.to_ortho(2, *f.ax);
-    pb.cdiff(0, 2, nx, 1.0 / sx_);
-    pb.dct(2, nx, f.ax->bwd_pre.p, nullptr);
-    pb.store(2, o0, nx);
-    pb.axpby(2, 0, 1.0, 0, 0.0, nx);
-    pb.dct(2, nx, f.ax->bwd_pre.p, nullptr);
-    pb.store(2, o1, nx);
-    add_line(pb, "S1 x: state -> phys-x, d/dx");
+    // two programs of two LDS slots each (the DCT works in place across slots 0 and 1), so
+    // that two workgroups fit on a CU; the price is reading the state line twice
+    for (int deriv = 0; deriv < 2; ++deriv) {
+      ProgramBuilder pb(2, slx, my);
+      pb.set_fft(*f.ax);
+      pb.load(0, pb.arr(f.st->p, ldx), mx);
+      pb.to_ortho(0, *f.ax);
+      if (deriv) pb.cdiff(0, 0, nx, 1.0 / sx_);
+      pb.dct(0, nx, f.ax->bwd_pre.p, nullptr);
+      pb.store(0, pb.arr((deriv ? f.w1 : f.w0)->p, ldx), nx);
+      add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
+    }
   }
   // ---- T1: to XY
   for (int k = 0; k < 6; ++k) add_transpose(Y_[k].p, ldx, X_[k].p, ldy, my, nx, 1, "T1");
@@ -413,24 +500,24 @@ void Navier2DEngine::build_confined() {
     AxisTables& ax = which == 2 ? xN : xD;
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(4, slx, ny);
+    ProgramBuilder pb(2, slx, ny);
     pb.set_fft(ax);
-    pb.load(2, pb.arr(Y_[which].p, ldx), nx);
-    pb.dct(2, nx, nullptr, ax.fwd_post.p);
-    pb.zero(2, cut_x, nx);
-    pb.loadx(0, pb.arr(state.p, ldx), mx, my, yD.low.p);     // S_y (cross-line), Dirichlet in y
-    pb.to_ortho(0, ax);                                       // S_x
-    pb.axpby(0, 0, 1.0, 2, -dt, nx);
+    pb.load(0, pb.arr(Y_[which].p, ldx), nx);                // conv term first: the DCT needs both slots
+    pb.dct(0, nx, nullptr, ax.fwd_post.p);
+    pb.zero(0, cut_x, nx);
+    pb.loadx(1, pb.arr(state.p, ldx), mx, my, yD.low.p);     // S_y (cross-line), Dirichlet in y
+    pb.to_ortho(1, ax);                                       // S_x
+    pb.axpby(0, 0, -dt, 1, 1.0, nx);
     if (which == 0) {
-      pb.load(2, pb.arr(P_.p, ldx), nx);
-      pb.cdiff(2, 2, nx, 1.0 / sx_);
-      pb.axpby(0, 0, 1.0, 2, -dt, nx);
+      pb.load(1, pb.arr(P_.p, ldx), nx);
+      pb.cdiff(1, 1, nx, 1.0 / sx_);
+      pb.axpby(0, 0, 1.0, 1, -dt, nx);
     } else if (which == 1) {
       pb.load(0, pb.arr(GY_.p, ldx), nx, -dt, true);
-      pb.loadx(2, pb.arr(T_.p, ldx), mx, my, yD.low.p);       // buoyancy: temp.to_ortho() + tempbc
-      pb.to_ortho(2, xN);
-      pb.load(2, pb.arr(TBC_.p, ldx), nx, 1.0, true);
-      pb.axpby(0, 0, 1.0, 2, dt, nx);
+      pb.loadx(1, pb.arr(T_.p, ldx), mx, my, yD.low.p);       // buoyancy: temp.to_ortho() + tempbc
+      pb.to_ortho(1, xN);
+      pb.load(1, pb.arr(TBC_.p, ldx), nx, 1.0, true);
+      pb.axpby(0, 0, 1.0, 1, dt, nx);
     } else {
       pb.load(0, pb.arr(TBC2_.p, ldx), nx, dt * ka_, true);
     }
@@ -447,7 +534,7 @@ void Navier2DEngine::build_confined() {
   // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(4, sly, mx);
+    ProgramBuilder pb(1, sly, mx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[which].p, ldy), ny);
     pb.pinv_matvec(0, yD);
@@ -469,14 +556,14 @@ void Navier2DEngine::build_confined() {
   // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
   PoissonOp& po = *pois_;
   {
-    ProgramBuilder pb(4, slx, ny);
+    ProgramBuilder pb(2, slx, ny);
     pb.set_fft(xD);
     pb.loadx(0, pb.arr(U_.p, ldx), mx, my, yD.low.p);
     pb.to_ortho(0, xD);
     pb.cdiff(0, 0, nx, 1.0 / sx_);
-    pb.load(2, pb.arr(Y_[0].p, ldx), mx);
-    pb.to_ortho(2, xD);
-    pb.axpby(0, 0, 1.0, 2, 1.0, nx);
+    pb.load(1, pb.arr(Y_[0].p, ldx), mx);
+    pb.to_ortho(1, xD);
+    pb.axpby(0, 0, 1.0, 1, 1.0, nx);
     pb.store(0, pb.arr(DIV_.p, ldx), nx);
     pb.pinv_matvec(0, xN);
     pb.store(0, pb.arr(Y_[1].p, ldx), mx, 1.0, po.half);
@@ -488,7 +575,7 @@ void Navier2DEngine::build_confined() {
            X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
   // ---- S6: y preconditioner + per-eigenvalue banded solves
   {
-    ProgramBuilder pb(4, sly, mx);
+    ProgramBuilder pb(1, sly, mx);
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy), ny);
     pb.pinv_matvec(0, yN);
@@ -505,15 +592,15 @@ void Navier2DEngine::build_confined() {
   }
   // ---- S7: y part of the velocity correction
   {
-    ProgramBuilder pb(4, sly, mx);
+    ProgramBuilder pb(2, sly, mx);
     pb.set_fft(yN);
     pb.load(0, pb.arr(PS_.p, ldy), my);
     pb.to_ortho(0, yN);
-    pb.cdiff(2, 0, ny, -1.0 / sy_);
+    pb.cdiff(1, 0, ny, -1.0 / sy_);
     pb.from_ortho(0, yD);
     pb.store(0, pb.arr(X_[2].p, ldy), my);
-    pb.from_ortho(2, yD);
-    pb.store(2, pb.arr(X_[3].p, ldy), my);
+    pb.from_ortho(1, yD);
+    pb.store(1, pb.arr(X_[3].p, ldy), my);
     add_line(pb, "S7 y: correction-y");
   }
   // ---- T5
@@ -522,7 +609,7 @@ void Navier2DEngine::build_confined() {
   add_transpose(PS_.p, ldy, Y_[4].p, ldx, mx, my, 1, "T5");
   // ---- S8: x part of the velocity correction
   {
-    ProgramBuilder pb(4, slx, my);
+    ProgramBuilder pb(1, slx, my);
     pb.set_fft(xD);
     pb.load(0, pb.arr(Y_[2].p, ldx), mx);
     pb.to_ortho(0, xN);
@@ -539,7 +626,7 @@ void Navier2DEngine::build_confined() {
   }
   // ---- S9: pressure update
   {
-    ProgramBuilder pb(4, slx, ny);
+    ProgramBuilder pb(1, slx, ny);
     pb.set_fft(xN);
     pb.loadx(0, pb.arr(Y_[4].p, ldx), mx, my, yN.low.p, 1.0 / dt);
     pb.to_ortho(0, xN);
@@ -551,7 +638,7 @@ void Navier2DEngine::build_confined() {
   // ---- T6 / S10 / T7: d/dy pres for the next step
   add_transpose(P_.p, ldx, X_[0].p, ldy, ny, nx, 1, "T6");
   {
-    ProgramBuilder pb(4, sly, nx);
+    ProgramBuilder pb(1, sly, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[0].p, ldy), ny);
     pb.cdiff(0, 0, ny, 1.0 / sy_);

@@ -39,6 +39,13 @@ class Navier2DEngine {
   double dt() const { return dt_; }
   double param(const std::string& key) const;
   double last_update_ms() const { return last_ms_; }
+  // per-launch profile: run `nsteps` with HIP events around every launch; returns a text table
+  // "tag<TAB>launches<TAB>ms_total<TAB>algorithmic_bytes_per_launch<TAB>flops_per_launch" per line
+  std::string profile(int nsteps);
+  // launches whose tag contains `tag` are bracketed by HIP events inside update() (empty: none)
+  void set_timed_tag(const std::string& tag) { timed_tag_ = tag; timed_ms_ = 0; timed_count_ = 0; }
+  void get_timed(double* ms, long* count) const { *ms = timed_ms_; *count = timed_count_; }
+  std::string describe_step() const;
   void grid(int axis, double* x, size_t len) const;
   void sync() { dev_sync(st_); }
   int nx() const { return nx_; }
@@ -85,7 +92,12 @@ class Navier2DEngine {
     long ldi = 0, ldb = 0, ldo = 0;
     int rows = 0, cols = 0, elem = 1, M = 0, N = 0, K = 0;
     const char* tag = "";
+    double bytes = 0.0;          // algorithmic HBM bytes of one launch (reads + writes)
+    double flops = 0.0;          // floating point operations of one launch (GEMMs)
   };
+  std::string timed_tag_;
+  double timed_ms_ = 0.0;
+  long timed_count_ = 0;
   std::vector<Launch> step_;
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,

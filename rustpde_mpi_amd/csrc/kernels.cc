@@ -8,9 +8,10 @@
 namespace rpde {
 
 // three compile-time configurations of the line kernel, selected by slot length
-using CfgS = LineCfg<64, 17, 2, 1024>;      // lines up to 1084 doubles
-using CfgM = LineCfg<128, 17, 1024, 2048>;  // lines up to 2172 doubles
-using CfgL = LineCfg<256, 17, 2048, 4096>;  // lines up to 4348 doubles
+using CfgS = LineCfg<128, 10, 2, 1024, 8>;      // slots up to 1280 doubles
+using CfgM = LineCfg<256, 10, 1024, 2048, 8>;   // slots up to 2560 doubles
+using CfgL = LineCfg<512, 10, 2048, 4096, 8>;   // slots up to 5120 doubles
+static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal EPT");
 
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(Cfg::T) void line_kernel(const Program pg) {
 
 template <class Cfg>
 static void launch_cfg(const Program& pg, Stream& st) {
-  const size_t bytes = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kCarryLen) * sizeof(double);
+  const size_t bytes = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kMaxSlotLen, Cfg::kCarryLen) * sizeof(double);
   RPDE_REQUIRE(bytes <= 160 * 1024, "line program needs more than 160 KiB of LDS");
   static size_t configured = 0;
   if (bytes > configured) {
@@ -222,7 +223,7 @@ void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, St
 // =================================================================================== EMU build
 template <class Cfg>
 static void launch_cfg(const Program& pg, Stream&) {
-  const size_t nd = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kCarryLen);
+  const size_t nd = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kMaxSlotLen, Cfg::kCarryLen);
   RPDE_REQUIRE(nd * sizeof(double) <= 160 * 1024, "line program needs more than 160 KiB of LDS");
   std::vector<double> lds(nd);
   for (int comp = 0; comp < pg.ncomp; ++comp)

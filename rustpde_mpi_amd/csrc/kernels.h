@@ -5,7 +5,15 @@
 namespace rpde {
 
 // slot length (doubles) needed for lines of `maxlen` doubles (room for the +2/+4 stencil reads)
-inline int slot_len_for(int maxlen) { return (maxlen + 4 + 1) & ~1; }
+// and for the padded FFT work area (two consecutive slots hold fft_work_doubles(N) doubles)
+inline int slot_len_for(int maxlen) {
+  int need = maxlen + 4;
+  int n = 1;
+  while (2 * n < maxlen) n *= 2;                  // largest FFT that can be asked for on this line
+  const int half_work = (fft_work_doubles(n) + 1) / 2;
+  if (half_work > need) need = half_work;
+  return (need + 1) & ~1;
+}
 
 // run a line program: grid = (nlines, ncomp), one workgroup per line
 void launch_line_program(const Program& pg, Stream& st);

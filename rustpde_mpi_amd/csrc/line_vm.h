@@ -23,6 +23,23 @@
 
 namespace rpde {
 
+// address-space qualified pointer types: without them every LDS / table access inside the
+// non-inlined device functions would be a FLAT instruction (generic pointer), which is several
+// times slower than ds_read / global_load and serialises the LDS and vector-memory counters.
+#ifdef RPDE_EMU
+using lds_t = double*;          // LDS (workgroup) memory
+using clds_t = const double*;
+using tab_t = const double*;    // read-only tables in global memory
+using gmem_t = double*;         // arrays in global memory
+using cgmem_t = const double*;
+#else
+using lds_t = __attribute__((address_space(3))) double*;
+using clds_t = const __attribute__((address_space(3))) double*;
+using tab_t = const __attribute__((address_space(1))) double*;
+using gmem_t = __attribute__((address_space(1))) double*;
+using cgmem_t = const __attribute__((address_space(1))) double*;
+#endif
+
 enum OpCode : int {
   OP_END = 0,
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][k]                  k < n   (zero tail if !acc)
@@ -79,20 +96,24 @@ struct Program {
 
 // ---------------------------------------------------------------------------------------------
 // kernel configuration (compile time): T threads, EPT elements per thread
-template <int T_, int EPT_, int FMIN_, int FMAX_>
+template <int T_, int EPT_, int FMIN_, int FMAX_, int RM_>
 struct LineCfg {
   static constexpr int T = T_;
   static constexpr int EPT = EPT_;
+  static constexpr int RM = RM_;                       // main FFT radix (8 or 16)
+  static constexpr int ZPT = (FMAX_ + T_ - 1) / T_;    // complex FFT points per thread
   static constexpr int FMIN = FMIN_;                   // smallest / largest complex FFT length
   static constexpr int FMAX = FMAX_;                   // instantiated in this configuration
   static constexpr int C = (EPT_ + 1) & ~1;           // scan chunk per thread (even)
   static constexpr int G = (T_ + 15) / 16;             // scan groups
   static constexpr int kMaxSlotLen = T_ * EPT_;
-  static constexpr int kCarryLen = (T_ + G) * 2 * 6;  // doubles
+  static constexpr int kCarryLen = 2 * ((T_ + 63) / 64) * 6 + 4;  // doubles: wave totals of a scan
 };
 
-RPDE_HD inline size_t line_lds_doubles(int nslots, int slot_len, int carry_len) {
-  return (size_t)nslots * slot_len + carry_len;
+// slots are slot_len apart; the last one is padded to T*EPT doubles so that unguarded reads of
+// k = tid + q T < T*EPT (+4 for the stencil taps) stay inside the allocation
+RPDE_HD inline size_t line_lds_doubles(int nslots, int slot_len, int t_ept, int carry_len) {
+  return (size_t)nslots * slot_len + (t_ept - slot_len) + 8 + carry_len;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,15 +185,23 @@ struct SmallDft {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Stockham pass of radix R on N interleaved complex numbers in LDS (in place through registers)
-template <class Cfg, int N, int R>
-RPDE_DEV void fft_pass(Blk& blk, double* w, int Ns, const double* tw) {
+// In-LDS complex FFT (Stockham autosort, forward sign).  The work area holds interleaved complex
+// numbers at the PADDED index pidx(i) = i + (i >> 4): one 16-byte gap every 16 elements makes
+// both the strided reads (i = j + t N/R) and the scattered writes (i = 16 j + t, ...) of every
+// pass fall on distinct LDS banks within a ds_read/write_b128 lane group.
+RPDE_HD inline int pidx(int i) { return i + (i >> 4); }
+RPDE_HD inline int fft_work_doubles(int n) { return 2 * (n + (n >> 4)); }
+
+template <class Cfg, int N, int R, int LGNS>
+RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
   constexpr int T = Cfg::T;
   constexpr int NB = N / R;                        // butterflies
   constexpr int Q = (NB + T - 1) / T;              // butterflies per thread
-  static_assert(Q * R <= 16, "FFT too large for this kernel configuration");
-  RPDE_TLS(blk, double, xr, 16);
-  RPDE_TLS(blk, double, xi, 16);
+  constexpr int Ns = 1 << LGNS;
+  constexpr int LGR = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
+  static_assert(Q * R <= 16 && true, "FFT too large for this kernel configuration");
+  RPDE_TLS(blk, double, xr, Q * R);
+  RPDE_TLS(blk, double, xi, Q * R);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -180,8 +209,9 @@ RPDE_DEV void fft_pass(Blk& blk, double* w, int Ns, const double* tw) {
       if (j < NB) {
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          RPDE_T(xr)[q * R + t] = w[2 * (j + t * NB)];
-          RPDE_T(xi)[q * R + t] = w[2 * (j + t * NB) + 1];
+          const int p = 2 * pidx(j + t * NB);
+          RPDE_T(xr)[q * R + t] = w[p];
+          RPDE_T(xi)[q * R + t] = w[p + 1];
         }
       }
     }
@@ -192,26 +222,40 @@ RPDE_DEV void fft_pass(Blk& blk, double* w, int Ns, const double* tw) {
     for (int q = 0; q < Q; ++q) {
       const int j = tid + q * T;
       if (j < NB) {
-        const int k = j % Ns;
-        const int tstep = N / (Ns * R);
+        const int k = j & (Ns - 1);
         double* pr = RPDE_T(xr) + q * R;
         double* pi = RPDE_T(xi) + q * R;
-        if (k != 0) {
+        if constexpr (LGNS > 0) {
+          // twiddles W^(t k tstep), t = 1..R-1, as powers of the table entry for t = 1
+          constexpr int tstep = N / (Ns * R);
+          double wc[R], ws[R];
+          wc[1] = tw[2 * (k * tstep)];
+          ws[1] = tw[2 * (k * tstep) + 1];
+#pragma unroll
+          for (int t = 2; t < R; ++t) {
+            if (t % 2 == 0) {
+              const double c = wc[t / 2], s = ws[t / 2];
+              wc[t] = c * c - s * s;
+              ws[t] = 2.0 * c * s;
+            } else {
+              wc[t] = wc[t - 1] * wc[1] - ws[t - 1] * ws[1];
+              ws[t] = wc[t - 1] * ws[1] + ws[t - 1] * wc[1];
+            }
+          }
 #pragma unroll
           for (int t = 1; t < R; ++t) {
-            const int idx = t * k * tstep;  // < N
-            const double c = tw[2 * idx], s = tw[2 * idx + 1];  // W = c + i s (s = -sin)
             const double ar = pr[t], ai = pi[t];
-            pr[t] = ar * c - ai * s;
-            pi[t] = ar * s + ai * c;
+            pr[t] = ar * wc[t] - ai * ws[t];
+            pi[t] = ar * ws[t] + ai * wc[t];
           }
         }
         SmallDft<R>::run(pr, pi);
-        const int j0 = (j / Ns) * Ns * R + k;
+        const int j0 = ((j >> LGNS) << (LGNS + LGR)) + k;
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          w[2 * (j0 + t * Ns)] = pr[t];
-          w[2 * (j0 + t * Ns) + 1] = pi[t];
+          const int p = 2 * pidx(j0 + t * Ns);
+          w[p] = pr[t];
+          w[p + 1] = pi[t];
         }
       }
     }
@@ -220,25 +264,27 @@ RPDE_DEV void fft_pass(Blk& blk, double* w, int Ns, const double* tw) {
 }
 
 template <class Cfg, int N>
-RPDE_DEV void fft_lds(Blk& blk, double* w, const double* tw) {
-  // radix schedule: as many 16s as possible, then one of {8,4,2}
+RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw) {
+  // radix schedule: one of {2,4,8} first (if log2 N is not a multiple of 4), then 16s
   constexpr int L = (N >= 8192) ? 13 : (N >= 4096) ? 12 : (N >= 2048) ? 11 : (N >= 1024) ? 10
                   : (N >= 512) ? 9 : (N >= 256) ? 8 : (N >= 128) ? 7 : (N >= 64) ? 6
                   : (N >= 32) ? 5 : (N >= 16) ? 4 : (N >= 8) ? 3 : (N >= 4) ? 2 : 1;
   static_assert((1 << L) == N, "power of two");
-  constexpr int n16 = L / 4;
-  constexpr int rem = L % 4;
-  int Ns = 1;
-  if constexpr (rem == 1) { fft_pass<Cfg, N, 2>(blk, w, Ns, tw); Ns *= 2; }
-  if constexpr (rem == 2) { fft_pass<Cfg, N, 4>(blk, w, Ns, tw); Ns *= 4; }
-  if constexpr (rem == 3) { fft_pass<Cfg, N, 8>(blk, w, Ns, tw); Ns *= 8; }
-  if constexpr (n16 >= 1) { fft_pass<Cfg, N, 16>(blk, w, Ns, tw); Ns *= 16; }
-  if constexpr (n16 >= 2) { fft_pass<Cfg, N, 16>(blk, w, Ns, tw); Ns *= 16; }
-  if constexpr (n16 >= 3) { fft_pass<Cfg, N, 16>(blk, w, Ns, tw); Ns *= 16; }
+  constexpr int RM = Cfg::RM;
+  constexpr int LG = (RM == 16) ? 4 : 3;
+  constexpr int nm = L / LG;
+  constexpr int rem = L % LG;
+  if constexpr (rem == 1) fft_pass<Cfg, N, 2, 0>(blk, w, tw);
+  if constexpr (rem == 2) fft_pass<Cfg, N, 4, 0>(blk, w, tw);
+  if constexpr (rem == 3) fft_pass<Cfg, N, 8, 0>(blk, w, tw);
+  if constexpr (nm >= 1) fft_pass<Cfg, N, RM, rem>(blk, w, tw);
+  if constexpr (nm >= 2) fft_pass<Cfg, N, RM, rem + LG>(blk, w, tw);
+  if constexpr (nm >= 3) fft_pass<Cfg, N, RM, rem + 2 * LG>(blk, w, tw);
+  if constexpr (nm >= 4) fft_pass<Cfg, N, RM, rem + 3 * LG>(blk, w, tw);
 }
 
 template <class Cfg>
-RPDE_DEV void fft_dispatch(Blk& blk, double* w, int n, const double* tw) {
+RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw) {
   switch (n) {
 #define RPDE_FFT_CASE(NN) \
   case NN: if constexpr (NN >= Cfg::FMIN && NN <= Cfg::FMAX) fft_lds<Cfg, NN>(blk, w, tw); break;
@@ -251,19 +297,18 @@ RPDE_DEV void fft_dispatch(Blk& blk, double* w, int n, const double* tw) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// DCT-I of the n = N+1 reals in slot x (work area = x .. x + 2N doubles, i.e. slot d and d+1):
+// DCT-I of the n = N+1 reals in slot x (work area = x .. x + fft_work_doubles(N), i.e. slot d, d+1):
 //   E_k = x_0 + (-1)^k x_N + 2 sum_{j=1}^{N-1} x_j cos(pi j k / N)
 // through an N-point complex FFT of the even extension (packed two reals per complex).
 template <class Cfg>
-RPDE_DEV void dct1_lds(Blk& blk, double* x, int N, const double* pre, const double* post,
-                       const double* tw, const double* tw2) {
+RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t tw, tab_t tw2) {
   constexpr int T = Cfg::T;
   {  // pack z_j = e_{2j} + i e_{2j+1}
-    RPDE_TLS(blk, double, zr, 16);
-    RPDE_TLS(blk, double, zi, 16);
+    RPDE_TLS(blk, double, zr, Cfg::ZPT);
+    RPDE_TLS(blk, double, zi, Cfg::ZPT);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < Cfg::ZPT; ++q) {
         const int j = tid + q * T;
         if (j < N) {
           int m0 = 2 * j, m1 = 2 * j + 1;
@@ -279,9 +324,9 @@ RPDE_DEV void dct1_lds(Blk& blk, double* x, int N, const double* pre, const doub
     RPDE_SYNC(blk);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < Cfg::ZPT; ++q) {
         const int j = tid + q * T;
-        if (j < N) { x[2 * j] = RPDE_T(zr)[q]; x[2 * j + 1] = RPDE_T(zi)[q]; }
+        if (j < N) { const int p = 2 * pidx(j); x[p] = RPDE_T(zr)[q]; x[p + 1] = RPDE_T(zi)[q]; }
       }
     }
     RPDE_SYNC(blk);
@@ -294,10 +339,10 @@ RPDE_DEV void dct1_lds(Blk& blk, double* x, int N, const double* pre, const doub
       for (int q = 0; q < Cfg::EPT; ++q) {
         const int k = tid + q * T;
         if (k <= N) {
-          const int ka = (k == N) ? 0 : k;
-          const int kb = (k == 0) ? 0 : N - k;
-          const double ar = x[2 * ka], ai = x[2 * ka + 1];
-          const double br = x[2 * kb], bi = x[2 * kb + 1];
+          const int ka = 2 * pidx((k == N) ? 0 : k);
+          const int kb = 2 * pidx((k == 0) ? 0 : N - k);
+          const double ar = x[ka], ai = x[ka + 1];
+          const double br = x[kb], bi = x[kb + 1];
           const double c = tw2[2 * k], s = tw2[2 * k + 1];
           double v = 0.5 * (ar + br) + 0.5 * (c * (ai + bi) - s * (ar - br));
           if (post) v *= post[k];
@@ -319,8 +364,7 @@ RPDE_DEV void dct1_lds(Blk& blk, double* x, int N, const double* pre, const doub
 
 // direct O(n^2) DCT-I for line lengths without an FFT plan (small / odd sizes); costab[m] = cos(pi m / N), m < 2N
 template <class Cfg>
-RPDE_DEV void dct1_direct(Blk& blk, double* x, int N, const double* pre, const double* post,
-                          const double* costab) {
+RPDE_DEVN void dct1_direct(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t costab) {
   constexpr int T = Cfg::T;
   RPDE_TLS(blk, double, e, Cfg::EPT);
   if (pre) {
@@ -352,10 +396,26 @@ RPDE_DEV void dct1_direct(Blk& blk, double* x, int N, const double* pre, const d
 
 // real FFT, nx reals -> nx/2+1 interleaved complex, unnormalised (forward) ; tw2[k] = (cos, sin)(2 pi k / nx)
 template <class Cfg>
-RPDE_DEV void rfft_forward_lds(Blk& blk, double* x, int nx, const double* tw, const double* tw2) {
+RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) {
   constexpr int T = Cfg::T;
   const int M = nx / 2;
-  fft_dispatch<Cfg>(blk, x, M, tw);  // z_j = x_{2j} + i x_{2j+1} is already the interleaved layout
+  {  // z_j = x_{2j} + i x_{2j+1}: move to the padded work layout
+    RPDE_TLS(blk, double, v, Cfg::EPT);
+    RPDE_PHASE(blk, tid) {
+#pragma unroll
+      for (int q = 0; q < Cfg::EPT; ++q) { const int e = tid + q * T; if (e < nx) RPDE_T(v)[q] = x[e]; }
+    }
+    RPDE_SYNC(blk);
+    RPDE_PHASE(blk, tid) {
+#pragma unroll
+      for (int q = 0; q < Cfg::EPT; ++q) {
+        const int e = tid + q * T;
+        if (e < nx) x[2 * pidx(e >> 1) + (e & 1)] = RPDE_T(v)[q];
+      }
+    }
+    RPDE_SYNC(blk);
+  }
+  fft_dispatch<Cfg>(blk, x, M, tw);
   RPDE_TLS(blk, double, yr, Cfg::EPT);
   RPDE_TLS(blk, double, yi, Cfg::EPT);
   RPDE_PHASE(blk, tid) {
@@ -363,10 +423,10 @@ RPDE_DEV void rfft_forward_lds(Blk& blk, double* x, int nx, const double* tw, co
     for (int q = 0; q < Cfg::EPT; ++q) {
       const int k = tid + q * T;
       if (k <= M) {
-        const int ka = (k == M) ? 0 : k;
-        const int kb = (k == 0) ? 0 : M - k;
-        const double ar = x[2 * ka], ai = x[2 * ka + 1];
-        const double br = x[2 * kb], bi = x[2 * kb + 1];
+        const int ka = 2 * pidx((k == M) ? 0 : k);
+        const int kb = 2 * pidx((k == 0) ? 0 : M - k);
+        const double ar = x[ka], ai = x[ka + 1];
+        const double br = x[kb], bi = x[kb + 1];
         const double c = tw2[2 * k], s = tw2[2 * k + 1];
         const double sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
         RPDE_T(yr)[q] = 0.5 * (sr + c * di - s * dr);
@@ -387,47 +447,55 @@ RPDE_DEV void rfft_forward_lds(Blk& blk, double* x, int nx, const double* tw, co
 
 // inverse: nx/2+1 interleaved complex -> nx reals, scaled by 1/nx (imaginary parts of k=0, nx/2 ignored)
 template <class Cfg>
-RPDE_DEV void rfft_backward_lds(Blk& blk, double* x, int nx, const double* tw, const double* tw2) {
+RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) {
   constexpr int T = Cfg::T;
   const int M = nx / 2;
-  RPDE_TLS(blk, double, zr, Cfg::EPT);
-  RPDE_TLS(blk, double, zi, Cfg::EPT);
-  RPDE_PHASE(blk, tid) {
+  {
+    RPDE_TLS(blk, double, zr, Cfg::EPT);
+    RPDE_TLS(blk, double, zi, Cfg::EPT);
+    RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) {
-      const int k = tid + q * T;
-      if (k < M) {
-        const int kb = M - k;
-        double ar = x[2 * k], ai = x[2 * k + 1];
-        double br = x[2 * kb], bi = -x[2 * kb + 1];  // conj X_{M-k}
-        if (k == 0) { ai = 0.0; bi = 0.0; }
-        const double c = tw2[2 * k], s = tw2[2 * k + 1];  // conj(W^k) = c + i s
-        const double sr = ar + br, si = ai + bi, dr = ar - br, di = ai - bi;
-        // Z_k = ( S + i (c + i s) D ) / 2 ;  store conj(Z_k) for the conjugate-FFT inverse
-        const double er = sr + (-(c * di) - s * dr);
-        const double ei = si + (c * dr - s * di);
-        RPDE_T(zr)[q] = 0.5 * er;
-        RPDE_T(zi)[q] = -0.5 * ei;
+      for (int q = 0; q < Cfg::EPT; ++q) {
+        const int k = tid + q * T;
+        if (k < M) {
+          const int kb = M - k;
+          double ar = x[2 * k], ai = x[2 * k + 1];
+          double br = x[2 * kb], bi = -x[2 * kb + 1];  // conj X_{M-k}
+          if (k == 0) { ai = 0.0; bi = 0.0; }
+          const double c = tw2[2 * k], s = tw2[2 * k + 1];  // conj(W^k) = c + i s
+          const double sr = ar + br, si = ai + bi, dr = ar - br, di = ai - bi;
+          // Z_k = ( S + i (c + i s) D ) / 2 ;  store conj(Z_k) for the conjugate-FFT inverse
+          const double er = sr + (-(c * di) - s * dr);
+          const double ei = si + (c * dr - s * di);
+          RPDE_T(zr)[q] = 0.5 * er;
+          RPDE_T(zi)[q] = -0.5 * ei;
+        }
       }
     }
-  }
-  RPDE_SYNC(blk);
-  RPDE_PHASE(blk, tid) {
+    RPDE_SYNC(blk);
+    RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) {
-      const int k = tid + q * T;
-      if (k < M) { x[2 * k] = RPDE_T(zr)[q]; x[2 * k + 1] = RPDE_T(zi)[q]; }
+      for (int q = 0; q < Cfg::EPT; ++q) {
+        const int k = tid + q * T;
+        if (k < M) { const int p = 2 * pidx(k); x[p] = RPDE_T(zr)[q]; x[p + 1] = RPDE_T(zi)[q]; }
+      }
     }
+    RPDE_SYNC(blk);
   }
-  RPDE_SYNC(blk);
   fft_dispatch<Cfg>(blk, x, M, tw);
   const double sc = 1.0 / (double)M;
+  RPDE_TLS(blk, double, v, Cfg::EPT);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
     for (int q = 0; q < Cfg::EPT; ++q) {
-      const int k = tid + q * T;
-      if (k < M) { x[2 * k] *= sc; x[2 * k + 1] *= -sc; }
+      const int e = tid + q * T;
+      if (e < nx) RPDE_T(v)[q] = x[2 * pidx(e >> 1) + (e & 1)] * ((e & 1) ? -sc : sc);
     }
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < Cfg::EPT; ++q) { const int e = tid + q * T; if (e < nx) x[e] = RPDE_T(v)[q]; }
   }
   RPDE_SYNC(blk);
 }
@@ -439,132 +507,184 @@ RPDE_DEV void rfft_backward_lds(Blk& blk, double* x, int nx, const double* tw, c
 //                 double q(int k)  coefficient of the first predecessor  (k -/+ 2)
 //                 double r(int k)  coefficient of the second predecessor (k -/+ 4)   [ORDER 2]
 // DIR = +1: ascending (predecessor k-2), DIR = -1: descending (predecessor k+2).
-template <class Cfg, int ORDER, int DIR, class Coef>
-RPDE_DEV void scan_recurrence(Blk& blk, double* dst, int n, double* carry, const Coef& cf) {
-  constexpr int T = Cfg::T, C = Cfg::C, G = Cfg::G;
-  constexpr int W = (ORDER == 1) ? 2 : 6;  // doubles per carried affine map
-  // thread t owns elements [t*C, t*C + C); scan order tau = t (ascending) or T-1-t (descending)
-  // ---- phase 1: per (thread, parity) affine map of the chunk
+//
+// Thread t owns the chunk of C consecutive elements number tau(t) = t (ascending) or T-1-t
+// (descending), so that the carry always flows from thread t-1 to thread t.  Phase 1 reduces a
+// chunk to an affine map of its inflow state, phase 2 turns the maps into inflow states (prefix
+// composition: wave shuffles + one LDS hop on the GPU; a plain loop in the host emulation),
+// phase 3 re-runs the chunk with the exact inflow.
+template <int ORDER>
+struct Affine {            // s -> M s + v   (ORDER 1: scalars m11, v1)
+  double m11, m12, m21, m22, v1, v2;
+};
+template <int ORDER>
+RPDE_HD inline Affine<ORDER> affine_identity() { return Affine<ORDER>{1.0, 0.0, 0.0, 1.0, 0.0, 0.0}; }
+// apply `first`, then `second`
+template <int ORDER>
+RPDE_HD inline Affine<ORDER> affine_compose(const Affine<ORDER>& second, const Affine<ORDER>& first) {
+  Affine<ORDER> r;
+  if constexpr (ORDER == 1) {
+    r.m11 = second.m11 * first.m11;
+    r.v1 = second.m11 * first.v1 + second.v1;
+    r.m12 = r.m21 = 0.0; r.m22 = 1.0; r.v2 = 0.0;
+  } else {
+    r.m11 = second.m11 * first.m11 + second.m12 * first.m21;
+    r.m12 = second.m11 * first.m12 + second.m12 * first.m22;
+    r.m21 = second.m21 * first.m11 + second.m22 * first.m21;
+    r.m22 = second.m21 * first.m12 + second.m22 * first.m22;
+    r.v1 = second.m11 * first.v1 + second.m12 * first.v2 + second.v1;
+    r.v2 = second.m21 * first.v1 + second.m22 * first.v2 + second.v2;
+  }
+  return r;
+}
+
+#ifndef RPDE_EMU
+template <int ORDER>
+__device__ __forceinline__ Affine<ORDER> affine_shfl_up(const Affine<ORDER>& a, int off) {
+  Affine<ORDER> r = affine_identity<ORDER>();
+  r.m11 = __shfl_up(a.m11, off);
+  r.v1 = __shfl_up(a.v1, off);
+  if constexpr (ORDER == 2) {
+    r.m12 = __shfl_up(a.m12, off); r.m21 = __shfl_up(a.m21, off); r.m22 = __shfl_up(a.m22, off);
+    r.v2 = __shfl_up(a.v2, off);
+  }
+  return r;
+}
+#endif
+
+// `fill(k, b, q, r)` supplies the coefficients of element k (it may read LDS / padded tables
+// freely, also for k >= n); all loads of a chunk are issued in one batch before the dependent
+// chains start.
+template <class Cfg, int ORDER, int DIR, class Fill>
+RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fill fill) {
+  constexpr int T = Cfg::T, C = Cfg::C;
+  constexpr int W = 6;  // doubles per stored map
+  RPDE_TLS(blk, double, bb, C);
+  RPDE_TLS(blk, double, qq, C);
+  RPDE_TLS(blk, double, rr, C);
+  RPDE_TLS(blk, double, cm, 2 * W);     // chunk map per parity, later the inflow state (v1, v2)
+  // ---- phase 0 + 1: batch the coefficient loads, then reduce the chunk to an affine map
   RPDE_PHASE(blk, tid) {
-    const int lo = tid * C;
+    const int lo = ((DIR > 0) ? tid : (T - 1 - tid)) * C;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      double b, q, r = 0.0;
+      fill(lo + i, b, q, r);
+      RPDE_T(bb)[i] = b; RPDE_T(qq)[i] = q; RPDE_T(rr)[i] = r;
+    }
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      double z1 = 0.0, z2 = 0.0;           // inhomogeneous run from zero state
-      double a11 = 1.0, a12 = 0.0;         // homogeneous runs: state after chunk from (1,0)
-      double a21 = 0.0, a22 = 1.0;         // ... and from (0,1)   [rows: (x1, x2)]
-      // state convention: x1 = most recent value, x2 = the one before
+      double z1 = 0.0, z2 = 0.0;           // inhomogeneous run from the zero state
+      double a11 = 1.0, a12 = 0.0;         // homogeneous runs from (1,0) and (0,1)
+      double a21 = 0.0, a22 = 1.0;         // state = (most recent value, the one before)
 #pragma unroll
       for (int i = 0; i < C / 2; ++i) {
-        const int k = (DIR > 0) ? (lo + par + 2 * i) : (lo + C - 2 + par - 2 * i);
-        if (k < n) {
-          const double q = cf.q(k);
-          const double bk = cf.b(k);
-          if constexpr (ORDER == 1) {
-            z1 = bk + q * z1;
-            a11 = q * a11;
-          } else {
-            const double r = cf.r(k);
-            const double nz = bk + q * z1 + r * z2; z2 = z1; z1 = nz;
-            const double n1 = q * a11 + r * a21; a21 = a11; a11 = n1;   // column from (1,0)
-            const double n2 = q * a12 + r * a22; a22 = a12; a12 = n2;   // column from (0,1)
-          }
-        }
-      }
-      const int tau = (DIR > 0) ? tid : (T - 1 - tid);
-      double* cp = carry + (size_t)(tau * 2 + par) * W;
-      if constexpr (ORDER == 1) { cp[0] = a11; cp[1] = z1; }
-      else { cp[0] = a11; cp[1] = a12; cp[2] = a21; cp[3] = a22; cp[4] = z1; cp[5] = z2; }
-    }
-  }
-  RPDE_SYNC(blk);
-  // ---- phase 2a: exclusive prefix inside groups of 16 (in place), group aggregate behind the carries
-  RPDE_PHASE(blk, tid) {
-    if (tid < 2 * G) {
-      const int g = tid >> 1, par = tid & 1;
-      double m11 = 1, m12 = 0, m21 = 0, m22 = 1, v1 = 0, v2 = 0;
-      for (int mth = 0; mth < 16; ++mth) {
-        const int tau = g * 16 + mth;
-        if (tau < T) {
-          double* cp = carry + (size_t)(tau * 2 + par) * W;
-          if constexpr (ORDER == 1) {
-            const double h = cp[0], z = cp[1];
-            cp[0] = m11; cp[1] = v1;
-            m11 = h * m11; v1 = h * v1 + z;
-          } else {
-            const double c11 = cp[0], c12 = cp[1], c21 = cp[2], c22 = cp[3], z1 = cp[4], z2 = cp[5];
-            cp[0] = m11; cp[1] = m12; cp[2] = m21; cp[3] = m22; cp[4] = v1; cp[5] = v2;
-            const double n11 = c11 * m11 + c12 * m21, n12 = c11 * m12 + c12 * m22;
-            const double n21 = c21 * m11 + c22 * m21, n22 = c21 * m12 + c22 * m22;
-            const double w1 = c11 * v1 + c12 * v2 + z1, w2 = c21 * v1 + c22 * v2 + z2;
-            m11 = n11; m12 = n12; m21 = n21; m22 = n22; v1 = w1; v2 = w2;
-          }
-        }
-      }
-      double* gp = carry + (size_t)(T * 2 + g * 2 + par) * W;
-      if constexpr (ORDER == 1) { gp[0] = m11; gp[1] = v1; }
-      else { gp[0] = m11; gp[1] = m12; gp[2] = m21; gp[3] = m22; gp[4] = v1; gp[5] = v2; }
-    }
-  }
-  RPDE_SYNC(blk);
-  // ---- phase 2b: exclusive prefix over the group aggregates (in place)
-  RPDE_PHASE(blk, tid) {
-    if (tid < 2) {
-      const int par = tid;
-      double m11 = 1, m12 = 0, m21 = 0, m22 = 1, v1 = 0, v2 = 0;
-      for (int g = 0; g < G; ++g) {
-        double* gp = carry + (size_t)(T * 2 + g * 2 + par) * W;
+        const int e = (DIR > 0) ? (par + 2 * i) : (C - 2 + par - 2 * i);
+        const bool ok = lo + e < n;
+        const double q = RPDE_T(qq)[e], bk = RPDE_T(bb)[e];
         if constexpr (ORDER == 1) {
-          const double h = gp[0], z = gp[1];
-          gp[0] = m11; gp[1] = v1;
-          m11 = h * m11; v1 = h * v1 + z;
+          z1 = ok ? bk + q * z1 : z1;
+          a11 = ok ? q * a11 : a11;
         } else {
-          const double c11 = gp[0], c12 = gp[1], c21 = gp[2], c22 = gp[3], z1 = gp[4], z2 = gp[5];
-          gp[0] = m11; gp[1] = m12; gp[2] = m21; gp[3] = m22; gp[4] = v1; gp[5] = v2;
-          const double n11 = c11 * m11 + c12 * m21, n12 = c11 * m12 + c12 * m22;
-          const double n21 = c21 * m11 + c22 * m21, n22 = c21 * m12 + c22 * m22;
-          const double w1 = c11 * v1 + c12 * v2 + z1, w2 = c21 * v1 + c22 * v2 + z2;
-          m11 = n11; m12 = n12; m21 = n21; m22 = n22; v1 = w1; v2 = w2;
+          const double r = RPDE_T(rr)[e];
+          const double nz = bk + q * z1 + r * z2;
+          const double n1 = q * a11 + r * a21;
+          const double n2 = q * a12 + r * a22;
+          z2 = ok ? z1 : z2; z1 = ok ? nz : z1;
+          a21 = ok ? a11 : a21; a11 = ok ? n1 : a11;
+          a22 = ok ? a12 : a22; a12 = ok ? n2 : a12;
         }
       }
+      double* m = RPDE_T(cm) + par * W;
+      m[0] = a11; m[1] = a12; m[2] = a21; m[3] = a22; m[4] = z1; m[5] = z2;
     }
   }
-  RPDE_SYNC(blk);
-  // ---- phase 3: re-run every chunk with its inflow state, results through registers
+  // ---- phase 2: inflow state of every chunk = (exclusive prefix of the maps)(0)
+#ifdef RPDE_EMU
+  {
+    Affine<ORDER> run[2] = {affine_identity<ORDER>(), affine_identity<ORDER>()};
+    RPDE_PHASE(blk, tid) {  // the emulation visits tid = 0 .. T-1 in order
+      for (int par = 0; par < 2; ++par) {
+        double* m = RPDE_T(cm) + par * W;
+        const Affine<ORDER> mine{m[0], m[1], m[2], m[3], m[4], m[5]};
+        m[4] = run[par].v1; m[5] = run[par].v2;
+        run[par] = affine_compose<ORDER>(mine, run[par]);
+      }
+    }
+    (void)carry;
+  }
+#else
+  {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = (T + 63) / 64;
+    Affine<ORDER> inc[2], exc[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      double* m = cm + par * W;
+      inc[par] = Affine<ORDER>{m[0], m[1], m[2], m[3], m[4], m[5]};
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {   // the two parities give two independent chains
+        const Affine<ORDER> prev = affine_shfl_up<ORDER>(inc[par], off);
+        if (lane >= off) inc[par] = affine_compose<ORDER>(inc[par], prev);
+      }
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      exc[par] = affine_shfl_up<ORDER>(inc[par], 1);
+      if (lane == 0) exc[par] = affine_identity<ORDER>();
+    }
+    if constexpr (NW > 1) {
+      if (lane == 63) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          lds_t wt = carry + (par * NW + wave) * W;
+          wt[0] = inc[par].m11; wt[1] = inc[par].m12; wt[2] = inc[par].m21; wt[3] = inc[par].m22;
+          wt[4] = inc[par].v1; wt[5] = inc[par].v2;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        Affine<ORDER> pre = affine_identity<ORDER>();
+        for (int w = 0; w < wave; ++w) {
+          clds_t p = carry + (par * NW + w) * W;
+          pre = affine_compose<ORDER>(Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]}, pre);
+        }
+        exc[par] = affine_compose<ORDER>(exc[par], pre);
+      }
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) { cm[par * W + 4] = exc[par].v1; cm[par * W + 5] = exc[par].v2; }
+  }
+#endif
+  // ---- phase 3: re-run every chunk with its inflow state (registers only), then write
   RPDE_TLS(blk, double, res, C);
   RPDE_PHASE(blk, tid) {
-    const int lo = tid * C;
-    const int tau = (DIR > 0) ? tid : (T - 1 - tid);
-    const int g = tau >> 4;
+    const int lo = ((DIR > 0) ? tid : (T - 1 - tid)) * C;
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      const double* cp = carry + (size_t)(tau * 2 + par) * W;
-      const double* gp = carry + (size_t)(T * 2 + g * 2 + par) * W;
-      double x1, x2 = 0.0;
-      if constexpr (ORDER == 1) {
-        x1 = cp[0] * gp[1] + cp[1];  // inflow = He * Zg + Ze
-      } else {
-        x1 = cp[0] * gp[4] + cp[1] * gp[5] + cp[4];
-        x2 = cp[2] * gp[4] + cp[3] * gp[5] + cp[5];
-      }
+      double x1 = RPDE_T(cm)[par * W + 4], x2 = RPDE_T(cm)[par * W + 5];
 #pragma unroll
       for (int i = 0; i < C / 2; ++i) {
-        const int k = (DIR > 0) ? (lo + par + 2 * i) : (lo + C - 2 + par - 2 * i);
-        if (k < n) {
-          const double q = cf.q(k);
-          const double bk = cf.b(k);
-          if constexpr (ORDER == 1) {
-            x1 = bk + q * x1;
-          } else {
-            const double nx1 = bk + q * x1 + cf.r(k) * x2; x2 = x1; x1 = nx1;
-          }
-          RPDE_T(res)[(DIR > 0) ? (par + 2 * i) : (C - 2 + par - 2 * i)] = x1;
+        const int e = (DIR > 0) ? (par + 2 * i) : (C - 2 + par - 2 * i);
+        const bool ok = lo + e < n;
+        const double q = RPDE_T(qq)[e], bk = RPDE_T(bb)[e];
+        if constexpr (ORDER == 1) {
+          x1 = ok ? bk + q * x1 : x1;
+        } else {
+          const double nx1 = bk + q * x1 + RPDE_T(rr)[e] * x2;
+          x2 = ok ? x1 : x2; x1 = ok ? nx1 : x1;
         }
+        RPDE_T(res)[e] = x1;
       }
     }
   }
-  RPDE_SYNC(blk);
+  RPDE_SYNC(blk);   // every thread has consumed its inputs (in-place operation is allowed)
   RPDE_PHASE(blk, tid) {
-    const int lo = tid * C;
+    const int lo = ((DIR > 0) ? tid : (T - 1 - tid)) * C;
 #pragma unroll
     for (int i = 0; i < C; ++i)
       if (lo + i < n) dst[lo + i] = RPDE_T(res)[i];
@@ -572,47 +692,63 @@ RPDE_DEV void scan_recurrence(Blk& blk, double* dst, int n, double* carry, const
   RPDE_SYNC(blk);
 }
 
-struct CoefRec {   // generic table-driven recurrence
-  const double* src; const double* pt; const double* qt; const double* rt;
-  RPDE_DEV double b(int k) const { return pt ? pt[k] * src[k] : src[k]; }
-  RPDE_DEV double q(int k) const { return qt[k]; }
-  RPDE_DEV double r(int k) const { return rt[k]; }
+struct FillRec {   // generic table-driven recurrence: x_k = p_k src_k + q_k x_pred (+ r_k x_pred2)
+  clds_t src; tab_t pt; tab_t qt; tab_t rt;
+  RPDE_DEV void operator()(int k, double& b, double& q, double& r) const {
+    const double s = src[k];
+    b = pt ? pt[k] * s : s;
+    q = qt[k];
+    if (rt) r = rt[k];
+  }
 };
-struct CoefDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
-  const double* src; int n;
-  RPDE_DEV double b(int k) const { return (k + 1 < n) ? 2.0 * (double)(k + 1) * src[k + 1] : 0.0; }
-  RPDE_DEV double q(int) const { return 1.0; }
-  RPDE_DEV double r(int) const { return 0.0; }
+struct FillDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
+  clds_t src; int n;
+  RPDE_DEV void operator()(int k, double& b, double& q, double&) const {
+    const double s = src[k + 1];
+    b = (k + 1 < n) ? 2.0 * (double)(k + 1) * s : 0.0;
+    q = 1.0;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
-// the interpreter
+// the interpreter.  Conventions that keep the inner loops free of divergent branches (with one
+// or two waves per SIMD there is little to hide a stall behind): a slot is addressable up to
+// T*EPT >= slot_len doubles (the LDS allocation is rounded up accordingly), so LDS reads are
+// never guarded; device tables carry kTableSlack doubles of zero padding, so table reads are
+// never guarded; results are selected and stores are masked.
+constexpr int kTableSlack = 5200;
+
 template <class Cfg>
 RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   constexpr int T = Cfg::T, EPT = Cfg::EPT;
   const int line = blk.line, comp = blk.comp;
   const int SL = pg.slot_len;
-  double* lds = blk.lds;
-  double* carry = lds + (size_t)pg.nslots * SL;
+  lds_t lds = (lds_t)blk.lds;
+  lds_t carry = lds + pg.nslots * SL + (T * EPT - SL) + 8;
   for (int ip = 0; ip < pg.nops; ++ip) {
     const Op& op = pg.ops[ip];
-    double* d = lds + (size_t)op.d * SL;
-    const double* a = lds + (size_t)op.a * SL;
-    const double* b = lds + (size_t)op.b * SL;
+    lds_t d = lds + op.d * SL;
+    clds_t a = lds + op.a * SL;
+    clds_t b = lds + op.b * SL;
     const int n = op.n;
     const long toff = op.tabld * line;
     switch (op.code) {
       case OP_LOAD: {
         const ArrayRef& A = pg.arr[op.arr];
-        const double* src = A.p + comp * A.coff + (long)line * A.ld;
+        cgmem_t src = (cgmem_t)(A.p + comp * A.coff + (long)line * A.ld);
+        const int es = A.es;
         RPDE_PHASE(blk, tid) {
+          double v[EPT];
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < SL) {
-              double v = (k < n) ? op.s0 * src[(long)k * A.es] : 0.0;
-              d[k] = op.acc ? (d[k] + v) : v;
-            }
+            v[q] = (k < n) ? src[(long)k * es] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) {
+            const int k = tid + q * T;
+            const double x = op.s0 * v[q];
+            if (k < SL) d[k] = op.acc ? (d[k] + x) : x;
           }
         }
         RPDE_SYNC(blk);
@@ -620,53 +756,55 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       case OP_LOADX: {
         const ArrayRef& A = pg.arr[op.arr];
         const bool has0 = line < op.i1, has2 = line >= 2 && (line - 2) < op.i1;
-        const double* s0p = A.p + comp * A.coff + (long)line * A.ld;
-        const double* s2p = A.p + comp * A.coff + (long)(line - 2) * A.ld;
-        const double c2 = has2 ? pg.tabs[op.tab][line - 2] : 0.0;
+        cgmem_t s0p = (cgmem_t)(A.p + comp * A.coff + (long)line * A.ld);
+        cgmem_t s2p = (cgmem_t)(A.p + comp * A.coff + (long)(line - 2) * A.ld);
+        const double c2 = has2 ? ((tab_t)pg.tabs[op.tab])[line - 2] : 0.0;
+        const int es = A.es;
         RPDE_PHASE(blk, tid) {
+          double v0[EPT], v2[EPT];
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < SL) {
-              double v = 0.0;
-              if (k < n) {
-                if (has0) v = s0p[(long)k * A.es];
-                if (has2) v += c2 * s2p[(long)k * A.es];
-                v *= op.s0;
-              }
-              d[k] = op.acc ? (d[k] + v) : v;
-            }
+            v0[q] = (has0 && k < n) ? s0p[(long)k * es] : 0.0;
+            v2[q] = (has2 && k < n) ? s2p[(long)k * es] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) {
+            const int k = tid + q * T;
+            const double x = op.s0 * (v0[q] + c2 * v2[q]);
+            if (k < SL) d[k] = op.acc ? (d[k] + x) : x;
           }
         }
         RPDE_SYNC(blk);
       } break;
       case OP_STORE: {
         const ArrayRef& A = pg.arr[op.arr];
-        double* dstp = A.p + comp * A.coff + (long)line * A.ld;
+        gmem_t dstp = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
+            const double x = op.s0 * a[k];
             if (k < n) {
               const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;
-              dstp[kk * A.es] = op.s0 * a[k];
+              dstp[kk * A.es] = x;
             }
           }
         }
         RPDE_SYNC(blk);  // the next op may overwrite the slot
       } break;
       case OP_STEN: {
-        const double* low = pg.tabs[op.tab] + toff;
+        tab_t low = (tab_t)(pg.tabs[op.tab] + toff);
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < n) {
-              double x = (k < n - 2) ? a[k] : 0.0;
-              if (k >= 2) x += low[k - 2] * a[k - 2];
-              RPDE_T(v)[q] = x;
-            }
+            const int k2 = (k >= 2) ? k - 2 : 0;
+            const double a0 = a[k], a2 = a[k2], l2 = low[k2];
+            double x = (k < n - 2) ? a0 : 0.0;
+            x += (k >= 2) ? l2 * a2 : 0.0;
+            RPDE_T(v)[q] = x;
           }
         }
         RPDE_SYNC(blk);
@@ -677,35 +815,30 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_MV3: {
-        const double* t0 = pg.tabs[op.tab] + toff;
-        const double* t1 = pg.tabs[op.tab + 1] + toff;
-        const double* t2 = pg.tabs[op.tab + 2] + toff;
+        tab_t t0 = (tab_t)(pg.tabs[op.tab] + toff);
+        tab_t t1 = (tab_t)(pg.tabs[op.tab + 1] + toff);
+        tab_t t2 = (tab_t)(pg.tabs[op.tab + 2] + toff);
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < n) {
-              // input line has n + 2 entries; the +4 tap exists for k < n - 2 only (matvec.rs:215-226)
-              double x = a[k] * t0[k] + a[k + 2] * t1[k];
-              if (k < n - 2) x += a[k + 4] * t2[k];
-              RPDE_T(v)[q] = x;
-            }
+            // input line has n + 2 entries; the +4 tap exists for k < n - 2 only (matvec.rs:215-226)
+            const double a0 = a[k], a2 = a[k + 2], a4 = a[k + 4];
+            double x = a0 * t0[k] + a2 * t1[k];
+            x += (k < n - 2) ? a4 * t2[k] : 0.0;
+            RPDE_T(v)[q] = x;
           }
         }
         RPDE_SYNC(blk);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
-          for (int q = 0; q < EPT; ++q) {
-            const int k = tid + q * T;
-            if (k < n) d[k] = RPDE_T(v)[q];
-          }
+          for (int q = 0; q < EPT; ++q) { const int k = tid + q * T; if (k < n) d[k] = RPDE_T(v)[q]; }
         }
         RPDE_SYNC(blk);
       } break;
       case OP_CDIFF: {
-        CoefDiff cf{a, n};
-        scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, cf);
+        scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, FillDiff{a, n});
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
@@ -716,27 +849,29 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_REC1: {
-        CoefRec cf{a, op.tab >= 0 ? pg.tabs[op.tab] + toff : nullptr, pg.tabs[op.i0] + toff, nullptr};
-        if (op.i1 > 0) scan_recurrence<Cfg, 1, +1>(blk, d, n, carry, cf);
-        else scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, cf);
+        const FillRec f{a, op.tab >= 0 ? (tab_t)(pg.tabs[op.tab] + toff) : (tab_t) nullptr, (tab_t)(pg.tabs[op.i0] + toff), (tab_t) nullptr};
+        if (op.i1 > 0) scan_recurrence<Cfg, 1, +1>(blk, d, n, carry, f);
+        else scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, f);
       } break;
       case OP_REC2: {
-        CoefRec cf{a, op.tab >= 0 ? pg.tabs[op.tab] + toff : nullptr, pg.tabs[op.i0] + toff,
-                   pg.tabs[op.i1] + toff};
-        scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, cf);
+        const FillRec f{a, op.tab >= 0 ? (tab_t)(pg.tabs[op.tab] + toff) : (tab_t) nullptr, (tab_t)(pg.tabs[op.i0] + toff),
+                        (tab_t)(pg.tabs[op.i1] + toff)};
+        scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f);
       } break;
       case OP_DCT: {
-        const double* pre = op.tab >= 0 ? pg.tabs[op.tab] : nullptr;
-        const double* post = op.i0 >= 0 ? pg.tabs[op.i0] : nullptr;
-        if (pg.fft_n > 0) dct1_lds<Cfg>(blk, d, n - 1, pre, post, pg.tabs[pg.tw], pg.tabs[pg.tw2]);
-        else dct1_direct<Cfg>(blk, d, n - 1, pre, post, pg.tabs[pg.tw2]);
+        tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
+        tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
+        if (pg.fft_n > 0) dct1_lds<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+        else dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
       } break;
       case OP_MUL: {
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < n) { const double v = op.s0 * a[k] * b[k]; d[k] = op.acc ? d[k] + v : v; }
+            const double v = op.s0 * a[k] * b[k];
+            const double old = d[k];
+            if (k < n) d[k] = op.acc ? old + v : v;
           }
         }
         RPDE_SYNC(blk);
@@ -746,7 +881,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < n) d[k] = op.s0 * a[k] + op.s1 * b[k];
+            const double v = op.s0 * a[k] + op.s1 * b[k];
+            if (k < n) d[k] = v;
           }
         }
         RPDE_SYNC(blk);
@@ -762,21 +898,23 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_TABDIV: {
-        const double* t = pg.tabs[op.tab] + toff;
+        tab_t t = (tab_t)(pg.tabs[op.tab] + toff);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            if (k < n) d[k] = a[k] / t[k >> op.i0];
+            const double den = (k < n) ? t[k >> op.i0] : 1.0;
+            const double v = a[k] / den;
+            if (k < n) d[k] = v;
           }
         }
         RPDE_SYNC(blk);
       } break;
       case OP_RFFT_F:
-        rfft_forward_lds<Cfg>(blk, d, n, pg.tabs[pg.tw], pg.tabs[pg.tw2]);
+        rfft_forward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
         break;
       case OP_RFFT_B:
-        rfft_backward_lds<Cfg>(blk, d, n, pg.tabs[pg.tw], pg.tabs[pg.tw2]);
+        rfft_backward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
         break;
       case OP_CIK: {
         RPDE_TLS(blk, double, vr, EPT);
@@ -784,12 +922,10 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int e = tid + q * T;  // double index
-            if (e < 2 * n) {
-              const int k = e >> 1;
-              const double f = op.s0 * (double)k;
-              if (op.i0 == 1) RPDE_T(vr)[q] = (e & 1) ? f * a[e - 1] : -f * a[e + 1];
-              else RPDE_T(vr)[q] = -(f * f) * a[e];
-            }
+            const int k = e >> 1;
+            const double f = op.s0 * (double)k;
+            const double partner = a[e ^ 1], self = a[e];
+            RPDE_T(vr)[q] = (op.i0 == 1) ? ((e & 1) ? f * partner : -f * partner) : -(f * f) * self;
           }
         }
         RPDE_SYNC(blk);

@@ -50,6 +50,7 @@ struct Error : std::runtime_error {
 #ifdef RPDE_EMU
 #define RPDE_HD
 #define RPDE_DEV
+#define RPDE_DEVN
 struct Blk {          // one workgroup
   int line;           // blockIdx.x
   int comp;           // blockIdx.y
@@ -63,6 +64,7 @@ struct Blk {          // one workgroup
 #else
 #define RPDE_HD __host__ __device__
 #define RPDE_DEV __device__ __forceinline__
+#define RPDE_DEVN __device__ __noinline__
 struct Blk {
   int line, comp, T;
   double* lds;
@@ -168,8 +170,11 @@ struct DBuf {
     n = count;
     p = static_cast<double*>(dev_alloc(count * sizeof(double)));
   }
+  // tables are uploaded with kUploadSlack zero doubles behind them: device code reads table
+  // entries without bounds checks up to the per-thread capacity of a line kernel
+  static constexpr size_t kUploadSlack = 5200;
   void upload(const std::vector<double>& h) {
-    if (h.size() != n) alloc(h.size());
+    alloc(h.size() + kUploadSlack);
     dev_upload(p, h.data(), h.size() * sizeof(double));
   }
 };
