@@ -386,7 +386,7 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
     Bands mtx = bands_axpy(hholtz_mat_a(make_base(kChebDirichlet, fourier ? 9 : n)), -1e-6,
                            hholtz_mat_b(make_base(kChebDirichlet, fourier ? 9 : n)));
     fdma_sweep(mtx);
-    FdmaDev fd = upload_fdma(fdma_tables(mtx));
+    FdmaDev fd = upload_fdma(fdma_tables(mtx), ax.slot_len);
     const long ld = pitch(n + 2);
     DBuf in((size_t)nlines * ld), out((size_t)nlines * ld);
     {

@@ -285,7 +285,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kTranspose: launch_transpose(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, st_); break;
     case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
-    case Launch::kSetElem: launch_set_element(l.out, 0, 0.0, st_); break;
+    case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
   }
 }
 
@@ -570,14 +570,16 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S5 x: div + poisson precond-x");
   }
   // ---- G1: eigen-space transform along x (NT GEMM absorbs the YX -> XY transpose)
-  add_gemm(false, po.me, ny, po.me, po.fwd_e.p(), po.fwd_e.ld, Y_[1].p, ldx, X_[0].p, ldy, "G1 even");
-  add_gemm(false, po.mo, ny, po.mo, po.fwd_o.p(), po.fwd_o.ld, Y_[1].p + po.half, ldx,
+  // only the first my = ny - 2 columns are needed: the B2 preconditioner of the next stage never
+  // reads the last two orthonormal coefficients (matvec.rs:215-226), and 4095 = 32 x 128 tiles
+  add_gemm(false, po.me, my, po.me, po.fwd_e.p(), po.fwd_e.ld, Y_[1].p, ldx, X_[0].p, ldy, "G1 even");
+  add_gemm(false, po.mo, my, po.mo, po.fwd_o.p(), po.fwd_o.ld, Y_[1].p + po.half, ldx,
            X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
   // ---- S6: y preconditioner + per-eigenvalue banded solves
   {
     ProgramBuilder pb(1, sly, mx);
     pb.set_fft(yN);
-    pb.load(0, pb.arr(X_[0].p, ldy), ny);
+    pb.load(0, pb.arr(X_[0].p, ldy), my);   // columns my, my+1 only meet zero table entries
     pb.pinv_matvec(0, yN);
     pb.fdma_solve(0, my, po.rows);
     pb.store(0, pb.arr(X_[1].p, ldy), my);
@@ -648,8 +650,195 @@ void Navier2DEngine::build_confined() {
   add_transpose(X_[1].p, ldy, GY_.p, ldx, nx, ny, 1, "T7");
 }
 
+// ==========================================================================================
+// periodic step: Fourier (x) x Chebyshev (y).  Same structure as the confined step; the x-line
+// programs use the real FFT, multiplication by i k and the diagonal Helmholtz factor instead of
+// DCT, stencils and banded solves, and there is no GEMM (the x operator is already diagonal:
+// src/field.rs:244, src/solver/fdma_tensor.rs:118-121).  Spectral x-lines are interleaved
+// complex; y-line programs run once per component (grid.y = 2, element stride 2).
 void Navier2DEngine::build_periodic() {
-  fail("periodic engine not built yet");
+  step_.clear();
+  const int nx = nx_, ny = ny_, my = my_, kx = kx_;
+  const int nc = 2 * kx;                         // doubles in a spectral x-line
+  AxisTables& xF = sp_vel_->axis(0);             // Fourier(nx)
+  AxisTables& yD = sp_vel_->axis(1);             // Dirichlet(ny)
+  AxisTables& yN = sp_pseu_->axis(1);            // Neumann(ny)
+  const int slx = xF.slot_len, sly = yD.slot_len;
+  const long ldx = ldx_, ldy = ldy_;
+  const double dt = dt_;
+  const int cut_x = kx * 2 / 3, cut_y = ny * 2 / 3;
+
+  // ---- S1: spectral x-lines -> physical x (value and x-derivative)
+  struct { DBuf* st; DBuf* w0; DBuf* w1; } s1[3] = {
+      {&U_, &Y_[0], &Y_[1]}, {&V_, &Y_[2], &Y_[3]}, {&T_, &Y_[4], &Y_[5]}};
+  for (auto& f : s1)
+    for (int deriv = 0; deriv < 2; ++deriv) {
+      ProgramBuilder pb(1, slx, my);
+      pb.set_fft(xF);
+      pb.load(0, pb.arr(f.st->p, ldx), nc);
+      if (deriv) pb.cik(0, 0, kx, 1.0 / sx_, 1);
+      pb.rfft_b(0, nx);
+      pb.store(0, pb.arr((deriv ? f.w1 : f.w0)->p, ldx), nx);
+      add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
+    }
+  for (int k = 0; k < 6; ++k) add_transpose(Y_[k].p, ldx, X_[k].p, ldy, my, nx, 1, "T1");
+  // ---- S2: identical to the confined case (real y-lines at physical x)
+  auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {
+    pb.load(2, pb.arr(src.p, ldy), my);
+    pb.to_ortho(2, yD);
+    if (deriv) pb.cdiff(2, 2, ny, 1.0 / sy_);
+    pb.dct(2, ny, yD.bwd_pre.p, nullptr);
+  };
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+    ProgramBuilder pb(4, sly, nx);
+    pb.set_fft(yD);
+    phys(pb, X_[0], false);
+    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
+    phys(pb, fx, false);
+    if (bx) pb.load(2, pb.arr(bx->p, ldy), ny, 1.0, true);
+    pb.mul(1, 0, 2, ny);
+    phys(pb, X_[2], false);
+    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
+    phys(pb, f0, true);
+    if (by) pb.load(2, pb.arr(by->p, ldy), ny, 1.0, true);
+    pb.mul(1, 0, 2, ny, 1.0, true);
+    pb.axpby(2, 1, 1.0, 1, 0.0, ny);
+    pb.dct(2, ny, nullptr, yD.fwd_post.p);
+    pb.zero(2, cut_y, ny);
+    pb.store(2, pb.arr(out.p, ldy), ny);
+    add_line(pb, tag);
+  };
+  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
+  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
+  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
+  for (int k = 0; k < 3; ++k) add_transpose(X_[6 + k].p, ldy, Y_[k].p, ldx, nx, ny, 1, "T2");
+  // ---- S3: forward real FFT in x, RHS assembly, diagonal Helmholtz factor in x
+  auto rhs = [&](int which, const char* tag) {
+    DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
+    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+    ProgramBuilder pb(2, slx, ny);
+    pb.set_fft(xF);
+    pb.load(0, pb.arr(Y_[which].p, ldx), nx);
+    pb.rfft_f(0, nx);
+    pb.zero(0, 2 * cut_x, nc);
+    pb.loadx(1, pb.arr(state.p, ldx), nc, my, yD.low.p);
+    pb.axpby(0, 0, -dt, 1, 1.0, nc);
+    if (which == 0) {
+      pb.load(1, pb.arr(P_.p, ldx), nc);
+      pb.cik(1, 1, kx, 1.0 / sx_, 1);
+      pb.axpby(0, 0, 1.0, 1, -dt, nc);
+    } else if (which == 1) {
+      pb.load(0, pb.arr(GY_.p, ldx), nc, -dt, true);
+      pb.loadx(1, pb.arr(T_.p, ldx), nc, my, yD.low.p);
+      pb.load(1, pb.arr(TBC_.p, ldx), nc, 1.0, true);
+      pb.axpby(0, 0, 1.0, 1, dt, nc);
+    } else {
+      pb.load(0, pb.arr(TBC2_.p, ldx), nc, dt * ka_, true);
+    }
+    pb.tabdiv(0, 0, nc, hh.diag0.p, 1);
+    pb.store(0, pb.arr(Y_[3 + which].p, ldx), nc);
+    add_line(pb, tag);
+  };
+  rhs(0, "S3 x: rhs + hholtz-x velx");
+  rhs(1, "S3 x: rhs + hholtz-x vely");
+  rhs(2, "S3 x: rhs + hholtz-x temp");
+  for (int k = 0; k < 3; ++k) add_transpose(Y_[3 + k].p, ldx, X_[k].p, ldy, ny, kx, 2, "T3");
+  // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
+  for (int which = 0; which < 3; ++which) {
+    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+    ProgramBuilder pb(1, sly, kx, 2);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), ny);
+    pb.pinv_matvec(0, yD);
+    pb.fdma_solve(0, my, hh.fdma[1]);
+    pb.store(0, pb.arr(X_[3 + which].p, ldy, 2, 1), my);
+    if (which == 1) {
+      pb.zero(0, my, sly);
+      pb.to_ortho(0, yD);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.store(0, pb.arr(X_[6].p, ldy, 2, 1), ny);
+    }
+    add_line(pb, "S4 y: hholtz-y");
+  }
+  add_transpose(X_[3].p, ldy, U_.p, ldx, kx, my, 2, "T4");
+  add_transpose(X_[4].p, ldy, V_.p, ldx, kx, my, 2, "T4");
+  add_transpose(X_[5].p, ldy, T_.p, ldx, kx, my, 2, "T4");
+  add_transpose(X_[6].p, ldy, Y_[0].p, ldx, kx, ny, 2, "T4");
+  // ---- S5: divergence
+  {
+    ProgramBuilder pb(1, slx, ny);
+    pb.set_fft(xF);
+    pb.loadx(0, pb.arr(U_.p, ldx), nc, my, yD.low.p);
+    pb.cik(0, 0, kx, 1.0 / sx_, 1);
+    pb.load(0, pb.arr(Y_[0].p, ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(DIV_.p, ldx), nc);
+    add_line(pb, "S5 x: div");
+  }
+  add_transpose(DIV_.p, ldx, X_[0].p, ldy, ny, kx, 2, "T5a");
+  // ---- S6: Poisson: y preconditioner + one banded solve per wavenumber
+  PoissonOp& po = *pois_;
+  {
+    ProgramBuilder pb(1, sly, kx, 2);
+    pb.set_fft(yN);
+    pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
+    pb.pinv_matvec(0, yN);
+    pb.fdma_solve(0, my, po.rows);
+    pb.store(0, pb.arr(PS_.p, ldy, 2, 1), my);
+    add_line(pb, "S6 y: poisson rows");
+  }
+  for (int e = 0; e < 2; ++e) {
+    Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.rows = e; l.tag = "pseu[0,0]=0"; step_.push_back(l);
+  }
+  // ---- S7: y part of the velocity correction
+  {
+    ProgramBuilder pb(2, sly, kx, 2);
+    pb.set_fft(yN);
+    pb.load(0, pb.arr(PS_.p, ldy, 2, 1), my);
+    pb.to_ortho(0, yN);
+    pb.cdiff(1, 0, ny, -1.0 / sy_);
+    pb.from_ortho(0, yD);
+    pb.store(0, pb.arr(X_[2].p, ldy, 2, 1), my);
+    pb.from_ortho(1, yD);
+    pb.store(1, pb.arr(X_[3].p, ldy, 2, 1), my);
+    add_line(pb, "S7 y: correction-y");
+  }
+  add_transpose(X_[2].p, ldy, Y_[2].p, ldx, kx, my, 2, "T5");
+  add_transpose(X_[3].p, ldy, Y_[3].p, ldx, kx, my, 2, "T5");
+  add_transpose(PS_.p, ldy, Y_[4].p, ldx, kx, my, 2, "T5");
+  // ---- S8: x part of the velocity correction
+  {
+    ProgramBuilder pb(1, slx, my);
+    pb.set_fft(xF);
+    pb.load(0, pb.arr(Y_[2].p, ldx), nc);
+    pb.cik(0, 0, kx, -1.0 / sx_, 1);
+    pb.load(0, pb.arr(U_.p, ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(U_.p, ldx), nc);
+    pb.load(0, pb.arr(Y_[3].p, ldx), nc);
+    pb.load(0, pb.arr(V_.p, ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(V_.p, ldx), nc);
+    add_line(pb, "S8 x: correction-x");
+  }
+  // ---- S9: pressure update
+  {
+    ProgramBuilder pb(1, slx, ny);
+    pb.set_fft(xF);
+    pb.loadx(0, pb.arr(Y_[4].p, ldx), nc, my, yN.low.p, 1.0 / dt);
+    pb.load(0, pb.arr(DIV_.p, ldx), nc, -nu_, true);
+    pb.load(0, pb.arr(P_.p, ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(P_.p, ldx), nc);
+    add_line(pb, "S9 x: pressure update");
+  }
+  // ---- d/dy pres for the next step
+  add_transpose(P_.p, ldx, X_[0].p, ldy, ny, kx, 2, "T6");
+  {
+    ProgramBuilder pb(1, sly, kx, 2);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
+    pb.cdiff(0, 0, ny, 1.0 / sy_);
+    pb.store(0, pb.arr(X_[1].p, ldy, 2, 1), ny);
+    add_line(pb, "S10 y: d/dy pres");
+  }
+  add_transpose(X_[1].p, ldy, GY_.p, ldx, kx, ny, 2, "T7");
 }
 
 }  // namespace rpde

@@ -276,16 +276,39 @@ void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, St
 #endif
 
 // =================================================================================== common
+static int class_index(int slot_len) {
+  if (slot_len <= CfgS::kMaxSlotLen) return 0;
+  if (slot_len <= CfgM::kMaxSlotLen) return 1;
+  if (slot_len <= CfgL::kMaxSlotLen) return 2;
+  return -1;
+}
+LineClass line_class_for(int slot_len) {
+  switch (class_index(slot_len)) {
+    case 0: return {CfgS::T, CfgS::C};
+    case 1: return {CfgM::T, CfgM::C};
+    case 2: return {CfgL::T, CfgL::C};
+    default: fail("line too long for one workgroup: slot length " + std::to_string(slot_len));
+  }
+}
+std::vector<double> chunk_major(const std::vector<double>& tab, LineClass lc, int dir, double pad) {
+  std::vector<double> out((size_t)lc.T * lc.C, pad);
+  for (int t = 0; t < lc.T; ++t)
+    for (int i = 0; i < lc.C; ++i) {
+      const size_t k = (size_t)(dir > 0 ? t : lc.T - 1 - t) * lc.C + i;
+      if (k < tab.size()) out[(size_t)i * lc.T + t] = tab[k];
+    }
+  return out;
+}
+
 void launch_line_program(const Program& pg, Stream& st) {
   RPDE_REQUIRE(pg.nops > 0 && pg.nops <= kMaxOps, "bad line program");
   if (pg.nlines <= 0 || pg.ncomp <= 0) return;
   const int sl = pg.slot_len;
-  auto fits = [&](int tmax, int fmin, int fmax) {
-    return sl <= tmax && (pg.fft_n == 0 || (pg.fft_n >= fmin && pg.fft_n <= fmax));
-  };
-  if (fits(CfgS::kMaxSlotLen, CfgS::FMIN, CfgS::FMAX)) launch_cfg<CfgS>(pg, st);
-  else if (fits(CfgM::kMaxSlotLen, CfgM::FMIN, CfgM::FMAX)) launch_cfg<CfgM>(pg, st);
-  else if (fits(CfgL::kMaxSlotLen, CfgL::FMIN, CfgL::FMAX)) launch_cfg<CfgL>(pg, st);
+  const int ci = class_index(sl);
+  auto fft_ok = [&](int fmin, int fmax) { return pg.fft_n == 0 || (pg.fft_n >= fmin && pg.fft_n <= fmax); };
+  if (ci == 0 && fft_ok(CfgS::FMIN, CfgS::FMAX)) launch_cfg<CfgS>(pg, st);
+  else if (ci == 1 && fft_ok(CfgM::FMIN, CfgM::FMAX)) launch_cfg<CfgM>(pg, st);
+  else if (ci == 2 && fft_ok(CfgL::FMIN, CfgL::FMAX)) launch_cfg<CfgL>(pg, st);
   else fail("no line-kernel configuration for slot length " + std::to_string(sl) +
             " / FFT length " + std::to_string(pg.fft_n) +
             " (supported: Chebyshev n = 2^k + 1 <= 4097, Fourier nx = 2^k <= 4096, or any n <= 500"

@@ -15,6 +15,14 @@ inline int slot_len_for(int maxlen) {
   return (need + 1) & ~1;
 }
 
+// kernel configuration (threads per line, scan chunk per thread) used for a given slot length
+struct LineClass { int T, C; };
+LineClass line_class_for(int slot_len);
+
+// Re-order a recurrence table for the chunked scans: out[i * T + t] = tab[tau(t) * C + i] with
+// tau(t) = t (dir > 0) or T - 1 - t (dir < 0); entries past the end of `tab` are `pad`.
+std::vector<double> chunk_major(const std::vector<double>& tab, LineClass lc, int dir, double pad = 0.0);
+
 // run a line program: grid = (nlines, ncomp), one workgroup per line
 void launch_line_program(const Program& pg, Stream& st);
 

@@ -538,6 +538,16 @@ RPDE_HD inline Affine<ORDER> affine_compose(const Affine<ORDER>& second, const A
   return r;
 }
 
+template <int ORDER>
+RPDE_HD inline Affine<ORDER> affine_select(bool c, const Affine<ORDER>& a, const Affine<ORDER>& b) {
+  Affine<ORDER> r = b;
+  r.m11 = c ? a.m11 : b.m11; r.v1 = c ? a.v1 : b.v1;
+  if constexpr (ORDER == 2) {
+    r.m12 = c ? a.m12 : b.m12; r.m21 = c ? a.m21 : b.m21; r.m22 = c ? a.m22 : b.m22; r.v2 = c ? a.v2 : b.v2;
+  }
+  return r;
+}
+
 #ifndef RPDE_EMU
 template <int ORDER>
 __device__ __forceinline__ Affine<ORDER> affine_shfl_up(const Affine<ORDER>& a, int off) {
@@ -569,7 +579,7 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
 #pragma unroll
     for (int i = 0; i < C; ++i) {
       double b, q, r = 0.0;
-      fill(lo + i, b, q, r);
+      fill(lo + i, i * T + tid, b, q, r);
       RPDE_T(bb)[i] = b; RPDE_T(qq)[i] = q; RPDE_T(rr)[i] = r;
     }
 #pragma unroll
@@ -628,13 +638,12 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
 #pragma unroll
       for (int par = 0; par < 2; ++par) {   // the two parities give two independent chains
         const Affine<ORDER> prev = affine_shfl_up<ORDER>(inc[par], off);
-        if (lane >= off) inc[par] = affine_compose<ORDER>(inc[par], prev);
+        inc[par] = affine_select<ORDER>(lane >= off, affine_compose<ORDER>(inc[par], prev), inc[par]);
       }
     }
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      exc[par] = affine_shfl_up<ORDER>(inc[par], 1);
-      if (lane == 0) exc[par] = affine_identity<ORDER>();
+      exc[par] = affine_select<ORDER>(lane == 0, affine_identity<ORDER>(), affine_shfl_up<ORDER>(inc[par], 1));
     }
     if constexpr (NW > 1) {
       if (lane == 63) {
@@ -648,11 +657,16 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
       __syncthreads();
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
-        Affine<ORDER> pre = affine_identity<ORDER>();
-        for (int w = 0; w < wave; ++w) {
+        Affine<ORDER> tot[NW];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) {   // one batch of LDS reads, then a register-only chain
           clds_t p = carry + (par * NW + w) * W;
-          pre = affine_compose<ORDER>(Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]}, pre);
+          tot[w] = Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]};
         }
+        Affine<ORDER> pre = affine_identity<ORDER>();
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+          pre = affine_select<ORDER>(w < wave, affine_compose<ORDER>(tot[w], pre), pre);
         exc[par] = affine_compose<ORDER>(exc[par], pre);
       }
     }
@@ -692,18 +706,22 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
   RPDE_SYNC(blk);
 }
 
-struct FillRec {   // generic table-driven recurrence: x_k = p_k src_k + q_k x_pred (+ r_k x_pred2)
+// generic table-driven recurrence: x_k = p_k src_k + q_k x_pred (+ r_k x_pred2).  The tables are
+// stored CHUNK-MAJOR for the kernel configuration (entry [i * T + t] belongs to element i of the
+// chunk thread t owns, see chunk_major() in kernels.h), so that a wave reads 512 contiguous bytes.
+template <bool HASP, bool HASR>
+struct FillRec {
   clds_t src; tab_t pt; tab_t qt; tab_t rt;
-  RPDE_DEV void operator()(int k, double& b, double& q, double& r) const {
+  RPDE_DEV void operator()(int k, int ti, double& b, double& q, double& r) const {
     const double s = src[k];
-    b = pt ? pt[k] * s : s;
-    q = qt[k];
-    if (rt) r = rt[k];
+    if constexpr (HASP) b = pt[ti] * s; else b = s;
+    q = qt[ti];
+    if constexpr (HASR) r = rt[ti];
   }
 };
 struct FillDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
   clds_t src; int n;
-  RPDE_DEV void operator()(int k, double& b, double& q, double&) const {
+  RPDE_DEV void operator()(int k, int, double& b, double& q, double&) const {
     const double s = src[k + 1];
     b = (k + 1 < n) ? 2.0 * (double)(k + 1) * s : 0.0;
     q = 1.0;
@@ -849,13 +867,20 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_REC1: {
-        const FillRec f{a, op.tab >= 0 ? (tab_t)(pg.tabs[op.tab] + toff) : (tab_t) nullptr, (tab_t)(pg.tabs[op.i0] + toff), (tab_t) nullptr};
-        if (op.i1 > 0) scan_recurrence<Cfg, 1, +1>(blk, d, n, carry, f);
-        else scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, f);
+        tab_t qt = (tab_t)(pg.tabs[op.i0] + toff);
+        if (op.tab >= 0) {
+          const FillRec<true, false> f{a, (tab_t)(pg.tabs[op.tab] + toff), qt, (tab_t) nullptr};
+          if (op.i1 > 0) scan_recurrence<Cfg, 1, +1>(blk, d, n, carry, f);
+          else scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, f);
+        } else {
+          const FillRec<false, false> f{a, (tab_t) nullptr, qt, (tab_t) nullptr};
+          if (op.i1 > 0) scan_recurrence<Cfg, 1, +1>(blk, d, n, carry, f);
+          else scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, f);
+        }
       } break;
       case OP_REC2: {
-        const FillRec f{a, op.tab >= 0 ? (tab_t)(pg.tabs[op.tab] + toff) : (tab_t) nullptr, (tab_t)(pg.tabs[op.i0] + toff),
-                        (tab_t)(pg.tabs[op.i1] + toff)};
+        const FillRec<true, true> f{a, (tab_t)(pg.tabs[op.tab] + toff), (tab_t)(pg.tabs[op.i0] + toff),
+                                    (tab_t)(pg.tabs[op.i1] + toff)};
         scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f);
       } break;
       case OP_DCT: {

@@ -29,7 +29,9 @@ AxisTables::AxisTables(const Base& b) : base(b) {
       low.upload(stencil_low(b));
       FromOrthoTables f = from_ortho_tables(b);
       fo_t0.upload(f.t0); fo_t1.upload(f.t1); fo_t2.upload(f.t2);
-      fo_pup.upload(f.p_up); fo_qup.upload(f.q_up); fo_qdn.upload(f.q_dn);
+      const LineClass lc = line_class_for(slot_len);
+      fo_pup.upload(chunk_major(f.p_up, lc, +1)); fo_qup.upload(chunk_major(f.q_up, lc, +1));
+      fo_qdn.upload(chunk_major(f.q_dn, lc, -1));
     }
   } else {
     RPDE_REQUIRE(is_pow2(b.n) && b.n >= 4 && b.n <= 4096,
@@ -41,10 +43,14 @@ AxisTables::AxisTables(const Base& b) : base(b) {
   }
 }
 
-FdmaDev upload_fdma(const FdmaTables& t) {
+FdmaDev upload_fdma(const FdmaTables& t, int slot_len) {
   FdmaDev d;
   d.n = (int)t.p2.size();
-  d.q1.upload(t.q1); d.p2.upload(t.p2); d.q2.upload(t.q2); d.r2.upload(t.r2);
+  const LineClass lc = line_class_for(slot_len);
+  d.q1.upload(chunk_major(t.q1, lc, +1));
+  d.p2.upload(chunk_major(t.p2, lc, -1, 1.0));
+  d.q2.upload(chunk_major(t.q2, lc, -1));
+  d.r2.upload(chunk_major(t.r2, lc, -1));
   return d;
 }
 
@@ -320,7 +326,7 @@ HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
       RPDE_REQUIRE(b.is_composite(), "HholtzAdi: orthonormal Chebyshev base is not supported");
       Bands mtx = bands_axpy(hholtz_mat_a(b), -c[axis], hholtz_mat_b(b));
       fdma_sweep(mtx);
-      fdma[axis] = upload_fdma(fdma_tables(mtx));
+      fdma[axis] = upload_fdma(fdma_tables(mtx), sp.axis(axis).slot_len);
     } else {
       Vec d(b.m);
       for (int k = 0; k < b.m; ++k) d[k] = 1.0 - (-(double)k * (double)k) * c[axis];
@@ -384,16 +390,19 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
   const Bands ay = bands_axpy(Bands{Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0)}, c1,
                               hholtz_mat_b(b1));
   const Bands cy = hholtz_mat_a(b1);
-  const long ld = pitch(m1);
+  const LineClass lc = line_class_for(sp.axis(1).slot_len);
+  const long ld = (long)lc.T * lc.C;   // one chunk-major table row per x-row
   Vec q1((size_t)m0 * ld, 0.0), p2((size_t)m0 * ld, 0.0), q2((size_t)m0 * ld, 0.0), r2((size_t)m0 * ld, 0.0);
   for (int r = 0; r < m0; ++r) {
     Bands mtx = bands_axpy(ay, lam[r], cy);
     fdma_sweep(mtx);
     FdmaTables t = fdma_tables(mtx);
-    std::copy(t.q1.begin(), t.q1.end(), q1.begin() + (size_t)r * ld);
-    std::copy(t.p2.begin(), t.p2.end(), p2.begin() + (size_t)r * ld);
-    std::copy(t.q2.begin(), t.q2.end(), q2.begin() + (size_t)r * ld);
-    std::copy(t.r2.begin(), t.r2.end(), r2.begin() + (size_t)r * ld);
+    const Vec a = chunk_major(t.q1, lc, +1), b = chunk_major(t.p2, lc, -1, 1.0),
+              c = chunk_major(t.q2, lc, -1), d = chunk_major(t.r2, lc, -1);
+    std::copy(a.begin(), a.end(), q1.begin() + (size_t)r * ld);
+    std::copy(b.begin(), b.end(), p2.begin() + (size_t)r * ld);
+    std::copy(c.begin(), c.end(), q2.begin() + (size_t)r * ld);
+    std::copy(d.begin(), d.end(), r2.begin() + (size_t)r * ld);
   }
   rows.n = m1;
   rows.tabld = ld;

@@ -38,7 +38,7 @@ struct FdmaDev {
   long tabld = 0;
   int n = 0;
 };
-FdmaDev upload_fdma(const FdmaTables& t);
+FdmaDev upload_fdma(const FdmaTables& t, int slot_len);
 
 // ------------------------------------------------------------------------------------------
 class ProgramBuilder {

@@ -44,6 +44,11 @@ def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 
 
+@pytest.mark.parametrize("nx,ny,steps,aspect", [(16, 17, 5, 1.0), (32, 33, 10, 1.0), (64, 33, 10, 1.0), (32, 17, 5, 2.0)])
+def test_periodic_step(emu_lib, nx, ny, steps, aspect):
+    K.check_step_parity(emu_lib, True, nx, ny, 1e5, 0.01, steps, aspect=aspect, check_at=[1, 2, steps])
+
+
 def test_errors_mirror_reference_panics(emu_lib):
     with pytest.raises(R.RpdeError, match="not recognized"):
         R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "xyz", library=emu_lib)

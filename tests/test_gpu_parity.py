@@ -64,3 +64,13 @@ def test_confined_step(hip_lib, nx, ny, ra, dt, steps):
 
 def test_confined_257(hip_lib):
     K.check_step_parity(hip_lib, False, 257, 257, 1e6, 0.005, 40, check_at=[40])
+
+
+@pytest.mark.parametrize("nx,ny,steps,aspect", [(16, 17, 5, 1.0), (64, 33, 10, 1.0), (128, 65, 20, 2.0), (256, 129, 50, 1.0)])
+def test_periodic_step(hip_lib, nx, ny, steps, aspect):
+    K.check_step_parity(hip_lib, True, nx, ny, 1e5, 0.01, steps, aspect=aspect, check_at=[1, 2, steps])
+
+
+def test_periodic_config3_first_steps(hip_lib):
+    """BASELINE.json configs[2]: periodic 4096 x 1025, Ra = 1e8 -- parity on the first 3 steps."""
+    K.check_step_parity(hip_lib, True, 4096, 1025, 1e8, 5e-4, 3, check_at=[1, 3])
