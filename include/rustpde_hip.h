@@ -47,6 +47,19 @@ int rpde_navier2d_create_confined(int nx, int ny, double ra, double pr, double d
 /* Navier2D::new_periodic(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes/navier.rs:336-428 */
 int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
                                   const char* bc, int device, rpde_navier2d** out);
+/* Pencil-sharded engine = Navier2DMpi (src/navier_stokes_mpi/navier.rs:216-336, 364-486): rank r of
+ * nranks owns a slab of every field; layout changes call `alltoallv` (the role of funspace's
+ * Decomp2d::transpose_x_to_y / transpose_y_to_x = MPI_Alltoallv, src/field_mpi.rs:456-477).
+ * The callback gets buffers that live where the engine's arrays live (HBM); segment q of `send`
+ * (sendcounts[q] doubles) goes to rank q, segment s of `recv` arrives from rank s; it must return 0
+ * once the data has landed.  rustpde_mpi_amd/dist.py implements it with torch.distributed (RCCL). */
+typedef int (*rpde_alltoallv_fn)(void* user, const double* send, const int64_t* sendcounts,
+                                 double* recv, const int64_t* recvcounts);
+int rpde_navier2d_create_sharded(int periodic, int nx, int ny, double ra, double pr, double dt,
+                                 double aspect, const char* bc, int device, int rank, int nranks,
+                                 rpde_alltoallv_fn alltoallv, void* user, rpde_navier2d** out);
+/* bytes this rank sends per time step through `alltoallv`, and the number of exchanges per step */
+int rpde_navier2d_comm_stats(rpde_navier2d* h, double* bytes_per_step, int* exchanges_per_step);
 int rpde_navier2d_destroy(rpde_navier2d* h);
 /* set_velocity / set_temperature / init_random / reset_time  src/navier_stokes/navier.rs:161-187 */
 int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n);

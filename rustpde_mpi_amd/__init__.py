@@ -116,22 +116,38 @@ class Navier2D:
             setattr(self, name, _FieldView(self, name))
 
     @classmethod
-    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic):
+    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic, comm=None):
         library = library or lib()
         h = C.c_void_p()
-        library.call(fn, int(nx), int(ny), float(ra), float(pr), float(dt), float(aspect),
-                     str(bc).encode(), int(device), C.byref(h))
-        return cls(h, int(nx), int(ny), periodic, library)
+        if comm is not None and comm.size > 1:
+            # pencil-sharded engine (the reference's Navier2DMpi): `comm` supplies rank, size and the
+            # all-to-all (rustpde_mpi_amd.dist.TorchComm); every rank passes the same arguments
+            library.call("rpde_navier2d_create_sharded", int(periodic), int(nx), int(ny), float(ra),
+                         float(pr), float(dt), float(aspect), str(bc).encode(), int(device),
+                         int(comm.rank), int(comm.size), C.cast(comm.c_callback, C.c_void_p), None,
+                         C.byref(h))
+        else:
+            library.call(fn, int(nx), int(ny), float(ra), float(pr), float(dt), float(aspect),
+                         str(bc).encode(), int(device), C.byref(h))
+        obj = cls(h, int(nx), int(ny), periodic, library)
+        obj._comm = comm   # keeps the ctypes callback alive
+        return obj
 
     @classmethod
-    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None):
         return cls._new("rpde_navier2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device,
-                        library, False)
+                        library, False, comm)
 
     @classmethod
-    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None):
         return cls._new("rpde_navier2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device,
-                        library, True)
+                        library, True, comm)
+
+    def comm_stats(self):
+        """(bytes this rank sends per step, exchanges per step) of the pencil all-to-alls."""
+        b, n = C.c_double(), C.c_int()
+        self._lib.call("rpde_navier2d_comm_stats", self._h, C.byref(b), C.byref(n))
+        return b.value, n.value
 
     def __del__(self):
         try:

@@ -26,6 +26,10 @@ SIGNATURES = {
                                                 C.c_double, C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "rpde_navier2d_create_periodic": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                 C.c_double, C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "rpde_navier2d_create_sharded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                               C.c_double, C.c_char_p, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                               C.POINTER(_vp)]),
+    "rpde_navier2d_comm_stats": (C.c_int, [_vp, _dp, _ip]),
     "rpde_navier2d_destroy": (C.c_int, [_vp]),
     "rpde_navier2d_set_velocity": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
     "rpde_navier2d_set_temperature": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
@@ -65,6 +69,9 @@ SIGNATURES = {
     "rpde_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]),
     "rpde_microbench": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }
+
+
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.POINTER(C.c_int64), _vp, C.POINTER(C.c_int64))
 
 
 class RpdeError(RuntimeError):

@@ -89,6 +89,32 @@ int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double d
                                   const char* bc, int device, rpde_navier2d** out) {
   return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, true, out);
 }
+int rpde_navier2d_create_sharded(int periodic, int nx, int ny, double ra, double pr, double dt,
+                                 double aspect, const char* bc, int device, int rank, int nranks,
+                                 rpde_alltoallv_fn alltoallv, void* user, rpde_navier2d** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out && bc, "null pointer");
+    select_device(device);
+    CommCb cb;
+    cb.rank = rank; cb.size = nranks; cb.fn = alltoallv; cb.user = user;
+    auto* h = new rpde_navier2d{nullptr, device};
+    try {
+      h->e = new Navier2DEngine(nx, ny, ra, pr, dt, aspect, bc, periodic != 0, &cb);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  })
+}
+int rpde_navier2d_comm_stats(rpde_navier2d* h, double* bytes_per_step, int* exchanges_per_step) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(bytes_per_step && exchanges_per_step, "null pointer");
+    *bytes_per_step = h->e->exchange_bytes_per_step();
+    *exchanges_per_step = h->e->exchanges_per_step();
+  })
+}
 int rpde_navier2d_destroy(rpde_navier2d* h) {
   RPDE_TRY({
     if (h) { select_device(h->device); delete h->e; delete h; }

@@ -17,9 +17,18 @@ struct Navier2DEngine::Field {
 static double get_nu(double ra, double pr, double h) { return std::sqrt(pr / (ra / std::pow(h, 3.0))); }
 static double get_ka(double ra, double pr, double h) { return std::sqrt(1.0 / ((ra / std::pow(h, 3.0)) * pr)); }
 
+std::vector<int> Navier2DEngine::split(int n, int parts) {
+  std::vector<int> p(parts + 1, 0);
+  for (int r = 0; r < parts; ++r) p[r + 1] = p[r] + n / parts + (r < n % parts ? 1 : 0);
+  return p;
+}
+
 Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                               const std::string& bc, bool periodic)
+                               const std::string& bc, bool periodic, const CommCb* comm)
     : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
+  if (comm) comm_ = *comm;
+  RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
+  RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr, "sharded engine needs an all-to-all callback");
   RPDE_REQUIRE(bc == "rbc", "Boundary condition type \"" + bc + "\" not recognized! (supported: \"rbc\")");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
@@ -43,13 +52,25 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
 
   ldx_ = pitch(periodic ? nx + 2 : nx);
   ldy_ = pitch((long)ny * ex_);
-  const size_t nyx = (size_t)ny * ldx_;
-  const size_t nxy = (size_t)nx * ldy_;
+  const int P = comm_.size;
+  ypart_ = split(ny, P);
+  xpart_ = split(nx, P);
+  kpart_ = periodic ? split(kx_, P) : xpart_;
+  yb_ = ypart_[comm_.rank]; ye_ = ypart_[comm_.rank + 1];
+  nyl_ = ye_ - yb_;
+  nxl_ = std::max(xpart_[comm_.rank + 1] - xpart_[comm_.rank], kpart_[comm_.rank + 1] - kpart_[comm_.rank]);
+  RPDE_REQUIRE(P == 1 || (nyl_ >= 2 && nxl_ >= 2), "too many ranks for this grid (need >= 2 lines per rank)");
+  const size_t nyx = (size_t)(nyl_ + 2) * ldx_;      // two halo rows in front (cross-line y stencil)
+  const size_t nxy = (size_t)nxl_ * ldy_;
   for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy);
   red_.alloc(2);
+  if (P > 1) {
+    const size_t m = std::max((size_t)nyl_ * ldx_, (size_t)nxl_ * ldy_) + 64;
+    sendbuf_.alloc(m); recvbuf_.alloc(m);
+  }
 
   auto mk = [&](const char* name, Space2Ops* sp, DBuf* buf, bool yx, bool ortho) {
     auto f = std::make_unique<Field>();
@@ -74,7 +95,9 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
     Arr2 v(nx, ny, 1), vh(so.ortho_rows(), ny, ex_), g(so.ortho_rows(), ny, ex_), g2(so.ortho_rows(), ny, ex_);
     dev_upload2d(v.p(), v.ld, prof.data(), nx, ny);
     so.forward(v, vh, st_);
-    launch_transpose(vh.p(), vh.ld, TBC_.p, ldx_, vh.rows, vh.cols, ex_, st_);
+    DBuf fyx((size_t)ny * ldx_), fxy((size_t)nx * ldy_);   // full-size staging (setup only)
+    launch_transpose(vh.p(), vh.ld, fyx.p, ldx_, vh.rows, vh.cols, ex_, st_);
+    scatter_rows_yx(fyx.p, ldx_, TBC_, ny, (int)ldx_);
     // dt * ka * (d2/dx2 + d2/dy2) tempbc enters solve_temp (navier_eq.rs:214-218)
     so.gradient(vh, 2, 0, sx_, sy_, g, st_);
     so.gradient(vh, 0, 2, sx_, sy_, g2, st_);
@@ -84,17 +107,16 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
       pb.load(0, a, ny); pb.load(0, b, ny, 1.0, true); pb.store(0, a, ny);
       pb.run(st_);
     }
-    launch_transpose(g.p(), g.ld, TBC2_.p, ldx_, g.rows, g.cols, ex_, st_);
+    launch_transpose(g.p(), g.ld, fyx.p, ldx_, g.rows, g.cols, ex_, st_);
+    scatter_rows_yx(fyx.p, ldx_, TBC2_, ny, (int)ldx_);
     // physical gradients of the lift for the temperature convection (navier_eq.rs:66-69)
     Arr2 ph(nx, ny, 1);
     so.gradient(vh, 1, 0, sx_, sy_, g, st_);
     so.backward(g, ph, st_);
-    launch_transpose(ph.p(), ph.ld, Y_[0].p, ldx_, nx, ny, 1, st_);
-    launch_transpose(Y_[0].p, ldx_, BX_.p, ldy_, ny, nx, 1, st_);
+    scatter_rows_xy(ph.p(), ph.ld, BX_, nx, ny, false);
     so.gradient(vh, 0, 1, sx_, sy_, g, st_);
     so.backward(g, ph, st_);
-    launch_transpose(ph.p(), ph.ld, Y_[0].p, ldx_, nx, ny, 1, st_);
-    launch_transpose(Y_[0].p, ldx_, BY_.p, ldy_, ny, nx, 1, st_);
+    scatter_rows_xy(ph.p(), ph.ld, BY_, nx, ny, false);
     dev_sync(st_);
   }
   if (periodic) build_periodic(); else build_confined();
@@ -139,10 +161,18 @@ void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
-  if (f.yx) launch_transpose(f.buf->p, ldx_, out.p(), out.ld, c, r, e, st_);
-  else {  // XY with pitch ldy_: two transposes through scratch keep the kernel set small
-    launch_transpose(f.buf->p, ldy_, Y_[0].p, ldx_, r, c, e, st_);
-    launch_transpose(Y_[0].p, ldx_, out.p(), out.ld, c, r, e, st_);
+  const bool spec = periodic_;
+  if (f.yx) {   // rows = y index (c of them), row length r * e doubles
+    DBuf full((size_t)ny_ * ldx_);
+    gather_rows(yx(*f.buf), ldx_, ny_, ypart_, full.p);
+    launch_transpose(full.p, ldx_, out.p(), out.ld, c, r, e, st_);
+    dev_sync(st_);
+  } else {      // XY with pitch ldy_: rows = x index
+    const std::vector<int>& part = spec ? kpart_ : xpart_;
+    DBuf full((size_t)part.back() * ldy_);
+    gather_rows(f.buf->p, ldy_, part.back(), part, full.p);
+    launch_copy2d(full.p, ldy_, out.p(), out.ld, r, c * e, st_);
+    dev_sync(st_);
   }
 }
 
@@ -150,12 +180,91 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(in.rows == r && in.cols == c && in.elem == e, "internal: canonical shape");
-  if (f.yx) launch_transpose(in.p(), in.ld, f.buf->p, ldx_, r, c, e, st_);
-  else {
-    launch_transpose(in.p(), in.ld, Y_[0].p, ldx_, r, c, e, st_);
-    launch_transpose(Y_[0].p, ldx_, f.buf->p, ldy_, c, r, e, st_);
+  if (f.yx) {
+    DBuf full((size_t)ny_ * ldx_);
+    launch_transpose(in.p(), in.ld, full.p, ldx_, r, c, e, st_);
+    scatter_rows_yx(full.p, ldx_, *f.buf, c, r * e);
+  } else {
+    scatter_rows_xy(in.p(), in.ld, *f.buf, r, c * e, periodic_);
   }
+  dev_sync(st_);
   if (f.name == "pres") refresh_gy();
+}
+
+// ------------------------------------------------------------------------------------------
+// communication helpers
+void Navier2DEngine::alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv,
+                               const std::vector<int64_t>& rc) {
+  dev_sync(st_);
+  const int rcode = comm_.fn(comm_.user, send, sc.data(), recv, rc.data());
+  RPDE_REQUIRE(rcode == 0, "all-to-all callback failed");
+}
+
+void Navier2DEngine::scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols) {
+  const int n = ylines(rows);
+  launch_copy2d(full + (size_t)yb_ * ldf, ldf, yx(dst), ldx_, n, ncols, st_);
+  dev_sync(st_);
+}
+void Navier2DEngine::scatter_rows_xy(const double* full, long ldf, DBuf& dst, int rows, int ncols, bool spec) {
+  const int n = xlines(rows, spec);
+  launch_copy2d(full + (size_t)xb(spec) * ldf, ldf, dst.p, ldy_, n, ncols, st_);
+  dev_sync(st_);
+}
+void Navier2DEngine::gather_rows(const double* local, long ld, int rows_global,
+                                 const std::vector<int>& part, double* full) {
+  const int P = comm_.size, me = comm_.rank;
+  const int nloc = clampi(std::min(part[me + 1], rows_global) - part[me], 0, rows_global);
+  if (P == 1) {
+    launch_copy2d(local, ld, full, ld, nloc, (int)ld, st_);
+    dev_sync(st_);
+    return;
+  }
+  DBuf snd((size_t)P * nloc * ld + 8);
+  std::vector<int64_t> sc(P), rc(P);
+  for (int q = 0; q < P; ++q) {
+    launch_copy2d(local, ld, snd.p + (size_t)q * nloc * ld, ld, nloc, (int)ld, st_);
+    sc[q] = (int64_t)nloc * ld;
+    rc[q] = (int64_t)clampi(std::min(part[q + 1], rows_global) - part[q], 0, rows_global) * ld;
+  }
+  alltoallv(snd.p, sc, full, rc);
+}
+
+void Navier2DEngine::exchange(const double* in, long ldi, double* out, long ldo, int rows, int cols,
+                              int elem, bool to_xy, bool spec) {
+  const int P = comm_.size, me = comm_.rank;
+  const std::vector<int>& xp = spec ? kpart_ : xpart_;
+  const std::vector<int>& inpart = to_xy ? ypart_ : xp;    // splits the input's rows
+  const std::vector<int>& outpart = to_xy ? xp : ypart_;   // splits the input's cols = output rows
+  auto cnt = [&](const std::vector<int>& p, int q, int n) { return clampi(std::min(p[q + 1], n) - std::min(p[q], n), 0, n); };
+  const int rl = cnt(inpart, me, rows);        // local input rows
+  const int cl = cnt(outpart, me, cols);       // local output rows
+  if (P == 1) { launch_transpose(in, ldi, out, ldo, rows, cols, elem, st_); return; }
+  std::vector<int64_t> sc(P), rc(P);
+  size_t off = 0;
+  for (int q = 0; q < P; ++q) {    // pack: block (rl x cq) -> transposed (cq x rl), contiguous per destination
+    const int c0 = std::min(outpart[q], cols), cq = cnt(outpart, q, cols);
+    launch_transpose(in + (size_t)c0 * elem, ldi, sendbuf_.p + off, (long)rl * elem, rl, cq, elem, st_);
+    sc[q] = (int64_t)cq * rl * elem;
+    off += (size_t)sc[q];
+    rc[q] = (int64_t)cl * cnt(inpart, q, rows) * elem;
+  }
+  alltoallv(sendbuf_.p, sc, recvbuf_.p, rc);
+  off = 0;
+  for (int s = 0; s < P; ++s) {    // unpack: segment (cl x rs) -> out[:, r0 : r0 + rs]
+    const int r0 = std::min(inpart[s], rows), rs = cnt(inpart, s, rows);
+    launch_copy2d(recvbuf_.p + off, (long)rs * elem, out + (size_t)r0 * elem, ldo, cl, rs * elem, st_);
+    off += (size_t)rc[s];
+  }
+}
+
+void Navier2DEngine::halo(double* base, long ld, int ncols) {
+  (void)ncols;
+  const int P = comm_.size, me = comm_.rank;
+  if (P == 1) return;
+  std::vector<int64_t> sc(P, 0), rc(P, 0);
+  if (me + 1 < P) sc[me + 1] = 2 * ld;
+  if (me > 0) rc[me - 1] = 2 * ld;
+  alltoallv(base + (size_t)(nyl_ - 2) * ld, sc, base - 2 * ld, rc);
 }
 
 void Navier2DEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
@@ -261,12 +370,24 @@ void Navier2DEngine::add_line(const ProgramBuilder& pb, const char* tag) {
   step_.push_back(l);
 }
 void Navier2DEngine::add_transpose(const double* in, long ldi, double* out, long ldo, int rows,
-                                   int cols, int elem, const char* tag) {
+                                   int cols, int elem, bool to_xy, bool spec, const char* tag) {
   Launch l;
   l.type = Launch::kTranspose;
   l.in = in; l.ldi = ldi; l.out = out; l.ldo = ldo; l.rows = rows; l.cols = cols; l.elem = elem;
+  l.to_xy = to_xy; l.spec = spec;
   l.tag = tag;
-  l.bytes = 16.0 * rows * (double)cols * elem;
+  l.bytes = 16.0 * rows * (double)cols * elem / comm_.size;
+  if (comm_.size > 1) {
+    xchg_bytes_ += 8.0 * rows * (double)cols * elem / comm_.size * (comm_.size - 1) / comm_.size;
+    xchg_count_ += 1;
+  }
+  step_.push_back(l);
+}
+void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
+  if (comm_.size == 1) return;
+  Launch l;
+  l.type = Launch::kHalo;
+  l.out = base; l.cols = ncols; l.tag = tag;
   step_.push_back(l);
 }
 void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, long lda,
@@ -282,7 +403,8 @@ void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, lon
 void Navier2DEngine::run_launch(const Launch& l) {
   switch (l.type) {
     case Launch::kLine: launch_line_program(l.pg, st_); break;
-    case Launch::kTranspose: launch_transpose(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, st_); break;
+    case Launch::kTranspose: exchange(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, l.to_xy, l.spec); break;
+    case Launch::kHalo: halo(l.out, ldx_, l.cols); break;
     case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
@@ -419,21 +541,31 @@ bool Navier2DEngine::exit() { return std::isnan(div_norm()); }
 
 // d/dy of the pressure in YX layout, used by the vely right-hand side (navier_eq.rs:195)
 void Navier2DEngine::refresh_gy() {
+  const bool spec = periodic_;
   const int rows_x = sp_ortho_->ortho_rows();
-  launch_transpose(P_.p, ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, st_);
-  ProgramBuilder pb(1, sp_ortho_->axis(1).slot_len, rows_x, ex_);
+  exchange(yx(P_), ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, true, spec);
+  ProgramBuilder pb(1, sp_ortho_->axis(1).slot_len, xlines(rows_x, spec), ex_);
   pb.set_fft(sp_ortho_->axis(1));
+  pb.set_line0(xb(spec));
   const int a = pb.arr(X_[0].p, ldy_, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(X_[1].p, ldy_, ex_, ex_ == 2 ? 1 : 0);
   pb.load(0, a, ny_); pb.cdiff(0, 0, ny_, 1.0 / sy_); pb.store(0, b, ny_);
   pb.run(st_);
-  launch_transpose(X_[1].p, ldy_, GY_.p, ldx_, rows_x, ny_, ex_, st_);
+  exchange(X_[1].p, ldy_, yx(GY_), ldx_, rows_x, ny_, ex_, false, spec);
+  dev_sync(st_);
 }
 
 // ==========================================================================================
+// The step.  One builder serves one GPU and P pencil-sharded ranks: line programs run on the local
+// lines (Program::line0 = global index of the first one), every layout change is
+// `add_transpose` = LDS-tiled transpose on one GPU, pack + all-to-all + unpack when sharded, and the
+// cross-line y stencils read two halo rows from the previous rank.
+//
 // confined step: Chebyshev x Chebyshev
 void Navier2DEngine::build_confined() {
   step_.clear();
+  xchg_bytes_ = 0.0; xchg_count_ = 0;
   const int nx = nx_, ny = ny_, mx = mx_, my = my_;
+  const int P = comm_.size;
   AxisTables& xD = sp_vel_->axis(0);   // Dirichlet(nx)
   AxisTables& xN = sp_temp_->axis(0);  // Neumann(nx)
   AxisTables& yD = sp_vel_->axis(1);   // Dirichlet(ny)
@@ -442,7 +574,25 @@ void Navier2DEngine::build_confined() {
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = nx * 2 / 3, cut_y = ny * 2 / 3;
+  // builders for programs over y-indexed lines (YX arrays) and x-indexed lines (XY arrays)
+  auto ypb = [&](int nslots, int rows) {
+    ProgramBuilder pb(nslots, slx, ylines(rows));
+    pb.set_line0(yb_);
+    return pb;
+  };
+  auto xpb = [&](int nslots, int rows) {
+    ProgramBuilder pb(nslots, sly, xlines(rows, false));
+    pb.set_line0(xb(false));
+    return pb;
+  };
+  auto T = [&](const double* in, double* out, int rows, int cols, bool to_xy, const char* tag) {
+    add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 1, to_xy, false, tag);
+  };
 
+  // ---- halos of the state for the cross-line y stencils of S3
+  add_halo(yx(U_), (int)ldx, "H0 halo velx");
+  add_halo(yx(V_), (int)ldx, "H0 halo vely");
+  add_halo(yx(T_), (int)ldx, "H0 halo temp");
   // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
   struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
@@ -450,29 +600,28 @@ void Navier2DEngine::build_confined() {
     // two programs of two LDS slots each (the DCT works in place across slots 0 and 1), so
     // that two workgroups fit on a CU; the price is reading the state line twice
     for (int deriv = 0; deriv < 2; ++deriv) {
-      ProgramBuilder pb(2, slx, my);
+      ProgramBuilder pb = ypb(2, my);
       pb.set_fft(*f.ax);
-      pb.load(0, pb.arr(f.st->p, ldx), mx);
+      pb.load(0, pb.arr(yx(*f.st), ldx), mx);
       pb.to_ortho(0, *f.ax);
       if (deriv) pb.cdiff(0, 0, nx, 1.0 / sx_);
       pb.dct(0, nx, f.ax->bwd_pre.p, nullptr);
-      pb.store(0, pb.arr((deriv ? f.w1 : f.w0)->p, ldx), nx);
+      pb.store(0, pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx), nx);
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
   }
   // ---- T1: to XY
-  for (int k = 0; k < 6; ++k) add_transpose(Y_[k].p, ldx, X_[k].p, ldy, my, nx, 1, "T1");
+  for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
   auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {  // slot 2 <- physical line
-    const int a = pb.arr(src.p, ldy);
-    pb.load(2, a, my);
+    pb.load(2, pb.arr(src.p, ldy), my);
     pb.to_ortho(2, yD);
     if (deriv) pb.cdiff(2, 2, ny, 1.0 / sy_);
     pb.dct(2, ny, yD.bwd_pre.p, nullptr);
   };
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ], u = W0U, v = W0V
-    ProgramBuilder pb(4, sly, nx);
+    ProgramBuilder pb = xpb(4, nx);
     pb.set_fft(yD);
     phys(pb, X_[0], false);                 // u
     pb.axpby(0, 2, 1.0, 2, 0.0, ny);
@@ -494,47 +643,47 @@ void Navier2DEngine::build_confined() {
   conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
   conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
   // ---- T2: conv terms to YX
-  for (int k = 0; k < 3; ++k) add_transpose(X_[6 + k].p, ldy, Y_[k].p, ldx, nx, ny, 1, "T2");
+  for (int k = 0; k < 3; ++k) T(X_[6 + k].p, yx(Y_[k]), nx, ny, false, "T2");
   // ---- S3: x-lines: forward x transform, RHS assembly, x part of the ADI Helmholtz solve
   auto rhs = [&](int which, const char* tag) {  // 0 velx, 1 vely, 2 temp
     AxisTables& ax = which == 2 ? xN : xD;
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(2, slx, ny);
+    ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(ax);
-    pb.load(0, pb.arr(Y_[which].p, ldx), nx);                // conv term first: the DCT needs both slots
+    pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
     pb.dct(0, nx, nullptr, ax.fwd_post.p);
     pb.zero(0, cut_x, nx);
-    pb.loadx(1, pb.arr(state.p, ldx), mx, my, yD.low.p);     // S_y (cross-line), Dirichlet in y
+    pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
     pb.to_ortho(1, ax);                                       // S_x
     pb.axpby(0, 0, -dt, 1, 1.0, nx);
     if (which == 0) {
-      pb.load(1, pb.arr(P_.p, ldx), nx);
+      pb.load(1, pb.arr(yx(P_), ldx), nx);
       pb.cdiff(1, 1, nx, 1.0 / sx_);
       pb.axpby(0, 0, 1.0, 1, -dt, nx);
     } else if (which == 1) {
-      pb.load(0, pb.arr(GY_.p, ldx), nx, -dt, true);
-      pb.loadx(1, pb.arr(T_.p, ldx), mx, my, yD.low.p);       // buoyancy: temp.to_ortho() + tempbc
+      pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
+      pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
       pb.to_ortho(1, xN);
-      pb.load(1, pb.arr(TBC_.p, ldx), nx, 1.0, true);
+      pb.load(1, pb.arr(yx(TBC_), ldx), nx, 1.0, true);
       pb.axpby(0, 0, 1.0, 1, dt, nx);
     } else {
-      pb.load(0, pb.arr(TBC2_.p, ldx), nx, dt * ka_, true);
+      pb.load(0, pb.arr(yx(TBC2_), ldx), nx, dt * ka_, true);
     }
     pb.pinv_matvec(0, ax);
     pb.fdma_solve(0, mx, hh.fdma[0]);
-    pb.store(0, pb.arr(Y_[3 + which].p, ldx), mx);
+    pb.store(0, pb.arr(yx(Y_[3 + which]), ldx), mx);
     add_line(pb, tag);
   };
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
   // ---- T3
-  for (int k = 0; k < 3; ++k) add_transpose(Y_[3 + k].p, ldx, X_[k].p, ldy, ny, mx, 1, "T3");
+  for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, ny, mx, true, "T3");
   // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(1, sly, mx);
+    ProgramBuilder pb = xpb(1, mx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[which].p, ldy), ny);
     pb.pinv_matvec(0, yD);
@@ -549,35 +698,46 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S4 y: hholtz-y");
   }
   // ---- T4: new (uncorrected) state back to YX
-  add_transpose(X_[3].p, ldy, U_.p, ldx, mx, my, 1, "T4");
-  add_transpose(X_[4].p, ldy, V_.p, ldx, mx, my, 1, "T4");
-  add_transpose(X_[5].p, ldy, T_.p, ldx, mx, my, 1, "T4");
-  add_transpose(X_[6].p, ldy, Y_[0].p, ldx, mx, ny, 1, "T4");
+  T(X_[3].p, yx(U_), mx, my, false, "T4");
+  T(X_[4].p, yx(V_), mx, my, false, "T4");
+  T(X_[5].p, yx(T_), mx, my, false, "T4");
+  T(X_[6].p, yx(Y_[0]), mx, ny, false, "T4");
+  add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
   PoissonOp& po = *pois_;
   {
-    ProgramBuilder pb(2, slx, ny);
+    ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(xD);
-    pb.loadx(0, pb.arr(U_.p, ldx), mx, my, yD.low.p);
+    pb.loadx(0, pb.arr(yx(U_), ldx), mx, my, yD.low.p);
     pb.to_ortho(0, xD);
     pb.cdiff(0, 0, nx, 1.0 / sx_);
-    pb.load(1, pb.arr(Y_[0].p, ldx), mx);
+    pb.load(1, pb.arr(yx(Y_[0]), ldx), mx);
     pb.to_ortho(1, xD);
     pb.axpby(0, 0, 1.0, 1, 1.0, nx);
-    pb.store(0, pb.arr(DIV_.p, ldx), nx);
+    pb.store(0, pb.arr(yx(DIV_), ldx), nx);
     pb.pinv_matvec(0, xN);
-    pb.store(0, pb.arr(Y_[1].p, ldx), mx, 1.0, po.half);
+    pb.store(0, pb.arr(yx(Y_[1]), ldx), mx, 1.0, po.half);
     add_line(pb, "S5 x: div + poisson precond-x");
   }
-  // ---- G1: eigen-space transform along x (NT GEMM absorbs the YX -> XY transpose)
-  // only the first my = ny - 2 columns are needed: the B2 preconditioner of the next stage never
-  // reads the last two orthonormal coefficients (matvec.rs:215-226), and 4095 = 32 x 128 tiles
-  add_gemm(false, po.me, my, po.me, po.fwd_e.p(), po.fwd_e.ld, Y_[1].p, ldx, X_[0].p, ldy, "G1 even");
-  add_gemm(false, po.mo, my, po.mo, po.fwd_o.p(), po.fwd_o.ld, Y_[1].p + po.half, ldx,
-           X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
-  // ---- S6: y preconditioner + per-eigenvalue banded solves
+  const int myl = ylines(my);
+  if (P == 1) {
+    // ---- G1: eigen-space transform along x (NT GEMM absorbs the YX -> XY transpose).
+    // only the first my = ny - 2 columns are needed: the B2 preconditioner of the next stage never
+    // reads the last two orthonormal coefficients (matvec.rs:215-226), and 4095 = 32 x 128 tiles
+    add_gemm(false, po.me, my, po.me, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[1]), ldx, X_[0].p, ldy, "G1 even");
+    add_gemm(false, po.mo, my, po.mo, po.fwd_o.p(), po.fwd_o.ld, yx(Y_[1]) + po.half, ldx,
+             X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
+  } else {
+    // sharded: x is complete on every rank in YX layout, so both GEMMs are local there
+    // (src/solver_mpi/poisson.rs:166,186): C[j, k] = sum_i R[j, i] fwd[k, i], then exchange
+    add_gemm(false, myl, po.me, po.me, yx(Y_[1]), ldx, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[2]), ldx, "G1 even");
+    add_gemm(false, myl, po.mo, po.mo, yx(Y_[1]) + po.half, ldx, po.fwd_o.p(), po.fwd_o.ld,
+             yx(Y_[2]) + po.me, ldx, "G1 odd");
+    T(yx(Y_[2]), X_[0].p, my, mx, true, "T4b");
+  }
+  // ---- S6: y preconditioner + per-eigenvalue banded solves (line index = eigen index)
   {
-    ProgramBuilder pb(1, sly, mx);
+    ProgramBuilder pb = xpb(1, mx);
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy), my);   // columns my, my+1 only meet zero table entries
     pb.pinv_matvec(0, yN);
@@ -585,16 +745,31 @@ void Navier2DEngine::build_confined() {
     pb.store(0, pb.arr(X_[1].p, ldy), my);
     add_line(pb, "S6 y: poisson rows");
   }
-  // ---- G2: back to coefficient space (rows of one parity are 2 ldy apart)
-  add_gemm(true, po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy, "G2 even");
-  add_gemm(true, po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
-           PS_.p + ldy, 2 * ldy, "G2 odd");
-  {
-    Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.tag = "pseu[0,0]=0"; step_.push_back(l);
+  if (P == 1) {
+    // ---- G2: back to coefficient space (rows of one parity are 2 ldy apart)
+    add_gemm(true, po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy, "G2 even");
+    add_gemm(true, po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
+             PS_.p + ldy, 2 * ldy, "G2 odd");
+    { Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.tag = "pseu[0,0]=0"; step_.push_back(l); }
+  } else {
+    T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");
+    // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land de-interleaved in x
+    add_gemm(false, myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[3]), ldx, "G2 even");
+    add_gemm(false, myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld,
+             yx(Y_[3]) + po.half, ldx, "G2 odd");
+    {
+      ProgramBuilder pb = ypb(1, my);
+      pb.set_fft(xN);
+      pb.load(0, pb.arr(yx(Y_[3]), ldx), mx, 1.0, false, po.half);
+      pb.store(0, pb.arr(yx(Y_[4]), ldx), mx);
+      add_line(pb, "G2 x: interleave parities");
+    }
+    if (yb_ == 0) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
+    T(yx(Y_[4]), PS_.p, my, mx, true, "T4d");
   }
   // ---- S7: y part of the velocity correction
   {
-    ProgramBuilder pb(2, sly, mx);
+    ProgramBuilder pb = xpb(2, mx);
     pb.set_fft(yN);
     pb.load(0, pb.arr(PS_.p, ldy), my);
     pb.to_ortho(0, yN);
@@ -606,48 +781,49 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S7 y: correction-y");
   }
   // ---- T5
-  add_transpose(X_[2].p, ldy, Y_[2].p, ldx, mx, my, 1, "T5");
-  add_transpose(X_[3].p, ldy, Y_[3].p, ldx, mx, my, 1, "T5");
-  add_transpose(PS_.p, ldy, Y_[4].p, ldx, mx, my, 1, "T5");
+  T(X_[2].p, yx(Y_[2]), mx, my, false, "T5");
+  T(X_[3].p, yx(Y_[3]), mx, my, false, "T5");
+  if (P == 1) T(PS_.p, yx(Y_[4]), mx, my, false, "T5");
+  add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   // ---- S8: x part of the velocity correction
   {
-    ProgramBuilder pb(1, slx, my);
+    ProgramBuilder pb = ypb(1, my);
     pb.set_fft(xD);
-    pb.load(0, pb.arr(Y_[2].p, ldx), mx);
+    pb.load(0, pb.arr(yx(Y_[2]), ldx), mx);
     pb.to_ortho(0, xN);
     pb.cdiff(0, 0, nx, -1.0 / sx_);
     pb.from_ortho(0, xD);
-    pb.load(0, pb.arr(U_.p, ldx), mx, 1.0, true);
-    pb.store(0, pb.arr(U_.p, ldx), mx);
-    pb.load(0, pb.arr(Y_[3].p, ldx), mx);
+    pb.load(0, pb.arr(yx(U_), ldx), mx, 1.0, true);
+    pb.store(0, pb.arr(yx(U_), ldx), mx);
+    pb.load(0, pb.arr(yx(Y_[3]), ldx), mx);
     pb.to_ortho(0, xN);
     pb.from_ortho(0, xD);
-    pb.load(0, pb.arr(V_.p, ldx), mx, 1.0, true);
-    pb.store(0, pb.arr(V_.p, ldx), mx);
+    pb.load(0, pb.arr(yx(V_), ldx), mx, 1.0, true);
+    pb.store(0, pb.arr(yx(V_), ldx), mx);
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
   {
-    ProgramBuilder pb(1, slx, ny);
+    ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xN);
-    pb.loadx(0, pb.arr(Y_[4].p, ldx), mx, my, yN.low.p, 1.0 / dt);
+    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt);
     pb.to_ortho(0, xN);
-    pb.load(0, pb.arr(DIV_.p, ldx), nx, -nu_, true);
-    pb.load(0, pb.arr(P_.p, ldx), nx, 1.0, true);
-    pb.store(0, pb.arr(P_.p, ldx), nx);
+    pb.load(0, pb.arr(yx(DIV_), ldx), nx, -nu_, true);
+    pb.load(0, pb.arr(yx(P_), ldx), nx, 1.0, true);
+    pb.store(0, pb.arr(yx(P_), ldx), nx);
     add_line(pb, "S9 x: pressure update");
   }
   // ---- T6 / S10 / T7: d/dy pres for the next step
-  add_transpose(P_.p, ldx, X_[0].p, ldy, ny, nx, 1, "T6");
+  T(yx(P_), X_[0].p, ny, nx, true, "T6");
   {
-    ProgramBuilder pb(1, sly, nx);
+    ProgramBuilder pb = xpb(1, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[0].p, ldy), ny);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.store(0, pb.arr(X_[1].p, ldy), ny);
     add_line(pb, "S10 y: d/dy pres");
   }
-  add_transpose(X_[1].p, ldy, GY_.p, ldx, nx, ny, 1, "T7");
+  T(X_[1].p, yx(GY_), nx, ny, false, "T7");
 }
 
 // ==========================================================================================
@@ -658,6 +834,7 @@ void Navier2DEngine::build_confined() {
 // complex; y-line programs run once per component (grid.y = 2, element stride 2).
 void Navier2DEngine::build_periodic() {
   step_.clear();
+  xchg_bytes_ = 0.0; xchg_count_ = 0;
   const int nx = nx_, ny = ny_, my = my_, kx = kx_;
   const int nc = 2 * kx;                         // doubles in a spectral x-line
   AxisTables& xF = sp_vel_->axis(0);             // Fourier(nx)
@@ -667,21 +844,41 @@ void Navier2DEngine::build_periodic() {
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = kx * 2 / 3, cut_y = ny * 2 / 3;
+  auto ypb = [&](int nslots, int rows) {
+    ProgramBuilder pb(nslots, slx, ylines(rows));
+    pb.set_line0(yb_);
+    return pb;
+  };
+  auto xpb = [&](int nslots, int rows, bool spec) {   // spec: spectral x rows (complex, 2 components)
+    ProgramBuilder pb(nslots, sly, xlines(rows, spec), spec ? 2 : 1);
+    pb.set_line0(xb(spec));
+    return pb;
+  };
+  // real physical-x arrays <-> XY rows over xpart_; complex spectral arrays <-> XY rows over kpart_
+  auto Tr = [&](const double* in, double* out, int rows, int cols, bool to_xy, const char* tag) {
+    add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 1, to_xy, false, tag);
+  };
+  auto Tc = [&](const double* in, double* out, int rows, int cols, bool to_xy, const char* tag) {
+    add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 2, to_xy, true, tag);
+  };
 
+  add_halo(yx(U_), (int)ldx, "H0 halo velx");
+  add_halo(yx(V_), (int)ldx, "H0 halo vely");
+  add_halo(yx(T_), (int)ldx, "H0 halo temp");
   // ---- S1: spectral x-lines -> physical x (value and x-derivative)
   struct { DBuf* st; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &Y_[0], &Y_[1]}, {&V_, &Y_[2], &Y_[3]}, {&T_, &Y_[4], &Y_[5]}};
   for (auto& f : s1)
     for (int deriv = 0; deriv < 2; ++deriv) {
-      ProgramBuilder pb(1, slx, my);
+      ProgramBuilder pb = ypb(1, my);
       pb.set_fft(xF);
-      pb.load(0, pb.arr(f.st->p, ldx), nc);
+      pb.load(0, pb.arr(yx(*f.st), ldx), nc);
       if (deriv) pb.cik(0, 0, kx, 1.0 / sx_, 1);
       pb.rfft_b(0, nx);
-      pb.store(0, pb.arr((deriv ? f.w1 : f.w0)->p, ldx), nx);
+      pb.store(0, pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx), nx);
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
-  for (int k = 0; k < 6; ++k) add_transpose(Y_[k].p, ldx, X_[k].p, ldy, my, nx, 1, "T1");
+  for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {
     pb.load(2, pb.arr(src.p, ldy), my);
@@ -690,7 +887,7 @@ void Navier2DEngine::build_periodic() {
     pb.dct(2, ny, yD.bwd_pre.p, nullptr);
   };
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
-    ProgramBuilder pb(4, sly, nx);
+    ProgramBuilder pb = xpb(4, nx, false);
     pb.set_fft(yD);
     phys(pb, X_[0], false);
     pb.axpby(0, 2, 1.0, 2, 0.0, ny);
@@ -711,42 +908,42 @@ void Navier2DEngine::build_periodic() {
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
   conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
   conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
-  for (int k = 0; k < 3; ++k) add_transpose(X_[6 + k].p, ldy, Y_[k].p, ldx, nx, ny, 1, "T2");
+  for (int k = 0; k < 3; ++k) Tr(X_[6 + k].p, yx(Y_[k]), nx, ny, false, "T2");
   // ---- S3: forward real FFT in x, RHS assembly, diagonal Helmholtz factor in x
   auto rhs = [&](int which, const char* tag) {
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(2, slx, ny);
+    ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(xF);
-    pb.load(0, pb.arr(Y_[which].p, ldx), nx);
+    pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);
     pb.rfft_f(0, nx);
     pb.zero(0, 2 * cut_x, nc);
-    pb.loadx(1, pb.arr(state.p, ldx), nc, my, yD.low.p);
+    pb.loadx(1, pb.arr(yx(state), ldx), nc, my, yD.low.p);
     pb.axpby(0, 0, -dt, 1, 1.0, nc);
     if (which == 0) {
-      pb.load(1, pb.arr(P_.p, ldx), nc);
+      pb.load(1, pb.arr(yx(P_), ldx), nc);
       pb.cik(1, 1, kx, 1.0 / sx_, 1);
       pb.axpby(0, 0, 1.0, 1, -dt, nc);
     } else if (which == 1) {
-      pb.load(0, pb.arr(GY_.p, ldx), nc, -dt, true);
-      pb.loadx(1, pb.arr(T_.p, ldx), nc, my, yD.low.p);
-      pb.load(1, pb.arr(TBC_.p, ldx), nc, 1.0, true);
+      pb.load(0, pb.arr(yx(GY_), ldx), nc, -dt, true);
+      pb.loadx(1, pb.arr(yx(T_), ldx), nc, my, yD.low.p);
+      pb.load(1, pb.arr(yx(TBC_), ldx), nc, 1.0, true);
       pb.axpby(0, 0, 1.0, 1, dt, nc);
     } else {
-      pb.load(0, pb.arr(TBC2_.p, ldx), nc, dt * ka_, true);
+      pb.load(0, pb.arr(yx(TBC2_), ldx), nc, dt * ka_, true);
     }
     pb.tabdiv(0, 0, nc, hh.diag0.p, 1);
-    pb.store(0, pb.arr(Y_[3 + which].p, ldx), nc);
+    pb.store(0, pb.arr(yx(Y_[3 + which]), ldx), nc);
     add_line(pb, tag);
   };
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  for (int k = 0; k < 3; ++k) add_transpose(Y_[3 + k].p, ldx, X_[k].p, ldy, ny, kx, 2, "T3");
+  for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, ny, kx, true, "T3");
   // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb(1, sly, kx, 2);
+    ProgramBuilder pb = xpb(1, kx, true);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), ny);
     pb.pinv_matvec(0, yD);
@@ -760,25 +957,26 @@ void Navier2DEngine::build_periodic() {
     }
     add_line(pb, "S4 y: hholtz-y");
   }
-  add_transpose(X_[3].p, ldy, U_.p, ldx, kx, my, 2, "T4");
-  add_transpose(X_[4].p, ldy, V_.p, ldx, kx, my, 2, "T4");
-  add_transpose(X_[5].p, ldy, T_.p, ldx, kx, my, 2, "T4");
-  add_transpose(X_[6].p, ldy, Y_[0].p, ldx, kx, ny, 2, "T4");
+  Tc(X_[3].p, yx(U_), kx, my, false, "T4");
+  Tc(X_[4].p, yx(V_), kx, my, false, "T4");
+  Tc(X_[5].p, yx(T_), kx, my, false, "T4");
+  Tc(X_[6].p, yx(Y_[0]), kx, ny, false, "T4");
+  add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence
   {
-    ProgramBuilder pb(1, slx, ny);
+    ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xF);
-    pb.loadx(0, pb.arr(U_.p, ldx), nc, my, yD.low.p);
+    pb.loadx(0, pb.arr(yx(U_), ldx), nc, my, yD.low.p);
     pb.cik(0, 0, kx, 1.0 / sx_, 1);
-    pb.load(0, pb.arr(Y_[0].p, ldx), nc, 1.0, true);
-    pb.store(0, pb.arr(DIV_.p, ldx), nc);
+    pb.load(0, pb.arr(yx(Y_[0]), ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(yx(DIV_), ldx), nc);
     add_line(pb, "S5 x: div");
   }
-  add_transpose(DIV_.p, ldx, X_[0].p, ldy, ny, kx, 2, "T5a");
+  Tc(yx(DIV_), X_[0].p, ny, kx, true, "T5a");
   // ---- S6: Poisson: y preconditioner + one banded solve per wavenumber
   PoissonOp& po = *pois_;
   {
-    ProgramBuilder pb(1, sly, kx, 2);
+    ProgramBuilder pb = xpb(1, kx, true);
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
     pb.pinv_matvec(0, yN);
@@ -786,12 +984,13 @@ void Navier2DEngine::build_periodic() {
     pb.store(0, pb.arr(PS_.p, ldy, 2, 1), my);
     add_line(pb, "S6 y: poisson rows");
   }
-  for (int e = 0; e < 2; ++e) {
-    Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.rows = e; l.tag = "pseu[0,0]=0"; step_.push_back(l);
-  }
+  if (xb(true) == 0)
+    for (int e = 0; e < 2; ++e) {
+      Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.rows = e; l.tag = "pseu[0,0]=0"; step_.push_back(l);
+    }
   // ---- S7: y part of the velocity correction
   {
-    ProgramBuilder pb(2, sly, kx, 2);
+    ProgramBuilder pb = xpb(2, kx, true);
     pb.set_fft(yN);
     pb.load(0, pb.arr(PS_.p, ldy, 2, 1), my);
     pb.to_ortho(0, yN);
@@ -802,43 +1001,44 @@ void Navier2DEngine::build_periodic() {
     pb.store(1, pb.arr(X_[3].p, ldy, 2, 1), my);
     add_line(pb, "S7 y: correction-y");
   }
-  add_transpose(X_[2].p, ldy, Y_[2].p, ldx, kx, my, 2, "T5");
-  add_transpose(X_[3].p, ldy, Y_[3].p, ldx, kx, my, 2, "T5");
-  add_transpose(PS_.p, ldy, Y_[4].p, ldx, kx, my, 2, "T5");
+  Tc(X_[2].p, yx(Y_[2]), kx, my, false, "T5");
+  Tc(X_[3].p, yx(Y_[3]), kx, my, false, "T5");
+  Tc(PS_.p, yx(Y_[4]), kx, my, false, "T5");
+  add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   // ---- S8: x part of the velocity correction
   {
-    ProgramBuilder pb(1, slx, my);
+    ProgramBuilder pb = ypb(1, my);
     pb.set_fft(xF);
-    pb.load(0, pb.arr(Y_[2].p, ldx), nc);
+    pb.load(0, pb.arr(yx(Y_[2]), ldx), nc);
     pb.cik(0, 0, kx, -1.0 / sx_, 1);
-    pb.load(0, pb.arr(U_.p, ldx), nc, 1.0, true);
-    pb.store(0, pb.arr(U_.p, ldx), nc);
-    pb.load(0, pb.arr(Y_[3].p, ldx), nc);
-    pb.load(0, pb.arr(V_.p, ldx), nc, 1.0, true);
-    pb.store(0, pb.arr(V_.p, ldx), nc);
+    pb.load(0, pb.arr(yx(U_), ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(yx(U_), ldx), nc);
+    pb.load(0, pb.arr(yx(Y_[3]), ldx), nc);
+    pb.load(0, pb.arr(yx(V_), ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(yx(V_), ldx), nc);
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
   {
-    ProgramBuilder pb(1, slx, ny);
+    ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xF);
-    pb.loadx(0, pb.arr(Y_[4].p, ldx), nc, my, yN.low.p, 1.0 / dt);
-    pb.load(0, pb.arr(DIV_.p, ldx), nc, -nu_, true);
-    pb.load(0, pb.arr(P_.p, ldx), nc, 1.0, true);
-    pb.store(0, pb.arr(P_.p, ldx), nc);
+    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), nc, my, yN.low.p, 1.0 / dt);
+    pb.load(0, pb.arr(yx(DIV_), ldx), nc, -nu_, true);
+    pb.load(0, pb.arr(yx(P_), ldx), nc, 1.0, true);
+    pb.store(0, pb.arr(yx(P_), ldx), nc);
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step
-  add_transpose(P_.p, ldx, X_[0].p, ldy, ny, kx, 2, "T6");
+  Tc(yx(P_), X_[0].p, ny, kx, true, "T6");
   {
-    ProgramBuilder pb(1, sly, kx, 2);
+    ProgramBuilder pb = xpb(1, kx, true);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.store(0, pb.arr(X_[1].p, ldy, 2, 1), ny);
     add_line(pb, "S10 y: d/dy pres");
   }
-  add_transpose(X_[1].p, ldy, GY_.p, ldx, kx, ny, 2, "T7");
+  Tc(X_[1].p, yx(GY_), kx, ny, false, "T7");
 }
 
 }  // namespace rpde

@@ -12,10 +12,23 @@
 
 namespace rpde {
 
+// personalised all-to-all on buffers of doubles that live where the engine's arrays live (HBM in
+// the HIP build): segment q of `send` (sendcounts[q] doubles) goes to rank q, segment s of `recv`
+// arrives from rank s.  Returns 0 on success.  Called from inside update() with the engine's
+// stream drained; the data must have landed when it returns.  (funspace Decomp2d::transpose_* =
+// MPI_Alltoallv in the reference, src/field_mpi.rs:456-477.)
+typedef int (*AllToAllvFn)(void* user, const double* send, const int64_t* sendcounts, double* recv,
+                           const int64_t* recvcounts);
+struct CommCb {
+  int rank = 0, size = 1;
+  AllToAllvFn fn = nullptr;
+  void* user = nullptr;
+};
+
 class Navier2DEngine {
  public:
   Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                 const std::string& bc, bool periodic);
+                 const std::string& bc, bool periodic, const CommCb* comm = nullptr);
   ~Navier2DEngine();
 
   // initial conditions (src/navier_stokes/navier.rs:161-182, functions.rs:85-126)
@@ -51,6 +64,9 @@ class Navier2DEngine {
   int nx() const { return nx_; }
   int ny() const { return ny_; }
   bool periodic() const { return periodic_; }
+  int nranks() const { return comm_.size; }
+  double exchange_bytes_per_step() const { return xchg_bytes_; }   // bytes this rank sends per step
+  int exchanges_per_step() const { return xchg_count_; }
 
   Stream st_;
 
@@ -62,6 +78,35 @@ class Navier2DEngine {
   void state_to_canonical(Field& f, Arr2& out);
   void canonical_to_state(const Arr2& in, Field& f);
   void refresh_gy();
+
+  // ---- pencil decomposition (P ranks): YX arrays are split by rows (y index), XY arrays by rows
+  // (x index: physical points `xpart_`, spectral modes `kpart_`); a layout change is an exchange
+  CommCb comm_;
+  std::vector<int> ypart_, xpart_, kpart_;
+  int yb_ = 0, ye_ = 0, nyl_ = 0, nxl_ = 0;
+  DBuf sendbuf_, recvbuf_;
+  double xchg_bytes_ = 0.0;
+  int xchg_count_ = 0;
+  double* yx(DBuf& b) const { return b.p + 2 * ldx_; }   // YX buffers carry two halo rows in front
+  static std::vector<int> split(int n, int parts);
+  static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+  int ylines(int rows) const { return clampi((ye_ < rows ? ye_ : rows) - yb_, 0, rows); }
+  int xlines(int rows, bool spec) const {
+    const std::vector<int>& p = spec ? kpart_ : xpart_;
+    const int b = p[comm_.rank], e = p[comm_.rank + 1];
+    return clampi((e < rows ? e : rows) - b, 0, rows);
+  }
+  int xb(bool spec) const { return (spec ? kpart_ : xpart_)[comm_.rank]; }
+  void alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv, const std::vector<int64_t>& rc);
+  // out = in^T across ranks.  to_xy: input YX (rows split by ypart_), output XY (rows split by
+  // xpart_/kpart_); otherwise the reverse.  rows/cols are the GLOBAL logical sizes of the input.
+  void exchange(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
+                bool to_xy, bool spec);
+  void halo(double* base, long ld, int ncols);   // rows [-2,0) <- last two local rows of rank-1
+  void scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols);
+  void scatter_rows_xy(const double* full, long ldf, DBuf& dst, int rows, int ncols, bool spec);
+  void gather_rows(const double* local, long ld, int rows_global, const std::vector<int>& part,
+                   double* full);
 
   int nx_, ny_, mx_, my_, kx_;   // kx_: x-modes of a spectral line (nx, or nx/2+1 complex)
   bool periodic_;
@@ -84,7 +129,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem } type;
+    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem, kHalo } type;
+    bool to_xy = true, spec = false;
     Program pg;                  // kLine
     const double* in = nullptr;  // transposes / gemm A
     const double* b = nullptr;   // gemm B
@@ -101,7 +147,8 @@ class Navier2DEngine {
   std::vector<Launch> step_;
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
-                     const char* tag);
+                     bool to_xy, bool spec, const char* tag);
+  void add_halo(double* base, int ncols, const char* tag);
   void add_gemm(bool nn, int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                 double* C, long ldc, const char* tag);
   void build_confined();

@@ -188,6 +188,20 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 }
 
 // ------------------------------------------------------------------------------- small kernels
+__global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ in, long ldi,
+                                                     double* __restrict__ out, long ldo, int rows,
+                                                     int cols) {
+  for (int r = blockIdx.y; r < rows; r += gridDim.y)
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cols; c += gridDim.x * 256)
+      out[(long)r * ldo + c] = in[(long)r * ldi + c];
+}
+void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream& st) {
+  if (rows <= 0 || cols <= 0) return;
+  dim3 grid((cols + 255) / 256 < 64 ? (cols + 255) / 256 : 64, rows < 4096 ? rows : 4096);
+  hipLaunchKernelGGL(copy2d_kernel, grid, dim3(256), 0, st.s, in, ldi, out, ldo, rows, cols);
+  RPDE_HIP(hipGetLastError());
+}
+
 __global__ void set_element_kernel(double* p, long idx, double v) { p[idx] = v; }
 void launch_set_element(double* p, long idx, double value, Stream& st) {
   hipLaunchKernelGGL(set_element_kernel, dim3(1), dim3(1), 0, st.s, p, idx, value);
@@ -262,6 +276,10 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
     }
     for (int n = 0; n < N; ++n) C[(long)m * ldc + n] = row[n];
   }
+}
+void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream&) {
+  for (int r = 0; r < rows; ++r)
+    for (int cc = 0; cc < cols; ++cc) out[(long)r * ldo + cc] = in[(long)r * ldi + cc];
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream&) {

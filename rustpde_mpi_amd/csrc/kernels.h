@@ -37,6 +37,9 @@ void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double
 void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream& st);
 
+// out[r * ldo + c] = in[r * ldi + c], r < rows, c < cols (doubles)
+void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream& st);
+
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
 

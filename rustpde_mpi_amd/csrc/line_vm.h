@@ -42,7 +42,7 @@ using cgmem_t = const __attribute__((address_space(1))) double*;
 
 enum OpCode : int {
   OP_END = 0,
-  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][k]                  k < n   (zero tail if !acc)
+  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]             k < n   (zero tail if !acc); i0 = 1: parity map
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1
   OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length)
@@ -84,7 +84,8 @@ struct Program {
   int nops;
   int nslots;
   int slot_len;   // doubles per slot
-  int nlines;     // grid.x
+  int nlines;     // grid.x (local lines of this rank)
+  int line0;      // global index of local line 0 (pencil-sharded runs; 0 otherwise)
   int ncomp;      // grid.y
   int fft_n;      // complex FFT length used by OP_DCT / OP_RFFT (0: direct O(n^2) DCT)
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
@@ -749,7 +750,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
     clds_t a = lds + op.a * SL;
     clds_t b = lds + op.b * SL;
     const int n = op.n;
-    const long toff = op.tabld * line;
+    const int gline = line + pg.line0;           // global line: tables and stencil coefficients
+    const long toff = op.tabld * gline;
     switch (op.code) {
       case OP_LOAD: {
         const ArrayRef& A = pg.arr[op.arr];
@@ -760,7 +762,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            v[q] = (k < n) ? src[(long)k * es] : 0.0;
+            const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
+            v[q] = (k < n) ? src[kk * es] : 0.0;
           }
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
@@ -773,10 +776,10 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       } break;
       case OP_LOADX: {
         const ArrayRef& A = pg.arr[op.arr];
-        const bool has0 = line < op.i1, has2 = line >= 2 && (line - 2) < op.i1;
+        const bool has0 = gline < op.i1, has2 = gline >= 2 && (gline - 2) < op.i1;
         cgmem_t s0p = (cgmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         cgmem_t s2p = (cgmem_t)(A.p + comp * A.coff + (long)(line - 2) * A.ld);
-        const double c2 = has2 ? ((tab_t)pg.tabs[op.tab])[line - 2] : 0.0;
+        const double c2 = has2 ? ((tab_t)pg.tabs[op.tab])[gline - 2] : 0.0;
         const int es = A.es;
         RPDE_PHASE(blk, tid) {
           double v0[EPT], v2[EPT];

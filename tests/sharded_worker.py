@@ -1,0 +1,62 @@
+"""Worker of the world-size-N tests of the pencil-sharded engine (spawned by test_sharded.py or run
+under torch.distributed.run).  Every rank builds the sharded engine, steps it, gathers the fields
+through the C ABI and rank 0 compares them with the oracle and with the single-rank engine."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(rank, world, port, lib_path, device_build, cases, out_path):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rustpde_mpi_amd as R
+    from rustpde_mpi_amd._capi import Lib
+    from rustpde_mpi_amd.dist import TorchComm
+    from oracle import navier as N
+
+    lib = Lib(lib_path)
+    comm = TorchComm(device_buffers=device_build)
+    results = []
+    for (periodic, nx, ny, ra, dt, steps, aspect) in cases:
+        ctor = "new_periodic" if periodic else "new_confined"
+        nav = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", library=lib, comm=comm)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(steps)
+        got = nav.physical_fields()          # collective: every rank gathers the full fields
+        got["pseu"] = nav.pseu.vhat
+        divn = nav.div_norm()
+        stats = nav.comm_stats()
+        if rank == 0:
+            ora = getattr(N.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", eig_mode="parity")
+            ora.set_velocity(0.2, 1.0, 1.0)
+            ora.set_temperature(0.2, 1.0, 1.0)
+            for _ in range(steps):
+                ora.update()
+            want = ora.physical_fields()
+            want["pseu"] = ora.pseu.vhat
+            err = {k: float(np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-300)) for k in want}
+            results.append({"case": [periodic, nx, ny, steps], "err": err, "div": [divn, ora.div_norm()],
+                            "comm": stats, "calls": comm.calls})
+        del nav
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(results, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    # torch.distributed.run entry: python tests/sharded_worker.py <lib_path> <device_build 0|1> <out.json>
+    cases = [(False, 33, 33, 1e5, 0.01, 5, 1.0), (True, 32, 33, 1e5, 0.01, 5, 1.0)]
+    run(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("MASTER_PORT", "29511")),
+        sys.argv[1], bool(int(sys.argv[2])), cases, sys.argv[3])
