@@ -68,7 +68,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy);
   red_.alloc(2);
   if (P > 1) {
-    const size_t m = std::max((size_t)nyl_ * ldx_, (size_t)nxl_ * ldy_) + 64;
+    const size_t m = kMaxBatch * std::max((size_t)nyl_ * ldx_, (size_t)nxl_ * ldy_) + 64;
     sendbuf_.alloc(m); recvbuf_.alloc(m);
   }
 
@@ -120,6 +120,19 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
     dev_sync(st_);
   }
   if (periodic) build_periodic(); else build_confined();
+  if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos
+    xchg_count_ = 0;
+    for (size_t i = 0; i < step_.size();) {
+      if (step_[i].type == Launch::kHalo) { ++xchg_count_; ++i; continue; }
+      if (step_[i].type != Launch::kTranspose) { ++i; continue; }
+      size_t j = i; int n = 0;
+      while (j < step_.size() && n < kMaxBatch && step_[j].type == Launch::kTranspose &&
+             step_[j].rows == step_[i].rows && step_[j].cols == step_[i].cols &&
+             step_[j].elem == step_[i].elem && step_[j].to_xy == step_[i].to_xy && step_[j].spec == step_[i].spec) { ++j; ++n; }
+      ++xchg_count_;
+      i = j;
+    }
+  }
 }
 
 Navier2DEngine::~Navier2DEngine() {
@@ -229,31 +242,39 @@ void Navier2DEngine::gather_rows(const double* local, long ld, int rows_global,
   alltoallv(snd.p, sc, full, rc);
 }
 
-void Navier2DEngine::exchange(const double* in, long ldi, double* out, long ldo, int rows, int cols,
-                              int elem, bool to_xy, bool spec) {
+void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem,
+                                    bool to_xy, bool spec) {
   const int P = comm_.size, me = comm_.rank;
+  if (P == 1) {
+    for (const Xfer& x : xs) launch_transpose(x.in, x.ldi, x.out, x.ldo, rows, cols, elem, st_);
+    return;
+  }
+  RPDE_REQUIRE((int)xs.size() <= kMaxBatch, "exchange batch too large");
   const std::vector<int>& xp = spec ? kpart_ : xpart_;
   const std::vector<int>& inpart = to_xy ? ypart_ : xp;    // splits the input's rows
   const std::vector<int>& outpart = to_xy ? xp : ypart_;   // splits the input's cols = output rows
   auto cnt = [&](const std::vector<int>& p, int q, int n) { return clampi(std::min(p[q + 1], n) - std::min(p[q], n), 0, n); };
   const int rl = cnt(inpart, me, rows);        // local input rows
   const int cl = cnt(outpart, me, cols);       // local output rows
-  if (P == 1) { launch_transpose(in, ldi, out, ldo, rows, cols, elem, st_); return; }
   std::vector<int64_t> sc(P), rc(P);
   size_t off = 0;
   for (int q = 0; q < P; ++q) {    // pack: block (rl x cq) -> transposed (cq x rl), contiguous per destination
     const int c0 = std::min(outpart[q], cols), cq = cnt(outpart, q, cols);
-    launch_transpose(in + (size_t)c0 * elem, ldi, sendbuf_.p + off, (long)rl * elem, rl, cq, elem, st_);
-    sc[q] = (int64_t)cq * rl * elem;
-    off += (size_t)sc[q];
-    rc[q] = (int64_t)cl * cnt(inpart, q, rows) * elem;
+    for (const Xfer& x : xs) {
+      launch_transpose(x.in + (size_t)c0 * elem, x.ldi, sendbuf_.p + off, (long)rl * elem, rl, cq, elem, st_);
+      off += (size_t)cq * rl * elem;
+    }
+    sc[q] = (int64_t)xs.size() * cq * rl * elem;
+    rc[q] = (int64_t)xs.size() * cl * cnt(inpart, q, rows) * elem;
   }
   alltoallv(sendbuf_.p, sc, recvbuf_.p, rc);
   off = 0;
   for (int s = 0; s < P; ++s) {    // unpack: segment (cl x rs) -> out[:, r0 : r0 + rs]
     const int r0 = std::min(inpart[s], rows), rs = cnt(inpart, s, rows);
-    launch_copy2d(recvbuf_.p + off, (long)rs * elem, out + (size_t)r0 * elem, ldo, cl, rs * elem, st_);
-    off += (size_t)rc[s];
+    for (const Xfer& x : xs) {
+      launch_copy2d(recvbuf_.p + off, (long)rs * elem, x.out + (size_t)r0 * elem, x.ldo, cl, rs * elem, st_);
+      off += (size_t)cl * rs * elem;
+    }
   }
 }
 
@@ -400,6 +421,22 @@ void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, lon
   l.bytes = 8.0 * ((double)M * K + (double)N * K + (double)M * N);
   step_.push_back(l);
 }
+size_t Navier2DEngine::run_from(size_t i) {
+  const Launch& l = step_[i];
+  if (l.type != Launch::kTranspose || comm_.size == 1) { run_launch(l); return i + 1; }
+  std::vector<Xfer> xs;
+  size_t j = i;
+  while (j < step_.size() && (int)xs.size() < kMaxBatch) {
+    const Launch& m = step_[j];
+    if (m.type != Launch::kTranspose || m.rows != l.rows || m.cols != l.cols || m.elem != l.elem ||
+        m.to_xy != l.to_xy || m.spec != l.spec) break;
+    xs.push_back(Xfer{m.in, m.ldi, m.out, m.ldo});
+    ++j;
+  }
+  exchange_batch(xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
+  return j;
+}
+
 void Navier2DEngine::run_launch(const Launch& l) {
   switch (l.type) {
     case Launch::kLine: launch_line_program(l.pg, st_); break;
@@ -425,20 +462,22 @@ void Navier2DEngine::update(int nsteps) {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
 #endif
   for (int s = 0; s < nsteps; ++s) {
-    for (const Launch& l : step_) {
+    for (size_t i = 0; i < step_.size();) {
+      const Launch& l = step_[i];
 #ifndef RPDE_EMU
       const bool timed = !timed_tag_.empty() && std::string(l.tag).find(timed_tag_) != std::string::npos;
       if (timed) {
         hipEvent_t a, b;
         RPDE_HIP(hipEventCreate(&a)); RPDE_HIP(hipEventCreate(&b));
         RPDE_HIP(hipEventRecord(a, st_.s));
-        run_launch(l);
+        i = run_from(i);
         RPDE_HIP(hipEventRecord(b, st_.s));
         tev.emplace_back(a, b);
         continue;
       }
 #endif
-      run_launch(l);
+      (void)l;
+      i = run_from(i);
     }
     time_ += dt_;
   }

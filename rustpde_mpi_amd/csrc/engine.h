@@ -100,8 +100,16 @@ class Navier2DEngine {
   void alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv, const std::vector<int64_t>& rc);
   // out = in^T across ranks.  to_xy: input YX (rows split by ypart_), output XY (rows split by
   // xpart_/kpart_); otherwise the reverse.  rows/cols are the GLOBAL logical sizes of the input.
+  struct Xfer { const double* in; long ldi; double* out; long ldo; };
+  void exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem, bool to_xy, bool spec);
   void exchange(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
-                bool to_xy, bool spec);
+                bool to_xy, bool spec) {
+    exchange_batch({Xfer{in, ldi, out, ldo}}, rows, cols, elem, to_xy, spec);
+  }
+  // runs step_[i] (and, when sharded, the compatible exchanges that directly follow it in one
+  // all-to-all); returns the index of the next launch
+  size_t run_from(size_t i);
+  static constexpr int kMaxBatch = 6;
   void halo(double* base, long ld, int ncols);   // rows [-2,0) <- last two local rows of rank-1
   void scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols);
   void scatter_rows_xy(const double* full, long ldf, DBuf& dst, int rows, int ncols, bool spec);
