@@ -40,6 +40,15 @@ using gmem_t = __attribute__((address_space(1))) double*;
 using cgmem_t = const __attribute__((address_space(1))) double*;
 #endif
 
+// a complex number / pair of doubles moved with one 16-byte LDS access
+#ifdef RPDE_EMU
+struct dbl2 { double x, y; };
+using lds2_t = dbl2*;
+#else
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+using lds2_t = __attribute__((address_space(3))) dbl2*;
+#endif
+
 enum OpCode : int {
   OP_END = 0,
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]             k < n   (zero tail if !acc); i0 = 1: parity map
@@ -200,7 +209,12 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
   constexpr int Q = (NB + T - 1) / T;              // butterflies per thread
   constexpr int Ns = 1 << LGNS;
   constexpr int LGR = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
-  static_assert(Q * R <= 16 && true, "FFT too large for this kernel configuration");
+  static_assert(Q * R <= 16, "FFT too large for this kernel configuration");
+  // with these conditions the padded index of element t of a butterfly is the padded index of
+  // element 0 plus a compile-time constant, so the accesses become base + immediate offset
+  constexpr bool kStaticRead = (NB % 16 == 0);
+  constexpr bool kStaticWrite = (Ns >= 16) || ((Ns * R) % 16 == 0);
+  lds2_t w2 = (lds2_t)w;
   RPDE_TLS(blk, double, xr, Q * R);
   RPDE_TLS(blk, double, xi, Q * R);
   RPDE_PHASE(blk, tid) {
@@ -208,11 +222,13 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
     for (int q = 0; q < Q; ++q) {
       const int j = tid + q * T;
       if (j < NB) {
+        const int base = pidx(j);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          const int p = 2 * pidx(j + t * NB);
-          RPDE_T(xr)[q * R + t] = w[p];
-          RPDE_T(xi)[q * R + t] = w[p + 1];
+          const int p = kStaticRead ? base + t * NB + ((t * NB) >> 4) : pidx(j + t * NB);
+          const dbl2 v = w2[p];
+          RPDE_T(xr)[q * R + t] = v.x;
+          RPDE_T(xi)[q * R + t] = v.y;
         }
       }
     }
@@ -252,11 +268,11 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
         }
         SmallDft<R>::run(pr, pi);
         const int j0 = ((j >> LGNS) << (LGNS + LGR)) + k;
+        const int b0 = pidx(j0);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          const int p = 2 * pidx(j0 + t * Ns);
-          w[p] = pr[t];
-          w[p + 1] = pi[t];
+          const int p = kStaticWrite ? b0 + t * Ns + ((t * Ns) >> 4) : pidx(j0 + t * Ns);
+          w2[p] = dbl2{pr[t], pi[t]};
         }
       }
     }
@@ -327,7 +343,7 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
 #pragma unroll
       for (int q = 0; q < Cfg::ZPT; ++q) {
         const int j = tid + q * T;
-        if (j < N) { const int p = 2 * pidx(j); x[p] = RPDE_T(zr)[q]; x[p + 1] = RPDE_T(zi)[q]; }
+        if (j < N) ((lds2_t)x)[pidx(j)] = dbl2{RPDE_T(zr)[q], RPDE_T(zi)[q]};
       }
     }
     RPDE_SYNC(blk);
@@ -340,10 +356,9 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
       for (int q = 0; q < Cfg::EPT; ++q) {
         const int k = tid + q * T;
         if (k <= N) {
-          const int ka = 2 * pidx((k == N) ? 0 : k);
-          const int kb = 2 * pidx((k == 0) ? 0 : N - k);
-          const double ar = x[ka], ai = x[ka + 1];
-          const double br = x[kb], bi = x[kb + 1];
+          const dbl2 za = ((lds2_t)x)[pidx((k == N) ? 0 : k)];
+          const dbl2 zb = ((lds2_t)x)[pidx((k == 0) ? 0 : N - k)];
+          const double ar = za.x, ai = za.y, br = zb.x, bi = zb.y;
           const double c = tw2[2 * k], s = tw2[2 * k + 1];
           double v = 0.5 * (ar + br) + 0.5 * (c * (ai + bi) - s * (ar - br));
           if (post) v *= post[k];

@@ -74,3 +74,28 @@ def test_periodic_step(hip_lib, nx, ny, steps, aspect):
 def test_periodic_config3_first_steps(hip_lib):
     """BASELINE.json configs[2]: periodic 4096 x 1025, Ra = 1e8 -- parity on the first 3 steps."""
     K.check_step_parity(hip_lib, True, 4096, 1025, 1e8, 5e-4, 3, check_at=[1, 3])
+
+
+def test_config2_golden_1025_200_steps(hip_lib):
+    """BASELINE.json configs[1]: confined 1025 x 1025, Ra = 1e7, 200 steps on one MI355X, validated
+    against the CPU oracle's committed samples (tests/golden/make_config2_golden.py): relative L2
+    over the 65 x 65 sample points <= 1e-10 for u, v, T, p after 10, 100 and 200 steps."""
+    import os
+    g = np.load(os.path.join(K.GOLDEN, "config2_1025_200steps.npz"))
+    nx, ny, stride = int(g["nx"]), int(g["ny"]), int(g["stride"])
+    nav = R.Navier2D.new_confined(nx, ny, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=hip_lib)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    done = 0
+    for s in (10, 100, 200):
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        for k in ("velx", "vely", "temp", "pres"):
+            want = g[f"{k}_{s}"]
+            got = f[k][::stride, ::stride]
+            err = np.linalg.norm(got - want) / np.linalg.norm(want)
+            assert err < 1e-10, (k, s, err)
+            # the full-field norm pins the points between the samples as well
+            assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < 1e-9 * float(g[f"{k}_{s}_norm"]), (k, s)
+    assert abs(nav.div_norm() - float(g["div_norm"])) < 1e-8 * max(1.0, float(g["div_norm"]))

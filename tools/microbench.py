@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, rustpde_mpi_amd as R
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 nl = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
