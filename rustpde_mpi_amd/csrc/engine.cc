@@ -65,8 +65,18 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
-  BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy);
+  BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   red_.alloc(2);
+  {  // dealias (functions.rs:72-82) folded into the post-scaling of the forward DCT
+    Vec py = cheb_fwd_post(ny);
+    for (int k = ny * 2 / 3; k < ny; ++k) py[k] = 0.0;
+    postcut_y_.upload(py);
+    if (!periodic) {
+      Vec px = cheb_fwd_post(nx);
+      for (int k = nx * 2 / 3; k < nx; ++k) px[k] = 0.0;
+      postcut_x_.upload(px);
+    }
+  }
   if (P > 1) {
     const size_t m = kMaxBatch * std::max((size_t)nyl_ * ldx_, (size_t)nxl_ * ldy_) + 64;
     sendbuf_.alloc(m); recvbuf_.alloc(m);
@@ -652,30 +662,35 @@ void Navier2DEngine::build_confined() {
   // ---- T1: to XY
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
-  auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {  // slot 2 <- physical line
-    pb.load(2, pb.arr(src.p, ldy), my);
-    pb.to_ortho(2, yD);
-    if (deriv) pb.cdiff(2, 2, ny, 1.0 / sy_);
-    pb.dct(2, ny, yD.bwd_pre.p, nullptr);
-  };
-  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
-    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ], u = W0U, v = W0V
-    ProgramBuilder pb = xpb(4, nx);
+  // physical velocities once per step (shared by the three convection programs)
+  for (int w = 0; w < 2; ++w) {
+    ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
-    phys(pb, X_[0], false);                 // u
-    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
-    phys(pb, fx, false);                    // d/dx f  (x-derivative taken in S1)
-    if (bx) pb.load(2, pb.arr(bx->p, ldy), ny, 1.0, true);
-    pb.mul(1, 0, 2, ny);
-    phys(pb, X_[2], false);                 // v
-    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
-    phys(pb, f0, true);                     // d/dy f
-    if (by) pb.load(2, pb.arr(by->p, ldy), ny, 1.0, true);
-    pb.mul(1, 0, 2, ny, 1.0, true);
-    pb.axpby(2, 1, 1.0, 1, 0.0, ny);
-    pb.dct(2, ny, nullptr, yD.fwd_post.p);
-    pb.zero(2, cut_y, ny);
-    pb.store(2, pb.arr(out.p, ldy), ny);
+    pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
+    pb.to_ortho(0, yD);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    pb.store(0, pb.arr((w ? VP_ : UP_).p, ldy), ny);
+    add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
+  }
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; accumulator = slot 2
+    ProgramBuilder pb = xpb(3, nx);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
+    pb.to_ortho(0, yD);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
+    pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+    pb.axpby(2, 0, 1.0, 0, 0.0, ny);
+    pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
+    pb.to_ortho(0, yD);
+    pb.cdiff(0, 0, ny, 1.0 / sy_);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
+    pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
+    pb.axpby(0, 0, 1.0, 2, 1.0, ny);
+    pb.dct(0, ny, nullptr, postcut_y_.p);    // forward transform + 2/3 rule in y
+    pb.store(0, pb.arr(out.p, ldy), ny);
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
@@ -691,8 +706,7 @@ void Navier2DEngine::build_confined() {
     ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(ax);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
-    pb.dct(0, nx, nullptr, ax.fwd_post.p);
-    pb.zero(0, cut_x, nx);
+    pb.dct(0, nx, nullptr, postcut_x_.p);                     // forward transform + 2/3 rule in x
     pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
     pb.to_ortho(1, ax);                                       // S_x
     pb.axpby(0, 0, -dt, 1, 1.0, nx);
@@ -919,29 +933,35 @@ void Navier2DEngine::build_periodic() {
     }
   for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
-  auto phys = [&](ProgramBuilder& pb, DBuf& src, bool deriv) {
-    pb.load(2, pb.arr(src.p, ldy), my);
-    pb.to_ortho(2, yD);
-    if (deriv) pb.cdiff(2, 2, ny, 1.0 / sy_);
-    pb.dct(2, ny, yD.bwd_pre.p, nullptr);
-  };
-  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
-    ProgramBuilder pb = xpb(4, nx, false);
+  // physical velocities once per step (shared by the three convection programs)
+  for (int w = 0; w < 2; ++w) {
+    ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
-    phys(pb, X_[0], false);
-    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
-    phys(pb, fx, false);
-    if (bx) pb.load(2, pb.arr(bx->p, ldy), ny, 1.0, true);
-    pb.mul(1, 0, 2, ny);
-    phys(pb, X_[2], false);
-    pb.axpby(0, 2, 1.0, 2, 0.0, ny);
-    phys(pb, f0, true);
-    if (by) pb.load(2, pb.arr(by->p, ldy), ny, 1.0, true);
-    pb.mul(1, 0, 2, ny, 1.0, true);
-    pb.axpby(2, 1, 1.0, 1, 0.0, ny);
-    pb.dct(2, ny, nullptr, yD.fwd_post.p);
-    pb.zero(2, cut_y, ny);
-    pb.store(2, pb.arr(out.p, ldy), ny);
+    pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
+    pb.to_ortho(0, yD);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    pb.store(0, pb.arr((w ? VP_ : UP_).p, ldy), ny);
+    add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
+  }
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; accumulator = slot 2
+    ProgramBuilder pb = xpb(3, nx, false);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
+    pb.to_ortho(0, yD);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
+    pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+    pb.axpby(2, 0, 1.0, 0, 0.0, ny);
+    pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
+    pb.to_ortho(0, yD);
+    pb.cdiff(0, 0, ny, 1.0 / sy_);
+    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
+    pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
+    pb.axpby(0, 0, 1.0, 2, 1.0, ny);
+    pb.dct(0, ny, nullptr, postcut_y_.p);    // forward transform + 2/3 rule in y
+    pb.store(0, pb.arr(out.p, ldy), ny);
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");

@@ -133,6 +133,8 @@ class Navier2DEngine {
   // XY layout work arrays (row = x index, contiguous y)
   DBuf X_[9], BX_, BY_, PS_;
   DBuf red_;                     // reduction scratch (2 doubles)
+  DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
+  DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
   std::map<std::string, std::unique_ptr<Field>> fields_;
 
   // the step as a list of launches

@@ -51,7 +51,7 @@ using lds2_t = __attribute__((address_space(3))) dbl2*;
 
 enum OpCode : int {
   OP_END = 0,
-  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]             k < n   (zero tail if !acc); i0 = 1: parity map
+  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1
   OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length)
@@ -217,11 +217,18 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
   lds2_t w2 = (lds2_t)w;
   RPDE_TLS(blk, double, xr, Q * R);
   RPDE_TLS(blk, double, xi, Q * R);
+  RPDE_TLS(blk, double, tw1, 2 * Q);   // table twiddle of each butterfly, fetched ahead of the barrier
   RPDE_PHASE(blk, tid) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int j = tid + q * T;
       if (j < NB) {
+        if constexpr (LGNS > 0) {
+          constexpr int tstep = N / (Ns * R);
+          const int k = j & (Ns - 1);
+          RPDE_T(tw1)[2 * q] = tw[2 * (k * tstep)];
+          RPDE_T(tw1)[2 * q + 1] = tw[2 * (k * tstep) + 1];
+        }
         const int base = pidx(j);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
@@ -244,10 +251,9 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
         double* pi = RPDE_T(xi) + q * R;
         if constexpr (LGNS > 0) {
           // twiddles W^(t k tstep), t = 1..R-1, as powers of the table entry for t = 1
-          constexpr int tstep = N / (Ns * R);
           double wc[R], ws[R];
-          wc[1] = tw[2 * (k * tstep)];
-          ws[1] = tw[2 * (k * tstep) + 1];
+          wc[1] = RPDE_T(tw1)[2 * q];
+          ws[1] = RPDE_T(tw1)[2 * q + 1];
 #pragma unroll
           for (int t = 2; t < R; ++t) {
             if (t % 2 == 0) {
@@ -784,7 +790,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
             const double x = op.s0 * v[q];
-            if (k < SL) d[k] = op.acc ? (d[k] + x) : x;
+            const double old = d[k];
+            if (k < SL) d[k] = (op.acc == 2) ? (k < n ? old * x : old) : (op.acc ? (old + x) : x);
           }
         }
         RPDE_SYNC(blk);

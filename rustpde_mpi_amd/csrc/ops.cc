@@ -95,6 +95,9 @@ void ProgramBuilder::load(int d, int a, int n, double s0, bool acc, int half) {
   RPDE_REQUIRE(n <= pg.slot_len, "line longer than the slot");
   Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = acc; o.i0 = half > 0; o.i1 = half;
 }
+void ProgramBuilder::loadmul(int d, int a, int n, double s0) {
+  Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = 2;
+}
 void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, double s0, bool acc) {
   Op& o = push(OP_LOADX); o.d = d; o.arr = a; o.n = n; o.i1 = rows; o.tab = tab(lowtab); o.s0 = s0; o.acc = acc;
 }
