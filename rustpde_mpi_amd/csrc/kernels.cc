@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
 
   double ra[8], rb[8];
   const int arow = tid >> 1, akk = (tid & 1) * 8;        // A (and B when !NN): row, first k
-  const int bk = tid >> 4, bnn = (tid & 15) * 8;          // B when NN: k, first n
+  const int bn = tid & 127, bkp = tid >> 7;               // B when NN: column n, k pair (k = 4e + 2 bkp + {0,1})
 
   auto gload = [&](int k0) {
     {
@@ -118,10 +118,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
 #pragma unroll
       for (int e = 0; e < 8; ++e) rb[e] = (r < N && k0 + akk + e < K) ? p[e] : 0.0;
     } else {
-      const int k = k0 + bk;
-      const double* p = B + (long)k * ldb + n0 + bnn;
+      // lanes run along n (coalesced 512-byte rows); each thread fetches the 8 k-values it will
+      // write to LDS as four 16-byte (k, k+1) pairs
+      const int n = n0 + bn;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb[e] = (k < K && n0 + bnn + e < N) ? p[e] : 0.0;
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + 4 * e + 2 * bkp;
+        rb[2 * e] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
+        rb[2 * e + 1] = (k + 1 < K && n < N) ? B[(long)(k + 1) * ldb + n] : 0.0;
+      }
     }
   };
   auto lstore = [&]() {
@@ -132,7 +137,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
       for (int e = 0; e < 8; ++e) Bs[(akk + e) >> 2][arow][(akk + e) & 3] = rb[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Bs[bk >> 2][bnn + e][bk & 3] = rb[e];
+      for (int e = 0; e < 4; ++e) {
+        Bs[e][bn][2 * bkp] = rb[2 * e];
+        Bs[e][bn][2 * bkp + 1] = rb[2 * e + 1];
+      }
     }
   };
 

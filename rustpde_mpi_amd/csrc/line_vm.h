@@ -582,6 +582,17 @@ __device__ __forceinline__ Affine<ORDER> affine_shfl_up(const Affine<ORDER>& a, 
   }
   return r;
 }
+template <int ORDER>
+__device__ __forceinline__ Affine<ORDER> affine_shfl_idx(const Affine<ORDER>& a, int src) {
+  Affine<ORDER> r = affine_identity<ORDER>();
+  r.m11 = __shfl(a.m11, src);
+  r.v1 = __shfl(a.v1, src);
+  if constexpr (ORDER == 2) {
+    r.m12 = __shfl(a.m12, src); r.m21 = __shfl(a.m21, src); r.m22 = __shfl(a.m22, src);
+    r.v2 = __shfl(a.v2, src);
+  }
+  return r;
+}
 #endif
 
 // `fill(k, b, q, r)` supplies the coefficients of element k (it may read LDS / padded tables
@@ -679,16 +690,19 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
       __syncthreads();
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
-        Affine<ORDER> tot[NW];
+        // prefix over the (at most 8) wave totals: lane l < NW holds total l, a 3-level shuffle
+        // scan composes them, wave w picks the inclusive prefix of wave w-1
+        static_assert(NW <= 8, "cross-wave scan assumes at most 8 waves");
+        clds_t p = carry + (par * NW + (lane < NW ? lane : 0)) * W;
+        Affine<ORDER> t = Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]};
+        t = affine_select<ORDER>(lane < NW, t, affine_identity<ORDER>());
 #pragma unroll
-        for (int w = 0; w < NW - 1; ++w) {   // one batch of LDS reads, then a register-only chain
-          clds_t p = carry + (par * NW + w) * W;
-          tot[w] = Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]};
+        for (int off = 1; off < NW; off <<= 1) {
+          const Affine<ORDER> prev = affine_shfl_up<ORDER>(t, off);
+          t = affine_select<ORDER>(lane >= off, affine_compose<ORDER>(t, prev), t);
         }
-        Affine<ORDER> pre = affine_identity<ORDER>();
-#pragma unroll
-        for (int w = 0; w < NW - 1; ++w)
-          pre = affine_select<ORDER>(w < wave, affine_compose<ORDER>(tot[w], pre), pre);
+        Affine<ORDER> pre = affine_shfl_idx<ORDER>(t, wave > 0 ? wave - 1 : 0);
+        pre = affine_select<ORDER>(wave > 0, pre, affine_identity<ORDER>());
         exc[par] = affine_compose<ORDER>(exc[par], pre);
       }
     }
