@@ -703,7 +703,9 @@ void Navier2DEngine::build_confined() {
     AxisTables& ax = which == 2 ? xN : xD;
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = ypb(2, ny);
+    // only the first my = ny - 2 orthonormal y-rows are needed: the B2-y preconditioner of S4 never
+    // reads the last two (matvec.rs:215-226) -- and 4095 lines fill the CUs without a ragged tail
+    ProgramBuilder pb = ypb(2, my);
     pb.set_fft(ax);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
     pb.dct(0, nx, nullptr, postcut_x_.p);                     // forward transform + 2/3 rule in x
@@ -732,13 +734,13 @@ void Navier2DEngine::build_confined() {
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
   // ---- T3
-  for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, ny, mx, true, "T3");
+  for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, my, mx, true, "T3");
   // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
     ProgramBuilder pb = xpb(1, mx);
     pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[which].p, ldy), ny);
+    pb.load(0, pb.arr(X_[which].p, ldy), my);                 // entries my, my+1 only meet zero table entries
     pb.pinv_matvec(0, yD);
     pb.fdma_solve(0, my, hh.fdma[1]);
     pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
@@ -972,7 +974,7 @@ void Navier2DEngine::build_periodic() {
   auto rhs = [&](int which, const char* tag) {
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = ypb(2, ny);
+    ProgramBuilder pb = ypb(2, my);
     pb.set_fft(xF);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);
     pb.rfft_f(0, nx);
@@ -998,13 +1000,13 @@ void Navier2DEngine::build_periodic() {
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, ny, kx, true, "T3");
+  for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, my, kx, true, "T3");
   // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
     ProgramBuilder pb = xpb(1, kx, true);
     pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), ny);
+    pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), my);
     pb.pinv_matvec(0, yD);
     pb.fdma_solve(0, my, hh.fdma[1]);
     pb.store(0, pb.arr(X_[3 + which].p, ldy, 2, 1), my);
