@@ -155,6 +155,11 @@ class Navier2DEngine {
   double timed_ms_ = 0.0;
   long timed_count_ = 0;
   std::vector<Launch> step_;
+#ifndef RPDE_EMU
+  hipGraphExec_t graph_exec_ = nullptr;   // the whole step captured once (single GPU): replay removes
+  bool graph_tried_ = false;              // the per-launch host cost that dominates small grids
+#endif
+  bool use_graph_ = true;
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);
