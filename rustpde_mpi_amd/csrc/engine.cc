@@ -397,6 +397,7 @@ void Navier2DEngine::add_line(const ProgramBuilder& pb, const char* tag) {
     const Op& o = l.pg.ops[i];
     if (o.code == OP_LOAD || o.code == OP_LOADX || o.code == OP_STORE)
       l.bytes += 8.0 * o.n * (double)l.pg.nlines * l.pg.ncomp;
+    if (o.code == OP_DCT && o.arr >= 0) l.bytes += 8.0 * o.b * (double)l.pg.nlines * l.pg.ncomp;
     if ((o.code == OP_REC1 || o.code == OP_REC2 || o.code == OP_MV3) && o.tabld != 0)
       l.bytes += 8.0 * o.n * (double)l.pg.nlines * l.pg.ncomp * (o.code == OP_REC2 ? 3 : o.code == OP_MV3 ? 3 : 1);
   }
@@ -679,10 +680,14 @@ void Navier2DEngine::build_confined() {
       ProgramBuilder pb = ypb(2, my);
       pb.set_fft(*f.ax);
       pb.load(0, pb.arr(yx(*f.st), ldx), mx);
-      pb.to_ortho(0, *f.ax);
-      if (deriv) pb.cdiff(0, 0, nx, 1.0 / sx_);
-      pb.dct(0, nx, f.ax->bwd_pre.p, nullptr);
-      pb.store(0, pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx), nx);
+      const int out = pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx);
+      if (deriv) {
+        pb.to_ortho(0, *f.ax);
+        pb.cdiff(0, 0, nx, 1.0 / sx_);
+        pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, out, nx);
+      } else {
+        pb.dct_fused(0, *f.ax, true, f.ax->bwd_pre.p, nullptr, out, nx);   // stencil + DCT + store
+      }
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
   }
@@ -694,9 +699,7 @@ void Navier2DEngine::build_confined() {
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
-    pb.to_ortho(0, yD);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
-    pb.store(0, pb.arr((w ? VP_ : UP_).p, ldy), ny);
+    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, pb.arr((w ? VP_ : UP_).p, ldy), ny);
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
@@ -704,8 +707,7 @@ void Navier2DEngine::build_confined() {
     ProgramBuilder pb = xpb(3, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
-    pb.to_ortho(0, yD);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
     pb.axpby(2, 0, 1.0, 0, 0.0, ny);
@@ -716,8 +718,7 @@ void Navier2DEngine::build_confined() {
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
     pb.axpby(0, 0, 1.0, 2, 1.0, ny);
-    pb.dct(0, ny, nullptr, postcut_y_.p);    // forward transform + 2/3 rule in y
-    pb.store(0, pb.arr(out.p, ldy), ny);
+    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
@@ -967,9 +968,7 @@ void Navier2DEngine::build_periodic() {
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
-    pb.to_ortho(0, yD);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
-    pb.store(0, pb.arr((w ? VP_ : UP_).p, ldy), ny);
+    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, pb.arr((w ? VP_ : UP_).p, ldy), ny);
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
@@ -977,8 +976,7 @@ void Navier2DEngine::build_periodic() {
     ProgramBuilder pb = xpb(3, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
-    pb.to_ortho(0, yD);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
     pb.axpby(2, 0, 1.0, 0, 0.0, ny);
@@ -989,8 +987,7 @@ void Navier2DEngine::build_periodic() {
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
     pb.axpby(0, 0, 1.0, 2, 1.0, ny);
-    pb.dct(0, ny, nullptr, postcut_y_.p);    // forward transform + 2/3 rule in y
-    pb.store(0, pb.arr(out.p, ldy), ny);
+    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");

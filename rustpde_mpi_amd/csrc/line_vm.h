@@ -202,8 +202,36 @@ struct SmallDft {
 RPDE_HD inline int pidx(int i) { return i + (i >> 4); }
 RPDE_HD inline int fft_work_doubles(int n) { return 2 * (n + (n >> 4)); }
 
-template <class Cfg, int N, int R, int LGNS>
-RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
+struct LdsSrc { static constexpr bool kLds = true; };   // butterfly inputs come from the work area
+
+// first-pass source of the DCT: packs z_i = e_{2i} + i e_{2i+1} of the even extension of the real
+// line x on the fly (optionally with the composite->ortho stencil and the pre-scaling), so the
+// separate pack step (one LDS round trip, two barriers) disappears
+template <bool STEN>
+struct DctSrc {
+  static constexpr bool kLds = false;
+  clds_t x; int N; tab_t pre; tab_t low;
+  RPDE_DEV double val(int m) const {
+    double v;
+    if constexpr (STEN) {
+      const int m2 = m >= 2 ? m - 2 : 0;
+      const double a0 = x[m], a2 = x[m2], l2 = low[m2];
+      v = (m < N - 1 ? a0 : 0.0) + (m >= 2 ? l2 * a2 : 0.0);
+    } else {
+      v = x[m];
+    }
+    return pre ? v * pre[m] : v;
+  }
+  RPDE_DEV dbl2 operator()(int i) const {
+    int m0 = 2 * i, m1 = 2 * i + 1;
+    if (m0 > N) m0 = 2 * N - m0;
+    if (m1 > N) m1 = 2 * N - m1;
+    return dbl2{val(m0), val(m1)};
+  }
+};
+
+template <class Cfg, int N, int R, int LGNS, class Src = LdsSrc>
+RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
   constexpr int T = Cfg::T;
   constexpr int NB = N / R;                        // butterflies
   constexpr int Q = (NB + T - 1) / T;              // butterflies per thread
@@ -232,8 +260,13 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
         const int base = pidx(j);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-          const int p = kStaticRead ? base + t * NB + ((t * NB) >> 4) : pidx(j + t * NB);
-          const dbl2 v = w2[p];
+          dbl2 v;
+          if constexpr (Src::kLds) {
+            const int p = kStaticRead ? base + t * NB + ((t * NB) >> 4) : pidx(j + t * NB);
+            v = w2[p];
+          } else {
+            v = src(j + t * NB);
+          }
           RPDE_T(xr)[q * R + t] = v.x;
           RPDE_T(xi)[q * R + t] = v.y;
         }
@@ -286,8 +319,8 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw) {
   RPDE_SYNC(blk);
 }
 
-template <class Cfg, int N>
-RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw) {
+template <class Cfg, int N, class Src = LdsSrc>
+RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
   // radix schedule: one of {2,4,8} first (if log2 N is not a multiple of 4), then 16s
   constexpr int L = (N >= 8192) ? 13 : (N >= 4096) ? 12 : (N >= 2048) ? 11 : (N >= 1024) ? 10
                   : (N >= 512) ? 9 : (N >= 256) ? 8 : (N >= 128) ? 7 : (N >= 64) ? 6
@@ -297,20 +330,23 @@ RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw) {
   constexpr int LG = (RM == 16) ? 4 : 3;
   constexpr int nm = L / LG;
   constexpr int rem = L % LG;
-  if constexpr (rem == 1) fft_pass<Cfg, N, 2, 0>(blk, w, tw);
-  if constexpr (rem == 2) fft_pass<Cfg, N, 4, 0>(blk, w, tw);
-  if constexpr (rem == 3) fft_pass<Cfg, N, 8, 0>(blk, w, tw);
-  if constexpr (nm >= 1) fft_pass<Cfg, N, RM, rem>(blk, w, tw);
+  if constexpr (rem == 1) fft_pass<Cfg, N, 2, 0, Src>(blk, w, tw, src);
+  if constexpr (rem == 2) fft_pass<Cfg, N, 4, 0, Src>(blk, w, tw, src);
+  if constexpr (rem == 3) fft_pass<Cfg, N, 8, 0, Src>(blk, w, tw, src);
+  if constexpr (nm >= 1) {
+    if constexpr (rem == 0) fft_pass<Cfg, N, RM, 0, Src>(blk, w, tw, src);
+    else fft_pass<Cfg, N, RM, rem>(blk, w, tw);
+  }
   if constexpr (nm >= 2) fft_pass<Cfg, N, RM, rem + LG>(blk, w, tw);
   if constexpr (nm >= 3) fft_pass<Cfg, N, RM, rem + 2 * LG>(blk, w, tw);
   if constexpr (nm >= 4) fft_pass<Cfg, N, RM, rem + 3 * LG>(blk, w, tw);
 }
 
-template <class Cfg>
-RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw) {
+template <class Cfg, class Src = LdsSrc>
+RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw, const Src src = Src()) {
   switch (n) {
 #define RPDE_FFT_CASE(NN) \
-  case NN: if constexpr (NN >= Cfg::FMIN && NN <= Cfg::FMAX) fft_lds<Cfg, NN>(blk, w, tw); break;
+  case NN: if constexpr (NN >= Cfg::FMIN && NN <= Cfg::FMAX) fft_lds<Cfg, NN, Src>(blk, w, tw, src); break;
     RPDE_FFT_CASE(2) RPDE_FFT_CASE(4) RPDE_FFT_CASE(8) RPDE_FFT_CASE(16) RPDE_FFT_CASE(32)
     RPDE_FFT_CASE(64) RPDE_FFT_CASE(128) RPDE_FFT_CASE(256) RPDE_FFT_CASE(512)
     RPDE_FFT_CASE(1024) RPDE_FFT_CASE(2048) RPDE_FFT_CASE(4096) RPDE_FFT_CASE(8192)
@@ -324,37 +360,13 @@ RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw) {
 //   E_k = x_0 + (-1)^k x_N + 2 sum_{j=1}^{N-1} x_j cos(pi j k / N)
 // through an N-point complex FFT of the even extension (packed two reals per complex).
 template <class Cfg>
-RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t tw, tab_t tw2) {
+RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t tw, tab_t tw2,
+                        tab_t low, gmem_t gdst, int ges, double gscale, int gn) {
   constexpr int T = Cfg::T;
-  {  // pack z_j = e_{2j} + i e_{2j+1}
-    RPDE_TLS(blk, double, zr, Cfg::ZPT);
-    RPDE_TLS(blk, double, zi, Cfg::ZPT);
-    RPDE_PHASE(blk, tid) {
-#pragma unroll
-      for (int q = 0; q < Cfg::ZPT; ++q) {
-        const int j = tid + q * T;
-        if (j < N) {
-          int m0 = 2 * j, m1 = 2 * j + 1;
-          if (m0 > N) m0 = 2 * N - m0;
-          if (m1 > N) m1 = 2 * N - m1;
-          double a = x[m0], b = x[m1];
-          if (pre) { a *= pre[m0]; b *= pre[m1]; }
-          RPDE_T(zr)[q] = a;
-          RPDE_T(zi)[q] = b;
-        }
-      }
-    }
-    RPDE_SYNC(blk);
-    RPDE_PHASE(blk, tid) {
-#pragma unroll
-      for (int q = 0; q < Cfg::ZPT; ++q) {
-        const int j = tid + q * T;
-        if (j < N) ((lds2_t)x)[pidx(j)] = dbl2{RPDE_T(zr)[q], RPDE_T(zi)[q]};
-      }
-    }
-    RPDE_SYNC(blk);
-  }
-  fft_dispatch<Cfg>(blk, x, N, tw);
+  // FFT with the pack step fused into the reads of its first pass (the work area overlaps x: every
+  // pass reads everything before the barrier that precedes its writes)
+  if (low) fft_dispatch<Cfg, DctSrc<true>>(blk, x, N, tw, DctSrc<true>{x, N, pre, low});
+  else fft_dispatch<Cfg, DctSrc<false>>(blk, x, N, tw, DctSrc<false>{x, N, pre, low});
   {  // split: E_k = (Zr_k + Zr_{N-k})/2 + (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2
     RPDE_TLS(blk, double, e, Cfg::EPT);
     RPDE_PHASE(blk, tid) {
@@ -369,18 +381,21 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
           double v = 0.5 * (ar + br) + 0.5 * (c * (ai + bi) - s * (ar - br));
           if (post) v *= post[k];
           RPDE_T(e)[q] = v;
+          if (gdst && k < gn) gdst[(long)k * ges] = gscale * v;   // fused OP_STORE
         }
       }
     }
     RPDE_SYNC(blk);
-    RPDE_PHASE(blk, tid) {
+    if (!gdst) {
+      RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) {
-        const int k = tid + q * T;
-        if (k <= N) x[k] = RPDE_T(e)[q];
+        for (int q = 0; q < Cfg::EPT; ++q) {
+          const int k = tid + q * T;
+          if (k <= N) x[k] = RPDE_T(e)[q];
+        }
       }
+      RPDE_SYNC(blk);
     }
-    RPDE_SYNC(blk);
   }
 }
 
@@ -925,8 +940,22 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       case OP_DCT: {
         tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
         tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
-        if (pg.fft_n > 0) dct1_lds<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
-        else dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
+        // fused forms (FFT path only): i1 >= 0: composite->ortho stencil table applied while packing;
+        // arr >= 0: results go straight to the global array (b = count, s0 = scale) instead of LDS
+        if (pg.fft_n > 0) {
+          tab_t low = op.i1 >= 0 ? (tab_t)pg.tabs[op.i1] : (tab_t) nullptr;
+          gmem_t gdst = (gmem_t) nullptr;
+          int ges = 1;
+          if (op.arr >= 0) {
+            const ArrayRef& A = pg.arr[op.arr];
+            gdst = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
+            ges = A.es;
+          }
+          dct1_lds<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2], low, gdst,
+                        ges, op.s0, op.b);
+        } else {
+          dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
+        }
       } break;
       case OP_MUL: {
         RPDE_PHASE(blk, tid) {

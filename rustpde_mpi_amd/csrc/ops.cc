@@ -126,7 +126,22 @@ void ProgramBuilder::rec2(int d, int a, int n, const double* p, const double* q,
 void ProgramBuilder::dct(int d, int n, const double* pre, const double* post) {
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
   const int ipre = pre ? tab(pre) : -1, ipost = post ? tab(post) : -1;
-  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost;
+  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost; o.i1 = -1; o.arr = -1;
+}
+void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const double* pre,
+                               const double* post, int store_arr, int nstore, double scale) {
+  const int n = ax.base.n;
+  if (ax.fft_n == 0) {   // direct transform: no fused forms
+    if (sten_) to_ortho(d, ax);
+    dct(d, n, pre, post);
+    if (store_arr >= 0) store(d, store_arr, nstore, scale);
+    return;
+  }
+  RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
+  const int ipre = pre ? tab(pre) : -1, ipost = post ? tab(post) : -1;
+  const int ilow = (sten_ && ax.base.is_composite()) ? tab(ax.low.p) : -1;
+  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost; o.i1 = ilow;
+  o.arr = store_arr; o.b = nstore; o.s0 = scale;
 }
 void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {
   Op& o = push(OP_MUL); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.acc = acc;

@@ -63,6 +63,11 @@ class ProgramBuilder {
   void rec1(int d, int a, int n, const double* p, const double* q, int dir, long tabld = 0);
   void rec2(int d, int a, int n, const double* p, const double* q, const double* r, long tabld = 0);
   void dct(int d, int n, const double* pre, const double* post);
+  // fused forms: `sten` = composite->ortho stencil of `ax` applied while packing (slot d holds the
+  // composite coefficients); `store_arr` >= 0 = results written straight to that array (nstore
+  // values, scaled).  Fall back to separate ops when the line uses the direct (non-FFT) transform.
+  void dct_fused(int d, const AxisTables& ax, bool sten, const double* pre, const double* post,
+                 int store_arr = -1, int nstore = 0, double scale = 1.0);
   void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
   void axpby(int d, int a, double s0, int b, double s1, int n);
   void zero(int d, int from, int to);
