@@ -91,6 +91,8 @@ int rpde_navier2d_param(rpde_navier2d* h, const char* key, double* value);
 int rpde_navier2d_exit(rpde_navier2d* h, int* flag);
 /* DivNorm::div_norm                                          src/navier_stokes/navier_eq.rs:33-51 */
 int rpde_navier2d_div_norm(rpde_navier2d* h, double* value);
+/* eval_nu / eval_nuvol / eval_re (callback diagnostics)     src/navier_stokes/functions.rs:146-233 */
+int rpde_navier2d_diagnostics(rpde_navier2d* h, double* nu, double* nuvol, double* re);
 /* integrate(&mut pde, max_time, None) without callbacks      src/lib.rs:187-219 ; returns steps taken */
 int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps);
 

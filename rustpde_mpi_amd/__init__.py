@@ -199,6 +199,16 @@ class Navier2D:
         self._lib.call("rpde_navier2d_div_norm", self._h, C.byref(v))
         return v.value
 
+    def diagnostics(self):
+        """(Nu, Nuvol, Re) as eval_nu / eval_nuvol / eval_re of the reference."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._lib.call("rpde_navier2d_diagnostics", self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def eval_nu(self): return self.diagnostics()[0]
+    def eval_nuvol(self): return self.diagnostics()[1]
+    def eval_re(self): return self.diagnostics()[2]
+
     def last_update_ms(self):
         v = C.c_double()
         self._lib.call("rpde_navier2d_last_update_ms", self._h, C.byref(v))

@@ -49,6 +49,7 @@ SIGNATURES = {
     "rpde_navier2d_param": (C.c_int, [_vp, C.c_char_p, _dp]),
     "rpde_navier2d_exit": (C.c_int, [_vp, _ip]),
     "rpde_navier2d_div_norm": (C.c_int, [_vp, _dp]),
+    "rpde_navier2d_diagnostics": (C.c_int, [_vp, _dp, _dp, _dp]),
     "rpde_navier2d_integrate": (C.c_int, [_vp, C.c_double, C.c_int, C.POINTER(C.c_long)]),
     "rpde_space2_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "rpde_space2_destroy": (C.c_int, [_vp]),

@@ -213,6 +213,14 @@ int rpde_navier2d_div_norm(rpde_navier2d* h, double* value) {
     *value = h->e->div_norm();
   })
 }
+int rpde_navier2d_diagnostics(rpde_navier2d* h, double* nu, double* nuvol, double* re) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(nu && nuvol && re, "null pointer");
+    select_device(h->device);
+    h->e->diagnostics(nu, nuvol, re);
+  })
+}
 int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps) {
   RPDE_TRY({
     RPDE_CHECK_HANDLE(h);

@@ -47,6 +47,9 @@ class Navier2DEngine {
 
   void update(int nsteps);           // n x Integrate::update
   double div_norm();                 // ||div||_2 of the current velocity (navier_eq.rs:33-51)
+  // Nusselt number at the plates, volumetric Nusselt number, Reynolds number
+  // (eval_nu / eval_nuvol / eval_re, src/navier_stokes/functions.rs:146-233; callback cadence only)
+  void diagnostics(double* nu, double* nuvol, double* re);
   bool exit();                       // NaN guard of Integrate::exit (navier.rs:482-489)
   double time() const { return time_; }
   double dt() const { return dt_; }

@@ -118,4 +118,7 @@ def check_step_parity(lib, periodic, nx, ny, ra, dt, steps, aspect=1.0, tol=1e-1
     assert abs(nav.get_time() - ora.time) < 1e-12
     assert abs(nav.div_norm() - ora.div_norm()) < 1e-9 * max(1.0, ora.div_norm())
     assert nav.exit() is False
+    # callback diagnostics (functions.rs:146-233)
+    for got, want in zip(nav.diagnostics(), (ora.eval_nu(), ora.eval_nuvol(), ora.eval_re())):
+        assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (got, want)
     return worst
