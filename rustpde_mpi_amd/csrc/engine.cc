@@ -268,26 +268,29 @@ void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int c
   auto cnt = [&](const std::vector<int>& p, int q, int n) { return clampi(std::min(p[q + 1], n) - std::min(p[q], n), 0, n); };
   const int rl = cnt(inpart, me, rows);        // local input rows
   const int cl = cnt(outpart, me, cols);       // local output rows
+  RPDE_REQUIRE(P <= 8, "at most 8 ranks per exchange");
   std::vector<int64_t> sc(P), rc(P);
-  size_t off = 0;
-  for (int q = 0; q < P; ++q) {    // pack: block (rl x cq) -> transposed (cq x rl), contiguous per destination
-    const int c0 = std::min(outpart[q], cols), cq = cnt(outpart, q, cols);
-    for (const Xfer& x : xs) {
-      launch_transpose(x.in + (size_t)c0 * elem, x.ldi, sendbuf_.p + off, (long)rl * elem, rl, cq, elem, st_);
-      off += (size_t)cq * rl * elem;
-    }
-    sc[q] = (int64_t)xs.size() * cq * rl * elem;
+  XchgDesc d{};
+  d.P = P; d.nA = (int)xs.size(); d.rl = rl; d.cl = cl; d.elem = elem;
+  d.ldi = xs[0].ldi; d.ldo = xs[0].ldo;
+  for (size_t a = 0; a < xs.size(); ++a) {
+    RPDE_REQUIRE(xs[a].ldi == d.ldi && xs[a].ldo == d.ldo, "batched exchange: mixed pitches");
+    d.in[a] = xs[a].in; d.out[a] = xs[a].out;
+  }
+  long so = 0, ro = 0;
+  for (int q = 0; q < P; ++q) {
+    d.c0[q] = std::min(outpart[q], cols);
+    d.r0[q] = std::min(inpart[q], rows);
+    d.soff[q] = so; d.roff[q] = ro;
+    sc[q] = (int64_t)xs.size() * cnt(outpart, q, cols) * rl * elem;
     rc[q] = (int64_t)xs.size() * cl * cnt(inpart, q, rows) * elem;
+    so += sc[q]; ro += rc[q];
   }
+  d.c0[P] = std::min(outpart[P], cols);
+  d.r0[P] = std::min(inpart[P], rows);
+  launch_xchg_pack(d, sendbuf_.p, st_);          // one launch: all destinations, all arrays
   alltoallv(sendbuf_.p, sc, recvbuf_.p, rc);
-  off = 0;
-  for (int s = 0; s < P; ++s) {    // unpack: segment (cl x rs) -> out[:, r0 : r0 + rs]
-    const int r0 = std::min(inpart[s], rows), rs = cnt(inpart, s, rows);
-    for (const Xfer& x : xs) {
-      launch_copy2d(recvbuf_.p + off, (long)rs * elem, x.out + (size_t)r0 * elem, x.ldo, cl, rs * elem, st_);
-      off += (size_t)cl * rs * elem;
-    }
-  }
+  launch_xchg_unpack(d, recvbuf_.p, st_);        // one launch: all sources, all arrays
 }
 
 void Navier2DEngine::halo(double* base, long ld, int ncols) {

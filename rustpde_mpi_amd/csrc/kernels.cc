@@ -3,6 +3,7 @@
 // loops that define the expected results of the HIP kernels.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace rpde {
@@ -195,6 +196,65 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
   RPDE_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------- exchange pack / unpack
+template <class E, int TS>
+__global__ __launch_bounds__(256) void xchg_pack_kernel(const XchgDesc d, E* __restrict__ send) {
+  __shared__ E tile[TS][TS + 1];
+  const int q = blockIdx.z / d.nA, a = blockIdx.z % d.nA;
+  const int c0 = d.c0[q], cq = d.c0[q + 1] - c0, rl = d.rl;
+  const int bc = blockIdx.x * TS, br = blockIdx.y * TS;
+  if (bc >= cq || br >= rl) return;
+  const E* in = reinterpret_cast<const E*>(d.in[a]);
+  const long ldi = d.ldi / (long)(sizeof(E) / sizeof(double));
+  E* out = send + d.soff[q] / (long)(sizeof(E) / sizeof(double)) + (long)a * cq * rl;
+  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+  constexpr int RY = 256 / TS;
+#pragma unroll
+  for (int i = ty; i < TS; i += RY) {
+    const int r = br + i, cc = bc + tx;
+    if (r < rl && cc < cq) tile[i][tx] = in[(long)r * ldi + c0 + cc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = ty; i < TS; i += RY) {
+    const int cc = bc + i, r = br + tx;
+    if (r < rl && cc < cq) out[(long)cc * rl + r] = tile[tx][i];
+  }
+}
+template <class E>
+__global__ __launch_bounds__(256) void xchg_unpack_kernel(const XchgDesc d, const E* __restrict__ recv) {
+  const int s = blockIdx.z / d.nA, a = blockIdx.z % d.nA;
+  const int r0 = d.r0[s], rs = d.r0[s + 1] - r0, cl = d.cl;
+  const E* in = recv + d.roff[s] / (long)(sizeof(E) / sizeof(double)) + (long)a * cl * rs;
+  E* out = reinterpret_cast<E*>(d.out[a]);
+  const long ldo = d.ldo / (long)(sizeof(E) / sizeof(double));
+  for (int r = blockIdx.y; r < cl; r += gridDim.y)
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < rs; c += gridDim.x * 256)
+      out[(long)r * ldo + r0 + c] = in[(long)r * rs + c];
+}
+void launch_xchg_pack(const XchgDesc& d, double* send, Stream& st) {
+  int cmax = 0;
+  for (int q = 0; q < d.P; ++q) cmax = std::max(cmax, d.c0[q + 1] - d.c0[q]);
+  if (cmax <= 0 || d.rl <= 0) return;
+  if (d.elem == 1) {
+    dim3 grid((cmax + 63) / 64, (d.rl + 63) / 64, d.P * d.nA);
+    hipLaunchKernelGGL((xchg_pack_kernel<double, 64>), grid, dim3(256), 0, st.s, d, send);
+  } else {
+    dim3 grid((cmax + 31) / 32, (d.rl + 31) / 32, d.P * d.nA);
+    hipLaunchKernelGGL((xchg_pack_kernel<double2, 32>), grid, dim3(256), 0, st.s, d, reinterpret_cast<double2*>(send));
+  }
+  RPDE_HIP(hipGetLastError());
+}
+void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st) {
+  int rmax = 0;
+  for (int s = 0; s < d.P; ++s) rmax = std::max(rmax, d.r0[s + 1] - d.r0[s]);
+  if (rmax <= 0 || d.cl <= 0) return;
+  dim3 grid(std::min((rmax + 255) / 256, 16), std::min(d.cl, 2048), d.P * d.nA);
+  if (d.elem == 1) hipLaunchKernelGGL((xchg_unpack_kernel<double>), grid, dim3(256), 0, st.s, d, recv);
+  else hipLaunchKernelGGL((xchg_unpack_kernel<double2>), grid, dim3(256), 0, st.s, d, reinterpret_cast<const double2*>(recv));
+  RPDE_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------- small kernels
 __global__ __launch_bounds__(256) void copy2d_kernel(const double* __restrict__ in, long ldi,
                                                      double* __restrict__ out, long ldo, int rows,
@@ -284,6 +344,25 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
     }
     for (int n = 0; n < N; ++n) C[(long)m * ldc + n] = row[n];
   }
+}
+void launch_xchg_pack(const XchgDesc& d, double* send, Stream&) {
+  for (int q = 0; q < d.P; ++q)
+    for (int a = 0; a < d.nA; ++a) {
+      const int c0 = d.c0[q], cq = d.c0[q + 1] - c0, e = d.elem;
+      double* out = send + d.soff[q] + (long)a * cq * d.rl * e;
+      for (int r = 0; r < d.rl; ++r)
+        for (int c = 0; c < cq; ++c)
+          for (int z = 0; z < e; ++z) out[((long)c * d.rl + r) * e + z] = d.in[a][(long)r * d.ldi + (long)(c0 + c) * e + z];
+    }
+}
+void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream&) {
+  for (int s = 0; s < d.P; ++s)
+    for (int a = 0; a < d.nA; ++a) {
+      const int r0 = d.r0[s], rs = d.r0[s + 1] - r0, e = d.elem;
+      const double* in = recv + d.roff[s] + (long)a * d.cl * rs * e;
+      for (int r = 0; r < d.cl; ++r)
+        for (int c = 0; c < rs * e; ++c) d.out[a][(long)r * d.ldo + (long)r0 * e + c] = in[(long)r * rs * e + c];
+    }
 }
 void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream&) {
   for (int r = 0; r < rows; ++r)

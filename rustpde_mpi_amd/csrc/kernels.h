@@ -40,6 +40,22 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 // out[r * ldo + c] = in[r * ldi + c], r < rows, c < cols (doubles)
 void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream& st);
 
+// pack / unpack of one batched pencil exchange (P ranks, up to 6 arrays), one launch each:
+//  pack  : for every destination q and array a, the block in_a[0:rl, c0[q]:c0[q+1]] is written
+//          transposed (cq x rl, contiguous) to send + soff[q] + a * cq * rl * elem
+//  unpack: for every source s and array a, the segment recv + roff[s] + a * cl * rs * elem
+//          (cl x rs, contiguous) is written to out_a[0:cl, r0[s]:r0[s+1]]
+struct XchgDesc {
+  int P, nA, rl, cl, elem;
+  int c0[9], r0[9];
+  long soff[9], roff[9];
+  long ldi, ldo;
+  const double* in[6];
+  double* out[6];
+};
+void launch_xchg_pack(const XchgDesc& d, double* send, Stream& st);
+void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
+
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
 
