@@ -54,6 +54,16 @@ def test_sharded_matches_oracle_hip(world, tmp_path, hip_lib):
             assert e < 1e-10, (r["case"], k, e)
 
 
+@pytest.mark.gpu
+def test_config4_geometry_sharded_equals_single_device(tmp_path, hip_lib):
+    """BASELINE.json configs[3] (confined, pencil-sharded, here 2049 x 2049 over 4 ranks sharing the
+    GPU): the sharded fields equal the single-device fields after 3 steps."""
+    res = _spawn(4, hip_lib.path, True, [(False, 2049, 2049, 1e8, 5e-4, 3, 1.0)], tmp_path)
+    for k, e in res[0]["err"].items():
+        assert e < 1e-11, (k, e)
+    assert res[0]["comm"][1] == 16   # 11 batched all-to-alls + 5 halos per step
+
+
 def _nccl_single(rank, port, out):
     import torch
     import torch.distributed as dist
