@@ -428,7 +428,9 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
       for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
       in.upload(hbuf);
     }
-    ProgramBuilder pb(4, ax.slot_len, nlines, 1);
+    int nslots = 4;
+    if (const char* e = std::getenv("RPDE_MB_SLOTS")) nslots = std::atoi(e);
+    ProgramBuilder pb(nslots, ax.slot_len, nlines, 1);
     pb.set_fft(ax);
     const int ai = pb.arr(in.p, ld), ao = pb.arr(out.p, ld);
     const int m = b.m;

@@ -787,7 +787,9 @@ struct FillDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
 // never guarded; results are selected and stores are masked.
 constexpr int kTableSlack = 5200;
 
-template <class Cfg>
+// FULL = false compiles the register-hungry second-order scan (OP_REC2) out, so that programs
+// without banded back-substitution run from a kernel that fits 4 waves per SIMD
+template <class Cfg, bool FULL = true>
 RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   constexpr int T = Cfg::T, EPT = Cfg::EPT;
   const int line = blk.line, comp = blk.comp;
@@ -933,9 +935,11 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
       } break;
       case OP_REC2: {
-        const FillRec<true, true> f{a, (tab_t)(pg.tabs[op.tab] + toff), (tab_t)(pg.tabs[op.i0] + toff),
-                                    (tab_t)(pg.tabs[op.i1] + toff)};
-        scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f);
+        if constexpr (FULL) {
+          const FillRec<true, true> f{a, (tab_t)(pg.tabs[op.tab] + toff), (tab_t)(pg.tabs[op.i0] + toff),
+                                      (tab_t)(pg.tabs[op.i1] + toff)};
+          scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f);
+        }
       } break;
       case OP_DCT: {
         tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
