@@ -63,6 +63,22 @@ def cpu_baseline(args):
                       f"(NumPy/SciPy oracle, OpenBLAS dgemm + pocketfft, setup {setup:.1f}s not timed)"}
 
 
+def pmc_traffic(workload, tag):
+    """HBM bytes per launch of kernel `tag` from the committed rocprofv3 --pmc passes
+    (tools/pmc_step.py + tools/pmc_traffic.py -> profiles/*pmc_traffic*.json, FETCH_SIZE and
+    WRITE_SIZE collected in separate passes and corrected as MI355X_MICROARCH.md prescribes).
+    None when no pass for this workload has been committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == workload and tag in d.get("per_launch", {}):
+            return d["per_launch"][tag]["traffic_bytes"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +154,11 @@ def main():
         achieved = dom["bytes"] / (per_launch_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+    traffic, traffic_src = pmc_traffic(f"{'periodic' if args.periodic else 'confined'} {args.nx}x{args.ny}", dom["tag"])
+    if world == 1 and traffic is not None:
+        roof["traffic"] = traffic
+        roof["traffic_source"] = traffic_src
+    roof["algorithmic_per_launch"] = dom["flops"] if dom["flops"] > 0 else dom["bytes"]
     roof["kernel"] = dom["tag"]
     roof["launches_timed"] = tag_n
     roof["ms_per_launch"] = per_launch_ms

@@ -225,6 +225,13 @@ class Navier2D:
                          "flops": float(fl)})
         return rows
 
+    def schedule(self):
+        """The launches of one step in issue order: list of (tag, algorithmic bytes, flops)."""
+        buf = C.create_string_buffer(1 << 16)
+        self._lib.call("rpde_navier2d_describe_step", self._h, buf, len(buf))
+        return [(t, float(b), float(f)) for t, b, f in
+                (line.split("\t") for line in buf.value.decode().splitlines())]
+
     def set_timed_tag(self, tag: str):
         self._lib.call("rpde_navier2d_set_timed_tag", self._h, tag.encode())
 

@@ -182,6 +182,14 @@ int rpde_navier2d_profile(rpde_navier2d* h, int nsteps, char* buf, size_t len) {
     std::memcpy(buf, s.c_str(), s.size() + 1);
   })
 }
+int rpde_navier2d_describe_step(rpde_navier2d* h, char* buf, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(buf && len > 0, "null pointer");
+    const std::string s = h->e->describe_step();
+    RPDE_REQUIRE(s.size() + 1 <= len, "schedule buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  })
+}
 int rpde_navier2d_set_timed_tag(rpde_navier2d* h, const char* tag) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(tag, "null pointer"); h->e->set_timed_tag(tag); })
 }

@@ -318,12 +318,13 @@ template <class Cfg>
 static void launch_cfg(const Program& pg, Stream&) {
   const size_t nd = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kMaxSlotLen, Cfg::kCarryLen);
   RPDE_REQUIRE(nd * sizeof(double) <= 160 * 1024, "line program needs more than 160 KiB of LDS");
-  std::vector<double> lds(nd);
+  constexpr size_t guard = 16;   // NaN in front of slot 0 as well
+  std::vector<double> lds(nd + guard);
   for (int comp = 0; comp < pg.ncomp; ++comp)
     for (int line = 0; line < pg.nlines; ++line) {
       // poison the LDS like uninitialised hardware memory would be
       std::fill(lds.begin(), lds.end(), std::nan(""));
-      Blk blk{line, comp, Cfg::T, lds.data()};
+      Blk blk{line, comp, Cfg::T, lds.data() + guard};
       run_line_program<Cfg>(blk, pg);
     }
 }

@@ -211,22 +211,33 @@ template <bool STEN>
 struct DctSrc {
   static constexpr bool kLds = false;
   clds_t x; int N; tab_t pre; tab_t low;
-  RPDE_DEV double val(int m) const {
+  // lo_edge / hi_edge: this element may touch the ends of the line (m < 2, m >= N-1); elsewhere the
+  // stencil needs no selects.  All three flags are compile-time constants after unrolling.
+  RPDE_DEV double val(int m, int n, bool lo_edge, bool hi_edge) const {
     double v;
     if constexpr (STEN) {
-      const int m2 = m >= 2 ? m - 2 : 0;
-      const double a0 = x[m], a2 = x[m2], l2 = low[m2];
-      v = (m < N - 1 ? a0 : 0.0) + (m >= 2 ? l2 * a2 : 0.0);
+      double a0 = x[m];
+      if (hi_edge) a0 = (m < n - 1) ? a0 : 0.0;
+      double t2;
+      if (lo_edge) {
+        const int m2 = m >= 2 ? m - 2 : 0;
+        const double a2 = x[m2], l2 = low[m2];
+        t2 = (m >= 2) ? l2 * a2 : 0.0;
+      } else {
+        t2 = low[m - 2] * x[m - 2];
+      }
+      v = a0 + t2;
     } else {
       v = x[m];
     }
     return pre ? v * pre[m] : v;
   }
-  RPDE_DEV dbl2 operator()(int i) const {
-    int m0 = 2 * i, m1 = 2 * i + 1;
-    if (m0 > N) m0 = 2 * N - m0;
-    if (m1 > N) m1 = 2 * N - m1;
-    return dbl2{val(m0), val(m1)};
+  // element i of the packed even extension, n = FFT length = DCT N (compile-time at the call
+  // site); hi: i >= n/2, where the extension runs backwards (m0 = 2n - 2i, m1 = m0 - 1)
+  RPDE_DEV dbl2 get(int i, int n, bool hi, bool lo_edge, bool hi_edge) const {
+    const int m0 = hi ? 2 * n - 2 * i : 2 * i;
+    const int m1 = hi ? m0 - 1 : m0 + 1;
+    return dbl2{val(m0, n, lo_edge, hi_edge), val(m1, n, lo_edge, hi_edge)};
   }
 };
 
@@ -265,7 +276,10 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
             const int p = kStaticRead ? base + t * NB + ((t * NB) >> 4) : pidx(j + t * NB);
             v = w2[p];
           } else {
-            v = src(j + t * NB);
+            // butterfly input t covers i in [t NB, (t+1) NB): one half of the extension; only the
+            // first and last inputs reach m < 2 (i = 0: m = 0, 1; i = N-1: m = 2, 1) and only the
+            // two middle ones reach m >= N-1
+            v = src.get(j + t * NB, N, t * NB >= N / 2, t == 0 || t == R - 1, t == R / 2 || t == R / 2 - 1);
           }
           RPDE_T(xr)[q * R + t] = v.x;
           RPDE_T(xi)[q * R + t] = v.y;
@@ -367,21 +381,31 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
   // pass reads everything before the barrier that precedes its writes)
   if (low) fft_dispatch<Cfg, DctSrc<true>>(blk, x, N, tw, DctSrc<true>{x, N, pre, low});
   else fft_dispatch<Cfg, DctSrc<false>>(blk, x, N, tw, DctSrc<false>{x, N, pre, low});
-  {  // split: E_k = (Zr_k + Zr_{N-k})/2 + (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2
-    RPDE_TLS(blk, double, e, Cfg::EPT);
+  {  // split: E_k = A + B, E_{N-k} = A - B with A = (Zr_k + Zr_{N-k})/2,
+     // B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2: one thread per pair (k, N-k)
+    constexpr int QH = Cfg::FMAX / 2 / T + 1;
+    static_assert(2 * QH <= Cfg::EPT + 2, "pair split needs 2 QH registers");
+    const int H = N >> 1;
+    RPDE_TLS(blk, double, e, 2 * QH);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) {
+      for (int q = 0; q < QH; ++q) {
         const int k = tid + q * T;
-        if (k <= N) {
-          const dbl2 za = ((lds2_t)x)[pidx((k == N) ? 0 : k)];
-          const dbl2 zb = ((lds2_t)x)[pidx((k == 0) ? 0 : N - k)];
+        if (k <= H) {
+          const int kn = N - k;
+          const dbl2 za = ((lds2_t)x)[pidx(k)];
+          const dbl2 zb = ((lds2_t)x)[pidx((k == 0) ? 0 : kn)];
           const double ar = za.x, ai = za.y, br = zb.x, bi = zb.y;
           const double c = tw2[2 * k], s = tw2[2 * k + 1];
-          double v = 0.5 * (ar + br) + 0.5 * (c * (ai + bi) - s * (ar - br));
-          if (post) v *= post[k];
-          RPDE_T(e)[q] = v;
-          if (gdst && k < gn) gdst[(long)k * ges] = gscale * v;   // fused OP_STORE
+          const double A = 0.5 * (ar + br), B = 0.5 * (c * (ai + bi) - s * (ar - br));
+          double ek = A + B, en = A - B;
+          if (post) { ek *= post[k]; en *= post[kn]; }
+          RPDE_T(e)[2 * q] = ek;
+          RPDE_T(e)[2 * q + 1] = en;
+          if (gdst) {   // fused OP_STORE
+            if (k < gn) gdst[(long)k * ges] = gscale * ek;
+            if (kn < gn) gdst[(long)kn * ges] = gscale * en;
+          }
         }
       }
     }
@@ -389,9 +413,9 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
     if (!gdst) {
       RPDE_PHASE(blk, tid) {
 #pragma unroll
-        for (int q = 0; q < Cfg::EPT; ++q) {
+        for (int q = 0; q < QH; ++q) {
           const int k = tid + q * T;
-          if (k <= N) x[k] = RPDE_T(e)[q];
+          if (k <= H) { x[k] = RPDE_T(e)[2 * q]; x[N - k] = RPDE_T(e)[2 * q + 1]; }
         }
       }
       RPDE_SYNC(blk);
@@ -809,13 +833,22 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         const ArrayRef& A = pg.arr[op.arr];
         cgmem_t src = (cgmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         const int es = A.es;
+        const bool plain = !op.i0 && es == 1;       // contiguous line: no 64-bit index arithmetic
         RPDE_PHASE(blk, tid) {
           double v[EPT];
+          if (plain) {
 #pragma unroll
-          for (int q = 0; q < EPT; ++q) {
-            const int k = tid + q * T;
-            const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
-            v[q] = (k < n) ? src[kk * es] : 0.0;
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              v[q] = (k < n) ? src[k] : 0.0;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
+              v[q] = (k < n) ? src[kk * es] : 0.0;
+            }
           }
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
@@ -854,14 +887,24 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       case OP_STORE: {
         const ArrayRef& A = pg.arr[op.arr];
         gmem_t dstp = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
+        const bool plain = !op.i0 && A.es == 1;
         RPDE_PHASE(blk, tid) {
+          if (plain) {
 #pragma unroll
-          for (int q = 0; q < EPT; ++q) {
-            const int k = tid + q * T;
-            const double x = op.s0 * a[k];
-            if (k < n) {
-              const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;
-              dstp[kk * A.es] = x;
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const double x = op.s0 * a[k];
+              if (k < n) dstp[k] = x;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const double x = op.s0 * a[k];
+              if (k < n) {
+                const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;
+                dstp[kk * A.es] = x;
+              }
             }
           }
         }

@@ -85,11 +85,15 @@ struct Stream {
 #endif
 };
 
+constexpr size_t kEmuGuardBytes = 256;
 inline void* dev_alloc(size_t bytes) {
 #ifdef RPDE_EMU
-  void* p = std::calloc(bytes ? bytes : 1, 1);
-  RPDE_REQUIRE(p, "host allocation failed");
-  return p;
+  // a NaN-filled guard in front of every buffer: a read below the start of a table or array
+  // (a page fault on the device when the buffer opens an allocation) poisons the results here
+  char* raw = static_cast<char*>(std::calloc(bytes + kEmuGuardBytes + 1, 1));
+  RPDE_REQUIRE(raw, "host allocation failed");
+  std::memset(raw, 0xFF, kEmuGuardBytes);
+  return raw + kEmuGuardBytes;
 #else
   void* p = nullptr;
   RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
@@ -99,7 +103,7 @@ inline void* dev_alloc(size_t bytes) {
 }
 inline void dev_free(void* p) {
 #ifdef RPDE_EMU
-  std::free(p);
+  if (p) std::free(static_cast<char*>(p) - kEmuGuardBytes);
 #else
   if (p) (void)hipFree(p);
 #endif
