@@ -64,12 +64,22 @@ struct Blk {          // one workgroup
 #else
 #define RPDE_HD __host__ __device__
 #define RPDE_DEV __device__ __forceinline__
-#define RPDE_DEVN __device__ __noinline__
+#define RPDE_DEVN __device__ __forceinline__
 struct Blk {
   int line, comp, T;
   double* lds;
 };
-#define RPDE_PHASE(blk, tid) for (int tid = (int)threadIdx.x, _once = 1; _once; _once = 0)
+// The thread index is laundered through an empty volatile asm in every phase: otherwise the
+// compiler hoists the per-thread index arithmetic of ALL ops out of the interpreter loop, keeps it
+// live across the whole program and spills it in the prologue (160 B/lane of scratch writes per
+// line -- more HBM traffic than the line itself; rocprofv3 WRITE_SIZE, profiles/README.md)
+__device__ __forceinline__ int rpde_tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < 1024);
+  return t;
+}
+#define RPDE_PHASE(blk, tid) for (int tid = rpde_tid(), _once = 1; _once; _once = 0)
 #define RPDE_SYNC(blk) __syncthreads()
 #define RPDE_TLS(blk, type, name, K) type name[K]
 #define RPDE_T(name) name
