@@ -20,7 +20,7 @@ static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal
 // 2 waves per SIMD) and the light one, held to 128 VGPRs (4 waves per SIMD) so that two or three
 // workgroups of a DCT / stencil / first-order-scan program share a CU.
 template <class Cfg, bool FULL>
-__global__ __launch_bounds__(Cfg::T, FULL ? 2 : 4) void line_kernel(const Program pg) {
+__global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
   Blk blk{(int)blockIdx.x, (int)blockIdx.y, Cfg::T, rpde_lds};
   run_line_program<Cfg, FULL>(blk, pg);
