@@ -754,21 +754,22 @@ void Navier2DEngine::build_confined() {
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
-    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; accumulator = slot 2
-    ProgramBuilder pb = xpb(3, nx);
+    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
+    // waits in the register stash, so two workgroups share a CU
+    ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-    pb.axpby(2, 0, 1.0, 0, 0.0, ny);
+    pb.stash(0);
     pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
     pb.to_ortho(0, yD);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.dct(0, ny, yD.bwd_pre.p, nullptr);
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
-    pb.axpby(0, 0, 1.0, 2, 1.0, ny);
+    pb.unstash_axpy(0, 1.0, 1.0, ny);
     pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };
@@ -1023,21 +1024,22 @@ void Navier2DEngine::build_periodic() {
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
-    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; accumulator = slot 2
-    ProgramBuilder pb = xpb(3, nx, false);
+    // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
+    // waits in the register stash
+    ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-    pb.axpby(2, 0, 1.0, 0, 0.0, ny);
+    pb.stash(0);
     pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
     pb.to_ortho(0, yD);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.dct(0, ny, yD.bwd_pre.p, nullptr);
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
-    pb.axpby(0, 0, 1.0, 2, 1.0, ny);
+    pb.unstash_axpy(0, 1.0, 1.0, ny);
     pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };

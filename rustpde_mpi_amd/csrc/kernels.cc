@@ -16,26 +16,26 @@ static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal
 
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
-// Two kernels per configuration: FULL (with the second-order back-substitution scan, ~240 VGPRs,
-// 2 waves per SIMD) and the light one, held to 128 VGPRs (4 waves per SIMD) so that two or three
-// workgroups of a DCT / stencil / first-order-scan program share a CU.
-template <class Cfg, bool FULL>
+// Three kernels per configuration (line_vm.h kVar*): light, with the second-order back-substitution
+// scan, with the register stash.  All are held to 128 VGPRs (4 waves per SIMD) so that two
+// workgroups of a two-slot program share a CU; none spills more than a few dwords.
+template <class Cfg, int VAR>
 __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
   Blk blk{(int)blockIdx.x, (int)blockIdx.y, Cfg::T, rpde_lds};
-  run_line_program<Cfg, FULL>(blk, pg);
+  run_line_program<Cfg, VAR>(blk, pg);
 }
 
-template <class Cfg, bool FULL>
+template <class Cfg, int VAR>
 static void launch_kernel(const Program& pg, size_t bytes, Stream& st) {
   static size_t configured = 0;
   if (bytes > configured) {
-    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg, FULL>),
+    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg, VAR>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     configured = bytes;
   }
   dim3 grid(pg.nlines, pg.ncomp), block(Cfg::T);
-  hipLaunchKernelGGL((line_kernel<Cfg, FULL>), grid, block, bytes, st.s, pg);
+  hipLaunchKernelGGL((line_kernel<Cfg, VAR>), grid, block, bytes, st.s, pg);
   RPDE_HIP(hipGetLastError());
 }
 
@@ -43,10 +43,15 @@ template <class Cfg>
 static void launch_cfg(const Program& pg, Stream& st) {
   const size_t bytes = line_lds_doubles(pg.nslots, pg.slot_len, Cfg::kMaxSlotLen, Cfg::kCarryLen) * sizeof(double);
   RPDE_REQUIRE(bytes <= 160 * 1024, "line program needs more than 160 KiB of LDS");
-  bool full = false;
-  for (int i = 0; i < pg.nops; ++i) full |= pg.ops[i].code == OP_REC2;
-  if (full) launch_kernel<Cfg, true>(pg, bytes, st);
-  else launch_kernel<Cfg, false>(pg, bytes, st);
+  bool rec2 = false, stash = false;
+  for (int i = 0; i < pg.nops; ++i) {
+    rec2 |= pg.ops[i].code == OP_REC2;
+    stash |= pg.ops[i].code == OP_PUSH || pg.ops[i].code == OP_POPAXPY;
+  }
+  RPDE_REQUIRE(!(rec2 && stash), "a line program cannot combine the register stash with a banded solve");
+  if (rec2) launch_kernel<Cfg, kVarRec2>(pg, bytes, st);
+  else if (stash) launch_kernel<Cfg, kVarStash>(pg, bytes, st);
+  else launch_kernel<Cfg, kVarLight>(pg, bytes, st);
 }
 
 // ------------------------------------------------------------------------------- transpose

@@ -67,7 +67,13 @@ enum OpCode : int {
   OP_RFFT_F,   // slot d: real (n = nx) -> interleaved complex (nx/2+1), unnormalised
   OP_RFFT_B,   // slot d: interleaved complex (nx/2+1) -> real (n = nx), scaled by 1/nx
   OP_CIK,      // complex line: d = (i k s0)^i0 * a  for k < n (complex count)
+  OP_PUSH,     // per-thread register stash <- a[k]   (one stash per program run; saves an LDS slot)
+  OP_POPAXPY,  // d[k] = s0 * d[k] + s1 * stash[k]    k < n
 };
+
+// kernel variants: which register-hungry features a program needs (each is compiled out of the
+// others so that every variant fits 128 VGPRs without scratch traffic worth mentioning)
+constexpr int kVarLight = 0, kVarRec2 = 1, kVarStash = 2, kVarAll = 3;
 
 struct ArrayRef {
   double* p;
@@ -811,11 +817,14 @@ struct FillDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
 // never guarded; results are selected and stores are masked.
 constexpr int kTableSlack = 5200;
 
-// FULL = false compiles the register-hungry second-order scan (OP_REC2) out, so that programs
-// without banded back-substitution run from a kernel that fits 4 waves per SIMD
-template <class Cfg, bool FULL = true>
+// VAR selects what is compiled in: the second-order scan (OP_REC2) and the register stash
+// (OP_PUSH / OP_POPAXPY, 2 EPT VGPRs live across the whole program) are each left out of the
+// variants that do not need them
+template <class Cfg, int VAR = kVarAll>
 RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   constexpr int T = Cfg::T, EPT = Cfg::EPT;
+  constexpr bool FULL = (VAR & kVarRec2) != 0, STASH = (VAR & kVarStash) != 0;
+  RPDE_TLS(blk, double, stash, STASH ? EPT : 1);
   const int line = blk.line, comp = blk.comp;
   const int SL = pg.slot_len;
   lds_t lds = (lds_t)blk.lds;
@@ -1026,6 +1035,28 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           }
         }
         RPDE_SYNC(blk);
+      } break;
+      case OP_PUSH: {
+        if constexpr (STASH) {
+          RPDE_PHASE(blk, tid) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) RPDE_T(stash)[q] = a[tid + q * T];
+          }
+          RPDE_SYNC(blk);  // the next op may overwrite the slot
+        }
+      } break;
+      case OP_POPAXPY: {
+        if constexpr (STASH) {
+          RPDE_PHASE(blk, tid) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const double v = op.s0 * d[k] + op.s1 * RPDE_T(stash)[q];
+              if (k < n) d[k] = v;
+            }
+          }
+          RPDE_SYNC(blk);
+        }
       } break;
       case OP_ZERO: {
         RPDE_PHASE(blk, tid) {

@@ -149,6 +149,10 @@ void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {
 void ProgramBuilder::axpby(int d, int a, double s0, int b, double s1, int n) {
   Op& o = push(OP_AXPBY); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.s1 = s1;
 }
+void ProgramBuilder::stash(int a) { Op& o = push(OP_PUSH); o.a = a; }
+void ProgramBuilder::unstash_axpy(int d, double s0, double s1, int n) {
+  Op& o = push(OP_POPAXPY); o.d = d; o.n = n; o.s0 = s0; o.s1 = s1;
+}
 void ProgramBuilder::zero(int d, int from, int to) {
   Op& o = push(OP_ZERO); o.d = d; o.i0 = from; o.i1 = to;
 }

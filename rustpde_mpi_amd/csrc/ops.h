@@ -70,6 +70,10 @@ class ProgramBuilder {
                  int store_arr = -1, int nstore = 0, double scale = 1.0);
   void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
   void axpby(int d, int a, double s0, int b, double s1, int n);
+  // per-thread register copy of slot a (kept until the end of the program), and
+  // d = s0 * d + s1 * stash: an accumulator that costs no LDS slot
+  void stash(int a);
+  void unstash_axpy(int d, double s0, double s1, int n);
   void zero(int d, int from, int to);
   void tabdiv(int d, int a, int n, const double* t, int shift);
   void rfft_f(int d, int nx);
