@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Attribute a rocprofv3 --kernel-trace (CSV) of a bench.py run to the launches of the step.
+
+All line programs share three kernel symbols, so the per-symbol --stats table cannot tell `S4` from
+`S6`.  The step issues the same L launches in the same order every step (tools/pmc_step.py writes
+that schedule); this script finds the longest stretch of the trace that is periodic with period L and
+whose kernel kinds match the schedule, and averages the durations per schedule position / tag.
+
+    python tools/trace_by_tag.py <dir with *kernel_trace.csv> <schedule.json> [out.csv]
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def kind_of_tag(tag):
+    if tag.startswith("T"): return "transpose"
+    if tag.startswith("G"): return "gemm"
+    if tag.startswith("pseu"): return "set_element"
+    if tag.startswith("H"): return "copy2d"
+    return "line_kernel"
+
+
+def kind_of_kernel(name):
+    for k in ("transpose", "gemm", "set_element", "line_kernel", "copy2d"):
+        if k in name: return k
+    return "other"
+
+
+def main():
+    d, sched = sys.argv[1], json.load(open(sys.argv[2]))
+    tags = [l["tag"] for l in sched["schedule"]]
+    want = [kind_of_tag(t) for t in tags]
+    L = len(tags)
+    path = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    kinds = [kind_of_kernel(r["Kernel_Name"]) for r in rows]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in rows]   # us
+    best = (0, 0)
+    i = 0
+    while i + L <= len(rows):
+        if kinds[i:i + L] == want:
+            n = 0
+            while i + (n + 1) * L <= len(rows) and kinds[i + n * L:i + (n + 1) * L] == want:
+                n += 1
+            if n > best[1]: best = (i, n)
+            i += n * L
+        else:
+            i += 1
+    start, nsteps = best
+    assert nsteps > 0, "no stretch of the trace matches the schedule"
+    acc = defaultdict(list)
+    for s in range(nsteps):
+        for p in range(L):
+            acc[tags[p]].append(dur[start + s * L + p])
+    step_us = sum(sum(v) for v in acc.values()) / nsteps
+    out = [("tag", "launches_per_step", "launches", "mean_us", "min_us", "max_us", "us_per_step", "share")]
+    for t in dict.fromkeys(tags):
+        v = acc[t]
+        out.append((t, tags.count(t), len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}",
+                    f"{sum(v)/nsteps:.1f}", f"{sum(v)/nsteps/step_us:.4f}"))
+    out.append(("TOTAL kernel time per step", L, nsteps * L, "", "", "", f"{step_us:.1f}", "1.0"))
+    w = csv.writer(open(sys.argv[3], "w") if len(sys.argv) > 3 else sys.stdout)
+    w.writerows(out)
+    print(f"# {nsteps} steps of {L} launches matched; kernel time {step_us/1e3:.3f} ms/step", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
