@@ -818,7 +818,7 @@ void Navier2DEngine::build_confined() {
   // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = xpb(1, mx);
+    ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[which].p, ldy), my);                 // entries my, my+1 only meet zero table entries
     pb.pinv_matvec(0, yD);
@@ -872,7 +872,7 @@ void Navier2DEngine::build_confined() {
   }
   // ---- S6: y preconditioner + per-eigenvalue banded solves (line index = eigen index)
   {
-    ProgramBuilder pb = xpb(1, mx);
+    ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy), my);   // columns my, my+1 only meet zero table entries
     pb.pinv_matvec(0, yN);
@@ -1081,7 +1081,7 @@ void Navier2DEngine::build_periodic() {
   // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
   for (int which = 0; which < 3; ++which) {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = xpb(1, kx, true);
+    ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), my);
     pb.pinv_matvec(0, yD);
@@ -1114,7 +1114,7 @@ void Navier2DEngine::build_periodic() {
   // ---- S6: Poisson: y preconditioner + one banded solve per wavenumber
   PoissonOp& po = *pois_;
   {
-    ProgramBuilder pb = xpb(1, kx, true);
+    ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
     pb.pinv_matvec(0, yN);

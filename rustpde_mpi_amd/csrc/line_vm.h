@@ -58,7 +58,7 @@ enum OpCode : int {
   OP_MV3,      // d[k] = t0[k] a[k] + t1[k] a[k+2] + t2[k] a[k+4]             k < n  (tables tab, tab+1, tab+2)
   OP_CDIFF,    // d = s0 * d/dx of the Chebyshev series a (length n)
   OP_REC1,     // first-order stride-2 recurrence, x_k = p_k b_k + q_k x_{k-2 dir}; p = tab (-1: ones), q = i0, dir = i1
-  OP_REC2,     // descending second-order: x_k = p_k b_k + q_k x_{k+2} + r_k x_{k+4}; p = tab, q = i0, r = i1
+  OP_REC2,     // descending second-order: x_k = p_k b_k + q_k x_{k+2} + r_k x_{k+4}; p = tab, q = i0, r = i1; slot b (the last one) = scratch
   OP_DCT,      // slot d (scratch d+1): x <- DCT-I(x * pre) * post ; pre = tab (-1 none), post = i0 (-1 none); n = N+1
   OP_MUL,      // d[k] = (acc ? d[k] : 0) + s0 * a[k] * b[k]
   OP_AXPBY,    // d[k] = s0 * a[k] + s1 * b[k]
@@ -643,8 +643,12 @@ __device__ __forceinline__ Affine<ORDER> affine_shfl_idx(const Affine<ORDER>& a,
 // `fill(k, b, q, r)` supplies the coefficients of element k (it may read LDS / padded tables
 // freely, also for k >= n); all loads of a chunk are issued in one batch before the dependent
 // chains start.
+// ORDER 2 parks its r coefficients in the LDS area `scr` (T * C doubles, thread-private entries
+// [i * T + tid]) between the chunk reduction and the re-run: 2 C fewer live VGPRs across the
+// prefix phase, which is what keeps the kernel at 128 VGPRs without scratch memory traffic.
 template <class Cfg, int ORDER, int DIR, class Fill>
-RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fill fill) {
+RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fill fill,
+                               lds_t scr = (lds_t) nullptr) {
   constexpr int T = Cfg::T, C = Cfg::C;
   constexpr int W = 6;  // doubles per stored map
   RPDE_TLS(blk, double, bb, C);
@@ -659,6 +663,7 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
       double b, q, r = 0.0;
       fill(lo + i, i * T + tid, b, q, r);
       RPDE_T(bb)[i] = b; RPDE_T(qq)[i] = q; RPDE_T(rr)[i] = r;
+      if constexpr (ORDER == 2) scr[i * T + tid] = r;
     }
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -770,7 +775,7 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
         if constexpr (ORDER == 1) {
           x1 = ok ? bk + q * x1 : x1;
         } else {
-          const double nx1 = bk + q * x1 + RPDE_T(rr)[e] * x2;
+          const double nx1 = bk + q * x1 + scr[e * T + tid] * x2;
           x2 = ok ? x1 : x2; x1 = ok ? nx1 : x1;
         }
         RPDE_T(res)[e] = x1;
@@ -990,7 +995,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         if constexpr (FULL) {
           const FillRec<true, true> f{a, (tab_t)(pg.tabs[op.tab] + toff), (tab_t)(pg.tabs[op.i0] + toff),
                                       (tab_t)(pg.tabs[op.i1] + toff)};
-          scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f);
+          scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f, lds + op.b * SL);
         }
       } break;
       case OP_DCT: {

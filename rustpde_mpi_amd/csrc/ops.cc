@@ -121,7 +121,10 @@ void ProgramBuilder::rec1(int d, int a, int n, const double* p, const double* q,
 }
 void ProgramBuilder::rec2(int d, int a, int n, const double* p, const double* q, const double* r, long tabld) {
   const int ip = p ? tab(p) : -1, iq = tab(q), ir = tab(r);
-  Op& o = push(OP_REC2); o.d = d; o.a = a; o.n = n; o.tab = ip; o.i0 = iq; o.i1 = ir; o.tabld = tabld;
+  // the kernel parks the r coefficients in the LAST slot (the only one addressable up to T * EPT)
+  const int scratch = pg.nslots - 1;
+  RPDE_REQUIRE(scratch != d && scratch != a, "OP_REC2 needs the last slot as scratch");
+  Op& o = push(OP_REC2); o.d = d; o.a = a; o.b = scratch; o.n = n; o.tab = ip; o.i0 = iq; o.i1 = ir; o.tabld = tabld;
 }
 void ProgramBuilder::dct(int d, int n, const double* pre, const double* post) {
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
