@@ -57,7 +57,15 @@ def cpu_baseline(args):
     for _ in range(args.cpu_steps):
         ora.update()
     dt = time.perf_counter() - t0
-    return {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": os.cpu_count(),
+    # threads actually used: OpenBLAS' pool for the two Poisson GEMMs, everything else (pocketfft,
+    # banded sweeps, NumPy elementwise) runs on one core
+    cores = 1
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": cores, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of the same {args.nx}x{args.ny} case after 1 warm-up step "
                       f"(NumPy/SciPy oracle, OpenBLAS dgemm + pocketfft, setup {setup:.1f}s not timed)"}
@@ -101,11 +109,38 @@ def main():
     import rustpde_mpi_amd as R
 
     comm = None
-    if world > 1:
-        from rustpde_mpi_amd.dist import TorchComm
-        comm = TorchComm(device_buffers=True)
+    transport = "none"
     ctor = R.Navier2D.new_periodic if args.periodic else R.Navier2D.new_confined
-    nav = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", device=local_rank, comm=comm)
+
+    def make(comm):
+        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", device=local_rank, comm=comm)
+
+    if world > 1:
+        from rustpde_mpi_amd.dist import RcclComm, TorchComm
+        import torch
+        # default: the native transport (grouped ncclSend/ncclRecv on the engine's stream);
+        # RPDE_TRANSPORT=torch selects the torch.distributed all_to_all_single callback instead.
+        # If the native communicator cannot be created on ANY rank, all ranks fall back together.
+        want_native = dist.get_backend() == "nccl" and os.environ.get("RPDE_TRANSPORT", "rccl") == "rccl"
+        nav = None
+        if want_native:
+            ok = 1
+            try:
+                nav = make(RcclComm())
+                transport = "rccl-native"
+            except Exception as exc:   # noqa: BLE001 - any failure means: use the other transport
+                print(f"[bench] rank {rank}: native RCCL transport unavailable ({exc}); falling back", flush=True)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                nav = None
+        if nav is None:
+            comm = TorchComm(device_buffers=True)
+            nav = make(comm)
+            transport = "torch-" + dist.get_backend()
+    else:
+        nav = make(None)
     nav.set_velocity(0.2, 1.0, 1.0)
     nav.set_temperature(0.2, 1.0, 1.0)
 
@@ -206,7 +241,7 @@ def main():
         "config": {"workload": f"Navier2D::new_{'periodic' if args.periodic else 'confined'} "
                                f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect=1 bc=rbc",
                    "parallelism": "single GPU" if world == 1 else
-                                  f"pencil-sharded over {world} GPUs (x-/y-pencils, all-to-all over RCCL)"},
+                                  f"pencil-sharded over {world} GPUs (x-/y-pencils, all-to-all over RCCL, transport {transport})"},
         "roofline": roof,
         "phases": phases,
         "transform_pass": transform_pass,

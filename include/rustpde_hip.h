@@ -58,6 +58,19 @@ typedef int (*rpde_alltoallv_fn)(void* user, const double* send, const int64_t* 
 int rpde_navier2d_create_sharded(int periodic, int nx, int ny, double ra, double pr, double dt,
                                  double aspect, const char* bc, int device, int rank, int nranks,
                                  rpde_alltoallv_fn alltoallv, void* user, rpde_navier2d** out);
+/* The same sharded engine with the NATIVE transport: every layout change is a grouped
+ * ncclSend/ncclRecv all-to-all on the engine's own HIP stream (RCCL over xGMI; no host round trip,
+ * no callback).  Rank 0 calls rpde_rccl_unique_id and distributes the 128 bytes to the other
+ * ranks by any host-side means (MPI_Bcast in a Rust/MPI host, torch.distributed in bench.py);
+ * rpde_navier2d_create_sharded_rccl is collective (ncclCommInitRank) and binds the communicator
+ * to `device`.  One process per GPU. */
+int rpde_rccl_unique_id(char* id128);
+/* transport self-test: one all-to-all of device buffers on a fresh communicator (collective) */
+int rpde_rccl_alltoallv_once(const char* id128, int rank, int nranks, int device, const double* send,
+                             const int64_t* sendcounts, double* recv, const int64_t* recvcounts);
+int rpde_navier2d_create_sharded_rccl(int periodic, int nx, int ny, double ra, double pr, double dt,
+                                      double aspect, const char* bc, int device, int rank, int nranks,
+                                      const char* id128, rpde_navier2d** out);
 /* bytes this rank sends per time step through `alltoallv`, and the number of exchanges per step */
 int rpde_navier2d_comm_stats(rpde_navier2d* h, double* bytes_per_step, int* exchanges_per_step);
 int rpde_navier2d_destroy(rpde_navier2d* h);

@@ -119,7 +119,12 @@ class Navier2D:
     def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic, comm=None):
         library = library or lib()
         h = C.c_void_p()
-        if comm is not None and comm.size > 1:
+        if comm is not None and comm.size > 1 and getattr(comm, "native_rccl", False):
+            # pencil-sharded engine, native transport: grouped ncclSend/ncclRecv on the engine's stream
+            library.call("rpde_navier2d_create_sharded_rccl", int(periodic), int(nx), int(ny), float(ra),
+                         float(pr), float(dt), float(aspect), str(bc).encode(), int(device),
+                         int(comm.rank), int(comm.size), comm.unique_id(library), C.byref(h))
+        elif comm is not None and comm.size > 1:
             # pencil-sharded engine (the reference's Navier2DMpi): `comm` supplies rank, size and the
             # all-to-all (rustpde_mpi_amd.dist.TorchComm); every rank passes the same arguments
             library.call("rpde_navier2d_create_sharded", int(periodic), int(nx), int(ny), float(ra),

@@ -29,6 +29,11 @@ SIGNATURES = {
     "rpde_navier2d_create_sharded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                C.c_double, C.c_char_p, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                                C.POINTER(_vp)]),
+    "rpde_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "rpde_rccl_alltoallv_once": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rpde_navier2d_create_sharded_rccl": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                    C.c_double, C.c_double, C.c_char_p, C.c_int, C.c_int,
+                                                    C.c_int, C.c_char_p, C.POINTER(_vp)]),
     "rpde_navier2d_comm_stats": (C.c_int, [_vp, _dp, _ip]),
     "rpde_navier2d_destroy": (C.c_int, [_vp]),
     "rpde_navier2d_set_velocity": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),

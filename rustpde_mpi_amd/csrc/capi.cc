@@ -6,6 +6,7 @@
 #include <string>
 
 #include "engine.h"
+#include "rccl_transport.h"
 
 using namespace rpde;
 
@@ -101,6 +102,52 @@ int rpde_navier2d_create_sharded(int periodic, int nx, int ny, double ra, double
     try {
       h->e = new Navier2DEngine(nx, ny, ra, pr, dt, aspect, bc, periodic != 0, &cb);
     } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  })
+}
+int rpde_rccl_unique_id(char* id128) {
+  RPDE_TRY({ RPDE_REQUIRE(id128, "null pointer"); rccl_unique_id(id128); })
+}
+int rpde_rccl_alltoallv_once(const char* id128, int rank, int nranks, int device, const double* send,
+                             const int64_t* sendcounts, double* recv, const int64_t* recvcounts) {
+  RPDE_TRY({
+    RPDE_REQUIRE(id128 && sendcounts && recvcounts, "null pointer");
+    select_device(device);
+    RcclComm* c = rccl_comm_create(rank, nranks, id128);
+    try {
+      Stream st;
+#ifndef RPDE_EMU
+      RPDE_HIP(hipStreamCreate(&st.s));
+#endif
+      rccl_alltoallv(c, send, sendcounts, recv, recvcounts, st);
+      dev_sync(st);
+#ifndef RPDE_EMU
+      (void)hipStreamDestroy(st.s);
+#endif
+    } catch (...) {
+      rccl_comm_destroy(c);
+      throw;
+    }
+    rccl_comm_destroy(c);
+  })
+}
+int rpde_navier2d_create_sharded_rccl(int periodic, int nx, int ny, double ra, double pr, double dt,
+                                      double aspect, const char* bc, int device, int rank, int nranks,
+                                      const char* id128, rpde_navier2d** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out && bc && id128, "null pointer");
+    select_device(device);
+    CommCb cb;
+    cb.rank = rank; cb.size = nranks;
+    cb.rccl = rccl_comm_create(rank, nranks, id128);   // collective: every rank is in this call
+    auto* h = new rpde_navier2d{nullptr, device};
+    try {
+      h->e = new Navier2DEngine(nx, ny, ra, pr, dt, aspect, bc, periodic != 0, &cb);
+    } catch (...) {
+      rccl_comm_destroy(cb.rccl);
       delete h;
       throw;
     }

@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "rccl_transport.h"
 
 #include <chrono>
 #include <cmath>
@@ -29,7 +30,8 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
-  RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr, "sharded engine needs an all-to-all callback");
+  RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr || comm_.rccl != nullptr,
+               "sharded engine needs an all-to-all transport");
   RPDE_REQUIRE(bc == "rbc", "Boundary condition type \"" + bc + "\" not recognized! (supported: \"rbc\")");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
@@ -149,7 +151,11 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
 Navier2DEngine::~Navier2DEngine() {
 #ifndef RPDE_EMU
   if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-  if (st_.s) { (void)hipStreamSynchronize(st_.s); (void)hipStreamDestroy(st_.s); }
+  if (st_.s) (void)hipStreamSynchronize(st_.s);
+  rccl_comm_destroy(comm_.rccl);
+  if (st_.s) (void)hipStreamDestroy(st_.s);
+#else
+  rccl_comm_destroy(comm_.rccl);
 #endif
 }
 
@@ -220,6 +226,10 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
 // communication helpers
 void Navier2DEngine::alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv,
                                const std::vector<int64_t>& rc) {
+  if (comm_.rccl) {   // stream-ordered: pack, exchange and unpack queue up without a host round trip
+    rccl_alltoallv(comm_.rccl, send, sc.data(), recv, rc.data(), st_);
+    return;
+  }
   dev_sync(st_);
   const int rcode = comm_.fn(comm_.user, send, sc.data(), recv, rc.data());
   RPDE_REQUIRE(rcode == 0, "all-to-all callback failed");
@@ -252,6 +262,7 @@ void Navier2DEngine::gather_rows(const double* local, long ld, int rows_global,
     rc[q] = (int64_t)clampi(std::min(part[q + 1], rows_global) - part[q], 0, rows_global) * ld;
   }
   alltoallv(snd.p, sc, full, rc);
+  dev_sync(st_);   // the RCCL transport is stream-ordered; `snd` dies here and callers read `full`
 }
 
 void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem,

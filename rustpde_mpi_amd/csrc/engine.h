@@ -19,10 +19,12 @@ namespace rpde {
 // MPI_Alltoallv in the reference, src/field_mpi.rs:456-477.)
 typedef int (*AllToAllvFn)(void* user, const double* send, const int64_t* sendcounts, double* recv,
                            const int64_t* recvcounts);
+struct RcclComm;
 struct CommCb {
   int rank = 0, size = 1;
-  AllToAllvFn fn = nullptr;
+  AllToAllvFn fn = nullptr;      // host callback transport (stream drained before every call), or
   void* user = nullptr;
+  RcclComm* rccl = nullptr;      // native RCCL transport on the engine's stream (rccl_transport.h); owned
 };
 
 class Navier2DEngine {

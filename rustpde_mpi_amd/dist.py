@@ -86,3 +86,30 @@ class TorchComm:
         if self.device_buffers:
             r.copy_(hr)
             torch.cuda.synchronize()
+
+
+class RcclComm:
+    """Native transport: the engine owns an RCCL communicator and runs every pencil exchange as a
+    grouped ncclSend/ncclRecv all-to-all on its own HIP stream (include/rustpde_hip.h,
+    rpde_navier2d_create_sharded_rccl).  torch.distributed is only used here to hand rank 0's
+    ncclUniqueId to the other ranks (the job of MPI_Bcast in an MPI host)."""
+    native_rccl = True
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self._uid = None
+
+    def unique_id(self, library) -> bytes:
+        if self._uid is None:
+            box = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                library.call("rpde_rccl_unique_id", buf)
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                       group=self.group)
+            self._uid = bytes(box[0])
+            assert len(self._uid) == 128
+        return self._uid

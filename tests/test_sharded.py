@@ -94,3 +94,49 @@ def test_torchcomm_over_rccl_single_rank(tmp_path, hip_lib):
     out = str(tmp_path / "nccl.txt")
     mp.spawn(_nccl_single, args=(_free_port(), out), nprocs=1, join=True)
     assert open(out).read() == "ok"
+
+
+def _native_rccl_single(rank, out):
+    import ctypes as C
+    import numpy as np
+    import torch
+    import rustpde_mpi_amd as R
+    from rustpde_mpi_amd._capi import lib
+    L = lib()
+    uid = C.create_string_buffer(128)
+    L.call("rpde_rccl_unique_id", uid)
+    torch.cuda.set_device(0)
+    a = torch.arange(5000, dtype=torch.float64, device="cuda")
+    b = torch.zeros(5000, dtype=torch.float64, device="cuda")
+    sc = (C.c_int64 * 1)(5000)
+    rc = (C.c_int64 * 1)(5000)
+    torch.cuda.synchronize()
+    L.call("rpde_rccl_alltoallv_once", uid.raw, 0, 1, 0, C.c_void_p(a.data_ptr()), C.cast(sc, C.c_void_p),
+           C.c_void_p(b.data_ptr()), C.cast(rc, C.c_void_p))
+    ok = bool(torch.equal(a, b))
+    # the engine constructor with the native transport (communicator bound to the engine's device)
+    h = C.c_void_p()
+    L.call("rpde_navier2d_create_sharded_rccl", 0, 33, 33, 1e4, 1.0, 1e-2, 1.0, b"rbc", 0, 0, 1, uid.raw, C.byref(h))
+    nav = R.Navier2D(h, 33, 33, False, L)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    nav.update(3)
+    ref = R.Navier2D.new_confined(33, 33, 1e4, 1.0, 1e-2, 1.0, "rbc")
+    ref.set_velocity(0.2, 1.0, 1.0)
+    ref.set_temperature(0.2, 1.0, 1.0)
+    ref.update(3)
+    ok = ok and bool(np.array_equal(nav.temp.v, ref.temp.v)) and not nav.exit()
+    with open(out, "w") as f:
+        f.write("ok" if ok else "bad")
+
+
+@pytest.mark.gpu
+def test_native_rccl_transport_single_rank(tmp_path, hip_lib):
+    """The native transport of bench.py --gpus N (grouped ncclSend/ncclRecv on the engine's stream):
+    communicator creation, a self all-to-all of device buffers, and an engine built on it.  World size
+    1 is all a one-GPU box can offer (RCCL refuses two ranks on one device); the exchange schedule and
+    counts are the ones the gloo tests above verify."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl_native.txt")
+    mp.spawn(_native_rccl_single, args=(out,), nprocs=1, join=True)
+    assert open(out).read() == "ok"
