@@ -63,7 +63,8 @@ int rpde_navier2d_create_sharded(int periodic, int nx, int ny, double ra, double
  * no callback).  Rank 0 calls rpde_rccl_unique_id and distributes the 128 bytes to the other
  * ranks by any host-side means (MPI_Bcast in a Rust/MPI host, torch.distributed in bench.py);
  * rpde_navier2d_create_sharded_rccl is collective (ncclCommInitRank) and binds the communicator
- * to `device`.  One process per GPU. */
+ * to `device`.  One process per GPU; an id serves exactly one communicator (take a fresh one per
+ * engine). */
 int rpde_rccl_unique_id(char* id128);
 /* transport self-test: one all-to-all of device buffers on a fresh communicator (collective) */
 int rpde_rccl_alltoallv_once(const char* id128, int rank, int nranks, int device, const double* send,

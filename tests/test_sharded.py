@@ -101,8 +101,7 @@ def _native_rccl_single(rank, out):
     import numpy as np
     import torch
     import rustpde_mpi_amd as R
-    from rustpde_mpi_amd._capi import lib
-    L = lib()
+    L = R.lib()
     uid = C.create_string_buffer(128)
     L.call("rpde_rccl_unique_id", uid)
     torch.cuda.set_device(0)
@@ -114,7 +113,9 @@ def _native_rccl_single(rank, out):
     L.call("rpde_rccl_alltoallv_once", uid.raw, 0, 1, 0, C.c_void_p(a.data_ptr()), C.cast(sc, C.c_void_p),
            C.c_void_p(b.data_ptr()), C.cast(rc, C.c_void_p))
     ok = bool(torch.equal(a, b))
-    # the engine constructor with the native transport (communicator bound to the engine's device)
+    # the engine constructor with the native transport (communicator bound to the engine's device);
+    # an ncclUniqueId serves exactly one communicator, so take a fresh one
+    L.call("rpde_rccl_unique_id", uid)
     h = C.c_void_p()
     L.call("rpde_navier2d_create_sharded_rccl", 0, 33, 33, 1e4, 1.0, 1e-2, 1.0, b"rbc", 0, 0, 1, uid.raw, C.byref(h))
     nav = R.Navier2D(h, 33, 33, False, L)
