@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--ra", type=float, default=1e8)
     p.add_argument("--dt", type=float, default=2e-4)
     p.add_argument("--periodic", action="store_true")
+    p.add_argument("--aspect", type=float, default=1.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--profile-steps", type=int, default=3)
@@ -48,7 +49,7 @@ def cpu_baseline(args):
     from oracle import navier as N
     ctor = N.Navier2D.new_periodic if args.periodic else N.Navier2D.new_confined
     t0 = time.perf_counter()
-    ora = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", eig_mode="parity")
+    ora = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", eig_mode="parity")
     ora.set_velocity(0.2, 1.0, 1.0)
     ora.set_temperature(0.2, 1.0, 1.0)
     setup = time.perf_counter() - t0
@@ -113,7 +114,7 @@ def main():
     ctor = R.Navier2D.new_periodic if args.periodic else R.Navier2D.new_confined
 
     def make(comm):
-        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, 1.0, "rbc", device=local_rank, comm=comm)
+        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", device=local_rank, comm=comm)
 
     if world > 1:
         from rustpde_mpi_amd.dist import RcclComm, TorchComm
@@ -239,7 +240,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))",
         "config": {"workload": f"Navier2D::new_{'periodic' if args.periodic else 'confined'} "
-                               f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect=1 bc=rbc",
+                               f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect={args.aspect:g} bc=rbc",
                    "parallelism": "single GPU" if world == 1 else
                                   f"pencil-sharded over {world} GPUs (x-/y-pencils, all-to-all over RCCL, transport {transport})"},
         "roofline": roof,

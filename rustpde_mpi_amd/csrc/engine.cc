@@ -1062,22 +1062,21 @@ void Navier2DEngine::build_periodic() {
   auto rhs = [&](int which, const char* tag) {
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = ypb(2, my);
+    // one LDS slot (the 16384-point configuration has no second one): every further term is
+    // accumulated straight from HBM
+    ProgramBuilder pb = ypb(1, my);
     pb.set_fft(xF);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);
     pb.rfft_f(0, nx);
     pb.zero(0, 2 * cut_x, nc);
-    pb.loadx(1, pb.arr(yx(state), ldx), nc, my, yD.low.p);
-    pb.axpby(0, 0, -dt, 1, 1.0, nc);
+    pb.axpby(0, 0, -dt, 0, 0.0, nc);                                   // -dt * conv
+    pb.loadx(0, pb.arr(yx(state), ldx), nc, my, yD.low.p, 1.0, true);   // + S_y state
     if (which == 0) {
-      pb.load(1, pb.arr(yx(P_), ldx), nc);
-      pb.cik(1, 1, kx, 1.0 / sx_, 1);
-      pb.axpby(0, 0, 1.0, 1, -dt, nc);
+      pb.load_cik(0, pb.arr(yx(P_), ldx), nc, -dt / sx_, true);         // - dt d/dx pres
     } else if (which == 1) {
       pb.load(0, pb.arr(yx(GY_), ldx), nc, -dt, true);
-      pb.loadx(1, pb.arr(yx(T_), ldx), nc, my, yD.low.p);
-      pb.load(1, pb.arr(yx(TBC_), ldx), nc, 1.0, true);
-      pb.axpby(0, 0, 1.0, 1, dt, nc);
+      pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
+      pb.load(0, pb.arr(yx(TBC_), ldx), nc, dt, true);
     } else {
       pb.load(0, pb.arr(yx(TBC2_), ldx), nc, dt * ka_, true);
     }

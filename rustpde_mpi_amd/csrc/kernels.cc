@@ -12,6 +12,7 @@ namespace rpde {
 using CfgS = LineCfg<128, 10, 2, 1024, 8>;      // slots up to 1280 doubles
 using CfgM = LineCfg<256, 10, 1024, 2048, 8>;   // slots up to 2560 doubles
 using CfgL = LineCfg<512, 10, 2048, 4096, 8>;   // slots up to 5120 doubles
+using CfgX = LineCfg<1024, 18, 4096, 8192, 8>;  // Fourier lines of 8192 / 16384 reals: one slot of up to 17408 doubles
 static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal EPT");
 
 #ifndef RPDE_EMU
@@ -49,9 +50,13 @@ static void launch_cfg(const Program& pg, Stream& st) {
     stash |= pg.ops[i].code == OP_PUSH || pg.ops[i].code == OP_POPAXPY;
   }
   RPDE_REQUIRE(!(rec2 && stash), "a line program cannot combine the register stash with a banded solve");
-  if (rec2) launch_kernel<Cfg, kVarRec2>(pg, bytes, st);
-  else if (stash) launch_kernel<Cfg, kVarStash>(pg, bytes, st);
-  else launch_kernel<Cfg, kVarLight>(pg, bytes, st);
+  if constexpr (Cfg::kCheb) {
+    if (rec2) { launch_kernel<Cfg, kVarRec2>(pg, bytes, st); return; }
+    if (stash) { launch_kernel<Cfg, kVarStash>(pg, bytes, st); return; }
+  } else {
+    RPDE_REQUIRE(!rec2 && !stash, "this line configuration has the light kernel only");
+  }
+  launch_kernel<Cfg, kVarLight>(pg, bytes, st);
 }
 
 // ------------------------------------------------------------------------------- transpose
@@ -402,6 +407,7 @@ static int class_index(int slot_len) {
   if (slot_len <= CfgS::kMaxSlotLen) return 0;
   if (slot_len <= CfgM::kMaxSlotLen) return 1;
   if (slot_len <= CfgL::kMaxSlotLen) return 2;
+  if (slot_len <= CfgX::kMaxSlotLen) return 3;
   return -1;
 }
 LineClass line_class_for(int slot_len) {
@@ -409,6 +415,7 @@ LineClass line_class_for(int slot_len) {
     case 0: return {CfgS::T, CfgS::C};
     case 1: return {CfgM::T, CfgM::C};
     case 2: return {CfgL::T, CfgL::C};
+    case 3: return {CfgX::T, CfgX::C};
     default: fail("line too long for one workgroup: slot length " + std::to_string(slot_len));
   }
 }
@@ -431,9 +438,19 @@ void launch_line_program(const Program& pg, Stream& st) {
   if (ci == 0 && fft_ok(CfgS::FMIN, CfgS::FMAX)) launch_cfg<CfgS>(pg, st);
   else if (ci == 1 && fft_ok(CfgM::FMIN, CfgM::FMAX)) launch_cfg<CfgM>(pg, st);
   else if (ci == 2 && fft_ok(CfgL::FMIN, CfgL::FMAX)) launch_cfg<CfgL>(pg, st);
+  else if (ci == 3 && fft_ok(CfgX::FMIN, CfgX::FMAX) && pg.fft_n > 0) {
+    for (int i = 0; i < pg.nops; ++i) {
+      const int c = pg.ops[i].code;
+      RPDE_REQUIRE(c != OP_DCT && c != OP_REC1 && c != OP_REC2 && c != OP_CDIFF && c != OP_PUSH && c != OP_POPAXPY &&
+                       c != OP_STEN && c != OP_MV3,
+                   "the long-line configuration (nx = 8192, 16384) runs Fourier programs only");
+    }
+    RPDE_REQUIRE(pg.nslots == 1, "the long-line configuration (nx = 8192, 16384) has one LDS slot");
+    launch_cfg<CfgX>(pg, st);
+  }
   else fail("no line-kernel configuration for slot length " + std::to_string(sl) +
             " / FFT length " + std::to_string(pg.fft_n) +
-            " (supported: Chebyshev n = 2^k + 1 <= 4097, Fourier nx = 2^k <= 4096, or any n <= 500"
+            " (supported: Chebyshev n = 2^k + 1 <= 4097, Fourier nx = 2^k <= 16384, or any n <= 500"
             " through the direct transform)");
 }
 

@@ -51,7 +51,8 @@ using lds2_t = __attribute__((address_space(3))) dbl2*;
 
 enum OpCode : int {
   OP_END = 0,
-  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map
+  OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;
+               // i0 = 2: interleaved complex line times i*kappa (kappa = pair index): d[2j] (+)= -s0 j Im A_j, d[2j+1] (+)= s0 j Re A_j
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1
   OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length)
@@ -123,6 +124,9 @@ struct LineCfg {
   static constexpr int C = (EPT_ + 1) & ~1;           // scan chunk per thread (even)
   static constexpr int G = (T_ + 15) / 16;             // scan groups
   static constexpr int kMaxSlotLen = T_ * EPT_;
+  // T = 1024 (16 waves) is the long-Fourier-line configuration: one 139 KB work area per
+  // workgroup, so no DCT (needs two slots) and no banded scans (a Fourier axis has none)
+  static constexpr bool kCheb = (T_ <= 512);
   static constexpr int kCarryLen = 2 * ((T_ + 63) / 64) * 6 + 4;  // doubles: wave totals of a scan
 };
 
@@ -465,17 +469,21 @@ RPDE_DEVN void dct1_direct(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_
 template <class Cfg>
 RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) {
   constexpr int T = Cfg::T;
+  // per-thread trip counts from the largest transform of the configuration (M <= FMAX complex
+  // points, nx = 2 M reals), not from EPT: the 1024-thread configuration has EPT = 18 but M / T = 8
+  constexpr int QM = (Cfg::FMAX / T + 1 < Cfg::EPT) ? Cfg::FMAX / T + 1 : Cfg::EPT;          // k <= M
+  constexpr int QE = (2 * Cfg::FMAX / T + 1 < Cfg::EPT) ? 2 * Cfg::FMAX / T + 1 : Cfg::EPT;  // e < nx + 2
   const int M = nx / 2;
   {  // z_j = x_{2j} + i x_{2j+1}: move to the padded work layout
-    RPDE_TLS(blk, double, v, Cfg::EPT);
+    RPDE_TLS(blk, double, v, QE);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) { const int e = tid + q * T; if (e < nx) RPDE_T(v)[q] = x[e]; }
+      for (int q = 0; q < QE; ++q) { const int e = tid + q * T; if (e < nx) RPDE_T(v)[q] = x[e]; }
     }
     RPDE_SYNC(blk);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) {
+      for (int q = 0; q < QE; ++q) {
         const int e = tid + q * T;
         if (e < nx) x[2 * pidx(e >> 1) + (e & 1)] = RPDE_T(v)[q];
       }
@@ -483,11 +491,11 @@ RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) 
     RPDE_SYNC(blk);
   }
   fft_dispatch<Cfg>(blk, x, M, tw);
-  RPDE_TLS(blk, double, yr, Cfg::EPT);
-  RPDE_TLS(blk, double, yi, Cfg::EPT);
+  RPDE_TLS(blk, double, yr, QM);
+  RPDE_TLS(blk, double, yi, QM);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) {
+    for (int q = 0; q < QM; ++q) {
       const int k = tid + q * T;
       if (k <= M) {
         const int ka = 2 * pidx((k == M) ? 0 : k);
@@ -504,7 +512,7 @@ RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) 
   RPDE_SYNC(blk);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) {
+    for (int q = 0; q < QM; ++q) {
       const int k = tid + q * T;
       if (k <= M) { x[2 * k] = RPDE_T(yr)[q]; x[2 * k + 1] = RPDE_T(yi)[q]; }
     }
@@ -516,13 +524,15 @@ RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) 
 template <class Cfg>
 RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) {
   constexpr int T = Cfg::T;
+  constexpr int QM = (Cfg::FMAX / T + 1 < Cfg::EPT) ? Cfg::FMAX / T + 1 : Cfg::EPT;
+  constexpr int QE = (2 * Cfg::FMAX / T + 1 < Cfg::EPT) ? 2 * Cfg::FMAX / T + 1 : Cfg::EPT;
   const int M = nx / 2;
   {
-    RPDE_TLS(blk, double, zr, Cfg::EPT);
-    RPDE_TLS(blk, double, zi, Cfg::EPT);
+    RPDE_TLS(blk, double, zr, QM);
+    RPDE_TLS(blk, double, zi, QM);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) {
+      for (int q = 0; q < QM; ++q) {
         const int k = tid + q * T;
         if (k < M) {
           const int kb = M - k;
@@ -542,7 +552,7 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
     RPDE_SYNC(blk);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
-      for (int q = 0; q < Cfg::EPT; ++q) {
+      for (int q = 0; q < QM; ++q) {
         const int k = tid + q * T;
         if (k < M) { const int p = 2 * pidx(k); x[p] = RPDE_T(zr)[q]; x[p + 1] = RPDE_T(zi)[q]; }
       }
@@ -551,10 +561,10 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
   }
   fft_dispatch<Cfg>(blk, x, M, tw);
   const double sc = 1.0 / (double)M;
-  RPDE_TLS(blk, double, v, Cfg::EPT);
+  RPDE_TLS(blk, double, v, QE);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) {
+    for (int q = 0; q < QE; ++q) {
       const int e = tid + q * T;
       if (e < nx) RPDE_T(v)[q] = x[2 * pidx(e >> 1) + (e & 1)] * ((e & 1) ? -sc : sc);
     }
@@ -562,7 +572,7 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
   RPDE_SYNC(blk);
   RPDE_PHASE(blk, tid) {
 #pragma unroll
-    for (int q = 0; q < Cfg::EPT; ++q) { const int e = tid + q * T; if (e < nx) x[e] = RPDE_T(v)[q]; }
+    for (int q = 0; q < QE; ++q) { const int e = tid + q * T; if (e < nx) x[e] = RPDE_T(v)[q]; }
   }
   RPDE_SYNC(blk);
 }
@@ -860,8 +870,13 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
               const int k = tid + q * T;
-              const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
-              v[q] = (k < n) ? src[kk * es] : 0.0;
+              if (op.i0 == 2) {   // (i kappa) * complex: swap re/im inside the pair, sign and wavenumber
+                const double w = (k & 1) ? (double)(k >> 1) : -(double)(k >> 1);
+                v[q] = (k < n) ? w * src[(long)(k ^ 1) * es] : 0.0;
+              } else {
+                const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
+                v[q] = (k < n) ? src[kk * es] : 0.0;
+              }
             }
           }
 #pragma unroll
@@ -924,7 +939,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
         RPDE_SYNC(blk);  // the next op may overwrite the slot
       } break;
-      case OP_STEN: {
+      case OP_STEN: if constexpr (Cfg::kCheb) {
         tab_t low = (tab_t)(pg.tabs[op.tab] + toff);
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
@@ -945,7 +960,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
         RPDE_SYNC(blk);
       } break;
-      case OP_MV3: {
+      case OP_MV3: if constexpr (Cfg::kCheb) {
         tab_t t0 = (tab_t)(pg.tabs[op.tab] + toff);
         tab_t t1 = (tab_t)(pg.tabs[op.tab + 1] + toff);
         tab_t t2 = (tab_t)(pg.tabs[op.tab + 2] + toff);
@@ -968,7 +983,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
         RPDE_SYNC(blk);
       } break;
-      case OP_CDIFF: {
+      case OP_CDIFF: if constexpr (Cfg::kCheb) {
         scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, FillDiff{a, n});
         RPDE_PHASE(blk, tid) {
 #pragma unroll
@@ -979,7 +994,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
         RPDE_SYNC(blk);
       } break;
-      case OP_REC1: {
+      case OP_REC1: if constexpr (Cfg::kCheb) {
         tab_t qt = (tab_t)(pg.tabs[op.i0] + toff);
         if (op.tab >= 0) {
           const FillRec<true, false> f{a, (tab_t)(pg.tabs[op.tab] + toff), qt, (tab_t) nullptr};
@@ -992,13 +1007,13 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
       } break;
       case OP_REC2: {
-        if constexpr (FULL) {
+        if constexpr (FULL && Cfg::kCheb) {
           const FillRec<true, true> f{a, (tab_t)(pg.tabs[op.tab] + toff), (tab_t)(pg.tabs[op.i0] + toff),
                                       (tab_t)(pg.tabs[op.i1] + toff)};
           scan_recurrence<Cfg, 2, -1>(blk, d, n, carry, f, lds + op.b * SL);
         }
       } break;
-      case OP_DCT: {
+      case OP_DCT: if constexpr (Cfg::kCheb) {
         tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
         tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
         // fused forms (FFT path only): i1 >= 0: composite->ortho stencil table applied while packing;

@@ -34,8 +34,8 @@ AxisTables::AxisTables(const Base& b) : base(b) {
       fo_qdn.upload(chunk_major(f.q_dn, lc, -1));
     }
   } else {
-    RPDE_REQUIRE(is_pow2(b.n) && b.n >= 4 && b.n <= 4096,
-                 "fourier_r2c needs nx = 2^k with 4 <= nx <= 4096 on one device");
+    RPDE_REQUIRE(is_pow2(b.n) && b.n >= 4 && b.n <= 16384,
+                 "fourier_r2c needs nx = 2^k with 4 <= nx <= 16384");
     fft_n = b.n / 2;
     tw.upload(fft_twiddles(fft_n));
     tw2.upload(rfft_split_twiddles(b.n));
@@ -94,6 +94,10 @@ Op& ProgramBuilder::push(int code) {
 void ProgramBuilder::load(int d, int a, int n, double s0, bool acc, int half) {
   RPDE_REQUIRE(n <= pg.slot_len, "line longer than the slot");
   Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = acc; o.i0 = half > 0; o.i1 = half;
+}
+void ProgramBuilder::load_cik(int d, int a, int n, double s0, bool acc) {
+  RPDE_REQUIRE(n <= pg.slot_len && n % 2 == 0, "load_cik: interleaved complex line expected");
+  Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = acc; o.i0 = 2; o.i1 = 0;
 }
 void ProgramBuilder::loadmul(int d, int a, int n, double s0) {
   Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = 2;
@@ -196,7 +200,9 @@ void Space2Ops::run_lines(Kind kind, const AxisTables& ax, const double* in, lon
                           double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st,
                           int order, double scale, const FdmaDev* fd, const double* diag) {
   // ncomp = 2: the lines are interleaved complex but the op is real (acts on re and im alike)
-  ProgramBuilder pb(2, ax.slot_len, nlines, ncomp);
+  // Chebyshev kinds need the second slot (DCT work area, scratch of the banded solve); a Fourier
+  // axis never does, and its longest configuration has room for one slot only
+  ProgramBuilder pb(ax.base.is_cheb() ? 2 : 1, ax.slot_len, nlines, ncomp);
   pb.set_fft(ax);
   const int es = ncomp, coff = ncomp == 2 ? 1 : 0;
   const int ai = pb.arr(in, ldi, es, coff);
@@ -278,7 +284,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
   launch_transpose(in.p(), in.ld, tin.p(), tin.ld, in.rows, in.cols, in.elem, st);
   if (fourier) {
     // lines are genuinely complex (or real <-> complex): one component, element stride 1
-    ProgramBuilder pb(2, ax.slot_len, ncols, 1);
+    ProgramBuilder pb(1, ax.slot_len, ncols, 1);
     pb.set_fft(ax);
     const int ai = pb.arr(tin.p(), tin.ld), ao = pb.arr(tout.p(), tout.ld);
     pb.load(0, ai, li * in.elem);

@@ -54,6 +54,8 @@ class ProgramBuilder {
   // ops (slot indices d, a, b)
   void load(int d, int arr, int n, double s0 = 1.0, bool acc = false, int interleave_half = 0);
   void loadmul(int d, int arr, int n, double s0 = 1.0);   // d[k] *= s0 * A[line][k]
+  // interleaved complex line (n doubles) times i*kappa while loading: d (+)= s0 * (i kappa) * A
+  void load_cik(int d, int arr, int n, double s0 = 1.0, bool acc = false);
   void set_line0(int line0) { pg.line0 = line0; }
   void loadx(int d, int arr, int n, int rows, const double* lowtab, double s0 = 1.0, bool acc = false);
   void store(int a, int arr, int n, double s0 = 1.0, int deinterleave_half = 0);

@@ -49,6 +49,13 @@ def test_periodic_step(emu_lib, nx, ny, steps, aspect):
     K.check_step_parity(emu_lib, True, nx, ny, 1e5, 0.01, steps, aspect=aspect, check_at=[1, 2, steps])
 
 
+@pytest.mark.parametrize("nx", [8192, 16384])
+def test_periodic_step_long_fourier_lines(emu_lib, nx):
+    """nx = 16384 (BASELINE config 5's line length) and 8192: the one-slot 1024-thread configuration
+    with a 4096- / 8192-point complex FFT per x-line; aspect 8 as in that config."""
+    K.check_step_parity(emu_lib, True, nx, 9, 1e5, 0.01, 2, aspect=8.0, check_at=[1, 2])
+
+
 def test_errors_mirror_reference_panics(emu_lib):
     with pytest.raises(R.RpdeError, match="not recognized"):
         R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "xyz", library=emu_lib)

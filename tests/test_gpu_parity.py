@@ -14,7 +14,9 @@ def test_library_is_hip_build(hip_lib):
 
 
 @pytest.mark.parametrize("k0,n0,k1,n1", SPACES + [("cheb_dirichlet", 1025, "cheb_dirichlet", 1025),
-                                                  ("fourier_r2c", 1024, "cheb_neumann", 513)])
+                                                  ("fourier_r2c", 1024, "cheb_neumann", 513),
+                                                  ("fourier_r2c", 16384, "cheb_dirichlet", 33),
+                                                  ("fourier_r2c", 8192, "cheb_neumann", 17)])
 def test_space_ops(hip_lib, k0, n0, k1, n1):
     K.check_space_ops(hip_lib, k0, n0, k1, n1)
 
@@ -74,6 +76,28 @@ def test_periodic_step(hip_lib, nx, ny, steps, aspect):
 def test_periodic_config3_first_steps(hip_lib):
     """BASELINE.json configs[2]: periodic 4096 x 1025, Ra = 1e8 -- parity on the first 3 steps."""
     K.check_step_parity(hip_lib, True, 4096, 1025, 1e8, 5e-4, 3, check_at=[1, 3])
+
+
+@pytest.mark.parametrize("nx,ny", [(16384, 129), (8192, 33)])
+def test_periodic_config5_line_length(hip_lib, nx, ny):
+    """BASELINE.json configs[4] (periodic 16384 x 2049, aspect 8) at its full LINE length: x-lines
+    of 16384 reals run in the one-slot 1024-thread configuration (8192-point complex FFT in
+    139 KB of LDS); ny is kept small so that the oracle finishes in seconds."""
+    K.check_step_parity(hip_lib, True, nx, ny, 1e6, 2e-3, 3, aspect=8.0, check_at=[1, 3])
+
+
+def test_periodic_config5_full_size_properties(hip_lib):
+    """The full 16384 x 2049 case on one GPU (7 GB of arrays): size-independent properties -- finite
+    fields and diagnostics, time advanced, no NaN in the divergence (Integrate::exit)."""
+    nav = R.Navier2D.new_periodic(16384, 2049, 1e9, 1.0, 1e-4, 8.0, "rbc", library=hip_lib)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    nav.update(3)
+    assert nav.exit() is False
+    assert abs(nav.get_time() - 3e-4) < 1e-15
+    t = nav.temp.v
+    assert t.shape == (16384, 2049) and np.isfinite(t).all()
+    assert all(np.isfinite(v) for v in nav.diagnostics())
 
 
 def test_config2_golden_1025_200_steps(hip_lib):
