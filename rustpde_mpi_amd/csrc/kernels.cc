@@ -23,7 +23,13 @@ static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal
 template <class Cfg, int VAR>
 __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
-  Blk blk{(int)blockIdx.x, (int)blockIdx.y, Cfg::T, rpde_lds};
+  // XCD-aware line map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+  // block b works on line (b % 8) * chunk + b / 8 -- every XCD sweeps one contiguous band of lines
+  // and the cross-line stencil (rows j and j-2, OP_LOADX) finds its second row in the local L2
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= pg.nlines) return;
+  Blk blk{line, (int)blockIdx.y, Cfg::T, rpde_lds};
   run_line_program<Cfg, VAR>(blk, pg);
 }
 
@@ -35,7 +41,7 @@ static void launch_kernel(const Program& pg, size_t bytes, Stream& st) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     configured = bytes;
   }
-  dim3 grid(pg.nlines, pg.ncomp), block(Cfg::T);
+  dim3 grid(8 * ((pg.nlines + 7) / 8), pg.ncomp), block(Cfg::T);   // 8 bands of ceil(nlines / 8) lines
   hipLaunchKernelGGL((line_kernel<Cfg, VAR>), grid, block, bytes, st.s, pg);
   RPDE_HIP(hipGetLastError());
 }
