@@ -10,8 +10,9 @@ resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME case is pencil-sharded over
 the N GPUs (the reference's Navier2DMpi path, BASELINE.json configs[3]); every layout change of
-the step is an all-to-all over RCCL (torch.distributed backend "nccl").  Total work is fixed, so
-`scaling` is "strong" and `value` is the steps/s of the whole job.
+the step is an all-to-all over RCCL (native grouped ncclSend/ncclRecv on the engine's stream by
+default; RPDE_TRANSPORT=torch for torch.distributed's all_to_all_single).  Total work is fixed, so
+`scaling` is "strong" at every N and `value` is the steps/s of the whole job.
 """
 import argparse
 import json
@@ -235,7 +236,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "device_ms_per_step": dev_ms / args.steps,
         "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong",
+        "scaling": "strong",      # the SAME case at every N (pencil-sharded when N > 1): total work is fixed
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))",
