@@ -496,6 +496,7 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
     else if (w == "fromortho") { pb.load(0, ai, n); pb.from_ortho(0, ax); }
     else if (w == "fdma") { pb.load(0, ai, m); pb.fdma_solve(0, m, fd); }
     else if (w == "dct") { pb.load(0, ai, n); pb.dct(0, n, ax.bwd_pre.p, nullptr); }
+    else if (w == "dct0") { pb.load(0, ai, n); pb.dct(0, n, nullptr, nullptr); }   // no scaling tables
     else if (w == "dct2") { pb.load(0, ai, n); pb.dct(0, n, ax.bwd_pre.p, nullptr); pb.dct(0, n, nullptr, ax.fwd_post.p); }
     else if (w == "rfft") { pb.load(0, ai, n); pb.rfft_f(0, n); pb.rfft_b(0, n); }
     else fail("unknown microbench \"" + w + "\"");

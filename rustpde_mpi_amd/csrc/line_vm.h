@@ -60,7 +60,8 @@ enum OpCode : int {
   OP_CDIFF,    // d = s0 * d/dx of the Chebyshev series a (length n)
   OP_REC1,     // first-order stride-2 recurrence, x_k = p_k b_k + q_k x_{k-2 dir}; p = tab (-1: ones), q = i0, dir = i1
   OP_REC2,     // descending second-order: x_k = p_k b_k + q_k x_{k+2} + r_k x_{k+4}; p = tab, q = i0, r = i1; slot b (the last one) = scratch
-  OP_DCT,      // slot d (scratch d+1): x <- DCT-I(x * pre) * post ; pre = tab (-1 none), post = i0 (-1 none); n = N+1
+  OP_DCT,      // slot d (scratch d+1): x <- DCT-I(x * pre) * post ; n = N+1; direct path: pre = table tab (-1 none), post = table i0;
+               // FFT path: tab / i0 >= 0 = standard backward pre / forward post scaling on, a = first zeroed coefficient, s1 = 1/N
   OP_MUL,      // d[k] = (acc ? d[k] : 0) + s0 * a[k] * b[k]
   OP_AXPBY,    // d[k] = s0 * a[k] + s1 * b[k]
   OP_ZERO,     // d[k] = 0 for i0 <= k < i1
@@ -220,10 +221,12 @@ struct LdsSrc { static constexpr bool kLds = true; };   // butterfly inputs come
 template <bool STEN>
 struct DctSrc {
   static constexpr bool kLds = false;
-  clds_t x; int N; tab_t pre; tab_t low;
+  clds_t x; int N; bool pre; tab_t low;
   // lo_edge / hi_edge: this element may touch the ends of the line (m < 2, m >= N-1); elsewhere the
-  // stencil needs no selects.  All three flags are compile-time constants after unrolling.
-  RPDE_DEV double val(int m, int n, bool lo_edge, bool hi_edge) const {
+  // stencil needs no selects.  `odd` = parity of m.  All flags are compile-time constants after
+  // unrolling.  pre: the backward pre-scaling (-1)^m / 2 (ends: 1) evaluated arithmetically --
+  // fetching it from a table cost 16 % of a DCT program (profiles/README.md).
+  RPDE_DEV double val(int m, int n, bool lo_edge, bool hi_edge, bool odd) const {
     double v;
     if constexpr (STEN) {
       double a0 = x[m];
@@ -240,14 +243,19 @@ struct DctSrc {
     } else {
       v = x[m];
     }
-    return pre ? v * pre[m] : v;
+    if (pre) {
+      double f = odd ? -0.5 : 0.5;
+      if (!odd && ((lo_edge && m == 0) || (hi_edge && m == n))) f = 1.0;   // n is even: the ends are even
+      v *= f;
+    }
+    return v;
   }
   // element i of the packed even extension, n = FFT length = DCT N (compile-time at the call
   // site); hi: i >= n/2, where the extension runs backwards (m0 = 2n - 2i, m1 = m0 - 1)
   RPDE_DEV dbl2 get(int i, int n, bool hi, bool lo_edge, bool hi_edge) const {
     const int m0 = hi ? 2 * n - 2 * i : 2 * i;
     const int m1 = hi ? m0 - 1 : m0 + 1;
-    return dbl2{val(m0, n, lo_edge, hi_edge), val(m1, n, lo_edge, hi_edge)};
+    return dbl2{val(m0, n, lo_edge, hi_edge, false), val(m1, n, lo_edge, hi_edge, true)};
   }
 };
 
@@ -384,8 +392,8 @@ RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw, const Src src = S
 //   E_k = x_0 + (-1)^k x_N + 2 sum_{j=1}^{N-1} x_j cos(pi j k / N)
 // through an N-point complex FFT of the even extension (packed two reals per complex).
 template <class Cfg>
-RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t tw, tab_t tw2,
-                        tab_t low, gmem_t gdst, int ges, double gscale, int gn) {
+RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, double inv_n, tab_t tw,
+                        tab_t tw2, tab_t low, gmem_t gdst, int ges, double gscale, int gn) {
   constexpr int T = Cfg::T;
   // FFT with the pack step fused into the reads of its first pass (the work area overlaps x: every
   // pass reads everything before the barrier that precedes its writes)
@@ -409,7 +417,12 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, tab_t pre, tab_t post, tab_t t
           const double c = tw2[2 * k], s = tw2[2 * k + 1];
           const double A = 0.5 * (ar + br), B = 0.5 * (c * (ai + bi) - s * (ar - br));
           double ek = A + B, en = A - B;
-          if (post) { ek *= post[k]; en *= post[kn]; }
+          if (post) {   // forward scaling (-1)^k / N (ends: half), zero from `cut` on; N even: k, N-k share the sign
+            double f = (k & 1) ? -inv_n : inv_n;
+            if (k == 0) f *= 0.5;
+            ek = (k < cut) ? ek * f : 0.0;
+            en = (kn < cut) ? en * f : 0.0;
+          }
           RPDE_T(e)[2 * q] = ek;
           RPDE_T(e)[2 * q + 1] = en;
           if (gdst) {   // fused OP_STORE
@@ -1014,8 +1027,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
       } break;
       case OP_DCT: if constexpr (Cfg::kCheb) {
-        tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
-        tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
+        // FFT path: tab / i0 >= 0 switch the standard scalings on (evaluated arithmetically, a = cut,
+        // s1 = 1/N); direct path: tab / i0 are table indices.
         // fused forms (FFT path only): i1 >= 0: composite->ortho stencil table applied while packing;
         // arr >= 0: results go straight to the global array (b = count, s0 = scale) instead of LDS
         if (pg.fft_n > 0) {
@@ -1027,9 +1040,11 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
             gdst = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
             ges = A.es;
           }
-          dct1_lds<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2], low, gdst,
-                        ges, op.s0, op.b);
+          dct1_lds<Cfg>(blk, d, n - 1, op.tab >= 0, op.i0 >= 0, op.a, op.s1, (tab_t)pg.tabs[pg.tw],
+                        (tab_t)pg.tabs[pg.tw2], low, gdst, ges, op.s0, op.b);
         } else {
+          tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
+          tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
           dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
         }
       } break;

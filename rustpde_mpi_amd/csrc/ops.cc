@@ -63,6 +63,7 @@ ProgramBuilder::ProgramBuilder(int nslots, int slot_len, int nlines, int ncomp) 
   pg.tw = pg.tw2 = 0;
 }
 void ProgramBuilder::set_fft(const AxisTables& ax) {
+  ax_ = &ax;
   pg.fft_n = ax.fft_n;
   pg.tw = ax.tw.p ? tab(ax.tw.p) : 0;
   pg.tw2 = tab(ax.tw2.p);
@@ -130,24 +131,40 @@ void ProgramBuilder::rec2(int d, int a, int n, const double* p, const double* q,
   RPDE_REQUIRE(scratch != d && scratch != a, "OP_REC2 needs the last slot as scratch");
   Op& o = push(OP_REC2); o.d = d; o.a = a; o.b = scratch; o.n = n; o.tab = ip; o.i0 = iq; o.i1 = ir; o.tabld = tabld;
 }
-void ProgramBuilder::dct(int d, int n, const double* pre, const double* post) {
+// FFT path: the scalings are flags (tab = pre on/off, i0 = post on/off), a = first zeroed
+// coefficient, s1 = 1/N; direct path: table indices as before
+void ProgramBuilder::dct_flags(Op& o, int n, const double* pre, const double* post, int cut) {
+  RPDE_REQUIRE(ax_ != nullptr && ax_->base.n == n, "OP_DCT: set_fft(axis) must name the transformed axis");
+  RPDE_REQUIRE(pre == nullptr || pre == ax_->bwd_pre.p, "OP_DCT (FFT path): only the standard backward pre-scaling");
+  RPDE_REQUIRE(post == nullptr || post == ax_->fwd_post.p || cut >= 0,
+               "OP_DCT (FFT path): only the standard forward post-scaling (optionally cut)");
+  o.tab = pre ? 0 : -1;
+  o.i0 = post ? 0 : -1;
+  o.a = (cut >= 0 && cut < n) ? cut : n;
+  o.s1 = 1.0 / (double)(n - 1);
+}
+void ProgramBuilder::dct(int d, int n, const double* pre, const double* post, int cut) {
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
-  const int ipre = pre ? tab(pre) : -1, ipost = post ? tab(post) : -1;
-  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost; o.i1 = -1; o.arr = -1;
+  Op& o = push(OP_DCT); o.d = d; o.n = n; o.i1 = -1; o.arr = -1;
+  if (pg.fft_n > 0) {
+    dct_flags(o, n, pre, post, cut);
+  } else {
+    o.tab = pre ? tab(pre) : -1; o.i0 = post ? tab(post) : -1;
+  }
 }
 void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const double* pre,
-                               const double* post, int store_arr, int nstore, double scale) {
+                               const double* post, int store_arr, int nstore, double scale, int cut) {
   const int n = ax.base.n;
   if (ax.fft_n == 0) {   // direct transform: no fused forms
     if (sten_) to_ortho(d, ax);
-    dct(d, n, pre, post);
+    dct(d, n, pre, post, cut);
     if (store_arr >= 0) store(d, store_arr, nstore, scale);
     return;
   }
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
-  const int ipre = pre ? tab(pre) : -1, ipost = post ? tab(post) : -1;
   const int ilow = (sten_ && ax.base.is_composite()) ? tab(ax.low.p) : -1;
-  Op& o = push(OP_DCT); o.d = d; o.n = n; o.tab = ipre; o.i0 = ipost; o.i1 = ilow;
+  Op& o = push(OP_DCT); o.d = d; o.n = n; o.i1 = ilow;
+  dct_flags(o, n, pre, post, cut);
   o.arr = store_arr; o.b = nstore; o.s0 = scale;
 }
 void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {

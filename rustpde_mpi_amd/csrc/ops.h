@@ -64,12 +64,16 @@ class ProgramBuilder {
   void cdiff(int d, int a, int n, double scale);
   void rec1(int d, int a, int n, const double* p, const double* q, int dir, long tabld = 0);
   void rec2(int d, int a, int n, const double* p, const double* q, const double* r, long tabld = 0);
-  void dct(int d, int n, const double* pre, const double* post);
+  // `pre` / `post`: nullptr or the STANDARD scalings of the axis given to set_fft (bwd_pre /
+  // fwd_post, the latter possibly zeroed from index `cut` on -- the 2/3 rule): on the FFT path the
+  // kernel evaluates them arithmetically ((-1)^k, 1/2, 1/N, the cut) instead of fetching tables;
+  // the tables themselves are only read by the direct O(n^2) transform of small lines.
+  void dct(int d, int n, const double* pre, const double* post, int cut = -1);
   // fused forms: `sten` = composite->ortho stencil of `ax` applied while packing (slot d holds the
   // composite coefficients); `store_arr` >= 0 = results written straight to that array (nstore
   // values, scaled).  Fall back to separate ops when the line uses the direct (non-FFT) transform.
   void dct_fused(int d, const AxisTables& ax, bool sten, const double* pre, const double* post,
-                 int store_arr = -1, int nstore = 0, double scale = 1.0);
+                 int store_arr = -1, int nstore = 0, double scale = 1.0, int cut = -1);
   void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
   void axpby(int d, int a, double s0, int b, double s1, int n);
   // per-thread register copy of slot a (kept until the end of the program), and
@@ -91,6 +95,8 @@ class ProgramBuilder {
  private:
   Op& push(int code);
   int narr_ = 0, ntab_ = 0;
+  const AxisTables* ax_ = nullptr;   // axis of set_fft
+  void dct_flags(Op& o, int n, const double* pre, const double* post, int cut);
 };
 
 // ------------------------------------------------------------------------------------------
