@@ -218,7 +218,9 @@ struct LdsSrc { static constexpr bool kLds = true; };   // butterfly inputs come
 // first-pass source of the DCT: packs z_i = e_{2i} + i e_{2i+1} of the even extension of the real
 // line x on the fly (optionally with the composite->ortho stencil and the pre-scaling), so the
 // separate pack step (one LDS round trip, two barriers) disappears
-template <bool STEN>
+// STEN: 0 = plain line, 1 = composite->ortho stencil with the table `low`, 2 = the Dirichlet stencil
+// (low = -1 everywhere: c_k = a_k - a_{k-2}) without a table fetch
+template <int STEN>
 struct DctSrc {
   static constexpr bool kLds = false;
   clds_t x; int N; bool pre; tab_t low;
@@ -228,16 +230,16 @@ struct DctSrc {
   // fetching it from a table cost 16 % of a DCT program (profiles/README.md).
   RPDE_DEV double val(int m, int n, bool lo_edge, bool hi_edge, bool odd) const {
     double v;
-    if constexpr (STEN) {
+    if constexpr (STEN != 0) {
       double a0 = x[m];
       if (hi_edge) a0 = (m < n - 1) ? a0 : 0.0;
       double t2;
       if (lo_edge) {
         const int m2 = m >= 2 ? m - 2 : 0;
-        const double a2 = x[m2], l2 = low[m2];
+        const double a2 = x[m2], l2 = (STEN == 2) ? -1.0 : low[m2];
         t2 = (m >= 2) ? l2 * a2 : 0.0;
       } else {
-        t2 = low[m - 2] * x[m - 2];
+        t2 = (STEN == 2) ? -x[m - 2] : low[m - 2] * x[m - 2];
       }
       v = a0 + t2;
     } else {
@@ -393,12 +395,13 @@ RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw, const Src src = S
 // through an N-point complex FFT of the even extension (packed two reals per complex).
 template <class Cfg>
 RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, double inv_n, tab_t tw,
-                        tab_t tw2, tab_t low, gmem_t gdst, int ges, double gscale, int gn) {
+                        tab_t tw2, int sten, tab_t low, gmem_t gdst, int ges, double gscale, int gn) {
   constexpr int T = Cfg::T;
   // FFT with the pack step fused into the reads of its first pass (the work area overlaps x: every
   // pass reads everything before the barrier that precedes its writes)
-  if (low) fft_dispatch<Cfg, DctSrc<true>>(blk, x, N, tw, DctSrc<true>{x, N, pre, low});
-  else fft_dispatch<Cfg, DctSrc<false>>(blk, x, N, tw, DctSrc<false>{x, N, pre, low});
+  if (sten == 2) fft_dispatch<Cfg, DctSrc<2>>(blk, x, N, tw, DctSrc<2>{x, N, pre, low});
+  else if (sten == 1) fft_dispatch<Cfg, DctSrc<1>>(blk, x, N, tw, DctSrc<1>{x, N, pre, low});
+  else fft_dispatch<Cfg, DctSrc<0>>(blk, x, N, tw, DctSrc<0>{x, N, pre, low});
   {  // split: E_k = A + B, E_{N-k} = A - B with A = (Zr_k + Zr_{N-k})/2,
      // B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2: one thread per pair (k, N-k)
     constexpr int QH = Cfg::FMAX / 2 / T + 1;
@@ -1032,7 +1035,9 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         // fused forms (FFT path only): i1 >= 0: composite->ortho stencil table applied while packing;
         // arr >= 0: results go straight to the global array (b = count, s0 = scale) instead of LDS
         if (pg.fft_n > 0) {
+          // i1: -1 no stencil, >= 0 stencil table, -2 Dirichlet stencil (constant -1, no table)
           tab_t low = op.i1 >= 0 ? (tab_t)pg.tabs[op.i1] : (tab_t) nullptr;
+          const int sten = op.i1 >= 0 ? 1 : (op.i1 == -2 ? 2 : 0);
           gmem_t gdst = (gmem_t) nullptr;
           int ges = 1;
           if (op.arr >= 0) {
@@ -1041,7 +1046,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
             ges = A.es;
           }
           dct1_lds<Cfg>(blk, d, n - 1, op.tab >= 0, op.i0 >= 0, op.a, op.s1, (tab_t)pg.tabs[pg.tw],
-                        (tab_t)pg.tabs[pg.tw2], low, gdst, ges, op.s0, op.b);
+                        (tab_t)pg.tabs[pg.tw2], sten, low, gdst, ges, op.s0, op.b);
         } else {
           tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
           tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;

@@ -162,7 +162,8 @@ void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const do
     return;
   }
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
-  const int ilow = (sten_ && ax.base.is_composite()) ? tab(ax.low.p) : -1;
+  // the Dirichlet stencil is the constant -1: no table
+  const int ilow = !(sten_ && ax.base.is_composite()) ? -1 : (ax.base.kind == kChebDirichlet ? -2 : tab(ax.low.p));
   Op& o = push(OP_DCT); o.d = d; o.n = n; o.i1 = ilow;
   dct_flags(o, n, pre, post, cut);
   o.arr = store_arr; o.b = nstore; o.s0 = scale;
