@@ -44,6 +44,14 @@ def test_sharded_matches_oracle_emulation(world, tmp_path, emu_lib):
         assert r["comm"][1] > 0 and r["comm"][0] > 0   # exchanges per step, bytes per step
 
 
+def test_sharded_long_fourier_lines_emulation(tmp_path, emu_lib):
+    """BASELINE configs[4] geometry in miniature: periodic, x-lines of 8192 reals (the one-slot
+    1024-thread line configuration), aspect 8, two ranks."""
+    res = _spawn(2, emu_lib.path, False, [(True, 8192, 9, 1e5, 0.01, 2, 8.0)], tmp_path)
+    for k, e in res[0]["err"].items():
+        assert e < 1e-10, (k, e)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_matches_oracle_hip(world, tmp_path, hip_lib):
