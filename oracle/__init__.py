@@ -25,8 +25,9 @@ Parity pin status
 * Step level (``update()``): **parity unpinned** -- the reference holds no
   golden output for a time step and cannot be built here (no Rust toolchain,
   funspace/hdf5/MPI absent).  The step-level oracle is defined by this
-  restatement; its pieces are cross-checked by the pinned tests above and by
-  physical sanity checks (divergence -> round-off, conduction state is a fixed
-  point, Nu behaviour across the critical Rayleigh number).
+  restatement; its pieces are cross-checked by the pinned tests above, and the
+  step as a whole is pinned PHYSICALLY: the critical Rayleigh number of the
+  square no-slip cavity extracted from its growth rates (dt -> 0) is 2585.5
+  against the literature value 2585.02 (``tests/test_physics_pin.py``).
 """
 from . import bases, solver, navier  # noqa: F401

@@ -1,0 +1,84 @@
+"""Step-level physical pin: the critical Rayleigh number of the 2-D square cavity.
+
+The reference has no golden output for `Navier2D::update()` ("step-level parity is
+unpinned by the reference"), so the oracle's time step is pinned against an independent
+literature value instead: for a square cavity with no-slip walls, isothermal top/bottom and
+adiabatic side walls -- exactly `Navier2D::new_confined(n, n, Ra, Pr=1, dt, aspect=1, "rbc")`,
+src/navier_stokes/navier.rs:215-308 with boundary_conditions.rs:18-36 -- the conduction state
+loses stability at Ra_c = 2585.02 (A. Yu. Gelfgat, "Different modes of Rayleigh-Benard instability
+in two- and three-dimensional rectangular enclosures", J. Comput. Phys. 156 (1999) 300-324, the 2-D
+square cavity; J. Mizushima, J. Phys. Soc. Jpn. 64 (1995) 2420 gives 2585.03).  The whole step enters this number: nondimensionalisation
+(get_nu/get_ka, functions.rs:12-21), the BC lift, buoyancy, pressure projection, ADI Helmholtz
+solves, transforms and derivatives.
+
+The ADI factorisation (hholtz_adi.rs:149-169) perturbs steady states by O(dt), so the neutral
+Rayleigh number is measured for dt and dt/2 (growth rate of an infinitesimal perturbation at two
+Rayleigh numbers bracketing onset, linear interpolation to zero) and Richardson-extrapolated to
+dt -> 0: 2611.6, 2598.5 -> 2585.5.
+"""
+import numpy as np
+import pytest
+
+RA_C_LITERATURE = 2585.02
+
+
+def growth_rate(make, ra, n, dt, t_end, amp=1e-5):
+    """Exponential growth rate of the velocity norm over the last third of [0, t_end]."""
+    nav = make(n, n, ra, 1.0, dt, 1.0, "rbc")
+    nav.set_velocity(amp, 1.0, 1.0)
+    nav.set_temperature(amp, 1.0, 1.0)
+    every = max(1, int(2.5 / dt))
+    t, e = [], []
+    for s in range(int(t_end / dt)):
+        nav.update()
+        if s % every == 0:
+            f = nav.physical_fields()
+            e.append(np.sqrt(np.mean(f["velx"] ** 2 + f["vely"] ** 2)))
+            t.append((s + 1) * dt)
+    t, e = np.array(t), np.array(e)
+    h = 2 * len(e) // 3
+    return np.polyfit(t[h:], np.log(e[h:]), 1)[0]
+
+
+def neutral_rayleigh(make, n, dt, t_end, bracket=(2560.0, 2640.0)):
+    rates = [growth_rate(make, ra, n, dt, t_end) for ra in bracket]
+    assert rates[0] < 0.0 < rates[1], rates
+    return float(np.interp(0.0, rates, bracket))
+
+
+def critical_rayleigh(make, n=17, t_end=120.0):
+    r1 = neutral_rayleigh(make, n, 0.05, t_end)
+    r2 = neutral_rayleigh(make, n, 0.025, t_end)
+    return 2.0 * r2 - r1, (r1, r2)
+
+
+def test_oracle_reproduces_the_critical_rayleigh_number():
+    from oracle import navier as N
+    rac, (r1, r2) = critical_rayleigh(N.Navier2D.new_confined)
+    assert abs(r1 - r2) < 20.0 and r1 > r2 > RA_C_LITERATURE      # O(dt) shift of the ADI splitting
+    assert abs(rac - RA_C_LITERATURE) < 2.0, (rac, r1, r2)          # 0.08 %
+
+
+def test_engine_growth_rates_through_the_same_probe(emu_lib):
+    """The emulation build of the engine through the same probe (short): decay below, growth above
+    onset, rates equal to the oracle's."""
+    import rustpde_mpi_amd as R
+    from oracle import navier as N
+
+    def make(*a):
+        return R.Navier2D.new_confined(*a, library=emu_lib)
+    for ra in (2000.0, 3500.0):
+        g = growth_rate(make, ra, 13, 0.05, 30.0)
+        o = growth_rate(N.Navier2D.new_confined, ra, 13, 0.05, 30.0)
+        assert (g < 0.0) == (ra < RA_C_LITERATURE)
+        assert abs(g - o) < 1e-8 * max(1.0, abs(o)), (ra, g, o)
+
+
+@pytest.mark.gpu
+def test_gpu_engine_reproduces_the_critical_rayleigh_number(hip_lib):
+    import rustpde_mpi_amd as R
+
+    def make(*a):
+        return R.Navier2D.new_confined(*a, library=hip_lib)
+    rac, (r1, r2) = critical_rayleigh(make)
+    assert abs(rac - RA_C_LITERATURE) < 2.0, (rac, r1, r2)
