@@ -28,6 +28,7 @@ Parity pin status
   restatement; its pieces are cross-checked by the pinned tests above, and the
   step as a whole is pinned PHYSICALLY: the critical Rayleigh number of the
   square no-slip cavity extracted from its growth rates (dt -> 0) is 2585.5
-  against the literature value 2585.02 (``tests/test_physics_pin.py``).
+  against the literature value 2585.02, and the threshold of the periodic
+  layer is 1708.2 against Chandrasekhar's 1707.762 (``tests/test_physics_pin.py``).
 """
 from . import bases, solver, navier  # noqa: F401

@@ -14,19 +14,26 @@ solves, transforms and derivatives.
 The ADI factorisation (hholtz_adi.rs:149-169) perturbs steady states by O(dt), so the neutral
 Rayleigh number is measured for dt and dt/2 (growth rate of an infinitesimal perturbation at two
 Rayleigh numbers bracketing onset, linear interpolation to zero) and Richardson-extrapolated to
-dt -> 0: 2611.6, 2598.5 -> 2585.5.
+dt -> 0: 2611.6, 2598.5 -> 2585.5.  The periodic constructor is pinned the same way against the
+classical threshold of the infinite layer, Ra_c = 1707.762 at k_c H = 3.117: 1725.9, 1717.0 -> 1708.2.
 """
 import numpy as np
 import pytest
 
 RA_C_LITERATURE = 2585.02
+# infinite layer between no-slip isothermal plates: Ra_c = 1707.762 at k_c H = 3.117
+# (Chandrasekhar, Hydrodynamic and Hydromagnetic Stability, 1961, Table III)
+RA_C_LAYER, KC_LAYER = 1707.762, 3.117
 
 
-def growth_rate(make, ra, n, dt, t_end, amp=1e-5):
+def growth_rate(make, ra, n, dt, t_end, amp=1e-5, nx=None, aspect=1.0, random_seed=None):
     """Exponential growth rate of the velocity norm over the last third of [0, t_end]."""
-    nav = make(n, n, ra, 1.0, dt, 1.0, "rbc")
-    nav.set_velocity(amp, 1.0, 1.0)
-    nav.set_temperature(amp, 1.0, 1.0)
+    nav = make(nx or n, n, ra, 1.0, dt, aspect, "rbc")
+    if random_seed is None:
+        nav.set_velocity(amp, 1.0, 1.0)
+        nav.set_temperature(amp, 1.0, 1.0)
+    else:
+        nav.init_random(amp, seed=random_seed)
     every = max(1, int(2.5 / dt))
     t, e = [], []
     for s in range(int(t_end / dt)):
@@ -57,6 +64,23 @@ def test_oracle_reproduces_the_critical_rayleigh_number():
     rac, (r1, r2) = critical_rayleigh(N.Navier2D.new_confined)
     assert abs(r1 - r2) < 20.0 and r1 > r2 > RA_C_LITERATURE      # O(dt) shift of the ADI splitting
     assert abs(rac - RA_C_LITERATURE) < 2.0, (rac, r1, r2)          # 0.08 %
+
+
+def test_oracle_reproduces_the_threshold_of_the_periodic_layer():
+    """`Navier2D::new_periodic` (Fourier x Chebyshev, navier.rs:336-428): the box length is chosen so
+    that two critical wavelengths fit (aspect = 2 lambda_c / 2 pi with lambda_c = 2 pi H / 3.117,
+    H = 2); the neutral Rayleigh number, extrapolated to dt -> 0, must be Chandrasekhar's 1707.762."""
+    from oracle import navier as N
+    aspect = 2.0 * (2.0 * np.pi / KC_LAYER * 2.0) / (2.0 * np.pi)
+    neutral = []
+    for dt in (0.05, 0.025):
+        bracket = (1690.0, 1750.0)
+        rates = [growth_rate(N.Navier2D.new_periodic, ra, 17, dt, 200.0, nx=16, aspect=aspect, random_seed=1)
+                 for ra in bracket]
+        assert rates[0] < 0.0 < rates[1], rates
+        neutral.append(float(np.interp(0.0, rates, bracket)))
+    rac = 2.0 * neutral[1] - neutral[0]
+    assert abs(rac - RA_C_LAYER) < 2.0, (rac, neutral)      # measured 1708.2
 
 
 def test_engine_growth_rates_through_the_same_probe(emu_lib):
