@@ -15,6 +15,43 @@ using CfgL = LineCfg<512, 10, 2048, 4096, 8>;   // slots up to 5120 doubles
 using CfgX = LineCfg<1024, 18, 4096, 8192, 8>;  // Fourier lines of 8192 / 16384 reals: one slot of up to 17408 doubles
 static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal EPT");
 
+// ------------------------------------------------------------------------------- transposed tile copy
+// out[(c0 + j) * ldo + r0 + i] = in[(r0 + i) * ldi + c0 + j] for one TS x TS tile through LDS
+// (padded pitch TS + 1), 256 threads.  Shared by the device kernels and the host emulation (same
+// source, RPDE_PHASE = thread loop there).  The K = TS * TS / 256 loads of a thread are issued as
+// one batch into registers before the first LDS write: written as `for (i = ty; i < TS; i += RY)`
+// the loop had a run-time trip count, was not unrolled, and kept a single load in flight.
+struct alignas(16) Cplx { double re, im; };
+
+template <class E, int TS>
+RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long ldi, E* __restrict__ out,
+                             long ldo, int rows, int cols, int r0, int c0) {
+  constexpr int RY = 256 / TS, K = TS / RY, LP = TS + 1;
+  static_assert(256 % TS == 0 && TS % RY == 0, "tile shape");
+  RPDE_PHASE(blk, tid) {
+    const int tx = tid % TS, ty = tid / TS;
+    const int c = c0 + tx;
+    E v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int r = r0 + ty + k * RY;
+      v[k] = (r < rows && c < cols) ? in[(long)r * ldi + c] : E{};
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) tile[(ty + k * RY) * LP + tx] = v[k];
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+    const int tx = tid % TS, ty = tid / TS;
+    const int r = r0 + tx;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = ty + k * RY, c = c0 + i;
+      if (r < rows && c < cols) out[(long)c * ldo + r] = tile[tx * LP + i];
+    }
+  }
+}
+
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
 // Three kernels per configuration (line_vm.h kVar*): light, with the second-order back-substitution
@@ -70,21 +107,9 @@ template <class E, int TS>
 __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ in, long ldi,
                                                         E* __restrict__ out, long ldo, int rows,
                                                         int cols) {
-  __shared__ E tile[TS][TS + 1];
-  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
-  constexpr int RY = 256 / TS;
-  const int c0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
-#pragma unroll
-  for (int i = ty; i < TS; i += RY) {
-    const int r = r0 + i, c = c0 + tx;
-    if (r < rows && c < cols) tile[i][tx] = in[(long)r * ldi + c];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = ty; i < TS; i += RY) {
-    const int c = c0 + i, r = r0 + tx;
-    if (r < rows && c < cols) out[(long)c * ldo + r] = tile[tx][i];
-  }
+  __shared__ E tile[TS * (TS + 1)];
+  Blk blk{0, 0, 256, nullptr};
+  transpose_tile<E, TS>(blk, tile, in, ldi, out, ldo, rows, cols, (int)blockIdx.y * TS, (int)blockIdx.x * TS);
 }
 
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
@@ -97,9 +122,9 @@ void launch_transpose(const double* in, long ldi, double* out, long ldo, int row
   } else {
     RPDE_REQUIRE(elem == 2 && ldi % 2 == 0 && ldo % 2 == 0, "complex transpose needs even pitches");
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-    hipLaunchKernelGGL((transpose_kernel<double2, 32>), grid, dim3(256), 0, st.s,
-                       reinterpret_cast<const double2*>(in), ldi / 2,
-                       reinterpret_cast<double2*>(out), ldo / 2, rows, cols);
+    hipLaunchKernelGGL((transpose_kernel<Cplx, 32>), grid, dim3(256), 0, st.s,
+                       reinterpret_cast<const Cplx*>(in), ldi / 2,
+                       reinterpret_cast<Cplx*>(out), ldo / 2, rows, cols);
   }
   RPDE_HIP(hipGetLastError());
 }
@@ -226,27 +251,17 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 // ------------------------------------------------------------------------------- exchange pack / unpack
 template <class E, int TS>
 __global__ __launch_bounds__(256) void xchg_pack_kernel(const XchgDesc d, E* __restrict__ send) {
-  __shared__ E tile[TS][TS + 1];
+  __shared__ E tile[TS * (TS + 1)];
   const int q = blockIdx.z / d.nA, a = blockIdx.z % d.nA;
   const int c0 = d.c0[q], cq = d.c0[q + 1] - c0, rl = d.rl;
   const int bc = blockIdx.x * TS, br = blockIdx.y * TS;
   if (bc >= cq || br >= rl) return;
-  const E* in = reinterpret_cast<const E*>(d.in[a]);
+  // the block of columns [c0, c0 + cq) of array a, transposed into destination q's segment
   const long ldi = d.ldi / (long)(sizeof(E) / sizeof(double));
+  const E* in = reinterpret_cast<const E*>(d.in[a]) + c0;
   E* out = send + d.soff[q] / (long)(sizeof(E) / sizeof(double)) + (long)a * cq * rl;
-  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
-  constexpr int RY = 256 / TS;
-#pragma unroll
-  for (int i = ty; i < TS; i += RY) {
-    const int r = br + i, cc = bc + tx;
-    if (r < rl && cc < cq) tile[i][tx] = in[(long)r * ldi + c0 + cc];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = ty; i < TS; i += RY) {
-    const int cc = bc + i, r = br + tx;
-    if (r < rl && cc < cq) out[(long)cc * rl + r] = tile[tx][i];
-  }
+  Blk blk{0, 0, 256, nullptr};
+  transpose_tile<E, TS>(blk, tile, in, ldi, out, (long)rl, rl, cq, br, bc);
 }
 template <class E>
 __global__ __launch_bounds__(256) void xchg_unpack_kernel(const XchgDesc d, const E* __restrict__ recv) {
@@ -268,7 +283,7 @@ void launch_xchg_pack(const XchgDesc& d, double* send, Stream& st) {
     hipLaunchKernelGGL((xchg_pack_kernel<double, 64>), grid, dim3(256), 0, st.s, d, send);
   } else {
     dim3 grid((cmax + 31) / 32, (d.rl + 31) / 32, d.P * d.nA);
-    hipLaunchKernelGGL((xchg_pack_kernel<double2, 32>), grid, dim3(256), 0, st.s, d, reinterpret_cast<double2*>(send));
+    hipLaunchKernelGGL((xchg_pack_kernel<Cplx, 32>), grid, dim3(256), 0, st.s, d, reinterpret_cast<Cplx*>(send));
   }
   RPDE_HIP(hipGetLastError());
 }
@@ -345,11 +360,22 @@ static void launch_cfg(const Program& pg, Stream&) {
     }
 }
 
+template <class E, int TS>
+static void emu_transpose(const E* in, long ldi, E* out, long ldo, int rows, int cols) {
+  std::vector<E> tile((size_t)TS * (TS + 1));
+  Blk blk{0, 0, 256, nullptr};
+  for (int r0 = 0; r0 < rows; r0 += TS)
+    for (int c0 = 0; c0 < cols; c0 += TS) transpose_tile<E, TS>(blk, tile.data(), in, ldi, out, ldo, rows, cols, r0, c0);
+}
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
                       int elem, Stream&) {
-  for (int r = 0; r < rows; ++r)
-    for (int c = 0; c < cols; ++c)
-      for (int e = 0; e < elem; ++e) out[(long)c * ldo + (long)r * elem + e] = in[(long)r * ldi + (long)c * elem + e];
+  if (rows <= 0 || cols <= 0) return;
+  if (elem == 1) {
+    emu_transpose<double, 64>(in, ldi, out, ldo, rows, cols);
+  } else {
+    RPDE_REQUIRE(elem == 2 && ldi % 2 == 0 && ldo % 2 == 0, "complex transpose needs even pitches");
+    emu_transpose<Cplx, 32>(reinterpret_cast<const Cplx*>(in), ldi / 2, reinterpret_cast<Cplx*>(out), ldo / 2, rows, cols);
+  }
 }
 void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream&) {
@@ -376,11 +402,14 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream&) {
   for (int q = 0; q < d.P; ++q)
     for (int a = 0; a < d.nA; ++a) {
-      const int c0 = d.c0[q], cq = d.c0[q + 1] - c0, e = d.elem;
-      double* out = send + d.soff[q] + (long)a * cq * d.rl * e;
-      for (int r = 0; r < d.rl; ++r)
-        for (int c = 0; c < cq; ++c)
-          for (int z = 0; z < e; ++z) out[((long)c * d.rl + r) * e + z] = d.in[a][(long)r * d.ldi + (long)(c0 + c) * e + z];
+      const int c0 = d.c0[q], cq = d.c0[q + 1] - c0;
+      if (cq <= 0 || d.rl <= 0) continue;
+      if (d.elem == 1) {
+        emu_transpose<double, 64>(d.in[a] + c0, d.ldi, send + d.soff[q] + (long)a * cq * d.rl, d.rl, d.rl, cq);
+      } else {
+        emu_transpose<Cplx, 32>(reinterpret_cast<const Cplx*>(d.in[a]) + c0, d.ldi / 2,
+                                reinterpret_cast<Cplx*>(send + d.soff[q]) + (long)a * cq * d.rl, d.rl, d.rl, cq);
+      }
     }
 }
 void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream&) {

@@ -53,7 +53,7 @@ def neutral_rayleigh(make, n, dt, t_end, bracket=(2560.0, 2640.0)):
     return float(np.interp(0.0, rates, bracket))
 
 
-def critical_rayleigh(make, n=17, t_end=120.0):
+def critical_rayleigh(make, n=13, t_end=90.0):
     r1 = neutral_rayleigh(make, n, 0.05, t_end)
     r2 = neutral_rayleigh(make, n, 0.025, t_end)
     return 2.0 * r2 - r1, (r1, r2)
@@ -75,7 +75,7 @@ def test_oracle_reproduces_the_threshold_of_the_periodic_layer():
     neutral = []
     for dt in (0.05, 0.025):
         bracket = (1690.0, 1750.0)
-        rates = [growth_rate(N.Navier2D.new_periodic, ra, 17, dt, 200.0, nx=16, aspect=aspect, random_seed=1)
+        rates = [growth_rate(N.Navier2D.new_periodic, ra, 13, dt, 150.0, nx=16, aspect=aspect, random_seed=1)
                  for ra in bracket]
         assert rates[0] < 0.0 < rates[1], rates
         neutral.append(float(np.interp(0.0, rates, bracket)))
