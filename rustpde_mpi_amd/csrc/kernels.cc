@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 namespace rpde {
@@ -72,11 +73,16 @@ __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
 
 template <class Cfg, int VAR>
 static void launch_kernel(const Program& pg, size_t bytes, Stream& st) {
-  static size_t configured = 0;
-  if (bytes > configured) {
+  // the dynamic-LDS permission of a kernel is raised lazily, per device (several handles on
+  // several devices / host threads in one process stay correct)
+  static std::atomic<size_t> configured[32];
+  int dev = 0;
+  RPDE_HIP(hipGetDevice(&dev));
+  std::atomic<size_t>& have = configured[dev & 31];
+  if (bytes > have.load(std::memory_order_acquire)) {
     RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg, VAR>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    configured = bytes;
+    have.store(bytes, std::memory_order_release);
   }
   dim3 grid(8 * ((pg.nlines + 7) / 8), pg.ncomp), block(Cfg::T);   // 8 bands of ceil(nlines / 8) lines
   hipLaunchKernelGGL((line_kernel<Cfg, VAR>), grid, block, bytes, st.s, pg);
