@@ -781,7 +781,7 @@ void Navier2DEngine::build_confined() {
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
     pb.unstash_axpy(0, 1.0, 1.0, ny);
-    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, ny * 2 / 3);   // forward + 2/3 rule + store
+    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
@@ -799,7 +799,7 @@ void Navier2DEngine::build_confined() {
     ProgramBuilder pb = ypb(2, my);
     pb.set_fft(ax);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
-    pb.dct(0, nx, nullptr, postcut_x_.p, nx * 2 / 3);                   // forward transform + 2/3 rule in x
+    pb.dct(0, nx, nullptr, postcut_x_.p, cut_x);                 // forward transform + 2/3 rule in x
     pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
     pb.to_ortho(1, ax);                                       // S_x
     pb.axpby(0, 0, -dt, 1, 1.0, nx);
@@ -1051,7 +1051,7 @@ void Navier2DEngine::build_periodic() {
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
     pb.unstash_axpy(0, 1.0, 1.0, ny);
-    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, ny * 2 / 3);   // forward + 2/3 rule + store
+    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
