@@ -41,12 +41,17 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--profile-steps", type=int, default=3)
+    # harness self-test on a box without a GPU (tests/test_bench_dryrun.py): runs the SAME script
+    # against the host emulation build of the kernel sources.  Never a measurement: the JSON line
+    # says so in `data` and carries "dry_run": true.
+    p.add_argument("--dry-run-emu", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
 
 
 def cpu_baseline(args):
     """The oracle (CPU restatement of rustpde, OpenBLAS path) timed on the host cores: a bounded
-    sample of the same workload."""
+    sample of the same workload.  Returns (baseline dict, oracle instance after 1 + cpu_steps
+    steps) -- the instance is the checker of the `parity` object."""
     from oracle import navier as N
     ctor = N.Navier2D.new_periodic if args.periodic else N.Navier2D.new_confined
     t0 = time.perf_counter()
@@ -67,10 +72,30 @@ def cpu_baseline(args):
         cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count()
-    return {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": cores, "host_cores": os.cpu_count(),
+    base = {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": cores, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of the same {args.nx}x{args.ny} case after 1 warm-up step "
                       f"(NumPy/SciPy oracle, OpenBLAS dgemm + pocketfft, setup {setup:.1f}s not timed)"}
+    return base, ora, 1 + args.cpu_steps
+
+
+PARITY_TOL = 1e-10   # BASELINE.json: u, v, T, p match the CPU reference within 1e-10 relative L2 (f64)
+
+
+def parity_vs_oracle(make, ora, nsteps):
+    """A FRESH engine, the same deterministic initial condition, the same number of steps as the
+    oracle instance of the cpu_baseline leg has taken: relative L2 of u, v, T, p in physical space."""
+    import numpy as np
+    nav = make(None)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    nav.update(nsteps)
+    got, want = nav.physical_fields(), ora.physical_fields()
+    rel = {k: float(np.linalg.norm(got[k] - want[k]) / np.linalg.norm(want[k])) for k in want}
+    del nav
+    return {"steps": nsteps, "rel_l2": rel, "tol": PARITY_TOL,
+            "checker": "oracle/navier.py (NumPy/SciPy restatement of Navier2D::update, eig_mode=parity)",
+            "ok": all(v < PARITY_TOL for v in rel.values())}
 
 
 def pmc_traffic(workload, tag):
@@ -114,8 +139,15 @@ def main():
     transport = "none"
     ctor = R.Navier2D.new_periodic if args.periodic else R.Navier2D.new_confined
 
+    library = None
+    if args.dry_run_emu:
+        from tests.emu.build_emu import build as build_emu
+        from rustpde_mpi_amd._capi import Lib
+        library = Lib(build_emu())
+
     def make(comm):
-        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", device=local_rank, comm=comm)
+        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", device=local_rank, comm=comm,
+                    library=library)
 
     if world > 1:
         from rustpde_mpi_amd.dist import RcclComm, TorchComm
@@ -175,14 +207,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    bad = nav.exit()          # collective when sharded: every rank takes part
+    # the loop a host that keeps rustpde::integrate runs (src/lib.rs:187-219): update(); exit(); per step
+    barrier()
+    t1 = time.perf_counter()
+    loop_steps = max(1, min(args.steps, 20))
+    bad_loop = False
+    for _ in range(loop_steps):
+        nav.update(1)
+        bad_loop = nav.exit() or bad_loop
+    barrier()
+    loop_ms = 1e3 * (time.perf_counter() - t1) / loop_steps
+
+    bad = nav.exit() or bad_loop          # collective when sharded: every rank takes part
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     assert not bad, "NaN in the divergence after the timed run"
 
-    per_launch_ms = tag_ms / max(tag_n, 1)
+    per_launch_ms = max(tag_ms / max(tag_n, 1), 1e-9)
     if dom["flops"] > 0:
         achieved = dom["flops"] / (per_launch_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -212,15 +255,28 @@ def main():
     # pencil transposes T1/T2 between the x and the y pass.
     def stage_ms(prefixes):
         return sum(r["ms_total"] for r in prof if r["tag"].split(" ")[0] in prefixes) / args.profile_steps
+
+    def stage_bytes(prefixes):   # algorithmic bytes the launches of these stages move in ONE step
+        return sum(r["bytes"] * r["launches"] for r in prof if r["tag"].split(" ")[0] in prefixes) / args.profile_steps
     line_ms = stage_ms(("S1", "S2", "S3"))
-    tr_bytes = 416.0 * args.nx * args.ny
-    pure = [r for r in prof if r["tag"] in ("S1 x: state -> phys-x", "S2 y: velx -> phys")]
+    moved = stage_bytes(("S1", "S2", "S3"))
+    moved_t = moved + stage_bytes(("T1", "T2"))
+    ms_t = line_ms + stage_ms(("T1", "T2"))
+    ref_bytes = 416.0 * args.nx * args.ny
+    pure = [r for r in prof if r["tag"] in ("S1 x: state -> phys-x + d/dx", "S1 x: state -> phys-x", "S2 y: velx, vely -> phys",
+                                            "S2 y: velx -> phys")]
     transform_pass = {
-        "bytes_reference_sequence": tr_bytes,
+        # the headline figure: bytes the transform stages REALLY move (their loads and stores) over their time
+        "bytes_moved_S1_S2_S3": moved,
         "ms_stages_S1_S2_S3": line_ms,
-        "GB/s": tr_bytes / (line_ms * 1e-3) / 1e9 if line_ms > 0 else None,
-        "frac_of_hbm_peak": tr_bytes / (line_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if line_ms > 0 else None,
-        "ms_with_transposes_T1_T2": line_ms + stage_ms(("T1", "T2")),
+        "GB/s": moved / (line_ms * 1e-3) / 1e9 if line_ms > 0 else None,
+        "frac_of_hbm_peak": moved / (line_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if line_ms > 0 else None,
+        "with_transposes_T1_T2": {"bytes_moved": moved_t, "ms": ms_t,
+                                  "frac_of_hbm_peak": moved_t / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_t > 0 else None},
+        # for comparison only: the reference op sequence has 13 two-dimensional transforms = 416 nx ny bytes
+        # (SURVEY.md 8d); this engine executes 11 of them (the lift's gradients are constants)
+        "reference_sequence_bytes": ref_bytes,
+        "reference_sequence_equiv_frac": ref_bytes / (line_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if line_ms > 0 else None,
         "pure_1d_transform_kernels": [
             {"kernel": r["tag"], "GB/s": round(r["bytes"] / (r["ms_total"] / r["launches"] * 1e-3) / 1e9, 1),
              "frac_of_hbm_peak": round(r["bytes"] / (r["ms_total"] / r["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -235,11 +291,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "device_ms_per_step": dev_ms / args.steps,
+        "ms_per_step_update_plus_exit": loop_ms,   # `update(1); exit()` per step, as rustpde::integrate drives it
         "higher_is_better": True,
         "scaling": "strong",      # the SAME case at every N (pencil-sharded when N > 1): total work is fixed
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))",
+        "data": ("DRY RUN on the host emulation build -- NOT a measurement" if args.dry_run_emu else
+                 "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))"),
         "config": {"workload": f"Navier2D::new_{'periodic' if args.periodic else 'confined'} "
                                f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect={args.aspect:g} bc=rbc",
                    "parallelism": "single GPU" if world == 1 else
@@ -248,14 +306,20 @@ def main():
         "phases": phases,
         "transform_pass": transform_pass,
     }
+    if args.dry_run_emu:
+        out["dry_run"] = True
     if world > 1:
         sent, nx_ = nav.comm_stats()
         out["exchange"] = {"alltoalls_per_step": nx_, "bytes_sent_per_gpu_per_step": sent,
                            "GB/s_per_gpu": sent * args.steps / elapsed / 1e9,
                            "xgmi_peak_GB/s_per_gpu": 7 * 153.0}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+        del nav   # free the timed engine's HBM before the parity engine is built
+        out["cpu_baseline"], ora, osteps = cpu_baseline(args)
+        out["parity"] = parity_vs_oracle(make, ora, osteps)
     print(json.dumps(out))
+    if "parity" in out and not out["parity"]["ok"]:
+        sys.exit(f"parity vs the oracle above {PARITY_TOL}: {out['parity']['rel_l2']}")
     if dist is not None:
         dist.destroy_process_group()
 

@@ -275,8 +275,9 @@ def integrate(pde, max_time, save_intervall=None):
         pde.update()
         timestep += 1
         if save_intervall is not None:
-            t = pde.get_time()
-            if (t + eps_dt) % save_intervall < pde.get_dt() / 2.0:
+            # lib.rs:196-203 verbatim: both sides of a multiple of the save interval count
+            t, dt = pde.get_time(), pde.get_dt()
+            if (t % save_intervall) < dt / 2.0 or (t % save_intervall) > save_intervall - dt / 2.0:
                 pde.callback()
         if pde.get_time() + eps_dt >= max_time:
             break

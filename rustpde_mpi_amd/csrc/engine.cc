@@ -30,13 +30,49 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
+  RPDE_REQUIRE(comm_.size <= 8, "at most 8 ranks (one xGMI-connected MI355X node; the exchange descriptors hold 8 peers)");
   RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr || comm_.rccl != nullptr,
                "sharded engine needs an all-to-all transport");
   RPDE_REQUIRE(bc == "rbc", "Boundary condition type \"" + bc + "\" not recognized! (supported: \"rbc\")");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
+  // everything that can throw comes after this block; the members below are released by
+  // release_device_objects() from the destructor AND from the constructor's catch-all
   RPDE_HIP(hipStreamCreate(&st_.s));
 #endif
+  try {
+    construct(nx, ny, ra, pr, dt, aspect, periodic);
+  } catch (...) {
+    release_device_objects();
+    throw;
+  }
+}
+
+void Navier2DEngine::release_device_objects() {
+#ifndef RPDE_EMU
+  if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+  if (st_.s) (void)hipStreamSynchronize(st_.s);
+  rccl_comm_destroy(comm_.rccl); comm_.rccl = nullptr;
+  if (ev0_) { (void)hipEventDestroy(ev0_); ev0_ = nullptr; }
+  if (ev1_) { (void)hipEventDestroy(ev1_); ev1_ = nullptr; }
+  if (hflag_) { (void)hipHostFree(hflag_); hflag_ = nullptr; }
+  if (st_.s) { (void)hipStreamDestroy(st_.s); st_.s = nullptr; }
+#else
+  rccl_comm_destroy(comm_.rccl); comm_.rccl = nullptr;
+  delete hflag_; hflag_ = nullptr;
+#endif
+}
+
+void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, double aspect, bool periodic) {
+  (void)aspect;
+#ifndef RPDE_EMU
+  RPDE_HIP(hipEventCreate(&ev0_));
+  RPDE_HIP(hipEventCreate(&ev1_));
+  RPDE_HIP(hipHostMalloc(reinterpret_cast<void**>(&hflag_), 16, hipHostMallocDefault));
+#else
+  hflag_ = new int(0);
+#endif
+  *hflag_ = 0;
   nu_ = get_nu(ra, pr, sy_ * 2.0);
   ka_ = get_ka(ra, pr, sy_ * 2.0);
   my_ = ny - 2;
@@ -70,6 +106,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   red_.alloc(2);
+  nanflag_.alloc(2);
   {  // dealias (functions.rs:72-82) folded into the post-scaling of the forward DCT
     Vec py = cheb_fwd_post(ny);
     for (int k = ny * 2 / 3; k < ny; ++k) py[k] = 0.0;
@@ -148,16 +185,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   }
 }
 
-Navier2DEngine::~Navier2DEngine() {
-#ifndef RPDE_EMU
-  if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-  if (st_.s) (void)hipStreamSynchronize(st_.s);
-  rccl_comm_destroy(comm_.rccl);
-  if (st_.s) (void)hipStreamDestroy(st_.s);
-#else
-  rccl_comm_destroy(comm_.rccl);
-#endif
-}
+Navier2DEngine::~Navier2DEngine() { release_device_objects(); }
 
 double Navier2DEngine::param(const std::string& key) const {
   if (key == "ra") return ra_;
@@ -220,6 +248,10 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
   }
   dev_sync(st_);
   if (f.name == "pres") refresh_gy();
+  // host write: the next exit() evaluates the divergence like the reference; the flag starts over
+  dirty_ = true;
+  dev_zero(nanflag_.p, 2 * sizeof(double), st_);
+  dev_sync(st_);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -399,6 +431,18 @@ void Navier2DEngine::init_random(double amp, unsigned long long seed) {
     for (double& x : v) x = dist(rng);
     set_field_physical(nm, v.data(), v.size());
   }
+  if (comm_.size > 1) {
+    // MPI flavour (src/navier_stokes_mpi/navier.rs:179-188): the lift is removed from the
+    // (projected) random temperature and the field is transformed again; the serial constructor
+    // has this block commented out (navier.rs:176-181)
+    get_field_physical("temp", v.data(), v.size());
+    const Vec y = base_coords(sp_ortho_->base(1));
+    const double x1 = y.front(), x2 = y.back(), y1 = 0.5, y2 = -0.5;
+    const double m = (y2 - y1) / (x2 - x1), n = (y1 * x2 - y2 * x1) / (x2 - x1);
+    for (int i = 0; i < nx_; ++i)
+      for (int j = 0; j < ny_; ++j) v[(size_t)i * ny_ + j] -= m * y[j] + n;
+    set_field_physical("temp", v.data(), v.size());
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -477,10 +521,9 @@ void Navier2DEngine::run_launch(const Launch& l) {
 
 void Navier2DEngine::update(int nsteps) {
   RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
+  if (nsteps > 0) dirty_ = false;
 #ifndef RPDE_EMU
-  hipEvent_t e0, e1;
-  RPDE_HIP(hipEventCreate(&e0));
-  RPDE_HIP(hipEventCreate(&e1));
+  hipEvent_t e0 = ev0_, e1 = ev1_;
   RPDE_HIP(hipEventRecord(e0, st_.s));
 #else
   auto t0 = std::chrono::steady_clock::now();
@@ -496,13 +539,18 @@ void Navier2DEngine::update(int nsteps) {
       --nsteps;
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(st_.s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (const Launch& l : step_) run_launch(l);
-        if (hipStreamEndCapture(st_.s, &g) == hipSuccess && g &&
-            hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0) != hipSuccess)
+        bool ok = true;
+        try {   // a throw between Begin and EndCapture must not leave the stream in capture mode
+          for (const Launch& l : step_) run_launch(l);
+        } catch (...) {
+          ok = false;
+        }
+        const bool ended = hipStreamEndCapture(st_.s, &g) == hipSuccess && g != nullptr;
+        if (ok && ended && hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0) != hipSuccess)
           graph_exec_ = nullptr;
         if (g) (void)hipGraphDestroy(g);
       }
-      (void)hipGetLastError();
+      (void)hipGetLastError();   // any failure above: fall back to plain launches below
     }
     if (graph_exec_) {
       for (int s = 0; s < nsteps; ++s) {
@@ -539,8 +587,6 @@ void Navier2DEngine::update(int nsteps) {
   float ms = 0.f;
   RPDE_HIP(hipEventElapsedTime(&ms, e0, e1));
   last_ms_ = ms;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   for (auto& p : tev) {
     float t = 0.f;
     RPDE_HIP(hipEventElapsedTime(&t, p.first, p.second));
@@ -628,7 +674,34 @@ double Navier2DEngine::div_norm() {
   return std::sqrt(h[0]);
 }
 
-bool Navier2DEngine::exit() { return std::isnan(div_norm()); }
+bool Navier2DEngine::read_nanflag() {
+#ifndef RPDE_EMU
+  RPDE_HIP(hipMemcpyAsync(hflag_, nanflag_.p, sizeof(int), hipMemcpyDeviceToHost, st_.s));
+  RPDE_HIP(hipStreamSynchronize(st_.s));
+#else
+  *hflag_ = *flagp();
+#endif
+  return *hflag_ != 0;
+}
+
+bool Navier2DEngine::exit() {
+  // fields written from the host since the last step: evaluate the divergence like the reference
+  if (dirty_) return std::isnan(div_norm());
+  bool bad = read_nanflag();
+  if (comm_.size > 1) {
+    // MPI flavour: every rank must take the same branch of the integrate() loop
+    // (src/mpi/mod.rs:39-76); one double per peer through the engine's own all-to-all
+    const int P = comm_.size;
+    Vec h((size_t)P, bad ? 1.0 : 0.0), r((size_t)P, 0.0);
+    dev_upload(sendbuf_.p, h.data(), P * sizeof(double));
+    std::vector<int64_t> cnt(P, 1);
+    alltoallv(sendbuf_.p, cnt, recvbuf_.p, cnt);
+    dev_sync(st_);
+    dev_download(r.data(), recvbuf_.p, P * sizeof(double));
+    for (double v : r) bad = bad || v != 0.0;
+  }
+  return bad;
+}
 
 void Navier2DEngine::diagnostics(double* nu_out, double* nuvol_out, double* re_out) {
   // Diagnostic path (the reference evaluates it in callback(), navier_io.rs:125-147): generic
@@ -835,6 +908,7 @@ void Navier2DEngine::build_confined() {
     pb.pinv_matvec(0, yD);
     pb.fdma_solve(0, my, hh.fdma[1]);
     pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
+    pb.guard_last_store(flagp());
     if (which == 1) {
       pb.zero(0, my, sly);
       pb.to_ortho(0, yD);
@@ -941,11 +1015,13 @@ void Navier2DEngine::build_confined() {
     pb.from_ortho(0, xD);
     pb.load(0, pb.arr(yx(U_), ldx), mx, 1.0, true);
     pb.store(0, pb.arr(yx(U_), ldx), mx);
+    pb.guard_last_store(flagp());
     pb.load(0, pb.arr(yx(Y_[3]), ldx), mx);
     pb.to_ortho(0, xN);
     pb.from_ortho(0, xD);
     pb.load(0, pb.arr(yx(V_), ldx), mx, 1.0, true);
     pb.store(0, pb.arr(yx(V_), ldx), mx);
+    pb.guard_last_store(flagp());
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
@@ -957,6 +1033,7 @@ void Navier2DEngine::build_confined() {
     pb.load(0, pb.arr(yx(DIV_), ldx), nx, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nx, 1.0, true);
     pb.store(0, pb.arr(yx(P_), ldx), nx);
+    pb.guard_last_store(flagp());
     add_line(pb, "S9 x: pressure update");
   }
   // ---- T6 / S10 / T7: d/dy pres for the next step
@@ -1161,9 +1238,11 @@ void Navier2DEngine::build_periodic() {
     pb.cik(0, 0, kx, -1.0 / sx_, 1);
     pb.load(0, pb.arr(yx(U_), ldx), nc, 1.0, true);
     pb.store(0, pb.arr(yx(U_), ldx), nc);
+    pb.guard_last_store(flagp());
     pb.load(0, pb.arr(yx(Y_[3]), ldx), nc);
     pb.load(0, pb.arr(yx(V_), ldx), nc, 1.0, true);
     pb.store(0, pb.arr(yx(V_), ldx), nc);
+    pb.guard_last_store(flagp());
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
@@ -1174,6 +1253,7 @@ void Navier2DEngine::build_periodic() {
     pb.load(0, pb.arr(yx(DIV_), ldx), nc, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nc, 1.0, true);
     pb.store(0, pb.arr(yx(P_), ldx), nc);
+    pb.guard_last_store(flagp());
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step

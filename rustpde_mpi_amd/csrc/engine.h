@@ -52,7 +52,15 @@ class Navier2DEngine {
   // Nusselt number at the plates, volumetric Nusselt number, Reynolds number
   // (eval_nu / eval_nuvol / eval_re, src/navier_stokes/functions.rs:146-233; callback cadence only)
   void diagnostics(double* nu, double* nuvol, double* re);
-  bool exit();                       // NaN guard of Integrate::exit (navier.rs:482-489)
+  // NaN guard of Integrate::exit (navier.rs:482-489).  The reference recomputes the divergence
+  // every step just to test its norm for NaN (src/lib.rs:214); here the stores of the corrected
+  // velocities, the pressure and (confined) the temperature raise a device flag, and exit() is one
+  // 4-byte read of it after the stream drained: no allocation, no extra pass over the fields.
+  // (A NaN spreads to every coefficient of every field within one step, so the flag and the
+  // reference's test agree from the step after the first NaN at the latest.)  After a host
+  // write to a field (set_field / init_random) and before the next update() the divergence is
+  // evaluated like the reference does.
+  bool exit();
   double time() const { return time_; }
   double dt() const { return dt_; }
   double param(const std::string& key) const;
@@ -77,8 +85,8 @@ class Navier2DEngine {
 
  private:
   struct Field;   // per-field bookkeeping
-  void build_programs();
-  void step();
+  void construct(int nx, int ny, double ra, double pr, double dt, double aspect, bool periodic);
+  void release_device_objects();   // stream, events, graph, communicator: also on a throwing constructor
   Field& field(const std::string& name);
   void state_to_canonical(Field& f, Arr2& out);
   void canonical_to_state(const Arr2& in, Field& f);
@@ -138,6 +146,11 @@ class Navier2DEngine {
   // XY layout work arrays (row = x index, contiguous y)
   DBuf X_[9], BX_, BY_, PS_;
   DBuf red_;                     // reduction scratch (2 doubles)
+  DBuf nanflag_;                 // device flag raised by the guarded stores of the step (int at offset 0)
+  int* hflag_ = nullptr;         // pinned host landing pad of the flag
+  bool dirty_ = false;           // a field was written from the host since the last update()
+  int* flagp() const { return reinterpret_cast<int*>(nanflag_.p); }
+  bool read_nanflag();
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
   DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
   std::map<std::string, std::unique_ptr<Field>> fields_;
@@ -163,6 +176,7 @@ class Navier2DEngine {
 #ifndef RPDE_EMU
   hipGraphExec_t graph_exec_ = nullptr;   // the whole step captured once (single GPU): replay removes
   bool graph_tried_ = false;              // the per-launch host cost that dominates small grids
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;   // brackets of update(), created once
 #endif
   bool use_graph_ = true;
   void add_line(const ProgramBuilder& pb, const char* tag);

@@ -245,8 +245,13 @@ bool try_open(Lapack& L, const std::string& path) {
 Lapack& lapack() {
   static Lapack L;
   if (L.h) return L;
+  // search order: RPDE_LAPACK_LIB (explicit), then the system's OpenBLAS / LAPACK by soname (what a
+  // Rust host links anyway: Cargo.toml:38-53 openblas-system / intel-mkl), and only then the
+  // OpenBLAS that ships inside SciPy wheels (the one this Python-only image happens to have)
   std::vector<std::string> cand;
   if (const char* e = std::getenv("RPDE_LAPACK_LIB")) cand.push_back(e);
+  for (const char* s : {"libopenblas.so.0", "libopenblas.so", "liblapack.so.3", "liblapack.so", "libmkl_rt.so.2", "libmkl_rt.so"})
+    cand.push_back(s);
   const char* pats[] = {
       "/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so",
       "/usr/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so",
@@ -259,8 +264,6 @@ Lapack& lapack() {
       for (size_t i = 0; i < g.gl_pathc; ++i) cand.push_back(g.gl_pathv[i]);
     globfree(&g);
   }
-  for (const char* s : {"libopenblas.so.0", "libopenblas.so", "liblapack.so.3", "liblapack.so"})
-    cand.push_back(s);
   for (const auto& c : cand)
     if (try_open(L, c)) return L;
   fail("rustpde_hip: no LAPACK (dgeev/dgetrf/dgetri/dgemm) found for the Poisson eigen-"
@@ -329,6 +332,12 @@ EigenX eigen_decomposition_parity(const Bands& a, const Bands& c) {
     L.dgeev("N", "V", &mb, x.data(), &mb, wr.data(), wi.data(), nullptr, &one, vr.data(), &mb,
             work.data(), &lwork, &info, 1, 1);
     RPDE_REQUIRE(info == 0, "dgeev failed");
+    {  // the x operator has a real spectrum; the reference keeps the real parts
+       // (src/solver/utils.rs:82-87) -- a complex pair here would mean a broken operator, not round-off
+      double wmax = 0.0, imax = 0.0;
+      for (int k = 0; k < mb; ++k) { wmax = std::max(wmax, std::fabs(wr[k])); imax = std::max(imax, std::fabs(wi[k])); }
+      RPDE_REQUIRE(imax <= 1e-8 * std::max(wmax, 1.0), "Poisson eigen-decomposition: complex eigenvalues");
+    }
     std::vector<int> perm(mb);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int i, int j) { return wr[i] > wr[j]; });

@@ -54,7 +54,8 @@ enum OpCode : int {
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;
                // i0 = 2: interleaved complex line times i*kappa (kappa = pair index): d[2j] (+)= -s0 j Im A_j, d[2j+1] (+)= s0 j Re A_j
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
-  OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1
+  OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1;
+               // acc = 1: NaN guard -- a stored NaN raises *Program::nanflag (Integrate::exit, navier.rs:482-489)
   OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length)
   OP_MV3,      // d[k] = t0[k] a[k] + t1[k] a[k+2] + t2[k] a[k+4]             k < n  (tables tab, tab+1, tab+2)
   OP_CDIFF,    // d = s0 * d/dx of the Chebyshev series a (length n)
@@ -107,6 +108,7 @@ struct Program {
   int fft_n;      // complex FFT length used by OP_DCT / OP_RFFT (0: direct O(n^2) DCT)
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
   int tw2;        // table index of the split twiddles (cos, sin)(pi k / N) resp. (2 pi k / nx)
+  int* nanflag;   // device flag raised by guarded stores (OP_STORE with acc = 1); may be null
   Op ops[kMaxOps];
   ArrayRef arr[kMaxArr];
   const double* tabs[kMaxTab];
@@ -933,14 +935,18 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         const ArrayRef& A = pg.arr[op.arr];
         gmem_t dstp = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         const bool plain = !op.i0 && A.es == 1;
+        const bool guard = op.acc != 0 && pg.nanflag != nullptr;
         RPDE_PHASE(blk, tid) {
           if (plain) {
+            bool bad = false;
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
               const int k = tid + q * T;
               const double x = op.s0 * a[k];
-              if (k < n) dstp[k] = x;
+              if (k < n) { dstp[k] = x; bad |= (x != x); }
             }
+            // device-side NaN guard: only a thread that actually stored a NaN touches the flag
+            if (guard && bad) *pg.nanflag = 1;
           } else {
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {

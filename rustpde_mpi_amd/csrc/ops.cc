@@ -109,6 +109,13 @@ void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, 
 void ProgramBuilder::store(int a, int ar, int n, double s0, int half) {
   Op& o = push(OP_STORE); o.a = a; o.arr = ar; o.n = n; o.s0 = s0; o.i0 = half > 0; o.i1 = half;
 }
+void ProgramBuilder::guard_last_store(int* flag) {
+  RPDE_REQUIRE(pg.nops > 0 && pg.ops[pg.nops - 1].code == OP_STORE && pg.ops[pg.nops - 1].i0 == 0,
+               "guard_last_store: the last op must be a plain store");
+  RPDE_REQUIRE(pg.arr[pg.ops[pg.nops - 1].arr].es == 1, "guard_last_store: contiguous lines only");
+  pg.ops[pg.nops - 1].acc = 1;
+  pg.nanflag = flag;
+}
 void ProgramBuilder::sten(int d, int a, int n_ortho, const double* low) {
   Op& o = push(OP_STEN); o.d = d; o.a = a; o.n = n_ortho; o.tab = tab(low);
 }

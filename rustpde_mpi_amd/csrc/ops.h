@@ -59,6 +59,9 @@ class ProgramBuilder {
   void set_line0(int line0) { pg.line0 = line0; }
   void loadx(int d, int arr, int n, int rows, const double* lowtab, double s0 = 1.0, bool acc = false);
   void store(int a, int arr, int n, double s0 = 1.0, int deinterleave_half = 0);
+  // the last op (a plain OP_STORE) raises *flag when it stores a NaN: the device-side form of
+  // Integrate::exit (navier.rs:482-489) -- no extra pass over the fields, no allocation
+  void guard_last_store(int* flag);
   void sten(int d, int a, int n_ortho, const double* low);
   void mv3(int d, int a, int n, const double* t0, const double* t1, const double* t2, long tabld = 0);
   void cdiff(int d, int a, int n, double scale);

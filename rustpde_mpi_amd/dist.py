@@ -99,17 +99,19 @@ class RcclComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
-        self._uid = None
 
     def unique_id(self, library) -> bytes:
-        if self._uid is None:
-            box = [None]
-            if self.rank == 0:
-                buf = C.create_string_buffer(128)
-                library.call("rpde_rccl_unique_id", buf)
-                box[0] = buf.raw
-            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
-                                       group=self.group)
-            self._uid = bytes(box[0])
-            assert len(self._uid) == 128
-        return self._uid
+        """A FRESH ncclUniqueId per call (collective): an id is valid for exactly one
+        ncclCommInitRank, so every engine built on this object gets its own (two engines from one
+        RcclComm -- e.g. a confined and a periodic one, or a rebuild after a failure -- must not
+        share one)."""
+        box = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            library.call("rpde_rccl_unique_id", buf)
+            box[0] = buf.raw
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group else 0,
+                                   group=self.group)
+        uid = bytes(box[0])
+        assert len(uid) == 128
+        return uid

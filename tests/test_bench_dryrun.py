@@ -1,0 +1,28 @@
+"""bench.py harness self-test on CPU: the same script, `--dry-run-emu` (host emulation build of the
+kernel sources), tiny grid.  Checks the JSON contract of the one line it prints -- not a number."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract(emu_lib):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-emu", "--nx", "33", "--ny", "33",
+                          "--ra", "1e5", "--dt", "0.01", "--steps", "3", "--warmup", "1", "--profile-steps", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] is True and "NOT a measurement" in d["data"]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity",
+                "ms_per_step_update_plus_exit", "transform_pass"):
+        assert key in d, key
+    assert d["dtype"] == "f64" and d["n_gpus"] == 1 and d["steps"] == 3 and "workload" in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["parity"]["ok"] and d["parity"]["steps"] == 3 and max(d["parity"]["rel_l2"].values()) < 1e-10

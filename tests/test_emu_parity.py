@@ -107,3 +107,31 @@ def test_random_initial_condition_parity(emu_lib):
     got, want = nav.physical_fields(), ora.physical_fields()
     for k in want:
         assert K.rel(got[k], want[k]) < 1e-10, k
+
+
+@pytest.mark.parametrize("periodic,nx,ny,pr", [(False, 33, 17, 0.7), (True, 32, 17, 7.0)])
+def test_prandtl_number_not_one(emu_lib, periodic, nx, ny, pr):
+    """nu != ka: a swap of the two diffusivities cannot hide (every other case runs Pr = 1)."""
+    K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 6, pr=pr, check_at=[1, 6])
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_exit_flag(emu_lib, periodic):
+    """Integrate::exit through the flag raised by the guarded stores of the step."""
+    ctor = R.Navier2D.new_periodic if periodic else R.Navier2D.new_confined
+    nav = ctor(32 if periodic else 33, 17, 1e5, 1.0, 0.01, 1.0, "rbc", library=emu_lib)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    assert nav.exit() is False
+    nav.update(3)
+    assert nav.exit() is False
+    t = nav.temp.v
+    t[5, 5] = np.nan
+    nav.temp.v = t
+    nav.update(1)
+    assert nav.exit() is True and np.isnan(nav.div_norm())
+
+
+def test_full_eigenbasis_solver(emu_lib):
+    """Engine (parity-block eigenbasis) vs the oracle with the reference's single full dgeev."""
+    K.check_solvers(emu_lib, "cheb_neumann", 33, "cheb_neumann", 17, [1.0, 1.0], eig_mode="full", poisson_tol=1e-6)

@@ -127,3 +127,73 @@ def test_config2_golden_1025_200_steps(hip_lib):
             # the full-field norm pins the points between the samples as well
             assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < tol * float(g[f"{k}_{s}_norm"]), (k, s)
     assert abs(nav.div_norm() - float(g["div_norm"])) < 1e-8 * max(1.0, float(g["div_norm"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# Parity at the sizes bench.py runs: the 512-thread line configuration
+# (4096-point FFT, 2048/2047-wide parity GEMMs, 4095 pre-factorised Poisson rows) against the oracle.
+
+def test_headline_config_4097_step_parity(hip_lib):
+    """Confined 4097 x 4097, Ra = 1e8, dt = 2e-4 (the bench.py workload, BASELINE.json configs[3] on
+    one GPU): u, v, T, p after 1 and 2 steps vs the oracle, 1e-10 relative L2.  The oracle needs
+    about a minute for its eigen-decomposition and 12 s per step."""
+    K.check_step_parity(hip_lib, False, 4097, 4097, 1e8, 2e-4, 2, check_at=[1, 2])
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1,c", [
+    ("cheb_neumann", 4097, "cheb_neumann", 65, [1.0, 1.0]),       # 2048 / 2047 parity GEMMs, 512-thread x-lines
+    ("cheb_dirichlet", 4097, "cheb_dirichlet", 65, [2e-8, 2e-8]), # Helmholtz constants of the bench workload
+    ("cheb_neumann", 2049, "cheb_neumann", 2049, [1.0, 1.0])])
+def test_solvers_at_bench_sizes(hip_lib, k0, n0, k1, n1, c):
+    K.check_solvers(hip_lib, k0, n0, k1, n1, c)
+
+
+def test_space_ops_4097_square(hip_lib):
+    """forward / backward / to_ortho / from_ortho / gradient on the full 4097 x 4097 array."""
+    K.check_space_ops(hip_lib, "cheb_dirichlet", 4097, "cheb_neumann", 4097)
+
+
+def test_periodic_config3_ten_steps(hip_lib):
+    """BASELINE.json configs[2] (periodic 4096 x 1025, Ra = 1e8): the first 10 steps."""
+    K.check_step_parity(hip_lib, True, 4096, 1025, 1e8, 5e-4, 10, check_at=[1, 5, 10])
+
+
+def test_periodic_config5_full_size_one_step(hip_lib):
+    """BASELINE.json configs[4] at FULL size (periodic 16384 x 2049, aspect 8) on one GPU: one step
+    vs the oracle (no eigen-decomposition on the Fourier path, so the oracle is affordable)."""
+    K.check_step_parity(hip_lib, True, 16384, 2049, 1e9, 1e-4, 1, aspect=8.0, check_at=[1])
+
+
+def test_full_eigenbasis_after_transient_257(hip_lib):
+    """The reference diagonalises the whole x operator with ONE dgeev (src/solver/utils.rs:67-99);
+    the engine (and the oracle in every other test) uses one dgeev per parity block.  Both are
+    eigenbases of the same matrix; with the -1e-10 shift of Poisson::new (poisson.rs:84-87) the first
+    steps of the incompatible initial condition amplify their round-off differences (1e-9 in p at
+    step 1), which then decay.  After the transient the engine must match the FULL-basis oracle."""
+    w = K.check_step_parity(hip_lib, False, 257, 257, 1e6, 0.005, 60, check_at=[60], eig_mode="full")
+    assert max(w.values()) < 1e-10
+    K.check_solvers(hip_lib, "cheb_neumann", 257, "cheb_neumann", 129, [1.0, 1.0], eig_mode="full", poisson_tol=1e-6)
+
+
+@pytest.mark.parametrize("periodic,nx,ny,pr", [(False, 65, 65, 0.7), (False, 129, 65, 7.0), (True, 64, 65, 0.7), (True, 128, 33, 7.0)])
+def test_prandtl_number_not_one(hip_lib, periodic, nx, ny, pr):
+    """nu != ka: a swap of the two diffusivities (velocity vs temperature Helmholtz solves, the
+    dt*ka factor of the lift's Laplacian, -nu*div in the pressure update, diagnostics) cannot hide."""
+    K.check_step_parity(hip_lib, periodic, nx, ny, 1e5, 0.01, 10, pr=pr, check_at=[1, 10])
+
+
+def test_exit_flag_device_side(hip_lib):
+    """Integrate::exit (navier.rs:482-489): the device flag agrees with the reference's NaN test of
+    the divergence norm -- clean run: False; NaN injected: True from the next step on."""
+    nav = R.Navier2D.new_confined(129, 129, 1e5, 1.0, 0.01, 1.0, "rbc", library=hip_lib)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    assert nav.exit() is False            # host-written fields: evaluated through the divergence
+    nav.update(5)
+    assert nav.exit() is False and np.isfinite(nav.div_norm())
+    t = nav.temp.v
+    t[64, 64] = np.nan
+    nav.temp.v = t
+    nav.update(1)
+    assert nav.exit() is True
+    assert np.isnan(nav.div_norm())

@@ -149,3 +149,59 @@ def test_native_rccl_transport_single_rank(tmp_path, hip_lib):
     out = str(tmp_path / "rccl_native.txt")
     mp.spawn(_native_rccl_single, args=(out,), nprocs=1, join=True)
     assert open(out).read() == "ok"
+
+
+def _native_rccl_two_ranks(rank, port, out):
+    """One process per GPU; two engines from ONE RcclComm (each takes a fresh ncclUniqueId)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+    import rustpde_mpi_amd as R
+    from rustpde_mpi_amd.dist import RcclComm
+    comm = RcclComm()
+    errs = {}
+    for periodic, nx, ny in ((False, 129, 65), (True, 128, 65)):
+        ctor = R.Navier2D.new_periodic if periodic else R.Navier2D.new_confined
+        nav = ctor(nx, ny, 1e5, 1.0, 0.01, 1.0, "rbc", device=rank, comm=comm)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(5)
+        bad = nav.exit()
+        got = nav.physical_fields()
+        if rank == 0:
+            one = ctor(nx, ny, 1e5, 1.0, 0.01, 1.0, "rbc", device=0)
+            one.set_velocity(0.2, 1.0, 1.0)
+            one.set_temperature(0.2, 1.0, 1.0)
+            one.update(5)
+            want = one.physical_fields()
+            for k in want:
+                errs[f"{'p' if periodic else 'c'}:{k}"] = float(np.linalg.norm(got[k] - want[k]) / np.linalg.norm(want[k]))
+            errs[f"{'p' if periodic else 'c'}:exit"] = float(bad)
+        del nav
+    if rank == 0:
+        with open(out, "w") as f:
+            json.dump(errs, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_rccl_two_ranks_two_gpus(tmp_path, hip_lib):
+    """The native RCCL transport (grouped ncclSend/ncclRecv over xGMI on the engine's stream) with a
+    REAL second rank: needs two GPUs, skips on a one-GPU box.  Also builds two engines from one
+    RcclComm object (an ncclUniqueId serves exactly one ncclCommInitRank)."""
+    import ctypes as C
+    n = C.c_int()
+    hip_lib.call("rpde_device_count", C.byref(n))
+    if n.value < 2:
+        pytest.skip(f"needs 2 GPUs for two RCCL ranks, this box has {n.value}")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl2.json")
+    mp.spawn(_native_rccl_two_ranks, args=(_free_port(), out), nprocs=2, join=True)
+    errs = json.load(open(out))
+    for k, e in errs.items():
+        assert e < (1e-11 if not k.endswith("exit") else 0.5), (k, e)
