@@ -137,6 +137,14 @@ int rpde_hholtz_adi_destroy(rpde_hholtz_adi* hs);
 int rpde_poisson_create(rpde_space2* s, double c0, double c1, rpde_poisson** out);
 int rpde_poisson_solve(rpde_poisson* ps, const double* in_ortho, size_t nin, double* out, size_t nout);
 int rpde_poisson_destroy(rpde_poisson* ps);
+/* The x eigen-decomposition Poisson::new builds once (FdmaTensor::from_matrix,                     *
+ * src/solver/fdma_tensor.rs:123-127; LAPACK dgeev/dgetri, src/solver/utils.rs:67-107): m = nx - 2    *
+ * eigenvalues `lam` (before the -1e-10 shift of poisson.rs:84-87), fwd = Q^-1 C^-1 and bwd = Q as     *
+ * dense m x m row-major matrices.  Setup data; read by checkers that must run the reference's       *
+ * algorithm on the SAME decomposition (the solve amplifies dgeev's own round-off).       *
+ * Chebyshev x axis only (a Fourier axis is already diagonal).                                       */
+int rpde_poisson_eigenbasis(rpde_poisson* ps, double* lam, double* fwd, double* bwd, size_t m);
+int rpde_navier2d_poisson_eigenbasis(rpde_navier2d* h, double* lam, double* fwd, double* bwd, size_t m);
 
 /* pencil transposes (single device: LDS-tiled kernel).  out[c][r] = in[r][c]; elem = 1 | 2        *
  * funspace Decomp2d::transpose_x_to_y / transpose_y_to_x     src/field_mpi.rs:456-477             */

@@ -257,6 +257,14 @@ class Navier2D:
     def physical_fields(self):
         return {k: getattr(self, k).v for k in ("velx", "vely", "temp", "pres")}
 
+    def poisson_eigenbasis(self):
+        """(lam, fwd, bwd) of the pressure solver's x eigen-decomposition as the reference's
+        FdmaTensor holds it (fdma_tensor.rs:123-127); confined engines only."""
+        m = self.nx - 2
+        lam, fwd, bwd = np.empty(m), np.empty((m, m)), np.empty((m, m))
+        self._lib.call("rpde_navier2d_poisson_eigenbasis", self._h, ptr(lam), ptr(fwd), ptr(bwd), m)
+        return lam, fwd, bwd
+
     def integrate(self, max_time, exit_check_every=1):
         n = C.c_long()
         self._lib.call("rpde_navier2d_integrate", self._h, float(max_time), int(exit_check_every),
@@ -364,6 +372,13 @@ class HholtzAdi(_Solver):
 class Poisson(_Solver):
     """`Poisson::new(&field, [c0, c1])` + `solve` (src/solver/poisson.rs:54-94,195-236)."""
     _create, _solve, _destroy = "rpde_poisson_create", "rpde_poisson_solve", "rpde_poisson_destroy"
+
+    def eigenbasis(self):
+        """(lam, fwd, bwd) of the x eigen-decomposition (fdma_tensor.rs:123-127)."""
+        m = self._space.shape("spectral")[0]
+        lam, fwd, bwd = np.empty(m), np.empty((m, m)), np.empty((m, m))
+        self._lib.call("rpde_poisson_eigenbasis", self._h, ptr(lam), ptr(fwd), ptr(bwd), m)
+        return lam, fwd, bwd
 
 
 def transpose(a, device=0, library=None):

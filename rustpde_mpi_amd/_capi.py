@@ -72,6 +72,8 @@ SIGNATURES = {
     "rpde_poisson_create": (C.c_int, [_vp, C.c_double, C.c_double, C.POINTER(_vp)]),
     "rpde_poisson_solve": (C.c_int, [_vp, _dp, C.c_size_t, _dp, C.c_size_t]),
     "rpde_poisson_destroy": (C.c_int, [_vp]),
+    "rpde_poisson_eigenbasis": (C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
+    "rpde_navier2d_poisson_eigenbasis": (C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
     "rpde_transpose": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, _dp, C.c_int]),
     "rpde_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]),
     "rpde_microbench": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),

@@ -431,6 +431,21 @@ int rpde_poisson_solve(rpde_poisson* ps, const double* in, size_t nin, double* o
     ps->op->solve(a, b, ps->s->st); dev_sync(ps->s->st); download(b, out);
   })
 }
+int rpde_poisson_eigenbasis(rpde_poisson* ps, double* lam, double* fwd, double* bwd, size_t m) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(ps); select_device(ps->s->device);
+    RPDE_REQUIRE(lam && fwd && bwd && (int)m == ps->op->me + ps->op->mo, "eigenbasis: m must be the x spectral size");
+    ps->op->export_eigenbasis(lam, fwd, bwd);
+  })
+}
+int rpde_navier2d_poisson_eigenbasis(rpde_navier2d* h, double* lam, double* fwd, double* bwd, size_t m) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); select_device(h->device);
+    const PoissonOp& po = h->e->poisson();
+    RPDE_REQUIRE(lam && fwd && bwd && (int)m == po.me + po.mo, "eigenbasis: m must be the x spectral size (nx - 2)");
+    po.export_eigenbasis(lam, fwd, bwd);
+  })
+}
 int rpde_poisson_destroy(rpde_poisson* ps) {
   RPDE_TRY({ if (ps) { delete ps->op; delete ps; } })
 }
@@ -469,6 +484,40 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
     select_device(device);
     const std::string w = what;
     Stream st;
+#ifndef RPDE_EMU
+    // non-line kernels: "gemm_nt" / "gemm_nn" (n x n x n, the Poisson GEMM shapes), "transpose"
+    // (n x nlines), "mfma_peak" (register-only MFMA loop; returns ms, flops = blocks*4*iters*8*2048)
+    if (w == "gemm_nt" || w == "gemm_nn" || w == "transpose" || w == "mfma_peak") {
+      const long ld = pitch(n), ld2 = pitch(nlines);
+      DBuf A((size_t)std::max(n, nlines) * std::max(ld, ld2)), B((size_t)std::max(n, nlines) * std::max(ld, ld2)),
+          Cc((size_t)std::max(n, nlines) * std::max(ld, ld2));
+      {
+        Vec hbuf(A.n);
+        for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
+        dev_upload(A.p, hbuf.data(), hbuf.size() * sizeof(double));
+        dev_upload(B.p, hbuf.data(), hbuf.size() * sizeof(double));
+      }
+      auto once = [&]() {
+        if (w == "gemm_nt") launch_gemm_nt(n, nlines, n, A.p, ld, B.p, ld, Cc.p, ld2, st);
+        else if (w == "gemm_nn") launch_gemm_nn(n, nlines, n, A.p, ld, B.p, ld2, Cc.p, ld2, st);
+        else if (w == "transpose") launch_transpose(A.p, ld, Cc.p, ld2, nlines, n, 1, st);
+        else launch_mfma_peak(Cc.p, n, nlines, st);   // n = workgroups, nlines = iterations
+      };
+      once();
+      dev_sync(st);
+      hipEvent_t e0, e1;
+      RPDE_HIP(hipEventCreate(&e0)); RPDE_HIP(hipEventCreate(&e1));
+      RPDE_HIP(hipEventRecord(e0, st.s));
+      for (int r = 0; r < reps; ++r) once();
+      RPDE_HIP(hipEventRecord(e1, st.s));
+      RPDE_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      RPDE_HIP(hipEventElapsedTime(&t, e0, e1));
+      *ms = t / reps;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      return 0;
+    }
+#endif
     const bool fourier = w == "rfft";
     AxisTables ax(make_base(fourier ? kFourierR2c : kChebDirichlet, n));
     const Base& b = ax.base;

@@ -64,6 +64,7 @@ class Navier2DEngine {
   double time() const { return time_; }
   double dt() const { return dt_; }
   double param(const std::string& key) const;
+  const PoissonOp& poisson() const { return *pois_; }
   double last_update_ms() const { return last_ms_; }
   // per-launch profile: run `nsteps` with HIP events around every launch; returns a text table
   // "tag<TAB>launches<TAB>ms_total<TAB>algorithmic_bytes_per_launch<TAB>flops_per_launch" per line

@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ in
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
                       int elem, Stream& st) {
   if (rows <= 0 || cols <= 0) return;
-  if (elem == 1) {
+  static const int tile = [] { const char* e = std::getenv("RPDE_TP_TILE"); return e ? std::atoi(e) : 64; }();
+  if (elem == 1 && tile == 32) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL((transpose_kernel<double, 32>), grid, dim3(256), 0, st.s, in, ldi, out, ldo,
+                       rows, cols);
+  } else if (elem == 1) {
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     hipLaunchKernelGGL((transpose_kernel<double, 64>), grid, dim3(256), 0, st.s, in, ldi, out, ldo,
                        rows, cols);
@@ -141,6 +146,7 @@ void launch_transpose(const double* in, long ldi, double* out, long ldo, int row
 // each wave 4 x 4 tiles of v_mfma_f64_16x16x4_f64.  LDS layout [k/4][row][k%4] makes every
 // fragment read one contiguous 512-byte ds_read_b64 per wave (conflict free).
 typedef double dbl4 __attribute__((ext_vector_type(4)));
+typedef double dbl2v __attribute__((ext_vector_type(2)));
 
 template <bool NN>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
@@ -163,8 +169,39 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
   double ra[8], rb[8];
   const int arow = tid >> 1, akk = (tid & 1) * 8;        // A (and B when !NN): row, first k
   const int bn = tid & 127, bkp = tid >> 7;               // B when NN: column n, k pair (k = 4e + 2 bkp + {0,1})
+  // interior tiles (every row / column of the 128 x 128 block and all 16 k exist) load without
+  // bounds checks and with 16-byte accesses; `vec16` = the operands allow aligned 16-byte loads
+  const bool tile_full = (m0 + 128 <= M) && (n0 + 128 <= N);
+  const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
 
   auto gload = [&](int k0) {
+    if (tile_full && k0 + 16 <= K) {
+      if (vec16) {
+        const dbl2v* p = reinterpret_cast<const dbl2v*>(A + (long)(m0 + arow) * lda + k0 + akk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
+      } else {
+        const double* p = A + (long)(m0 + arow) * lda + k0 + akk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e] = p[e];
+      }
+      if constexpr (!NN) {
+        if (vec16) {
+          const dbl2v* p = reinterpret_cast<const dbl2v*>(B + (long)(n0 + arow) * ldb + k0 + akk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const dbl2v v = p[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
+        } else {
+          const double* p = B + (long)(n0 + arow) * ldb + k0 + akk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rb[e] = p[e];
+        }
+      } else {
+        const double* p = B + (long)(k0 + 2 * bkp) * ldb + n0 + bn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rb[2 * e] = p[(long)(4 * e) * ldb]; rb[2 * e + 1] = p[(long)(4 * e + 1) * ldb]; }
+      }
+      return;
+    }
     {
       const int r = m0 + arow;
       const double* p = A + (long)r * lda + k0 + akk;
@@ -189,17 +226,24 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
     }
   };
   auto lstore = [&]() {
+    // 16-byte LDS stores: the 8 k-values of a thread are two runs of four (k % 4 = 0..3) of one row
 #pragma unroll
-    for (int e = 0; e < 8; ++e) As[(akk + e) >> 2][arow][(akk + e) & 3] = ra[e];
+    for (int h = 0; h < 2; ++h) {
+      dbl2v* d = reinterpret_cast<dbl2v*>(&As[(akk >> 2) + h][arow][0]);
+      d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
+      d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
+    }
     if constexpr (!NN) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Bs[(akk + e) >> 2][arow][(akk + e) & 3] = rb[e];
+      for (int h = 0; h < 2; ++h) {
+        dbl2v* d = reinterpret_cast<dbl2v*>(&Bs[(akk >> 2) + h][arow][0]);
+        d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
+        d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
+      }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Bs[e][bn][2 * bkp] = rb[2 * e];
-        Bs[e][bn][2 * bkp + 1] = rb[2 * e + 1];
-      }
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<dbl2v*>(&Bs[e][bn][2 * bkp]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
     }
   };
 
@@ -251,6 +295,28 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
   dim3 grid((N + 127) / 128, (M + 127) / 128);
   hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C,
                      ldc);
+  RPDE_HIP(hipGetLastError());
+}
+
+// sustained f64 MFMA rate of the chip (no memory traffic): 4 waves per workgroup, 8 independent
+// accumulator chains per wave, `iters` x 8 v_mfma_f64_16x16x4_f64 per wave.  The achievable peak a
+// GEMM can be priced against once the clock has settled under the matrix load.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  dbl4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = dbl4{0.0, 0.0, 0.0, 0.0};
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;   // keep the chains alive
+}
+void launch_mfma_peak(double* out, int blocks, int iters, Stream& st) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st.s, out, iters);
   RPDE_HIP(hipGetLastError());
 }
 
@@ -432,6 +498,7 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
     for (int cc = 0; cc < cols; ++cc) out[(long)r * ldo + cc] = in[(long)r * ldi + cc];
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
+void launch_mfma_peak(double*, int, int, Stream&) {}
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream&) {
   double s = 0.0, nn = 0.0;
   for (int r = 0; r < rows; ++r)

@@ -56,6 +56,9 @@ struct XchgDesc {
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream& st);
 void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 
+// measurement only: `blocks` workgroups x 4 waves x `iters` x 8 independent v_mfma_f64_16x16x4_f64 chains
+void launch_mfma_peak(double* out, int blocks, int iters, Stream& st);
+
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
 

@@ -438,6 +438,7 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
     for (int k = 0; k < m0; ++k) lam[k] = -((double)k * (double)k) * c0;
   }
   half = (me + 1) & ~1;
+  lam_raw = lam;
   // singularity fix (src/solver/poisson.rs:84-87): lam[0] of the descending list is the largest
   const double lmax = *std::max_element(lam.begin(), lam.end());
   if (std::fabs(lmax) < 1e-10)
@@ -463,6 +464,27 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
   rows.n = m1;
   rows.tabld = ld;
   rows.q1.upload(q1); rows.p2.upload(p2); rows.q2.upload(q2); rows.r2.upload(r2);
+}
+
+void PoissonOp::export_eigenbasis(double* lam_out, double* fwd_out, double* bwd_out) const {
+  RPDE_REQUIRE(sp.base(0).is_cheb(), "the Fourier x axis is diagonal: no eigenbasis");
+  const int m = me + mo;
+  std::copy(lam_raw.begin(), lam_raw.end(), lam_out);
+  std::fill(fwd_out, fwd_out + (size_t)m * m, 0.0);
+  std::fill(bwd_out, bwd_out + (size_t)m * m, 0.0);
+  for (int par = 0; par < 2; ++par) {
+    const int mb = par ? mo : me, off = par ? me : 0;
+    const Arr2& f = par ? fwd_o : fwd_e;
+    const Arr2& b = par ? bwd_o : bwd_e;
+    Vec hf((size_t)mb * mb), hb((size_t)mb * mb);
+    dev_download2d(hf.data(), f.p(), f.ld, mb, mb);
+    dev_download2d(hb.data(), b.p(), b.ld, mb, mb);
+    for (int k = 0; k < mb; ++k)
+      for (int i = 0; i < mb; ++i) {
+        fwd_out[(size_t)(off + k) * m + (par + 2 * i)] = hf[(size_t)k * mb + i];   // fwd[eigen k, coefficient]
+        bwd_out[(size_t)(par + 2 * i) * m + (off + k)] = hb[(size_t)i * mb + k];   // bwd[coefficient, eigen k]
+      }
+  }
 }
 
 void PoissonOp::solve(const Arr2& in, Arr2& out, Stream& st) {

@@ -172,6 +172,13 @@ class PoissonOp {
   // x direction
   int me = 0, mo = 0, half = 0;  // parity block sizes; column offset of the odd block in split arrays
   Vec lam;                       // eigenvalues (after the singularity shift), engine order
+  Vec lam_raw;                   // the same before the shift (what LAPACK returned)
+  // the x eigen-decomposition in the reference's form (fdma_tensor.rs:123-127): m eigenvalues
+  // (unshifted, order [even block | odd block]), fwd = Q^-1 C^-1 and bwd = Q as dense m x m row-major
+  // matrices over the natural coefficient index.  Setup data, exported so that a checker can run
+  // the same algorithm on the same decomposition (the Poisson solve amplifies the round-off of
+  // dgeev itself).  Confined (Chebyshev x) only.
+  void export_eigenbasis(double* lam_out, double* fwd_out, double* bwd_out) const;
   Arr2 fwd_e, fwd_o, bwd_e, bwd_o;
   // y direction: per-x-row swept tables, row index = eigen index (confined) or wavenumber (periodic)
   FdmaDev rows;

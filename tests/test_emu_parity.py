@@ -135,3 +135,18 @@ def test_exit_flag(emu_lib, periodic):
 def test_full_eigenbasis_solver(emu_lib):
     """Engine (parity-block eigenbasis) vs the oracle with the reference's single full dgeev."""
     K.check_solvers(emu_lib, "cheb_neumann", 33, "cheb_neumann", 17, [1.0, 1.0], eig_mode="full", poisson_tol=1e-6)
+
+
+@pytest.mark.parametrize("k0,n0,k1,n1", [("cheb_dirichlet", 4097, "cheb_dirichlet", 9), ("cheb_neumann", 9, "cheb_dirichlet", 2049),
+                                         ("cheb_dirichlet", 1025, "cheb_neumann", 17)])
+def test_hholtz_long_lines(emu_lib, k0, n0, k1, n1):
+    """The wave-serial scans of the Helmholtz Fdma solve at the line lengths of the BASELINE configs
+    (chunk lengths 33, 17, 9 per lane)."""
+    sp, osp = K.spaces(emu_lib, k0, n0, k1, n1)
+    rhs = np.random.default_rng(2).standard_normal(osp.shape_ortho)
+    for c in ([2e-8, 2e-8], [1e-3, 5e-4]):
+        assert K.rel(R.HholtzAdi(sp, c).solve(rhs), K.S.HholtzAdi(osp, c).solve(rhs)) < 1e-11
+
+
+def test_poisson_513(emu_lib):
+    K.check_solvers(emu_lib, "cheb_neumann", 513, "cheb_neumann", 9, [1.0, 1.0])
