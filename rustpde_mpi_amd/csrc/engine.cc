@@ -107,6 +107,12 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   red_.alloc(2);
   nanflag_.alloc(2);
+  if (P == 1) {   // block carries of the column scans
+    const size_t nb = (size_t)((ny + kColBlockRows - 1) / kColBlockRows);
+    colv1_.alloc(3 * nb * 2 * ldx_); cols1_.alloc(3 * nb * 2 * ldx_);
+    colv2_.alloc(3 * nb * 4 * ldx_); cols2_.alloc(3 * nb * 4 * ldx_);
+    coldv_.alloc(nb * 2 * ldx_); colds_.alloc(nb * 2 * ldx_);
+  }
   {  // dealias (functions.rs:72-82) folded into the post-scaling of the forward DCT
     Vec py = cheb_fwd_post(ny);
     for (int k = ny * 2 / 3; k < ny; ++k) py[k] = 0.0;
@@ -492,6 +498,35 @@ void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, lon
   l.bytes = 8.0 * ((double)M * K + (double)N * K + (double)M * N);
   step_.push_back(l);
 }
+void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols,
+                                    const char* tag) {
+  Launch l;
+  l.type = Launch::kColHholtz;
+  l.tag = tag;
+  ColHhArgs& a = l.ch;
+  const ColHhDev& cv = hh_vel_->col_y;
+  a.n = my_; a.nin = my_; a.ncols = ncols; a.BR = cv.BR; a.NB = cv.NB; a.ld = ldx_; a.nf = 3;
+  for (int f = 0; f < 3; ++f) {
+    a.in[f] = in[f]; a.z[f] = z[f]; a.out[f] = out[f];
+    a.tab[f] = (f == 2 ? hh_temp_->col_y : hh_vel_->col_y).tabs();
+  }
+  a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p;
+  a.nanflag = flagp();
+  l.bytes = 3.0 * 6.0 * 8.0 * (double)my_ * ncols;   // three passes, each reads and writes the three arrays once
+  step_.push_back(l);
+}
+void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale,
+                                  const char* tag) {
+  Launch l;
+  l.type = Launch::kColDiff;
+  l.tag = tag;
+  ColDiffArgs& a = l.cd;
+  a.nout = ny_; a.m = m_in; a.ncols = ncols; a.BR = kColBlockRows; a.NB = (ny_ + kColBlockRows - 1) / kColBlockRows;
+  a.ldi = ldx_; a.ldo = ldx_; a.in = in; a.out = out; a.low = low; a.scale = scale;
+  a.vd = coldv_.p; a.sd = colds_.p;
+  l.bytes = 8.0 * ncols * (2.0 * m_in + ny_);          // the input twice (block sums, final pass), the output once
+  step_.push_back(l);
+}
 size_t Navier2DEngine::run_from(size_t i) {
   const Launch& l = step_[i];
   if (l.type != Launch::kTranspose || comm_.size == 1) { run_launch(l); return i + 1; }
@@ -516,6 +551,8 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
+    case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
+    case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
   }
 }
 
@@ -897,31 +934,41 @@ void Navier2DEngine::build_confined() {
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  // ---- T3
-  for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, my, mx, true, "T3");
-  // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
-  for (int which = 0; which < 3; ++which) {
-    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[which].p, ldy), my);                 // entries my, my+1 only meet zero table entries
-    pb.pinv_matvec(0, yD);
-    pb.fdma_solve(0, my, hh.fdma[1]);
-    pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
-    pb.guard_last_store(flagp());
-    if (which == 1) {
-      pb.zero(0, my, sly);
-      pb.to_ortho(0, yD);
-      pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.store(0, pb.arr(X_[6].p, ldy), ny);
+  if (P == 1) {
+    // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays: no T3, no T4
+    const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
+    double* cz[3] = {yx(Y_[0]), yx(Y_[1]), yx(Y_[2])};
+    double* cout[3] = {yx(U_), yx(V_), yx(T_)};
+    add_col_hholtz(cin, cz, cout, mx, "C4 y: hholtz-y (column scan)");
+    // d/dy vely for the divergence (rows ny, composite x)
+    add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, mx, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
+  } else {
+    // ---- T3
+    for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, my, mx, true, "T3");
+    // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
+    for (int which = 0; which < 3; ++which) {
+      HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+      ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(X_[which].p, ldy), my);                 // entries my, my+1 only meet zero table entries
+      pb.pinv_matvec(0, yD);
+      pb.fdma_solve(0, my, hh.fdma[1]);
+      pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
+      pb.guard_last_store(flagp());
+      if (which == 1) {
+        pb.zero(0, my, sly);
+        pb.to_ortho(0, yD);
+        pb.cdiff(0, 0, ny, 1.0 / sy_);
+        pb.store(0, pb.arr(X_[6].p, ldy), ny);
+      }
+      add_line(pb, "S4 y: hholtz-y");
     }
-    add_line(pb, "S4 y: hholtz-y");
+    // ---- T4: new (uncorrected) state back to YX
+    T(X_[3].p, yx(U_), mx, my, false, "T4");
+    T(X_[4].p, yx(V_), mx, my, false, "T4");
+    T(X_[5].p, yx(T_), mx, my, false, "T4");
+    T(X_[6].p, yx(Y_[0]), mx, ny, false, "T4");
   }
-  // ---- T4: new (uncorrected) state back to YX
-  T(X_[3].p, yx(U_), mx, my, false, "T4");
-  T(X_[4].p, yx(V_), mx, my, false, "T4");
-  T(X_[5].p, yx(T_), mx, my, false, "T4");
-  T(X_[6].p, yx(Y_[0]), mx, ny, false, "T4");
   add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
   PoissonOp& po = *pois_;
@@ -1036,17 +1083,21 @@ void Navier2DEngine::build_confined() {
     pb.guard_last_store(flagp());
     add_line(pb, "S9 x: pressure update");
   }
-  // ---- T6 / S10 / T7: d/dy pres for the next step
-  T(yx(P_), X_[0].p, ny, nx, true, "T6");
-  {
-    ProgramBuilder pb = xpb(1, nx);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[0].p, ldy), ny);
-    pb.cdiff(0, 0, ny, 1.0 / sy_);
-    pb.store(0, pb.arr(X_[1].p, ldy), ny);
-    add_line(pb, "S10 y: d/dy pres");
+  // ---- d/dy pres for the next step
+  if (P == 1) {
+    add_col_diff(yx(P_), yx(GY_), ny, nullptr, nx, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
+  } else {
+    T(yx(P_), X_[0].p, ny, nx, true, "T6");
+    {
+      ProgramBuilder pb = xpb(1, nx);
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(X_[0].p, ldy), ny);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.store(0, pb.arr(X_[1].p, ldy), ny);
+      add_line(pb, "S10 y: d/dy pres");
+    }
+    T(X_[1].p, yx(GY_), nx, ny, false, "T7");
   }
-  T(X_[1].p, yx(GY_), nx, ny, false, "T7");
 }
 
 // ==========================================================================================
@@ -1164,28 +1215,39 @@ void Navier2DEngine::build_periodic() {
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, my, kx, true, "T3");
-  // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
-  for (int which = 0; which < 3; ++which) {
-    HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-    ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), my);
-    pb.pinv_matvec(0, yD);
-    pb.fdma_solve(0, my, hh.fdma[1]);
-    pb.store(0, pb.arr(X_[3 + which].p, ldy, 2, 1), my);
-    if (which == 1) {
-      pb.zero(0, my, sly);
-      pb.to_ortho(0, yD);
-      pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.store(0, pb.arr(X_[6].p, ldy, 2, 1), ny);
+  const int P = comm_.size;
+  if (P == 1) {
+    // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays (real-linear: the
+    // interleaved re / im columns are independent columns)
+    const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
+    double* cz[3] = {yx(Y_[0]), yx(Y_[1]), yx(Y_[2])};
+    double* cout[3] = {yx(U_), yx(V_), yx(T_)};
+    add_col_hholtz(cin, cz, cout, nc, "C4 y: hholtz-y (column scan)");
+    add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
+  } else {
+    for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, my, kx, true, "T3");
+    // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
+    for (int which = 0; which < 3; ++which) {
+      HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+      ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), my);
+      pb.pinv_matvec(0, yD);
+      pb.fdma_solve(0, my, hh.fdma[1]);
+      pb.store(0, pb.arr(X_[3 + which].p, ldy, 2, 1), my);
+      if (which == 1) {
+        pb.zero(0, my, sly);
+        pb.to_ortho(0, yD);
+        pb.cdiff(0, 0, ny, 1.0 / sy_);
+        pb.store(0, pb.arr(X_[6].p, ldy, 2, 1), ny);
+      }
+      add_line(pb, "S4 y: hholtz-y");
     }
-    add_line(pb, "S4 y: hholtz-y");
+    Tc(X_[3].p, yx(U_), kx, my, false, "T4");
+    Tc(X_[4].p, yx(V_), kx, my, false, "T4");
+    Tc(X_[5].p, yx(T_), kx, my, false, "T4");
+    Tc(X_[6].p, yx(Y_[0]), kx, ny, false, "T4");
   }
-  Tc(X_[3].p, yx(U_), kx, my, false, "T4");
-  Tc(X_[4].p, yx(V_), kx, my, false, "T4");
-  Tc(X_[5].p, yx(T_), kx, my, false, "T4");
-  Tc(X_[6].p, yx(Y_[0]), kx, ny, false, "T4");
   add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence
   {
@@ -1257,16 +1319,20 @@ void Navier2DEngine::build_periodic() {
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step
-  Tc(yx(P_), X_[0].p, ny, kx, true, "T6");
-  {
-    ProgramBuilder pb = xpb(1, kx, true);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
-    pb.cdiff(0, 0, ny, 1.0 / sy_);
-    pb.store(0, pb.arr(X_[1].p, ldy, 2, 1), ny);
-    add_line(pb, "S10 y: d/dy pres");
+  if (P == 1) {
+    add_col_diff(yx(P_), yx(GY_), ny, nullptr, nc, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
+  } else {
+    Tc(yx(P_), X_[0].p, ny, kx, true, "T6");
+    {
+      ProgramBuilder pb = xpb(1, kx, true);
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.store(0, pb.arr(X_[1].p, ldy, 2, 1), ny);
+      add_line(pb, "S10 y: d/dy pres");
+    }
+    Tc(X_[1].p, yx(GY_), kx, ny, false, "T7");
   }
-  Tc(X_[1].p, yx(GY_), kx, ny, false, "T7");
 }
 
 }  // namespace rpde

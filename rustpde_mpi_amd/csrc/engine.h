@@ -154,11 +154,14 @@ class Navier2DEngine {
   bool read_nanflag();
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
   DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
+  DBuf colv1_, cols1_, colv2_, cols2_, coldv_, colds_;   // block carries of the column scans (colscan.h)
   std::map<std::string, std::unique_ptr<Field>> fields_;
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem, kHalo } type;
+    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
+    ColHhArgs ch{};              // kColHholtz
+    ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;
     Program pg;                  // kLine
     const double* in = nullptr;  // transposes / gemm A
@@ -184,6 +187,10 @@ class Navier2DEngine {
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);
   void add_halo(double* base, int ncols, const char* tag);
+  // Helmholtz solve along y of the three fields on YX arrays / Chebyshev y-derivative of a YX array
+  // (single GPU: column scans instead of transpose -> line program -> transpose)
+  void add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols, const char* tag);
+  void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   void add_gemm(bool nn, int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                 double* C, long ldc, const char* tag);
   void build_confined();

@@ -202,6 +202,43 @@ FdmaTables fdma_tables(const Bands& s) {
   return t;
 }
 
+ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR) {
+  RPDE_REQUIRE(BR >= 2 && BR % 2 == 0, "column-scan block must hold an even number of rows");
+  ColHhHost h;
+  const int n = (int)f.p2.size();
+  h.n = n; h.BR = BR; h.NB = (n + BR - 1) / BR;
+  auto padded = [&](const Vec& v) { Vec o(n, 0.0); std::copy(v.begin(), v.begin() + std::min<size_t>(v.size(), n), o.begin()); return o; };
+  h.t0 = padded(pv.t0); h.t1 = padded(pv.t1); h.t2 = padded(pv.t2);
+  h.q1 = padded(f.q1); h.p2 = padded(f.p2); h.q2 = padded(f.q2); h.r2 = padded(f.r2);
+  h.h1a.assign(n, 0.0); h.h1b.assign(n, 0.0); h.h2b.assign(n, 0.0);
+  h.m1.assign((size_t)h.NB * 2, 0.0);
+  h.m2.assign((size_t)h.NB * 8, 0.0);
+  for (int b = 0; b < h.NB; ++b) {
+    const int j0 = b * BR, j1 = std::min(j0 + BR, n);
+    for (int par = 0; par < 2; ++par) {
+      // forward chain (ascending): response to a unit inflow y_{j0+par-2} = 1
+      long double y = 1.0L;
+      for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; h.h1a[j] = (double)y; }
+      h.m1[(size_t)b * 2 + par] = (double)y;   // an empty chain keeps the inflow (m = 1)
+      // backward chain (descending): runs from the inflow states (1,0) and (0,1)
+      long double x1[2] = {1.0L, 0.0L}, x2[2] = {0.0L, 1.0L};
+      int jt = j1 - 1;
+      if ((jt & 1) != par) --jt;                // highest row of this parity in the block
+      for (int j = jt; j >= j0; j -= 2) {
+        for (int c = 0; c < 2; ++c) {
+          const long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
+          x2[c] = x1[c]; x1[c] = nw;
+        }
+        h.h1b[j] = (double)x1[0];
+        h.h2b[j] = (double)x1[1];
+      }
+      double* m = &h.m2[((size_t)b * 2 + par) * 4];
+      m[0] = (double)x1[0]; m[1] = (double)x1[1]; m[2] = (double)x2[0]; m[3] = (double)x2[1];
+    }
+  }
+  return h;
+}
+
 // ------------------------------------------------------------------------------------- LAPACK
 namespace {
 using dgeev_t = void (*)(const char*, const char*, const int*, double*, const int*, double*,

@@ -63,6 +63,15 @@ void fdma_sweep(Bands& m);            // in place, reference op order
 struct FdmaTables { Vec q1, p2, q2, r2; };
 FdmaTables fdma_tables(const Bands& swept);
 
+// Tables of the column-scan Helmholtz solve (colscan.h) for one swept Fdma and its B2 preconditioner,
+// rows cut into blocks of BR: per-row coefficients, the responses to unit block inflows and the
+// block transfer matrices of the forward (first-order) and backward (second-order) chains.
+struct ColHhHost {
+  int n = 0, BR = 0, NB = 0;
+  Vec t0, t1, t2, q1, h1a, m1, p2, q2, r2, h1b, h2b, m2;
+};
+ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR);
+
 // dense helpers (row-major) + LAPACK (loaded at run time from the OpenBLAS that ships with SciPy,
 // the same library family the reference links: Cargo.toml:39,45-46)
 struct EigenX {

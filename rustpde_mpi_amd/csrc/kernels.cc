@@ -298,6 +298,44 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
   RPDE_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------- column scans (colscan.h)
+template <int PASS>
+__global__ __launch_bounds__(256) void col_hholtz_kernel(const ColHhArgs a) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x), f = (int)blockIdx.z;
+  if (i >= a.ncols) return;
+  if constexpr (PASS == 0) colhh_fwd(a, f, (int)blockIdx.y, i);
+  if constexpr (PASS == 1) colhh_carry1(a, f, i);
+  if constexpr (PASS == 2) colhh_mid(a, f, (int)blockIdx.y, i);
+  if constexpr (PASS == 3) colhh_carry2(a, f, i);
+  if constexpr (PASS == 4) colhh_fin(a, f, (int)blockIdx.y, i);
+}
+void launch_col_hholtz(const ColHhArgs& a, Stream& st) {
+  if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0) return;
+  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB, a.nf), gc((a.ncols + 255) / 256, 1, a.nf);
+  hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_hholtz_kernel<2>, gb, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_hholtz_kernel<3>, gc, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_hholtz_kernel<4>, gb, blk, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void col_diff_kernel(const ColDiffArgs a) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= a.ncols) return;
+  if constexpr (PASS == 0) coldiff_pass<false>(a, (int)blockIdx.y, i);
+  if constexpr (PASS == 1) coldiff_carry(a, i);
+  if constexpr (PASS == 2) coldiff_pass<true>(a, (int)blockIdx.y, i);
+}
+void launch_col_diff(const ColDiffArgs& a, Stream& st) {
+  if (a.ncols <= 0 || a.nout <= 0) return;
+  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB), gc((a.ncols + 255) / 256, 1);
+  hipLaunchKernelGGL(col_diff_kernel<0>, gb, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_diff_kernel<1>, gc, blk, 0, st.s, a);
+  hipLaunchKernelGGL(col_diff_kernel<2>, gb, blk, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+}
+
 // sustained f64 MFMA rate of the chip (no memory traffic): 4 waves per workgroup, 8 independent
 // accumulator chains per wave, `iters` x 8 v_mfma_f64_16x16x4_f64 per wave.  The achievable peak a
 // GEMM can be priced against once the clock has settled under the matrix load.
@@ -499,6 +537,21 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
 void launch_mfma_peak(double*, int, int, Stream&) {}
+void launch_col_hholtz(const ColHhArgs& a, Stream&) {
+  for (int f = 0; f < a.nf; ++f) {
+    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fwd(a, f, b, i);
+    for (int i = 0; i < a.ncols; ++i) colhh_carry1(a, f, i);
+    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_mid(a, f, b, i);
+    for (int i = 0; i < a.ncols; ++i) colhh_carry2(a, f, i);
+    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fin(a, f, b, i);
+  }
+}
+void launch_col_diff(const ColDiffArgs& a, Stream&) {
+  for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
+  for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i);
+  for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
+}
+
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream&) {
   double s = 0.0, nn = 0.0;
   for (int r = 0; r < rows; ++r)

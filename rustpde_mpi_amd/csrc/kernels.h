@@ -1,5 +1,6 @@
 // Host-callable launchers of the device kernels (HIP build) or their host emulation (EMU build).
 #pragma once
+#include "colscan.h"
 #include "line_vm.h"
 
 namespace rpde {
@@ -55,6 +56,11 @@ struct XchgDesc {
 };
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream& st);
 void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
+
+// column scans (colscan.h): the Helmholtz solve along y of up to three YX fields (five launches: pass A,
+// carry, pass B, carry, pass C) and the Chebyshev y-derivative of one YX array (three launches)
+void launch_col_hholtz(const ColHhArgs& a, Stream& st);
+void launch_col_diff(const ColDiffArgs& a, Stream& st);
 
 // measurement only: `blocks` workgroups x 4 waves x `iters` x 8 independent v_mfma_f64_16x16x4_f64 chains
 void launch_mfma_peak(double* out, int blocks, int iters, Stream& st);

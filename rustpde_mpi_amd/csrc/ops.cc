@@ -374,6 +374,12 @@ void Space2Ops::gradient(const Arr2& vhat, int d0, int d1, double s0, double s1,
 }
 
 // ------------------------------------------------------------------------------------------
+void ColHhDev::upload(const ColHhHost& h) {
+  n = h.n; BR = h.BR; NB = h.NB;
+  t0.upload(h.t0); t1.upload(h.t1); t2.upload(h.t2); q1.upload(h.q1); h1a.upload(h.h1a); m1.upload(h.m1);
+  p2.upload(h.p2); q2.upload(h.q2); r2.upload(h.r2); h1b.upload(h.h1b); h2b.upload(h.h2b); m2.upload(h.m2);
+}
+
 HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
   const double c[2] = {c0, c1};
   for (int axis = 0; axis < 2; ++axis) {
@@ -383,6 +389,7 @@ HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
       Bands mtx = bands_axpy(hholtz_mat_a(b), -c[axis], hholtz_mat_b(b));
       fdma_sweep(mtx);
       fdma[axis] = upload_fdma(fdma_tables(mtx), sp.axis(axis).slot_len);
+      if (axis == 1) col_y.upload(build_colhh_tables(pinv_tables(b), fdma_tables(mtx), kColBlockRows));
     } else {
       Vec d(b.m);
       for (int k = 0; k < b.m; ++k) d[k] = 1.0 - (-(double)k * (double)k) * c[axis];

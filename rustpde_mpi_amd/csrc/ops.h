@@ -153,12 +153,22 @@ class Space2Ops {
                  double scale, const FdmaDev* fd, const double* diag);
 };
 
+// device tables of the column-scan form of one Helmholtz-y solve (colscan.h)
+struct ColHhDev {
+  DBuf t0, t1, t2, q1, h1a, m1, p2, q2, r2, h1b, h2b, m2;
+  int n = 0, BR = 0, NB = 0;
+  void upload(const ColHhHost& h);
+  ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, h1a.p, m1.p, p2.p, q2.p, r2.p, h1b.p, h2b.p, m2.p}; }
+};
+constexpr int kColBlockRows = 64;
+
 // HholtzAdi (src/solver/hholtz_adi.rs:48-76,149-169) on canonical arrays
 class HholtzAdiOp {
  public:
   HholtzAdiOp(Space2Ops& sp, double c0, double c1);
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
   FdmaDev fdma[2];      // Chebyshev axes
+  ColHhDev col_y;       // axis 1 as a column scan over YX arrays (the fused step on one GPU)
   DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
   Space2Ops& sp;
 };

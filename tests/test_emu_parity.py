@@ -150,3 +150,10 @@ def test_hholtz_long_lines(emu_lib, k0, n0, k1, n1):
 
 def test_poisson_513(emu_lib):
     K.check_solvers(emu_lib, "cheb_neumann", 513, "cheb_neumann", 9, [1.0, 1.0])
+
+
+@pytest.mark.parametrize("periodic,nx,ny", [(False, 17, 129), (False, 9, 257), (True, 16, 257)])
+def test_column_scans_several_blocks(emu_lib, periodic, nx, ny):
+    """The Helmholtz-y solve and the y-derivatives as column scans (colscan.h) with more than one block of
+    64 rows: block carries, partial last block (127 = 64 + 63 rows, 255 = 3 x 64 + 63)."""
+    K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 4, check_at=[1, 4])
