@@ -741,12 +741,14 @@ bool Navier2DEngine::exit() {
 }
 
 void Navier2DEngine::diagnostics(double* nu_out, double* nuvol_out, double* re_out) {
-  // Diagnostic path (the reference evaluates it in callback(), navier_io.rs:125-147): generic
-  // operators on gathered canonical arrays, weighted averages (field/average.rs:26-59) on the host.
+  // Callback cadence only (the reference evaluates it in callback(), navier_io.rs:125-147): the
+  // physical fields come from the generic operators on gathered canonical arrays; the weighted
+  // averages (field/average.rs:26-59) are reduced on the device -- 32 bytes cross PCIe.
   const int nx = nx_, ny = ny_;
   Space2Ops& so = *sp_ortho_;
   const int ro = so.ortho_rows();
-  Arr2 th(sp_temp_->spec_rows(), sp_temp_->spec_cols(), ex_), tot(ro, ny, ex_), g(ro, ny, ex_), ph(nx, ny, 1);
+  Arr2 th(sp_temp_->spec_rows(), sp_temp_->spec_cols(), ex_), tot(ro, ny, ex_), g(ro, ny, ex_);
+  Arr2 tphys(nx, ny, 1), dtdz(nx, ny, 1), ux(nx, ny, 1), uy(nx, ny, 1);
   // temp.to_ortho() + tempbc.to_ortho()
   state_to_canonical(field("temp"), th);
   sp_temp_->to_ortho(th, tot, st_);
@@ -760,32 +762,35 @@ void Navier2DEngine::diagnostics(double* nu_out, double* nuvol_out, double* re_o
     pb.run(st_);
     dev_sync(st_);
   }
-  Vec temp_phys((size_t)nx * ny), dtdz((size_t)nx * ny), ux((size_t)nx * ny), uy((size_t)nx * ny);
-  so.backward(tot, ph, st_);
-  dev_download2d(temp_phys.data(), ph.p(), ph.ld, nx, ny);
+  so.backward(tot, tphys, st_);
   so.gradient(tot, 0, 1, 1.0, 1.0, g, st_);           // d/dy in unscaled coordinates (scale = None)
-  so.backward(g, ph, st_);
-  dev_download2d(dtdz.data(), ph.p(), ph.ld, nx, ny);
-  get_field_physical("velx", ux.data(), ux.size());
-  get_field_physical("vely", uy.data(), uy.size());
+  so.backward(g, dtdz, st_);
+  {
+    Arr2 vh(sp_vel_->spec_rows(), sp_vel_->spec_cols(), ex_);
+    state_to_canonical(field("velx"), vh);
+    sp_vel_->backward(vh, ux, st_);
+    state_to_canonical(field("vely"), vh);
+    sp_vel_->backward(vh, uy, st_);
+  }
   // weights dx / length of the (unscaled) grid of `field`
   const Vec x0 = base_coords(so.base(0)), y0 = base_coords(so.base(1));
   Vec wx = base_dx(so.base(0), x0), wy = base_dx(so.base(1), y0);
   const double lx = std::fabs(x0.back() - x0.front()), ly = std::fabs(y0.back() - y0.front());
   for (double& w : wx) w /= lx;
   for (double& w : wy) w /= ly;
-  auto xavg = [&](const Vec& f, int j) { double s = 0; for (int i = 0; i < nx; ++i) s += f[(size_t)i * ny + j] * wx[i]; return s; };
-  auto vavg = [&](const Vec& f) { double s = 0; for (int j = 0; j < ny; ++j) s += xavg(f, j) * wy[j]; return s; };
-  // eval_nu: (<-2/sy dT/dy>_x at the top + at the bottom) / 2
-  Vec f((size_t)nx * ny);
-  for (size_t i = 0; i < f.size(); ++i) f[i] = dtdz[i] * (-2.0 / sy_);
-  *nu_out = (xavg(f, ny - 1) + xavg(f, 0)) / 2.0;
+  DBuf dwx, dwy, part((size_t)4 * nx), out4(4);
+  dwx.upload(wx); dwy.upload(wy);
+  // eval_nu:    (< -2/sy dT/dy >_x at the top + at the bottom) / 2
   // eval_nuvol: < (dT/dy / (-sy) + vely T / ka) * 2 sy >_V
-  for (size_t i = 0; i < f.size(); ++i) f[i] = (dtdz[i] / (sy_ * -1.0) + temp_phys[i] * uy[i] / ka_) * 2.0 * sy_;
-  *nuvol_out = vavg(f);
-  // eval_re: < sqrt(u^2 + v^2) * 2 sy / nu >_V
-  for (size_t i = 0; i < f.size(); ++i) f[i] = std::sqrt(ux[i] * ux[i] + uy[i] * uy[i]) * (2.0 * sy_ / nu_);
-  *re_out = vavg(f);
+  // eval_re:    < sqrt(u^2 + v^2) * 2 sy / nu >_V
+  launch_diag_reduce(tphys.p(), dtdz.p(), ux.p(), uy.p(), tphys.ld, nx, ny, dwx.p, dwy.p, -2.0 / sy_,
+                     (1.0 / (sy_ * -1.0)) * 2.0 * sy_, (1.0 / ka_) * 2.0 * sy_, 2.0 * sy_ / nu_, part.p, out4.p, st_);
+  dev_sync(st_);
+  double h[4];
+  dev_download(h, out4.p, sizeof(h));
+  *nu_out = (h[1] + h[0]) / 2.0;
+  *nuvol_out = h[2];
+  *re_out = h[3];
 }
 
 // d/dy of the pressure in YX layout, used by the vely right-hand side (navier_eq.rs:195)

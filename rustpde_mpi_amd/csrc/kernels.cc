@@ -298,20 +298,71 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
   RPDE_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------- callback diagnostics
+__global__ __launch_bounds__(256) void diag_rows_kernel(const double* __restrict__ T, const double* __restrict__ dT,
+                                                        const double* __restrict__ ux, const double* __restrict__ uy,
+                                                        long ld, int ny, const double* __restrict__ wx,
+                                                        const double* __restrict__ wy, double c_nu, double c_v1,
+                                                        double c_v2, double c_re, double* __restrict__ partial) {
+  __shared__ double sv[256], sr[256];
+  const int i = (int)blockIdx.x;
+  const long row = (long)i * ld;
+  double av = 0.0, ar = 0.0;
+  for (int j = (int)threadIdx.x; j < ny; j += 256) {
+    const double w = wy[j], u = ux[row + j], v = uy[row + j];
+    av += w * (c_v1 * dT[row + j] + c_v2 * T[row + j] * v);
+    ar += w * (c_re * sqrt(u * u + v * v));
+  }
+  sv[threadIdx.x] = av; sr[threadIdx.x] = ar;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sv[threadIdx.x] += sv[threadIdx.x + o]; sr[threadIdx.x] += sr[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double w = wx[i];
+    partial[4 * i + 0] = w * c_nu * dT[row];
+    partial[4 * i + 1] = w * c_nu * dT[row + ny - 1];
+    partial[4 * i + 2] = w * sv[0];
+    partial[4 * i + 3] = w * sr[0];
+  }
+}
+__global__ __launch_bounds__(256) void diag_final_kernel(const double* __restrict__ partial, int nx, double* out4) {
+  __shared__ double s[4][256];
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = (int)threadIdx.x; i < nx; i += 256)
+    for (int c = 0; c < 4; ++c) a[c] += partial[4 * i + c];
+  for (int c = 0; c < 4; ++c) s[c][threadIdx.x] = a[c];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int c = 0; c < 4; ++c) s[c][threadIdx.x] += s[c][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out4[threadIdx.x] = s[threadIdx.x][0];
+}
+void launch_diag_reduce(const double* T, const double* dT, const double* ux, const double* uy, long ld, int nx, int ny,
+                        const double* wx, const double* wy, double c_nu, double c_v1, double c_v2, double c_re,
+                        double* partial, double* out4, Stream& st) {
+  hipLaunchKernelGGL(diag_rows_kernel, dim3(nx), dim3(256), 0, st.s, T, dT, ux, uy, ld, ny, wx, wy, c_nu, c_v1, c_v2, c_re, partial);
+  hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(256), 0, st.s, partial, nx, out4);
+  RPDE_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------- column scans (colscan.h)
 template <int PASS>
 __global__ __launch_bounds__(256) void col_hholtz_kernel(const ColHhArgs a) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x), f = (int)blockIdx.z;
   if (i >= a.ncols) return;
   if constexpr (PASS == 0) colhh_fwd(a, f, (int)blockIdx.y, i);
-  if constexpr (PASS == 1) colhh_carry1(a, f, i);
+  if constexpr (PASS == 1) colhh_carry1(a, f, i, (int)blockIdx.y);
   if constexpr (PASS == 2) colhh_mid(a, f, (int)blockIdx.y, i);
-  if constexpr (PASS == 3) colhh_carry2(a, f, i);
+  if constexpr (PASS == 3) colhh_carry2(a, f, i, (int)blockIdx.y);
   if constexpr (PASS == 4) colhh_fin(a, f, (int)blockIdx.y, i);
 }
 void launch_col_hholtz(const ColHhArgs& a, Stream& st) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0) return;
-  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB, a.nf), gc((a.ncols + 255) / 256, 1, a.nf);
+  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB, a.nf), gc((a.ncols + 255) / 256, 2, a.nf);
   hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_hholtz_kernel<2>, gb, blk, 0, st.s, a);
@@ -324,12 +375,12 @@ __global__ __launch_bounds__(256) void col_diff_kernel(const ColDiffArgs a) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= a.ncols) return;
   if constexpr (PASS == 0) coldiff_pass<false>(a, (int)blockIdx.y, i);
-  if constexpr (PASS == 1) coldiff_carry(a, i);
+  if constexpr (PASS == 1) coldiff_carry(a, i, (int)blockIdx.y);
   if constexpr (PASS == 2) coldiff_pass<true>(a, (int)blockIdx.y, i);
 }
 void launch_col_diff(const ColDiffArgs& a, Stream& st) {
   if (a.ncols <= 0 || a.nout <= 0) return;
-  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB), gc((a.ncols + 255) / 256, 1);
+  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB), gc((a.ncols + 255) / 256, 2);
   hipLaunchKernelGGL(col_diff_kernel<0>, gb, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_diff_kernel<1>, gc, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_diff_kernel<2>, gb, blk, 0, st.s, a);
@@ -537,18 +588,37 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
 void launch_mfma_peak(double*, int, int, Stream&) {}
+void launch_diag_reduce(const double* T, const double* dT, const double* ux, const double* uy, long ld, int nx, int ny,
+                        const double* wx, const double* wy, double c_nu, double c_v1, double c_v2, double c_re,
+                        double* partial, double* out4, Stream&) {
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < nx; ++i) {
+    const long row = (long)i * ld;
+    double av = 0.0, ar = 0.0;
+    for (int j = 0; j < ny; ++j) {
+      av += wy[j] * (c_v1 * dT[row + j] + c_v2 * T[row + j] * uy[row + j]);
+      ar += wy[j] * (c_re * std::sqrt(ux[row + j] * ux[row + j] + uy[row + j] * uy[row + j]));
+    }
+    partial[4 * i + 0] = wx[i] * c_nu * dT[row];
+    partial[4 * i + 1] = wx[i] * c_nu * dT[row + ny - 1];
+    partial[4 * i + 2] = wx[i] * av;
+    partial[4 * i + 3] = wx[i] * ar;
+    for (int c = 0; c < 4; ++c) a[c] += partial[4 * i + c];
+  }
+  for (int c = 0; c < 4; ++c) out4[c] = a[c];
+}
 void launch_col_hholtz(const ColHhArgs& a, Stream&) {
   for (int f = 0; f < a.nf; ++f) {
     for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fwd(a, f, b, i);
-    for (int i = 0; i < a.ncols; ++i) colhh_carry1(a, f, i);
+    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry1(a, f, i, par);
     for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_mid(a, f, b, i);
-    for (int i = 0; i < a.ncols; ++i) colhh_carry2(a, f, i);
+    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry2(a, f, i, par);
     for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fin(a, f, b, i);
   }
 }
 void launch_col_diff(const ColDiffArgs& a, Stream&) {
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
-  for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i);
+  for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i, par);
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
 }
 

@@ -62,6 +62,16 @@ void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 void launch_col_hholtz(const ColHhArgs& a, Stream& st);
 void launch_col_diff(const ColDiffArgs& a, Stream& st);
 
+// weighted averages of the callback diagnostics on the device (field/average.rs:26-59 applied to
+// eval_nu / eval_nuvol / eval_re, functions.rs:146-233).  Inputs are physical (nx x ny, pitch ld) arrays:
+// total temperature T, its unscaled y-derivative dT, ux, uy; wx / wy = dx / length of the two axes.
+//   out[0] = sum_i wx_i c_nu dT(i, 0)       out[1] = sum_i wx_i c_nu dT(i, ny-1)
+//   out[2] = sum_ij wx_i wy_j (c_v1 dT + c_v2 T uy)      out[3] = sum_ij wx_i wy_j c_re sqrt(ux^2 + uy^2)
+// two launches (per-row partial sums, then one workgroup), fixed summation order; `partial`: 4 nx doubles
+void launch_diag_reduce(const double* T, const double* dT, const double* ux, const double* uy, long ld, int nx, int ny,
+                        const double* wx, const double* wy, double c_nu, double c_v1, double c_v2, double c_re,
+                        double* partial, double* out4, Stream& st);
+
 // measurement only: `blocks` workgroups x 4 waves x `iters` x 8 independent v_mfma_f64_16x16x4_f64 chains
 void launch_mfma_peak(double* out, int blocks, int iters, Stream& st);
 

@@ -160,7 +160,7 @@ struct ColHhDev {
   void upload(const ColHhHost& h);
   ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, h1a.p, m1.p, p2.p, q2.p, r2.p, h1b.p, h2b.p, m2.p}; }
 };
-constexpr int kColBlockRows = 64;
+constexpr int kColBlockRows = 32;   // multiple of colscan.h's kColBatch; 128 blocks at 4097: three full rounds of waves
 
 // HholtzAdi (src/solver/hholtz_adi.rs:48-76,149-169) on canonical arrays
 class HholtzAdiOp {
