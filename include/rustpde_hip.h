@@ -110,6 +110,28 @@ int rpde_navier2d_exit(rpde_navier2d* h, int* flag);
 int rpde_navier2d_div_norm(rpde_navier2d* h, double* value);
 /* eval_nu / eval_nuvol / eval_re (callback diagnostics)     src/navier_stokes/functions.rs:146-233 */
 int rpde_navier2d_diagnostics(rpde_navier2d* h, double* nu, double* nuvol, double* re);
+/* Snapshots in the reference's HDF5 layout (Navier2D::write / read, src/navier_stokes/navier_io.rs:21-62;  *
+ * per field src/field/io.rs:74-110): groups ux, uy, temp, pres, tempbc with x, dx, y, dy,    *
+ * v, vhat (vhat_re + vhat_im when complex) and root scalars time, ra, pr, nu, ka.  read restores vhat of     *
+ * ux, uy, temp, pres and `time`; another resolution is truncated / zero-padded in spectral space           *
+ * (field/io.rs:151-176).  Files are classic-format HDF5 (what libhdf5 writes by default) produced and        *
+ * parsed by the library itself -- a Rust host that links libhdf5 can keep its own writer instead.           */
+int rpde_navier2d_write(rpde_navier2d* h, const char* filename);
+int rpde_navier2d_read(rpde_navier2d* h, const char* filename);
+/* Integrate::callback (navier.rs:476-480) = callback_from_filename("data/flow{time:0>8.2}.h5",             *
+ * "data/info.txt", false, write_intervall); callback_from_filename: navier_io.rs:84-149 (snapshot on its   *
+ * interval -- pass a negative interval for `None` = always --, then "time |div| Nu Nuv Re" on stdout and    *
+ * "time nu nuv re" appended to info_name unless suppress_io)                                               */
+int rpde_navier2d_set_write_intervall(rpde_navier2d* h, double dt_save);
+int rpde_navier2d_callback(rpde_navier2d* h);
+int rpde_navier2d_callback_from_filename(rpde_navier2d* h, const char* flow_name, const char* info_name,
+                                         int suppress_io, double write_flow_intervall);
+/* the same HDF5 subset for hosts without libhdf5: contiguous f64 datasets of rank 1 or 2, one group level  *
+ * (src/io/read_write_hdf5.rs:38-188: read_from_hdf5 / write_to_hdf5 "create or append, overwrite")          */
+int rpde_h5_shape(const char* filename, const char* path, int* rank, uint64_t* dims2);
+int rpde_h5_read(const char* filename, const char* path, double* out, size_t len);
+int rpde_h5_write(const char* filename, const char* path, int rank, const uint64_t* dims, const double* data);
+int rpde_h5_list(const char* filename, char* buf, size_t len);   /* newline-separated dataset paths */
 /* integrate(&mut pde, max_time, None) without callbacks      src/lib.rs:187-219 ; returns steps taken */
 int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps);
 

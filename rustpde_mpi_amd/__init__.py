@@ -195,8 +195,44 @@ class Navier2D:
         return bool(f.value)
 
     def callback(self):
-        """I/O callback of the reference (HDF5 snapshot + info.txt); host-side, not part of the
-        accelerated path."""
+        """`Integrate::callback` (navier.rs:476-480): snapshot data/flow{time:0>8.2}.h5 (on
+        `write_intervall` when set) + the diagnostics line on stdout and in data/info.txt."""
+        self._lib.call("rpde_navier2d_callback", self._h)
+
+    def callback_from_filename(self, flow_name, info_name, suppress_io=False, write_flow_intervall=None):
+        """navier_io.rs:84-149."""
+        self._lib.call("rpde_navier2d_callback_from_filename", self._h, str(flow_name).encode(), str(info_name).encode(),
+                       int(bool(suppress_io)), -1.0 if write_flow_intervall is None else float(write_flow_intervall))
+
+    @property
+    def write_intervall(self):
+        return getattr(self, "_write_intervall", None)
+
+    @write_intervall.setter
+    def write_intervall(self, value):
+        self._write_intervall = value
+        self._lib.call("rpde_navier2d_set_write_intervall", self._h, -1.0 if value is None else float(value))
+
+    def write(self, filename):
+        """`Navier2D::write` (navier_io.rs:44-62): HDF5 snapshot in the reference's layout."""
+        self._lib.call("rpde_navier2d_write", self._h, str(filename).encode())
+
+    def read(self, filename):
+        """`Navier2D::read` (navier_io.rs:21-29): restore ux, uy, temp, pres and the time."""
+        self._lib.call("rpde_navier2d_read", self._h, str(filename).encode())
+
+    def write_unwrap(self, filename):
+        try:
+            self.write(filename)
+        except RpdeError as exc:
+            print(f"Error while writing file {filename!r}. Error: {exc}")
+
+    def read_unwrap(self, filename):
+        try:
+            self.read(filename)
+            print(f"Reading file {filename!r} was successfull.")
+        except RpdeError as exc:
+            print(f"Error while reading file {filename!r}. Error: {exc}")
 
     # ---- extras
     def div_norm(self):
@@ -400,6 +436,34 @@ def gemm(a, b, transb=False, device=0, library=None):
     out = np.empty((M, N))
     library.call("rpde_gemm", M, N, K, ptr(a), ptr(b), 1 if transb else 0, ptr(out), int(device))
     return out
+
+
+class h5:
+    """The HDF5 subset of the snapshots through the library's own reader / writer (csrc/h5lite)."""
+
+    @staticmethod
+    def paths(filename, library=None):
+        library = library or lib()
+        buf = C.create_string_buffer(1 << 16)
+        library.call("rpde_h5_list", str(filename).encode(), buf, len(buf))
+        return buf.value.decode().split()
+
+    @staticmethod
+    def read(filename, path, library=None):
+        library = library or lib()
+        rank, dims = C.c_int(), (C.c_uint64 * 2)()
+        library.call("rpde_h5_shape", str(filename).encode(), path.encode(), C.byref(rank), dims)
+        shape = tuple(int(dims[i]) for i in range(rank.value))
+        out = np.empty(shape)
+        library.call("rpde_h5_read", str(filename).encode(), path.encode(), ptr(out), out.size)
+        return out
+
+    @staticmethod
+    def write(filename, path, array, library=None):
+        library = library or lib()
+        a = as_f64(array)
+        dims = (C.c_uint64 * 2)(*a.shape)
+        library.call("rpde_h5_write", str(filename).encode(), path.encode(), a.ndim, dims, ptr(a))
 
 
 def microbench(what, n, nlines, reps=20, device=0, library=None):

@@ -56,6 +56,15 @@ SIGNATURES = {
     "rpde_navier2d_exit": (C.c_int, [_vp, _ip]),
     "rpde_navier2d_div_norm": (C.c_int, [_vp, _dp]),
     "rpde_navier2d_diagnostics": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "rpde_navier2d_write": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_navier2d_read": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_navier2d_set_write_intervall": (C.c_int, [_vp, C.c_double]),
+    "rpde_navier2d_callback": (C.c_int, [_vp]),
+    "rpde_navier2d_callback_from_filename": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
+    "rpde_h5_shape": (C.c_int, [C.c_char_p, C.c_char_p, _ip, C.POINTER(C.c_uint64)]),
+    "rpde_h5_read": (C.c_int, [C.c_char_p, C.c_char_p, _dp, C.c_size_t]),
+    "rpde_h5_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), _dp]),
+    "rpde_h5_list": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "rpde_navier2d_integrate": (C.c_int, [_vp, C.c_double, C.c_int, C.POINTER(C.c_long)]),
     "rpde_space2_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "rpde_space2_destroy": (C.c_int, [_vp]),

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "engine.h"
+#include "h5lite.h"
 #include "rccl_transport.h"
 
 using namespace rpde;
@@ -276,6 +277,69 @@ int rpde_navier2d_diagnostics(rpde_navier2d* h, double* nu, double* nuvol, doubl
     h->e->diagnostics(nu, nuvol, re);
   })
 }
+int rpde_navier2d_write(rpde_navier2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->write(filename); })
+}
+int rpde_navier2d_read(rpde_navier2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->read(filename); })
+}
+int rpde_navier2d_set_write_intervall(rpde_navier2d* h, double dt_save) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); h->e->set_write_intervall(dt_save); })
+}
+int rpde_navier2d_callback(rpde_navier2d* h) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->callback(); })
+}
+int rpde_navier2d_callback_from_filename(rpde_navier2d* h, const char* flow_name, const char* info_name, int suppress_io,
+                                         double write_flow_intervall) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(flow_name && info_name, "null pointer");
+    select_device(h->device);
+    h->e->callback_from_filename(flow_name, info_name, suppress_io != 0, write_flow_intervall);
+  })
+}
+// h5lite access for hosts without libhdf5 (tests, Python mirror): datasets of rank 1 / 2, f64
+int rpde_h5_shape(const char* filename, const char* path, int* rank, uint64_t* dims2) {
+  RPDE_TRY({
+    RPDE_REQUIRE(filename && path && rank && dims2, "null pointer");
+    h5::Reader r(filename);
+    const std::vector<uint64_t> d = r.shape(path);
+    RPDE_REQUIRE(d.size() <= 2, "rank > 2");
+    *rank = (int)d.size();
+    for (size_t i = 0; i < d.size(); ++i) dims2[i] = d[i];
+  })
+}
+int rpde_h5_read(const char* filename, const char* path, double* out, size_t len) {
+  RPDE_TRY({
+    RPDE_REQUIRE(filename && path && out, "null pointer");
+    h5::Reader r(filename);
+    const h5::Dataset d = r.read(path);
+    RPDE_REQUIRE(d.data.size() == len, "h5 read: wrong buffer length for " + std::string(path));
+    std::copy(d.data.begin(), d.data.end(), out);
+  })
+}
+int rpde_h5_write(const char* filename, const char* path, int rank, const uint64_t* dims, const double* data) {
+  RPDE_TRY({
+    RPDE_REQUIRE(filename && path && dims && data && (rank == 1 || rank == 2), "bad argument");
+    h5::Dataset d;
+    size_t n = 1;
+    for (int i = 0; i < rank; ++i) { d.dims.push_back(dims[i]); n *= dims[i]; }
+    d.data.assign(data, data + n);
+    h5::Tree t;
+    t[path] = std::move(d);
+    h5::update_file(filename, t);
+  })
+}
+int rpde_h5_list(const char* filename, char* buf, size_t len) {
+  RPDE_TRY({
+    RPDE_REQUIRE(filename && buf && len > 0, "bad argument");
+    h5::Reader r(filename);
+    std::string s;
+    for (const std::string& p : r.paths()) s += p + "\n";
+    RPDE_REQUIRE(s.size() < len, "buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  })
+}
+
 int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps) {
   RPDE_TRY({
     RPDE_CHECK_HANDLE(h);

@@ -1,5 +1,10 @@
 #include "engine.h"
+#include "h5lite.h"
 #include "rccl_transport.h"
+
+#include <sys/stat.h>
+
+#include <charconv>
 
 #include <chrono>
 #include <cmath>
@@ -138,6 +143,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   mk("temp", sp_temp_.get(), &T_, true, false);
   mk("pres", sp_ortho_.get(), &P_, true, true);
   mk("pseu", sp_pseu_.get(), &PS_, false, false);
+  mk("tempbc", sp_ortho_.get(), &TBC_, true, true);   // the lift: read-only (snapshots)
 
   // ---- boundary-condition lift (boundary_conditions.rs:18-36 / 143-161) and its constants
   {
@@ -353,6 +359,7 @@ void Navier2DEngine::halo(double* base, long ld, int ncols) {
 }
 
 void Navier2DEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
+  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
   Field& f = field(name);
   int r, c, e;
   spectral_shape(name, &r, &c, &e);
@@ -375,6 +382,7 @@ void Navier2DEngine::get_field_spectral(const std::string& name, double* host, s
 }
 
 void Navier2DEngine::set_field_physical(const std::string& name, const double* host, size_t len) {
+  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
   Field& f = field(name);
   RPDE_REQUIRE(len == (size_t)nx_ * ny_, "set_field: physical arrays are nx*ny doubles");
   int r, c, e;
@@ -791,6 +799,127 @@ void Navier2DEngine::diagnostics(double* nu_out, double* nuvol_out, double* re_o
   *nu_out = (h[1] + h[0]) / 2.0;
   *nuvol_out = h[2];
   *re_out = h[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// snapshots and the I/O callback
+static const char* const kSnapFields[5][2] = {{"velx", "ux"}, {"vely", "uy"}, {"temp", "temp"}, {"pres", "pres"},
+                                              {"tempbc", "tempbc"}};
+
+void Navier2DEngine::write(const std::string& filename) {
+  h5::Tree t;
+  Vec x((size_t)nx_), y((size_t)ny_);
+  grid(0, x.data(), x.size());
+  grid(1, y.data(), y.size());
+  for (const auto& fg : kSnapFields) {
+    const std::string g = fg[1];
+    // field/io.rs:96-99: `dx` / `dy` are written from x[0] / x[1] (coordinates, not spacings)
+    t[g + "/x"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/dx"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/y"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[g + "/dy"] = h5::Dataset{{(uint64_t)ny_}, y};
+    h5::Dataset v{{(uint64_t)nx_, (uint64_t)ny_}, Vec((size_t)nx_ * ny_)};
+    get_field_physical(fg[0], v.data.data(), v.data.size());
+    t[g + "/v"] = std::move(v);
+    int r, c, e;
+    spectral_shape(fg[0], &r, &c, &e);
+    Vec vh((size_t)r * c * e);
+    get_field_spectral(fg[0], vh.data(), vh.size());
+    if (e == 1) {
+      t[g + "/vhat"] = h5::Dataset{{(uint64_t)r, (uint64_t)c}, std::move(vh)};
+    } else {   // read_write_hdf5.rs:171-188: complex arrays as two real datasets
+      h5::Dataset re{{(uint64_t)r, (uint64_t)c}, Vec((size_t)r * c)}, im = re;
+      for (size_t k = 0; k < (size_t)r * c; ++k) { re.data[k] = vh[2 * k]; im.data[k] = vh[2 * k + 1]; }
+      t[g + "/vhat_re"] = std::move(re);
+      t[g + "/vhat_im"] = std::move(im);
+    }
+  }
+  t["time"] = h5::Dataset{{1}, {time_}};
+  for (const char* k : {"ra", "pr", "nu", "ka"}) t[k] = h5::Dataset{{1}, {param(k)}};
+  if (comm_.rank == 0) h5::update_file(filename, t);
+}
+
+void Navier2DEngine::read(const std::string& filename) {
+  h5::Reader rd(filename);
+  for (int k = 0; k < 4; ++k) {
+    const std::string name = kSnapFields[k][0], g = kSnapFields[k][1];
+    int r, c, e;
+    spectral_shape(name, &r, &c, &e);
+    Vec neu((size_t)r * c * e, 0.0);
+    uint64_t ro = 0, co = 0;
+    auto place = [&](const h5::Dataset& d, int comp) {
+      RPDE_REQUIRE(d.dims.size() == 2, "snapshot: " + g + "/vhat must be two-dimensional");
+      ro = d.dims[0]; co = d.dims[1];
+      const uint64_t rm = std::min<uint64_t>(ro, r), cm = std::min<uint64_t>(co, c);
+      for (uint64_t i = 0; i < rm; ++i)
+        for (uint64_t j = 0; j < cm; ++j) neu[(i * c + j) * e + comp] = d.data[i * co + j];
+    };
+    if (e == 1) place(rd.read(g + "/vhat"), 0);
+    else { place(rd.read(g + "/vhat_re"), 0); place(rd.read(g + "/vhat_im"), 1); }
+    if (((int)ro != r || (int)co != c) && periodic_) {
+      // field/io.rs:167-175: the unnormalised Fourier coefficients scale with the number of points
+      const double norm = (double)(r - 1) / (double)(ro - 1);
+      for (double& v : neu) v *= norm;
+    }
+    set_field_spectral(name, neu.data(), neu.size());
+  }
+  time_ = rd.read("time").data.at(0);
+}
+
+static std::string rust_exp(double v, int prec) {   // Rust's {:.Ne}: d.dd..e[-]x, no padding of the exponent
+  if (std::isnan(v)) return "NaN";
+  if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%.*e", prec, v);
+  std::string s = buf;
+  const size_t epos = s.find('e');
+  const int ex = std::atoi(s.c_str() + epos + 1);
+  return s.substr(0, epos) + "e" + std::to_string(ex);
+}
+static std::string rust_display(double v) {          // shortest representation that round-trips
+  char buf[64];
+  auto res = std::to_chars(buf, buf + sizeof buf, v);
+  return std::string(buf, res.ptr);
+}
+
+void Navier2DEngine::callback_from_filename(const std::string& flow_name, const std::string& info_name,
+                                            bool suppress_io, double write_flow_intervall) {
+  if (comm_.rank == 0) (void)::mkdir("data", 0777);   // std::fs::create_dir_all("data")
+  bool do_write = true;
+  if (write_flow_intervall >= 0.0) do_write = std::fmod(time_ + dt_ / 2.0, write_flow_intervall) < dt_;
+  if (do_write) {
+    try { write(flow_name); }                          // write_unwrap: report, do not abort the run
+    catch (const std::exception& ex) {
+      std::fprintf(stderr, "Error while writing file \"%s\". Error: %s\n", flow_name.c_str(), ex.what());
+    }
+  }
+  if (suppress_io) return;
+  const double div = div_norm();
+  double nu, nuv, re;
+  diagnostics(&nu, &nuv, &re);
+  if (comm_.rank != 0) return;
+  char tbuf[64];
+  std::snprintf(tbuf, sizeof tbuf, "%4.2f", time_);
+  std::printf("time = %s      |div| = %s     Nu = %s     Nuv = %s    Re = %s\n", tbuf, rust_exp(div, 2).c_str(),
+              rust_exp(nu, 3).c_str(), rust_exp(nuv, 3).c_str(), rust_exp(re, 3).c_str());
+  std::fflush(stdout);
+  if (FILE* fp = std::fopen(info_name.c_str(), "a")) {
+    std::fprintf(fp, "%s %s %s %s\n", rust_display(time_).c_str(), rust_display(nu).c_str(), rust_display(nuv).c_str(),
+                 rust_display(re).c_str());
+    std::fclose(fp);
+  } else {
+    std::fprintf(stderr, "Couldn't write to file: %s\n", info_name.c_str());
+  }
+}
+
+void Navier2DEngine::callback() {
+  char name[64];
+  char tb[32];
+  std::snprintf(tb, sizeof tb, "%.2f", time_);          // {:0>8.2}: two decimals, left-padded with zeros to width 8
+  std::string t = tb;
+  while (t.size() < 8) t = "0" + t;
+  std::snprintf(name, sizeof name, "data/flow%s.h5", t.c_str());
+  callback_from_filename(name, "data/info.txt", false, write_intervall_);
 }
 
 // d/dy of the pressure in YX layout, used by the vely right-hand side (navier_eq.rs:195)

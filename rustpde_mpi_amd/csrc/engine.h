@@ -61,6 +61,19 @@ class Navier2DEngine {
   // write to a field (set_field / init_random) and before the next update() the divergence is
   // evaluated like the reference does.
   bool exit();
+  // Snapshots in the reference's HDF5 layout (navier_io.rs:21-62, field/io.rs:74-110):
+  // groups ux, uy, temp, pres, tempbc with x, dx, y, dy, v, vhat (vhat_re / vhat_im when complex), root
+  // scalars time, ra, pr, nu, ka.  read() restores vhat of ux, uy, temp, pres and the time; a snapshot
+  // of another resolution is truncated / zero-padded in spectral space (field/io.rs:151-176).
+  // Written and parsed by csrc/h5lite (no libhdf5 in this image).  Sharded: collective, rank 0 writes.
+  void write(const std::string& filename);
+  void read(const std::string& filename);
+  // callback_from_filename (navier_io.rs:84-149): snapshot (on its interval when write_flow_intervall >= 0,
+  // always when < 0 = None), then "time |div| Nu Nuv Re" to stdout and "time nu nuv re" appended to info_name
+  void callback_from_filename(const std::string& flow_name, const std::string& info_name, bool suppress_io,
+                              double write_flow_intervall);
+  void callback();                       // Integrate::callback (navier.rs:476-480): data/flow{time:0>8.2}.h5, data/info.txt
+  void set_write_intervall(double v) { write_intervall_ = v; }   // `write_intervall: Option<f64>`; < 0 = None
   double time() const { return time_; }
   double dt() const { return dt_; }
   double param(const std::string& key) const;
@@ -150,6 +163,7 @@ class Navier2DEngine {
   DBuf nanflag_;                 // device flag raised by the guarded stores of the step (int at offset 0)
   int* hflag_ = nullptr;         // pinned host landing pad of the flag
   bool dirty_ = false;           // a field was written from the host since the last update()
+  double write_intervall_ = -1.0;   // navier.rs:79 `write_intervall: Option<f64>` (None)
   int* flagp() const { return reinterpret_cast<int*>(nanflag_.p); }
   bool read_nanflag();
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
