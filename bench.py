@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--dry-run-emu", action="store_true", help=argparse.SUPPRESS)
     # also report the parity with an oracle that ran its own dgeev (about a minute more at 4097^2)
     p.add_argument("--parity-independent", action="store_true")
+    p.add_argument("--no-cpu-single-thread", action="store_true")
     return p.parse_args()
 
 
@@ -65,12 +66,17 @@ def cpu_baseline(args, eig=None):
     ora.set_temperature(0.2, 1.0, 1.0)
     setup = time.perf_counter() - t0
     ora.update()  # warm-up (FFT plans, page faults)
+    from oracle import timing
+    timing.reset(True)
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
         ora.update()
     dt = time.perf_counter() - t0
-    # threads actually used: OpenBLAS' pool for the two Poisson GEMMs, everything else (pocketfft,
-    # banded sweeps, NumPy elementwise) runs on one core
+    phases = {k: v / args.cpu_steps for k, v in timing.ACC.items()}
+    phases["other (elementwise, copies)"] = dt / args.cpu_steps - sum(phases.values())
+    timing.reset(False)
+    # threads actually used: OpenBLAS' pool for the two Poisson GEMMs and pocketfft's workers for the
+    # transforms (scipy.fft workers = -1); the banded sweeps and NumPy elementwise code run on one core
     cores = 1
     try:
         from threadpoolctl import threadpool_info
@@ -80,7 +86,28 @@ def cpu_baseline(args, eig=None):
     base = {"value": args.cpu_steps / dt, "unit": "timesteps/s", "cores": cores, "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{args.cpu_steps} steps of the same {args.nx}x{args.ny} case after 1 warm-up step "
-                      f"(NumPy/SciPy oracle, OpenBLAS dgemm + pocketfft, setup {setup:.1f}s not timed)"}
+                      f"(NumPy/SciPy oracle, OpenBLAS dgemm on {cores} threads + pocketfft on all cores; setup {setup:.1f}s not timed)",
+            "seconds_per_step_by_phase": {k: round(v, 4) for k, v in sorted(phases.items(), key=lambda kv: -kv[1])}}
+    if not args.no_cpu_single_thread:
+        # the reference's advised setting OPENBLAS_NUM_THREADS=1 (README.md:45-47): one more step on a COPY of
+        # nothing -- the same instance simply takes one more step with BLAS limited to one thread; the
+        # parity engine below takes the same number of steps
+        try:
+            from threadpoolctl import threadpool_limits
+            import scipy.fft as _sfft
+            with threadpool_limits(limits=1), _sfft.set_workers(1):
+                from oracle import bases as _B
+                saved = _B.WORKERS
+                _B.WORKERS = 1
+                t0 = time.perf_counter()
+                ora.update()
+                one = time.perf_counter() - t0
+                _B.WORKERS = saved
+            base["single_thread"] = {"value": 1.0 / one, "unit": "timesteps/s", "cores": 1,
+                                     "sample": "1 further step with OpenBLAS and pocketfft limited to one thread"}
+            return base, ora, 2 + args.cpu_steps
+        except Exception as exc:   # noqa: BLE001
+            base["single_thread"] = {"error": repr(exc)}
     return base, ora, 1 + args.cpu_steps
 
 

@@ -14,6 +14,7 @@ import numpy as np
 import scipy.fft as _fft
 
 WORKERS = -1  # scipy.fft worker threads (rayon lanes in the reference)
+from .timing import timed  # noqa: E402  (per-phase CPU baseline of bench.py)
 
 CHEBYSHEV = "chebyshev"
 CHEB_DIRICHLET = "cheb_dirichlet"
@@ -95,6 +96,7 @@ class Base:
         f[-1] *= 2.0
         return f
 
+    @timed("transforms")
     def forward_ortho(self, v, axis):
         """physical (n) -> ORTHO coefficients (n real | n/2+1 complex)   (App. A.2, A.5)."""
         if self.is_cheb:
@@ -104,6 +106,7 @@ class Base:
             return y * self._cheb_fwd_factor().reshape(shape)
         return _fft.rfft(v, axis=axis, workers=WORKERS)  # unnormalised forward
 
+    @timed("transforms")
     def backward_ortho(self, c, axis):
         """ORTHO coefficients -> physical (n)."""
         if self.is_cheb:
@@ -114,6 +117,7 @@ class Base:
         return _fft.irfft(c, n=self.n, axis=axis, workers=WORKERS)  # carries 1/n
 
     # ------------------------------------------------- composite <-> ortho
+    @timed("stencil_gradient")
     def to_ortho(self, a, axis):
         """composite (m) -> ortho (n): c = S a   (``field.rs:113-115``)."""
         if not self.is_composite:
@@ -126,6 +130,7 @@ class Base:
         c[2:] += self.low[:, None] * a
         return c
 
+    @timed("stencil_gradient")
     def from_ortho(self, c, axis):
         """ortho (n) -> composite (m): least squares (S^T S) a = S^T c, stride-2 TDMA."""
         if not self.is_composite:
@@ -165,6 +170,7 @@ class Base:
         return self.backward_ortho(self.to_ortho(a, axis), axis)
 
     # ------------------------------------------------------- differentiation
+    @timed("stencil_gradient")
     def differentiate(self, a, order, axis):
         """coefficients -> ORTHO coefficients of the ``order``-th derivative (App. A.4).
 

@@ -16,6 +16,7 @@ import numpy as np
 import scipy.linalg as _la
 
 from .bases import Base, Space2, FOURIER_R2C, _axis0
+from .timing import phase, timed
 
 
 # --------------------------------------------------------------------------- Fdma
@@ -137,6 +138,7 @@ class HholtzAdi:
                 self.solver.append(Fdma(a_low, a_dia - b_dia * ci, a_up1 - b_up1 * ci, a_up2))
                 self.matvec.append(MatVecFdma(*precond, n_in=base.n))
 
+    @timed("helmholtz")
     def solve(self, inp):
         rhs = inp
         for axis in (0, 1):
@@ -272,14 +274,18 @@ class Poisson:
 
     def solve(self, inp):
         rhs = inp
-        for axis in (0, 1):
-            if self.matvec[axis] is not None:
-                rhs = self.matvec[axis].apply(rhs, axis)
-        out = self.fwd @ rhs if self.fwd is not None else rhs
-        # rows i of `out` are lanes along y; batch them: (ny_m, nx_m)
-        out = np.ascontiguousarray(fdma_solve0(self.row_bands(), np.ascontiguousarray(out.T)).T)
-        if self.bwd is not None:
-            out = self.bwd @ out
+        with phase("poisson_rows"):      # preconditioner + per-row factorisation and solve (poisson.rs:205-229)
+            for axis in (0, 1):
+                if self.matvec[axis] is not None:
+                    rhs = self.matvec[axis].apply(rhs, axis)
+        with phase("poisson_gemm"):      # poisson.rs:214-216
+            out = self.fwd @ rhs if self.fwd is not None else rhs
+        with phase("poisson_rows"):
+            # rows i of `out` are lanes along y; batch them: (ny_m, nx_m)
+            out = np.ascontiguousarray(fdma_solve0(self.row_bands(), np.ascontiguousarray(out.T)).T)
+        with phase("poisson_gemm"):      # poisson.rs:232-235
+            if self.bwd is not None:
+                out = self.bwd @ out
         return out
 
 
