@@ -267,10 +267,11 @@ class Navier2D:
         return rows
 
     def schedule(self):
-        """The launches of one step in issue order: list of (tag, algorithmic bytes, flops)."""
+        """The launches of one step in issue order: list of (tag, algorithmic bytes, flops, kernel
+        dispatches behind the launch -- a column scan is 5 or 3 kernels)."""
         buf = C.create_string_buffer(1 << 16)
         self._lib.call("rpde_navier2d_describe_step", self._h, buf, len(buf))
-        return [(t, float(b), float(f)) for t, b, f in
+        return [(t, float(b), float(f), int(n)) for t, b, f, n in
                 (line.split("\t") for line in buf.value.decode().splitlines())]
 
     def set_timed_tag(self, tag: str):

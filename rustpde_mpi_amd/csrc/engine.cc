@@ -691,7 +691,8 @@ std::string Navier2DEngine::describe_step() const {
   std::string out;
   for (const Launch& l : step_) {
     char buf[512];
-    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\n", l.tag, l.bytes, l.flops);
+    const int ndisp = l.type == Launch::kColHholtz ? 5 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
+    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\n", l.tag, l.bytes, l.flops, ndisp);
     out += buf;
   }
   return out;
@@ -979,7 +980,23 @@ void Navier2DEngine::build_confined() {
   // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
   struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
+  static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
   for (auto& f : s1) {
+    if (s1_merge) {
+      // one program per field: the orthonormal coefficients wait in the register stash while the value is
+      // transformed, then come back for the derivative -- the state line is read once instead of twice
+      ProgramBuilder pb = ypb(2, my);
+      pb.set_fft(*f.ax);
+      pb.load(0, pb.arr(yx(*f.st), ldx), mx);
+      pb.to_ortho(0, *f.ax);
+      pb.stash(0);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
+      pb.unstash_axpy(0, 0.0, 1.0, nx);
+      pb.cdiff(0, 0, nx, 1.0 / sx_);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
+      add_line(pb, "S1 x: state -> phys-x + d/dx");
+      continue;
+    }
     // two programs of two LDS slots each (the DCT works in place across slots 0 and 1), so
     // that two workgroups fit on a CU; the price is reading the state line twice
     for (int deriv = 0; deriv < 2; ++deriv) {

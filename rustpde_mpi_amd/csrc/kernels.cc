@@ -147,14 +147,20 @@ void launch_transpose(const double* in, long ldi, double* out, long ldo, int row
 // fragment read one contiguous 512-byte ds_read_b64 per wave (conflict free).
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 typedef double dbl2v __attribute__((ext_vector_type(2)));
+constexpr int kGemmDefaultVariant = 0;   // see gemm_f64_kernel: 0 = BK 16, 1 = + s_setprio, 2 = BK 32, 3 = BK 32 + s_setprio
 
-template <bool NN>
+// BK: k-depth of one LDS stage (16: 32 KB of LDS, 32: 64 KB and half as many barriers per flop);
+// PRIO: raise the wave priority around the MFMA bursts (s_setprio) so that the partner wave's memory
+// phase does not delay them.  The variant is chosen by the launcher (RPDE_GEMM_VARIANT, default below).
+template <bool NN, int BK, bool PRIO>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
                                                        const double* __restrict__ A, long lda,
                                                        const double* __restrict__ B, long ldb,
                                                        double* __restrict__ C, long ldc) {
-  __shared__ __attribute__((aligned(16))) double As[4][128][4];
-  __shared__ __attribute__((aligned(16))) double Bs[4][128][4];
+  constexpr int KS = BK / 4;      // k sub-steps (one MFMA k-depth each) per stage
+  constexpr int KT = BK / 2;      // doubles per thread and operand per stage
+  __shared__ __attribute__((aligned(16))) double As[KS][128][4];
+  __shared__ __attribute__((aligned(16))) double Bs[KS][128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
@@ -166,39 +172,39 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
-  const int arow = tid >> 1, akk = (tid & 1) * 8;        // A (and B when !NN): row, first k
+  double ra[KT], rb[KT];
+  const int arow = tid >> 1, akk = (tid & 1) * KT;       // A (and B when !NN): row, first k
   const int bn = tid & 127, bkp = tid >> 7;               // B when NN: column n, k pair (k = 4e + 2 bkp + {0,1})
-  // interior tiles (every row / column of the 128 x 128 block and all 16 k exist) load without
+  // interior tiles (every row / column of the 128 x 128 block and all BK k exist) load without
   // bounds checks and with 16-byte accesses; `vec16` = the operands allow aligned 16-byte loads
   const bool tile_full = (m0 + 128 <= M) && (n0 + 128 <= N);
   const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
 
   auto gload = [&](int k0) {
-    if (tile_full && k0 + 16 <= K) {
+    if (tile_full && k0 + BK <= K) {
       if (vec16) {
         const dbl2v* p = reinterpret_cast<const dbl2v*>(A + (long)(m0 + arow) * lda + k0 + akk);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
+        for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
       } else {
         const double* p = A + (long)(m0 + arow) * lda + k0 + akk;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ra[e] = p[e];
+        for (int e = 0; e < KT; ++e) ra[e] = p[e];
       }
       if constexpr (!NN) {
         if (vec16) {
           const dbl2v* p = reinterpret_cast<const dbl2v*>(B + (long)(n0 + arow) * ldb + k0 + akk);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const dbl2v v = p[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
+          for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
         } else {
           const double* p = B + (long)(n0 + arow) * ldb + k0 + akk;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) rb[e] = p[e];
+          for (int e = 0; e < KT; ++e) rb[e] = p[e];
         }
       } else {
         const double* p = B + (long)(k0 + 2 * bkp) * ldb + n0 + bn;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { rb[2 * e] = p[(long)(4 * e) * ldb]; rb[2 * e + 1] = p[(long)(4 * e + 1) * ldb]; }
+        for (int e = 0; e < KS; ++e) { rb[2 * e] = p[(long)(4 * e) * ldb]; rb[2 * e + 1] = p[(long)(4 * e + 1) * ldb]; }
       }
       return;
     }
@@ -206,19 +212,19 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
       const int r = m0 + arow;
       const double* p = A + (long)r * lda + k0 + akk;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ra[e] = (r < M && k0 + akk + e < K) ? p[e] : 0.0;
+      for (int e = 0; e < KT; ++e) ra[e] = (r < M && k0 + akk + e < K) ? p[e] : 0.0;
     }
     if constexpr (!NN) {
       const int r = n0 + arow;
       const double* p = B + (long)r * ldb + k0 + akk;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb[e] = (r < N && k0 + akk + e < K) ? p[e] : 0.0;
+      for (int e = 0; e < KT; ++e) rb[e] = (r < N && k0 + akk + e < K) ? p[e] : 0.0;
     } else {
-      // lanes run along n (coalesced 512-byte rows); each thread fetches the 8 k-values it will
-      // write to LDS as four 16-byte (k, k+1) pairs
+      // lanes run along n (coalesced 512-byte rows); each thread fetches the k-values it will
+      // write to LDS as 16-byte (k, k+1) pairs
       const int n = n0 + bn;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < KS; ++e) {
         const int k = k0 + 4 * e + 2 * bkp;
         rb[2 * e] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
         rb[2 * e + 1] = (k + 1 < K && n < N) ? B[(long)(k + 1) * ldb + n] : 0.0;
@@ -226,44 +232,46 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
     }
   };
   auto lstore = [&]() {
-    // 16-byte LDS stores: the 8 k-values of a thread are two runs of four (k % 4 = 0..3) of one row
+    // 16-byte LDS stores: the KT k-values of a thread are KT / 4 runs of four (k % 4 = 0..3) of one row
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < KT / 4; ++h) {
       dbl2v* d = reinterpret_cast<dbl2v*>(&As[(akk >> 2) + h][arow][0]);
       d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
       d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
     }
     if constexpr (!NN) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < KT / 4; ++h) {
         dbl2v* d = reinterpret_cast<dbl2v*>(&Bs[(akk >> 2) + h][arow][0]);
         d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
         d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < KS; ++e)
         *reinterpret_cast<dbl2v*>(&Bs[e][bn][2 * bkp]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
     }
   };
 
   gload(0);
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = 0; k0 < K; k0 += BK) {
     lstore();
     __syncthreads();
-    if (k0 + 16 < K) gload(k0 + 16);
+    if (k0 + BK < K) gload(k0 + BK);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       double a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = As[s][wm * 64 + i * 16 + l15][l4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = Bs[s][wn * 64 + j * 16 + l15][l4];
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
@@ -281,21 +289,27 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
     }
 }
 
+template <bool NN>
+static void launch_gemm(int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                        Stream& st) {
+  if (M <= 0 || N <= 0) return;
+  static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+    case 2: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+    case 3: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+    default: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+  }
+  RPDE_HIP(hipGetLastError());
+}
 void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream& st) {
-  if (M <= 0 || N <= 0) return;
-  dim3 grid((N + 127) / 128, (M + 127) / 128);
-  hipLaunchKernelGGL(gemm_f64_kernel<false>, grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C,
-                     ldc);
-  RPDE_HIP(hipGetLastError());
+  launch_gemm<false>(M, N, K, A, lda, B, ldb, C, ldc, st);
 }
 void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream& st) {
-  if (M <= 0 || N <= 0) return;
-  dim3 grid((N + 127) / 128, (M + 127) / 128);
-  hipLaunchKernelGGL(gemm_f64_kernel<true>, grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C,
-                     ldc);
-  RPDE_HIP(hipGetLastError());
+  launch_gemm<true>(M, N, K, A, lda, B, ldb, C, ldc, st);
 }
 
 // ------------------------------------------------------------------------------- callback diagnostics

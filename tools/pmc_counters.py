@@ -8,7 +8,9 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 d, sched = sys.argv[1], json.load(open(sys.argv[2]))
-L, steps = len(sched["schedule"]), sched["steps"]
+steps = sched["steps"]
+owner = [i for i, l in enumerate(sched["schedule"]) for _ in range(int(l.get("dispatches", 1)))]   # dispatch -> launch
+L = len(owner)
 path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 disp = defaultdict(lambda: defaultdict(float))
 for r in csv.DictReader(open(path)):
@@ -17,7 +19,7 @@ ids = sorted(disp)[-steps * L:]
 assert len(ids) == steps * L
 tags = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
 for n, i in enumerate(ids):
-    tag = sched["schedule"][n % L]["tag"]
+    tag = sched["schedule"][owner[n % L]]["tag"]
     cnt[tag] += 1
     for k, v in disp[i].items():
         tags[tag][k] += v

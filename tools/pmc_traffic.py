@@ -42,9 +42,17 @@ def main():
     p.add_argument("--out", required=True)
     a = p.parse_args()
     sch = json.load(open(a.schedule))
-    L, steps = len(sch["schedule"]), sch["steps"]
-    fe = per_position(a.fetch, "FETCH_SIZE", steps, L)
-    wr = per_position(a.write, "WRITE_SIZE", steps, L)
+    steps = sch["steps"]
+    # a launch of the schedule is one kernel dispatch, except the column scans (5 / 3 kernels)
+    nd = [int(l.get("dispatches", 1)) for l in sch["schedule"]]
+    L = sum(nd)
+    fe_d = per_position(a.fetch, "FETCH_SIZE", steps, L)
+    wr_d = per_position(a.write, "WRITE_SIZE", steps, L)
+    fe, wr, p = [], [], 0
+    for n in nd:   # fold the dispatches of a launch into one entry
+        fe.append((fe_d[p][0], sum(x[1] for x in fe_d[p:p + n])))
+        wr.append((wr_d[p][0], sum(x[1] for x in wr_d[p:p + n])))
+        p += n
     tags = {}
     for i, l in enumerate(sch["schedule"]):
         t = tags.setdefault(l["tag"], {"launches_per_step": 0, "algorithmic_bytes": l["bytes"], "flops": l["flops"],

@@ -17,18 +17,24 @@ def kind_of_tag(tag):
     if tag.startswith("G"): return "gemm"
     if tag.startswith("pseu"): return "set_element"
     if tag.startswith("H"): return "copy2d"
+    if tag.startswith("C4 y: hholtz"): return "col_hholtz"
+    if tag.startswith("C"): return "col_diff"
     return "line_kernel"
 
 
 def kind_of_kernel(name):
-    for k in ("transpose", "gemm", "set_element", "line_kernel", "copy2d"):
+    for k in ("transpose", "gemm", "set_element", "line_kernel", "copy2d", "col_hholtz", "col_diff"):
         if k in name: return k
     return "other"
 
 
 def main():
     d, sched = sys.argv[1], json.load(open(sys.argv[2]))
-    tags = [l["tag"] for l in sched["schedule"]]
+    # one entry per kernel dispatch: a column scan is 5 (Helmholtz) or 3 (derivative) kernels
+    tags = [l["tag"] for l in sched["schedule"] for _ in range(int(l.get("dispatches", 1)))]
+    launches = {}
+    for l in sched["schedule"]:
+        launches[l["tag"]] = launches.get(l["tag"], 0) + 1
     want = [kind_of_tag(t) for t in tags]
     L = len(tags)
     path = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
@@ -56,7 +62,16 @@ def main():
     out = [("tag", "launches_per_step", "launches", "mean_us", "min_us", "max_us", "us_per_step", "share")]
     for t in dict.fromkeys(tags):
         v = acc[t]
-        out.append((t, tags.count(t), len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}",
+        per = tags.count(t) // launches[t]          # kernels per launch of this tag
+        # mean / min / max per LAUNCH (the kernels of a column scan added up)
+        lv = [sum(v[i:i + per]) for i in range(0, len(v), per)] if per > 1 else v
+        if per > 1:   # acc appends dispatch by dispatch within a step: regroup per step first
+            lv = []
+            nl = launches[t]
+            for s_ in range(nsteps):
+                chunk = v[s_ * nl * per:(s_ + 1) * nl * per]
+                lv += [sum(chunk[i:i + per]) for i in range(0, len(chunk), per)]
+        out.append((t, launches[t], len(lv), f"{sum(lv)/len(lv):.2f}", f"{min(lv):.2f}", f"{max(lv):.2f}",
                     f"{sum(v)/nsteps:.1f}", f"{sum(v)/nsteps/step_us:.4f}"))
     out.append(("TOTAL kernel time per step", L, nsteps * L, "", "", "", f"{step_us:.1f}", "1.0"))
     w = csv.writer(open(sys.argv[3], "w") if len(sys.argv) > 3 else sys.stdout)
