@@ -138,15 +138,25 @@ class Navier2D:
         obj._comm = comm   # keeps the ctypes callback alive
         return obj
 
+    # The reference's constructors end with `navier.init_random(0.1)` (navier.rs:305, 425; an unseeded
+    # RNG).  The C ABI creates the engine with an all-zero state (a host calls rpde_navier2d_init_random
+    # itself); this mirror does what the reference does, with a fixed seed so that runs are reproducible.
+    # Pass init_random=None to keep the zero state.
     @classmethod
-    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None):
-        return cls._new("rpde_navier2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device,
-                        library, False, comm)
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None, init_random=0.1, seed=0):
+        obj = cls._new("rpde_navier2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device,
+                       library, False, comm)
+        if init_random is not None:
+            obj.init_random(init_random, seed)
+        return obj
 
     @classmethod
-    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None):
-        return cls._new("rpde_navier2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device,
-                        library, True, comm)
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None, init_random=0.1, seed=0):
+        obj = cls._new("rpde_navier2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device,
+                       library, True, comm)
+        if init_random is not None:
+            obj.init_random(init_random, seed)
+        return obj
 
     def comm_stats(self):
         """(bytes this rank sends per step, exchanges per step) of the pencil all-to-alls."""

@@ -92,7 +92,6 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
   hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, dt * nu_ / (sx_ * sx_), dt * nu_ / (sy_ * sy_));
   hh_temp_ = std::make_unique<HholtzAdiOp>(*sp_temp_, dt * ka_ / (sx_ * sx_), dt * ka_ / (sy_ * sy_));
-  pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_));
 
   ldx_ = pitch(periodic ? nx + 2 : nx);
   ldy_ = pitch((long)ny * ex_);
@@ -100,6 +99,10 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   ypart_ = split(ny, P);
   xpart_ = split(nx, P);
   kpart_ = periodic ? split(kx_, P) : xpart_;
+  // the factorised y-systems of the Poisson solve, one per x-row: a pencil-sharded rank keeps the rows
+  // of its own x-pencil only (0.67 GB at 4097^2 on one GPU, 84 MB per rank on eight)
+  pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_),
+                                      P > 1 ? kpart_[comm_.rank] : 0, P > 1 ? kpart_[comm_.rank + 1] : -1);
   yb_ = ypart_[comm_.rank]; ye_ = ypart_[comm_.rank + 1];
   nyl_ = ye_ - yb_;
   nxl_ = std::max(xpart_[comm_.rank + 1] - xpart_[comm_.rank], kpart_[comm_.rank + 1] - kpart_[comm_.rank]);

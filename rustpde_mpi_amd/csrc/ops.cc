@@ -207,8 +207,10 @@ void ProgramBuilder::from_ortho(int d, const AxisTables& ax) {
   rec1(d, d, m, nullptr, ax.fo_qdn.p, -1);
 }
 void ProgramBuilder::fdma_solve(int d, int n, const FdmaDev& f) {
-  rec1(d, d, n, nullptr, f.q1.p, +1, f.tabld);
-  rec2(d, d, n, f.p2.p, f.q2.p, f.r2.p, f.tabld);
+  // per-line tables hold the lines [row0, ...): the kernel indexes them with the global line number
+  const long off = f.row0 * f.tabld;
+  rec1(d, d, n, nullptr, f.q1.p - off, +1, f.tabld);
+  rec2(d, d, n, f.p2.p - off, f.q2.p - off, f.r2.p - off, f.tabld);
 }
 void ProgramBuilder::pinv_matvec(int d, const AxisTables& ax) {
   mv3(d, d, ax.base.n - 2, ax.pv0.p, ax.pv1.p, ax.pv2.p);
@@ -423,7 +425,7 @@ static Arr2 upload_dense(const double* src, int rows, int cols) {
   return a;
 }
 
-PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
+PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_end) : sp(s) {
   const Base& b0 = sp.base(0);
   const Base& b1 = sp.base(1);
   RPDE_REQUIRE(b1.is_composite(), "Poisson: axis 1 must be a composite Chebyshev base");
@@ -456,18 +458,21 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1) : sp(s) {
   const Bands cy = hholtz_mat_a(b1);
   const LineClass lc = line_class_for(sp.axis(1).slot_len);
   const long ld = (long)lc.T * lc.C;   // one chunk-major table row per x-row
-  Vec q1((size_t)m0 * ld, 0.0), p2((size_t)m0 * ld, 0.0), q2((size_t)m0 * ld, 0.0), r2((size_t)m0 * ld, 0.0);
-  for (int r = 0; r < m0; ++r) {
+  const int rb = std::max(0, row_begin), re = (row_end < 0 || row_end > m0) ? m0 : row_end;
+  const size_t nr = (size_t)std::max(0, re - rb);
+  Vec q1(nr * ld, 0.0), p2(nr * ld, 0.0), q2(nr * ld, 0.0), r2(nr * ld, 0.0);
+  for (int r = rb; r < re; ++r) {
     Bands mtx = bands_axpy(ay, lam[r], cy);
     fdma_sweep(mtx);
     FdmaTables t = fdma_tables(mtx);
     const Vec a = chunk_major(t.q1, lc, +1), b = chunk_major(t.p2, lc, -1, 1.0),
               c = chunk_major(t.q2, lc, -1), d = chunk_major(t.r2, lc, -1);
-    std::copy(a.begin(), a.end(), q1.begin() + (size_t)r * ld);
-    std::copy(b.begin(), b.end(), p2.begin() + (size_t)r * ld);
-    std::copy(c.begin(), c.end(), q2.begin() + (size_t)r * ld);
-    std::copy(d.begin(), d.end(), r2.begin() + (size_t)r * ld);
+    std::copy(a.begin(), a.end(), q1.begin() + (size_t)(r - rb) * ld);
+    std::copy(b.begin(), b.end(), p2.begin() + (size_t)(r - rb) * ld);
+    std::copy(c.begin(), c.end(), q2.begin() + (size_t)(r - rb) * ld);
+    std::copy(d.begin(), d.end(), r2.begin() + (size_t)(r - rb) * ld);
   }
+  rows.row0 = rb;
   rows.n = m1;
   rows.tabld = ld;
   rows.q1.upload(q1); rows.p2.upload(p2); rows.q2.upload(q2); rows.r2.upload(r2);

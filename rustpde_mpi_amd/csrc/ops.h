@@ -35,6 +35,7 @@ struct AxisTables {
 // swept Fdma solve tables on device: constant (tabld = 0) or one row of tables per line
 struct FdmaDev {
   DBuf q1, p2, q2, r2;
+  long row0 = 0;   // per-line tables: global index of the first line they hold (pencil-sharded engines keep their own rows only)
   long tabld = 0;
   int n = 0;
 };
@@ -176,7 +177,9 @@ class HholtzAdiOp {
 // Poisson (src/solver/poisson.rs:54-94,195-236) on canonical arrays
 class PoissonOp {
  public:
-  PoissonOp(Space2Ops& sp, double c0, double c1);
+  // row_begin / row_end: the x-rows (eigen index, or wavenumber when periodic) whose factorised y-systems
+  // are kept on this device; the default keeps all of them.  A pencil-sharded rank only solves its own rows.
+  PoissonOp(Space2Ops& sp, double c0, double c1, int row_begin = 0, int row_end = -1);
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
   Space2Ops& sp;
   // x direction
