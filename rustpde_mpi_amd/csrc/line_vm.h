@@ -820,6 +820,84 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
   RPDE_SYNC(blk);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chebyshev derivative d_k = d_{k+2} + 2 (k+1) a_{k+1} (funspace gradient, src/field.rs:127-129) as a
+// plain suffix sum: the affine maps of scan_recurrence all have the matrix 1, so a chunk is reduced
+// to ONE number per parity, the prefix moves one double per step (no map composition) and the
+// re-run of the chunk becomes an addition.  0.109 ms against 0.117 ms per 4097 x 4096 launch for the
+// generic scan.  (The same idea with TABULATED matrices for the banded solves -- two doubles per
+// step times a fetched 2 x 2 window matrix, homogeneous responses fetched instead of re-run -- was
+// measured SLOWER than composing the maps on the fly, 0.33 vs 0.27 ms for the Helmholtz solve: the
+// extra table fetches from L2 cost more than the arithmetic they replace.  Dropped.)
+template <class Cfg>
+RPDE_DEVN void scan_cheb_diff(Blk& blk, lds_t dst, clds_t src, int n, lds_t carry, double scale) {
+  constexpr int T = Cfg::T, C = Cfg::C, NW = (T + 63) / 64;
+  RPDE_TLS(blk, double, zz, C);        // suffix sums of the chunk from a zero inflow, later the result
+  RPDE_TLS(blk, double, vv, 2);        // chunk totals per parity, later the chunk inflows
+  RPDE_PHASE(blk, tid) {
+    const int lo = (T - 1 - tid) * C;  // descending: the carry flows from thread t-1 to thread t
+    double bb[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const int k = lo + i;
+      const double sv = src[k + 1];
+      bb[i] = (k + 1 < n) ? 2.0 * (double)(k + 1) * sv : 0.0;
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      double z = 0.0;
+#pragma unroll
+      for (int i = 0; i < C / 2; ++i) {
+        const int e = C - 2 + par - 2 * i;
+        z += (lo + e < n) ? bb[e] : 0.0;
+        RPDE_T(zz)[e] = z;
+      }
+      RPDE_T(vv)[par] = z;
+    }
+  }
+#ifdef RPDE_EMU
+  for (int par = 0; par < 2; ++par) {
+    double run = 0.0;
+    for (int t = 0; t < T; ++t) { const double mine = vv_st[(size_t)t * 2 + par]; vv_st[(size_t)t * 2 + par] = run; run += mine; }
+  }
+  (void)carry;
+#else
+  {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double v[2] = {vv[0], vv[1]};
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const double u = __shfl_up(v[par], o);
+        v[par] += (lane >= o) ? u : 0.0;
+      }
+    double S[2] = {0.0, 0.0};
+    if constexpr (NW > 1) {
+      if (lane == 63) { carry[wave] = v[0]; carry[NW + wave] = v[1]; }
+      __syncthreads();
+      for (int u = 0; u < wave; ++u) { S[0] += carry[u]; S[1] += carry[NW + u]; }
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const double e = __shfl_up(v[par], 1);
+      vv[par] = ((lane == 0) ? 0.0 : e) + S[par];
+    }
+  }
+#endif
+  RPDE_SYNC(blk);   // every thread has consumed its inputs (in-place operation is allowed)
+  RPDE_PHASE(blk, tid) {
+    const int lo = (T - 1 - tid) * C;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const int k = lo + i;
+      const double x = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * scale : scale);
+      if (k < n) dst[k] = x;
+    }
+  }
+  RPDE_SYNC(blk);
+}
+
 // generic table-driven recurrence: x_k = p_k src_k + q_k x_pred (+ r_k x_pred2).  The tables are
 // stored CHUNK-MAJOR for the kernel configuration (entry [i * T + t] belongs to element i of the
 // chunk thread t owns, see chunk_major() in kernels.h), so that a wave reads 512 contiguous bytes.
@@ -831,14 +909,6 @@ struct FillRec {
     if constexpr (HASP) b = pt[ti] * s; else b = s;
     q = qt[ti];
     if constexpr (HASR) r = rt[ti];
-  }
-};
-struct FillDiff {  // d_k = d_{k+2} + 2 (k+1) a_{k+1}
-  clds_t src; int n;
-  RPDE_DEV void operator()(int k, int, double& b, double& q, double&) const {
-    const double s = src[k + 1];
-    b = (k + 1 < n) ? 2.0 * (double)(k + 1) * s : 0.0;
-    q = 1.0;
   }
 };
 
@@ -1006,15 +1076,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_CDIFF: if constexpr (Cfg::kCheb) {
-        scan_recurrence<Cfg, 1, -1>(blk, d, n, carry, FillDiff{a, n});
-        RPDE_PHASE(blk, tid) {
-#pragma unroll
-          for (int q = 0; q < EPT; ++q) {
-            const int k = tid + q * T;
-            if (k < n) d[k] *= (k == 0) ? 0.5 * op.s0 : op.s0;
-          }
-        }
-        RPDE_SYNC(blk);
+        scan_cheb_diff<Cfg>(blk, d, a, n, carry, op.s0);
       } break;
       case OP_REC1: if constexpr (Cfg::kCheb) {
         tab_t qt = (tab_t)(pg.tabs[op.i0] + toff);
