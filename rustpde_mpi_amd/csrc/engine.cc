@@ -930,6 +930,16 @@ void Navier2DEngine::callback() {
 void Navier2DEngine::refresh_gy() {
   const bool spec = periodic_;
   const int rows_x = sp_ortho_->ortho_rows();
+  if (comm_.size == 1) {
+    // the same column scan the step runs (C10): a restarted run continues bit-identically
+    ColDiffArgs a{};
+    a.nout = ny_; a.m = ny_; a.ncols = rows_x * ex_; a.BR = kColBlockRows; a.NB = (ny_ + kColBlockRows - 1) / kColBlockRows;
+    a.ldi = ldx_; a.ldo = ldx_; a.in = yx(P_); a.out = yx(GY_); a.low = nullptr; a.scale = 1.0 / sy_;
+    a.vd = coldv_.p; a.sd = colds_.p;
+    launch_col_diff(a, st_);
+    dev_sync(st_);
+    return;
+  }
   exchange(yx(P_), ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, true, spec);
   ProgramBuilder pb(1, sp_ortho_->axis(1).slot_len, xlines(rows_x, spec), ex_);
   pb.set_fft(sp_ortho_->axis(1));

@@ -126,3 +126,26 @@ def test_callback_cadence_and_info_file(emu_lib, tmp_path, monkeypatch, capfd):
     assert abs(File("data/flow00000.08.h5").datasets["time"][0] - 0.08) < 1e-12
     out = capfd.readouterr().out
     assert out.count("|div| =") == 5 and "Nu = " in out and "Re = " in out
+
+
+@pytest.mark.gpu
+def test_snapshot_restart_and_callback_on_the_gpu(hip_lib, tmp_path, monkeypatch):
+    """The same I/O path through the HIP build: write / independent parse / bit-exact restart, callback
+    with the device-side reduction of Nu, Nuvol, Re."""
+    monkeypatch.chdir(tmp_path)
+    nav, ora = K.make_pair(hip_lib, False, 129, 65, 1e5, 1.0, 0.01, 1.0)
+    nav.update(5)
+    nav.write("snap.h5")
+    f = File("snap.h5").datasets
+    assert np.array_equal(f["temp/v"], nav.temp.v) and np.array_equal(f["ux/vhat"], nav.velx.vhat)
+    nav2 = R.Navier2D.new_confined(129, 65, 1e5, 1.0, 0.01, 1.0, "rbc", library=hip_lib)
+    nav2.read("snap.h5")
+    nav.update(3); nav2.update(3)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert np.array_equal(getattr(nav, k).vhat, getattr(nav2, k).vhat), k
+    nav.callback()
+    for _ in range(8):
+        ora.update()
+    t, nu, nuv, re = (float(v) for v in open("data/info.txt").read().split())
+    assert abs(nu - ora.eval_nu()) < 1e-9 and abs(nuv - ora.eval_nuvol()) < 1e-9 and abs(re - ora.eval_re()) < 1e-9 * ora.eval_re()
+    assert os.path.exists("data/flow00000.08.h5")
