@@ -48,6 +48,7 @@ SIGNATURES = {
     "rpde_navier2d_last_update_ms": (C.c_int, [_vp, _dp]),
     "rpde_navier2d_profile": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_size_t]),
     "rpde_navier2d_describe_step": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "rpde_navier2d_trace_launch": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_size_t]),
     "rpde_navier2d_set_timed_tag": (C.c_int, [_vp, C.c_char_p]),
     "rpde_navier2d_get_timed": (C.c_int, [_vp, _dp, C.POINTER(C.c_long)]),
     "rpde_navier2d_time": (C.c_int, [_vp, _dp]),

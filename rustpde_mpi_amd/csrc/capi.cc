@@ -230,6 +230,15 @@ int rpde_navier2d_profile(rpde_navier2d* h, int nsteps, char* buf, size_t len) {
     std::memcpy(buf, s.c_str(), s.size() + 1);
   })
 }
+int rpde_navier2d_trace_launch(rpde_navier2d* h, const char* tag, char* buf, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(buf && len > 0, "null pointer"); select_device(h->device);
+    const std::string s = h->e->trace_launch(tag ? tag : "");
+    RPDE_REQUIRE(s.size() + 1 <= len, "trace buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  })
+}
+
 int rpde_navier2d_describe_step(rpde_navier2d* h, char* buf, size_t len) {
   RPDE_TRY({
     RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(buf && len > 0, "null pointer");

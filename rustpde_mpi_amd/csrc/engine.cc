@@ -34,6 +34,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
     : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RPDE_DCT_PAIR")) dct_pair_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
   RPDE_REQUIRE(comm_.size <= 8, "at most 8 ranks (one xGMI-connected MI355X node; the exchange descriptors hold 8 peers)");
   RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr || comm_.rccl != nullptr,
@@ -701,6 +702,58 @@ std::string Navier2DEngine::describe_step() const {
   return out;
 }
 
+std::string Navier2DEngine::trace_launch(const std::string& tag) {
+  static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct", "dct2",
+                                         "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy"};
+  size_t which = step_.size();
+  for (size_t i = 0; i < step_.size(); ++i)
+    if (step_[i].type == Launch::kLine && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
+  RPDE_REQUIRE(which < step_.size(), "trace_launch: no line program with tag containing \"" + tag + "\"");
+  std::string out;
+#ifndef RPDE_EMU
+  Launch l = step_[which];
+  const long nblk = 8L * ((l.pg.nlines + 7) / 8) * l.pg.ncomp;
+  DBuf buf;
+  buf.alloc((size_t)nblk * kTraceStride);            // doubles and long longs are both 8 bytes
+  RPDE_HIP(hipMemsetAsync(buf.p, 0, (size_t)nblk * kTraceStride * 8, st_.s));
+  l.pg.trace = reinterpret_cast<long long*>(buf.p);
+  for (size_t i = 0; i < step_.size(); ++i) run_launch(i == which ? l : step_[i]);
+  dev_sync(st_);
+  time_ += dt_;
+  std::vector<long long> h((size_t)nblk * kTraceStride);
+  dev_download(h.data(), buf.p, h.size() * 8);
+  const int nops = l.pg.nops;
+  std::vector<std::vector<double>> dur(nops + 1);
+  long long w0 = 0, w1 = 0;
+  for (long b = 0; b < nblk; ++b) {
+    const long long* t = &h[(size_t)b * kTraceStride];
+    if (t[1] == 0) continue;                           // padding workgroup (line >= nlines)
+    if (w0 == 0 || t[0] < w0) w0 = t[0];
+    if (t[1] > w1) w1 = t[1];
+    for (int ip = 0; ip < nops; ++ip) dur[ip].push_back((double)(t[3 + ip] - t[2 + ip]));
+    dur[nops].push_back((double)(t[2 + nops] - t[2]));
+  }
+  char line[256];
+  snprintf(line, sizeof line, "%s\t%ld\t%.3f\n", l.tag, (long)dur[nops].size(), (double)(w1 - w0) * 1e-5);   // tag, workgroups, span in ms (100 MHz)
+  out += line;
+  for (int ip = 0; ip <= nops; ++ip) {
+    std::vector<double>& d = dur[ip];
+    std::sort(d.begin(), d.end());
+    double mean = 0;
+    for (double v : d) mean += v;
+    mean /= std::max<size_t>(1, d.size());
+    const double med = d.empty() ? 0 : d[d.size() / 2], p10 = d.empty() ? 0 : d[d.size() / 10], p90 = d.empty() ? 0 : d[d.size() * 9 / 10];
+    const int code = ip < nops ? l.pg.ops[ip].code : 0;
+    snprintf(line, sizeof line, "%d\t%s\t%.0f\t%.0f\t%.0f\t%.0f\n", ip, ip < nops ? kOpNames[code] : "program", mean, p10, med, p90);
+    out += line;
+  }
+#else
+  (void)kOpNames;
+  out = std::string(step_[which].tag) + "\t0\t0\n";
+#endif
+  return out;
+}
+
 double Navier2DEngine::div_norm() {
   // div = d/dx velx + d/dy vely in the orthonormal space (navier_eq.rs:19-24), through the
   // generic operators (diagnostic path, not part of the step)
@@ -971,6 +1024,7 @@ void Navier2DEngine::build_confined() {
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = nx * 2 / 3, cut_y = ny * 2 / 3;
+  const bool pair = dct_pair_ && xD.pair_dct_ok() && yD.pair_dct_ok();   // OP_DCT2 where two lines go together
   // builders for programs over y-indexed lines (YX arrays) and x-indexed lines (XY arrays)
   auto ypb = [&](int nslots, int rows) {
     ProgramBuilder pb(nslots, slx, ylines(rows));
@@ -1002,11 +1056,19 @@ void Navier2DEngine::build_confined() {
       pb.set_fft(*f.ax);
       pb.load(0, pb.arr(yx(*f.st), ldx), mx);
       pb.to_ortho(0, *f.ax);
-      pb.stash(0);
-      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
-      pb.unstash_axpy(0, 0.0, 1.0, nx);
-      pb.cdiff(0, 0, nx, 1.0 / sx_);
-      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
+      if (pair) {
+        // value and x-derivative of the line are transformed TOGETHER (one complex sequence, dct_pair.h)
+        pb.cdiff(1, 0, nx, 1.0 / sx_);
+        pb.dct_pair(0, nx, f.ax->bwd_pre.p, nullptr);
+        pb.store(0, pb.arr(yx(*f.w0), ldx), nx);
+        pb.store(1, pb.arr(yx(*f.w1), ldx), nx);
+      } else {
+        pb.stash(0);
+        pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
+        pb.unstash_axpy(0, 0.0, 1.0, nx);
+        pb.cdiff(0, 0, nx, 1.0 / sx_);
+        pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
+      }
       add_line(pb, "S1 x: state -> phys-x + d/dx");
       continue;
     }
@@ -1031,6 +1093,18 @@ void Navier2DEngine::build_confined() {
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
   // physical velocities once per step (shared by the three convection programs)
+  if (pair) {   // u and v of an x-row are transformed together (dct_pair.h)
+    ProgramBuilder pb = xpb(2, nx);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[0].p, ldy), my);
+    pb.to_ortho(0, yD);
+    pb.load(1, pb.arr(X_[2].p, ldy), my);
+    pb.to_ortho(1, yD);
+    pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
+    pb.store(0, pb.arr(UP_.p, ldy), ny);
+    pb.store(1, pb.arr(VP_.p, ldy), ny);
+    add_line(pb, "S2 y: velx, vely -> phys");
+  } else
   for (int w = 0; w < 2; ++w) {
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
@@ -1043,6 +1117,23 @@ void Navier2DEngine::build_confined() {
     // waits in the register stash, so two workgroups share a CU
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
+    if (pair) {
+      // d/dx f and d/dy f of the x-row go to physical space together; no register stash needed
+      pb.load(0, pb.arr(fx.p, ldy), my);      // d/dx f (x-derivative taken in S1)
+      pb.to_ortho(0, yD);
+      pb.load(1, pb.arr(f0.p, ldy), my);      // d/dy f
+      pb.to_ortho(1, yD);
+      pb.cdiff(1, 1, ny, 1.0 / sy_);
+      pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
+      if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+      if (by) pb.load(1, pb.arr(by->p, ldy), ny, 1.0, true);
+      pb.loadmul(1, pb.arr(VP_.p, ldy), ny);
+      pb.axpby(0, 0, 1.0, 1, 1.0, ny);
+      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+      add_line(pb, tag);
+      return;
+    }
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
@@ -1279,6 +1370,7 @@ void Navier2DEngine::build_periodic() {
   AxisTables& yD = sp_vel_->axis(1);             // Dirichlet(ny)
   AxisTables& yN = sp_pseu_->axis(1);            // Neumann(ny)
   const int slx = xF.slot_len, sly = yD.slot_len;
+  const bool pair = dct_pair_ && yD.pair_dct_ok();   // OP_DCT2 where two lines go together
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = kx * 2 / 3, cut_y = ny * 2 / 3;
@@ -1319,6 +1411,18 @@ void Navier2DEngine::build_periodic() {
   for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
+  if (pair) {   // u and v of an x-row are transformed together (dct_pair.h)
+    ProgramBuilder pb = xpb(2, nx, false);
+    pb.set_fft(yD);
+    pb.load(0, pb.arr(X_[0].p, ldy), my);
+    pb.to_ortho(0, yD);
+    pb.load(1, pb.arr(X_[2].p, ldy), my);
+    pb.to_ortho(1, yD);
+    pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
+    pb.store(0, pb.arr(UP_.p, ldy), ny);
+    pb.store(1, pb.arr(VP_.p, ldy), ny);
+    add_line(pb, "S2 y: velx, vely -> phys");
+  } else
   for (int w = 0; w < 2; ++w) {
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
@@ -1331,6 +1435,23 @@ void Navier2DEngine::build_periodic() {
     // waits in the register stash
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
+    if (pair) {
+      // d/dx f and d/dy f of the x-row go to physical space together; no register stash needed
+      pb.load(0, pb.arr(fx.p, ldy), my);      // d/dx f (x-derivative taken in S1)
+      pb.to_ortho(0, yD);
+      pb.load(1, pb.arr(f0.p, ldy), my);      // d/dy f
+      pb.to_ortho(1, yD);
+      pb.cdiff(1, 1, ny, 1.0 / sy_);
+      pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
+      if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+      if (by) pb.load(1, pb.arr(by->p, ldy), ny, 1.0, true);
+      pb.loadmul(1, pb.arr(VP_.p, ldy), ny);
+      pb.axpby(0, 0, 1.0, 1, 1.0, ny);
+      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+      add_line(pb, tag);
+      return;
+    }
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);

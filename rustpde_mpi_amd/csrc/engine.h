@@ -86,6 +86,9 @@ class Navier2DEngine {
   void set_timed_tag(const std::string& tag) { timed_tag_ = tag; timed_ms_ = 0; timed_count_ = 0; }
   void get_timed(double* ms, long* count) const { *ms = timed_ms_; *count = timed_count_; }
   std::string describe_step() const;
+  // diagnostics: one step with the first line-program launch whose tag contains `tag` instrumented
+  // (Program::trace); text table of the per-op shader-clock durations over its workgroups
+  std::string trace_launch(const std::string& tag);
   void grid(int axis, double* x, size_t len) const;
   void sync() { dev_sync(st_); }
   int nx() const { return nx_; }
@@ -197,6 +200,7 @@ class Navier2DEngine {
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;   // brackets of update(), created once
 #endif
   bool use_graph_ = true;
+  bool dct_pair_ = true;   // backward DCTs of two lines of a row as one complex transform (dct_pair.h); RPDE_DCT_PAIR=0: one by one
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);

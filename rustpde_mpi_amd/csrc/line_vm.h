@@ -63,6 +63,8 @@ enum OpCode : int {
   OP_REC2,     // descending second-order: x_k = p_k b_k + q_k x_{k+2} + r_k x_{k+4}; p = tab, q = i0, r = i1; slot b (the last one) = scratch
   OP_DCT,      // slot d (scratch d+1): x <- DCT-I(x * pre) * post ; n = N+1; direct path: pre = table tab (-1 none), post = table i0;
                // FFT path: tab / i0 >= 0 = standard backward pre / forward post scaling on, a = first zeroed coefficient, s1 = 1/N
+  OP_DCT2,     // FFT path only: the lines in slots d and d + 1 (n = N + 1 reals each) are transformed TOGETHER as one
+               // complex sequence (dct_pair.h); tab / i0 / a / s1 as the FFT-path flags of OP_DCT
   OP_MUL,      // d[k] = (acc ? d[k] : 0) + s0 * a[k] * b[k]
   OP_AXPBY,    // d[k] = s0 * a[k] + s1 * b[k]
   OP_ZERO,     // d[k] = 0 for i0 <= k < i1
@@ -95,6 +97,7 @@ struct Op {
 };
 
 constexpr int kMaxOps = 40;
+constexpr int kTraceStride = kMaxOps + 4;   // [0], [1]: 100 MHz wall clock at entry / exit; [2 + ip]: shader clock when thread 0 reaches op ip; [2 + nops]: at exit
 constexpr int kMaxArr = 16;
 constexpr int kMaxTab = 24;
 
@@ -109,6 +112,7 @@ struct Program {
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
   int tw2;        // table index of the split twiddles (cos, sin)(pi k / N) resp. (2 pi k / nx)
   int* nanflag;   // device flag raised by guarded stores (OP_STORE with acc = 1); may be null
+  long long* trace;   // diagnostics (tools/trace_ops.py): kTraceStride stamps per workgroup, see run_line_program; normally null
   Op ops[kMaxOps];
   ArrayRef arr[kMaxArr];
   const double* tabs[kMaxTab];
@@ -450,6 +454,10 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, 
     }
   }
 }
+
+}  // namespace rpde
+#include "dct_pair.h"
+namespace rpde {
 
 // direct O(n^2) DCT-I for line lengths without an FFT plan (small / odd sizes); costab[m] = cos(pi m / N), m < 2N
 template <class Cfg>
@@ -932,8 +940,15 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   const int SL = pg.slot_len;
   lds_t lds = (lds_t)blk.lds;
   lds_t carry = lds + pg.nslots * SL + (T * EPT - SL) + 8;
+#ifndef RPDE_EMU
+  long long* const trc = pg.trace ? pg.trace + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride : nullptr;
+  if (trc && threadIdx.x == 0) trc[0] = (long long)wall_clock64();
+#endif
   for (int ip = 0; ip < pg.nops; ++ip) {
     const Op& op = pg.ops[ip];
+#ifndef RPDE_EMU
+    if (trc && threadIdx.x == 0) trc[2 + ip] = (long long)clock64();
+#endif
     lds_t d = lds + op.d * SL;
     clds_t a = lds + op.a * SL;
     clds_t b = lds + op.b * SL;
@@ -1121,6 +1136,10 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
         }
       } break;
+      case OP_DCT2: if constexpr (Cfg::kCheb) {
+        dct1_pair_lds<Cfg>(blk, d, SL, n - 1, op.tab >= 0, op.i0 >= 0, op.a, op.s1, (tab_t)pg.tabs[pg.tw],
+                           (tab_t)pg.tabs[pg.tw2]);
+      } break;
       case OP_MUL: {
         RPDE_PHASE(blk, tid) {
 #pragma unroll
@@ -1217,6 +1236,9 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       default: break;
     }
   }
+#ifndef RPDE_EMU
+  if (trc && threadIdx.x == 0) { trc[2 + pg.nops] = (long long)clock64(); trc[1] = (long long)wall_clock64(); }
+#endif
 }
 
 }  // namespace rpde

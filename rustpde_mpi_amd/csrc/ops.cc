@@ -175,6 +175,17 @@ void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const do
   dct_flags(o, n, pre, post, cut);
   o.arr = store_arr; o.b = nstore; o.s0 = scale;
 }
+void ProgramBuilder::dct_pair(int d, int n, const double* pre, const double* post, int cut) {
+  RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT2 transforms slots d and d + 1");
+  if (pg.fft_n == 0) {   // direct O(n^2) transform: in place, one line after the other
+    Op& o1 = push(OP_DCT); o1.d = d; o1.n = n; o1.i1 = -1; o1.arr = -1; o1.tab = pre ? tab(pre) : -1; o1.i0 = post ? tab(post) : -1;
+    Op& o2 = push(OP_DCT); o2.d = d + 1; o2.n = n; o2.i1 = -1; o2.arr = -1; o2.tab = pre ? tab(pre) : -1; o2.i0 = post ? tab(post) : -1;
+    return;
+  }
+  RPDE_REQUIRE(pg.fft_n >= 8 && pg.fft_n <= 4096, "OP_DCT2: lines of 9 .. 4097 points (AxisTables::pair_dct_ok)");
+  Op& o = push(OP_DCT2); o.d = d; o.n = n; o.i1 = -1; o.arr = -1;
+  dct_flags(o, n, pre, post, cut);
+}
 void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {
   Op& o = push(OP_MUL); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.acc = acc;
 }

@@ -25,6 +25,8 @@ struct AxisTables {
   DBuf fo_t0, fo_t1, fo_t2, fo_pup, fo_qup, fo_qdn;  // from_ortho
   DBuf pv0, pv1, pv2;                           // B2 pseudo-inverse rows (Chebyshev family)
   explicit AxisTables(const Base& b);
+  // OP_DCT2 (two lines per transform, dct_pair.h) handles the direct path and FFT lines of 9 .. 4097 points
+  bool pair_dct_ok() const { return base.is_cheb() && (fft_n == 0 || (fft_n >= 8 && fft_n <= 4096)); }
   int n_phys() const { return base.n; }
   int n_ortho() const { return base.n_ortho(); }   // complex count for Fourier
   int n_spec() const { return base.m; }
@@ -78,6 +80,9 @@ class ProgramBuilder {
   // values, scaled).  Fall back to separate ops when the line uses the direct (non-FFT) transform.
   void dct_fused(int d, const AxisTables& ax, bool sten, const double* pre, const double* post,
                  int store_arr = -1, int nstore = 0, double scale = 1.0, int cut = -1);
+  // the lines in slots d and d + 1 transformed together (two DCT-I for the price of one: dct_pair.h);
+  // same `pre` / `post` / `cut` meaning as dct().  Lines without an FFT plan get two direct transforms.
+  void dct_pair(int d, int n, const double* pre, const double* post, int cut = -1);
   void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
   void axpby(int d, int a, double s0, int b, double s1, int n);
   // per-thread register copy of slot a (kept until the end of the program), and

@@ -59,6 +59,8 @@ struct Blk {          // one workgroup
 };
 #define RPDE_PHASE(blk, tid) for (int tid = 0; tid < (blk).T; ++tid)
 #define RPDE_SYNC(blk) ((void)0)
+#define RPDE_WSYNC() ((void)0)
+#define RPDE_CLZ(x) __builtin_clz((unsigned)(x))
 #define RPDE_TLS(blk, type, name, K) std::vector<type> name##_st((size_t)(blk).T * (K)); const int name##_K = (K)
 #define RPDE_T(name) (&name##_st[(size_t)tid * name##_K])
 #else
@@ -81,6 +83,11 @@ __device__ __forceinline__ int rpde_tid() {
 }
 #define RPDE_PHASE(blk, tid) for (int tid = rpde_tid(), _once = 1; _once; _once = 0)
 #define RPDE_SYNC(blk) __syncthreads()
+// ordering point for LDS traffic INSIDE one wavefront (lanes of a wave run in lockstep and the LDS serves
+// a wave's accesses in order): the compiler must not move LDS accesses across it, the hardware needs nothing
+#define RPDE_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define RPDE_CLZ(x) __clz((int)(x))
 #define RPDE_TLS(blk, type, name, K) type name[K]
 #define RPDE_T(name) name
 #endif
