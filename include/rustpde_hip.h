@@ -100,9 +100,10 @@ int rpde_navier2d_set_timed_tag(rpde_navier2d* h, const char* tag);
 int rpde_navier2d_describe_step(rpde_navier2d* h, char* buf, size_t len);
 int rpde_navier2d_get_timed(rpde_navier2d* h, double* ms_total, long* launches);
 /* diagnostics (tools/trace_ops.py): runs one step with the first line program whose tag contains `tag`     *
- * instrumented; "tag\tworkgroups\tspan_ms\n" then "ip\top\tmean\tp10\tmedian\tp90\n" per op of the program   *
- * (shader clocks from the moment thread 0 reaches the op to the moment it reaches the next one), last row  *
- * = the whole program                                                                                     */
+ * instrumented: thread 0 of every workgroup records the shader clock when it reaches an op and when it    *
+ * leaves a barrier.  "tag\tworkgroups\tspan_ms\tmarks\n", then one row per mark in program order,          *
+ * "id\tname\tmean\tp10\tmedian\tp90\n" = clocks since the previous mark over the workgroups (id >= 0: op  *
+ * id starts, -1: a barrier inside the op, first row (-2) = the whole program)                            */
 int rpde_navier2d_trace_launch(rpde_navier2d* h, const char* tag, char* buf, size_t len);
 /* Integrate::get_time / get_dt                               src/navier_stokes/navier.rs:468-474 */
 int rpde_navier2d_time(rpde_navier2d* h, double* t);

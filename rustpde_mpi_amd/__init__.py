@@ -286,12 +286,13 @@ class Navier2D:
 
     def trace_launch(self, tag: str):
         """Diagnostics: one step with the first line program whose tag contains `tag` instrumented.
-        Returns (tag, workgroups, span_ms, rows) with rows = (ip, op, mean, p10, median, p90) in shader
-        clocks per op of the program; the last row is the whole program."""
-        buf = C.create_string_buffer(1 << 16)
+        Returns (tag, workgroups, span_ms, rows); rows = (id, name, mean, p10, median, p90): shader clocks
+        since the previous mark; id >= 0: op id starts, -1: a barrier inside the op, -2 (first row): the
+        whole program."""
+        buf = C.create_string_buffer(1 << 17)
         self._lib.call("rpde_navier2d_trace_launch", self._h, tag.encode(), buf, len(buf))
         lines = buf.value.decode().splitlines()
-        t, n, span = lines[0].split("\t")
+        t, n, span, _ = lines[0].split("\t")
         rows = [(int(a), b, float(c), float(d), float(e), float(f)) for a, b, c, d, e, f in (l.split("\t") for l in lines[1:])]
         return t, int(n), float(span), rows
 

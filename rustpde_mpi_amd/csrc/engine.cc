@@ -34,7 +34,6 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
     : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
-  if (const char* e = std::getenv("RPDE_DCT_PAIR")) dct_pair_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
   RPDE_REQUIRE(comm_.size <= 8, "at most 8 ranks (one xGMI-connected MI355X node; the exchange descriptors hold 8 peers)");
   RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr || comm_.rccl != nullptr,
@@ -703,7 +702,7 @@ std::string Navier2DEngine::describe_step() const {
 }
 
 std::string Navier2DEngine::trace_launch(const std::string& tag) {
-  static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct", "dct2",
+  static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct",
                                          "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy"};
   size_t which = step_.size();
   for (size_t i = 0; i < step_.size(); ++i)
@@ -722,29 +721,37 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   time_ += dt_;
   std::vector<long long> h((size_t)nblk * kTraceStride);
   dev_download(h.data(), buf.p, h.size() * 8);
-  const int nops = l.pg.nops;
-  std::vector<std::vector<double>> dur(nops + 1);
+  // marks: (id, clock) pairs in the order thread 0 passed them -- the same sequence in every workgroup
+  int nm = 0;
+  const long long* ref = nullptr;
+  for (long b = 0; b < nblk && !ref; ++b)
+    if (h[(size_t)b * kTraceStride + 1] != 0) { ref = &h[(size_t)b * kTraceStride]; nm = (int)std::min<long long>(ref[2], kTraceMarks); }
+  RPDE_REQUIRE(ref && nm >= 2, "trace_launch: no workgroup left a record");
+  std::vector<std::vector<double>> dur(nm);           // dur[i]: clocks from mark i-1 to mark i; dur[0]: whole program
   long long w0 = 0, w1 = 0;
   for (long b = 0; b < nblk; ++b) {
     const long long* t = &h[(size_t)b * kTraceStride];
     if (t[1] == 0) continue;                           // padding workgroup (line >= nlines)
     if (w0 == 0 || t[0] < w0) w0 = t[0];
     if (t[1] > w1) w1 = t[1];
-    for (int ip = 0; ip < nops; ++ip) dur[ip].push_back((double)(t[3 + ip] - t[2 + ip]));
-    dur[nops].push_back((double)(t[2 + nops] - t[2]));
+    for (int i = 1; i < nm; ++i) dur[i].push_back((double)(t[5 + 2 * i] - t[5 + 2 * (i - 1)]));
+    dur[0].push_back((double)(t[5 + 2 * (nm - 1)] - t[5]));
   }
   char line[256];
-  snprintf(line, sizeof line, "%s\t%ld\t%.3f\n", l.tag, (long)dur[nops].size(), (double)(w1 - w0) * 1e-5);   // tag, workgroups, span in ms (100 MHz)
+  snprintf(line, sizeof line, "%s\t%ld\t%.3f\t%d\n", l.tag, (long)dur[0].size(), (double)(w1 - w0) * 1e-5, (int)ref[2]);   // tag, workgroups, span in ms (100 MHz clock), marks
   out += line;
-  for (int ip = 0; ip <= nops; ++ip) {
-    std::vector<double>& d = dur[ip];
+  for (int i = 0; i < nm; ++i) {
+    std::vector<double>& d = dur[i];
     std::sort(d.begin(), d.end());
     double mean = 0;
     for (double v : d) mean += v;
     mean /= std::max<size_t>(1, d.size());
     const double med = d.empty() ? 0 : d[d.size() / 2], p10 = d.empty() ? 0 : d[d.size() / 10], p90 = d.empty() ? 0 : d[d.size() * 9 / 10];
-    const int code = ip < nops ? l.pg.ops[ip].code : 0;
-    snprintf(line, sizeof line, "%d\t%s\t%.0f\t%.0f\t%.0f\t%.0f\n", ip, ip < nops ? kOpNames[code] : "program", mean, p10, med, p90);
+    const long long id = i == 0 ? -2 : ref[4 + 2 * i];   // -2: the whole program, -1: a barrier, >= 0: op ip starts (nops: end)
+    const long long prev = i == 0 ? -2 : ref[4 + 2 * (i - 1)];
+    const char* name = id == -2 ? "program" : (id == -1 ? "sync" : (id < l.pg.nops ? kOpNames[l.pg.ops[id].code] : "end"));
+    (void)prev;
+    snprintf(line, sizeof line, "%lld\t%s\t%.0f\t%.0f\t%.0f\t%.0f\n", id, name, mean, p10, med, p90);
     out += line;
   }
 #else
@@ -1024,7 +1031,6 @@ void Navier2DEngine::build_confined() {
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = nx * 2 / 3, cut_y = ny * 2 / 3;
-  const bool pair = dct_pair_ && xD.pair_dct_ok() && yD.pair_dct_ok();   // OP_DCT2 where two lines go together
   // builders for programs over y-indexed lines (YX arrays) and x-indexed lines (XY arrays)
   auto ypb = [&](int nslots, int rows) {
     ProgramBuilder pb(nslots, slx, ylines(rows));
@@ -1056,19 +1062,11 @@ void Navier2DEngine::build_confined() {
       pb.set_fft(*f.ax);
       pb.load(0, pb.arr(yx(*f.st), ldx), mx);
       pb.to_ortho(0, *f.ax);
-      if (pair) {
-        // value and x-derivative of the line are transformed TOGETHER (one complex sequence, dct_pair.h)
-        pb.cdiff(1, 0, nx, 1.0 / sx_);
-        pb.dct_pair(0, nx, f.ax->bwd_pre.p, nullptr);
-        pb.store(0, pb.arr(yx(*f.w0), ldx), nx);
-        pb.store(1, pb.arr(yx(*f.w1), ldx), nx);
-      } else {
-        pb.stash(0);
-        pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
-        pb.unstash_axpy(0, 0.0, 1.0, nx);
-        pb.cdiff(0, 0, nx, 1.0 / sx_);
-        pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
-      }
+      pb.stash(0);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
+      pb.unstash_axpy(0, 0.0, 1.0, nx);
+      pb.cdiff(0, 0, nx, 1.0 / sx_);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
       add_line(pb, "S1 x: state -> phys-x + d/dx");
       continue;
     }
@@ -1093,18 +1091,6 @@ void Navier2DEngine::build_confined() {
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
   // physical velocities once per step (shared by the three convection programs)
-  if (pair) {   // u and v of an x-row are transformed together (dct_pair.h)
-    ProgramBuilder pb = xpb(2, nx);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[0].p, ldy), my);
-    pb.to_ortho(0, yD);
-    pb.load(1, pb.arr(X_[2].p, ldy), my);
-    pb.to_ortho(1, yD);
-    pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
-    pb.store(0, pb.arr(UP_.p, ldy), ny);
-    pb.store(1, pb.arr(VP_.p, ldy), ny);
-    add_line(pb, "S2 y: velx, vely -> phys");
-  } else
   for (int w = 0; w < 2; ++w) {
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
@@ -1117,34 +1103,19 @@ void Navier2DEngine::build_confined() {
     // waits in the register stash, so two workgroups share a CU
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
-    if (pair) {
-      // d/dx f and d/dy f of the x-row go to physical space together; no register stash needed
-      pb.load(0, pb.arr(fx.p, ldy), my);      // d/dx f (x-derivative taken in S1)
-      pb.to_ortho(0, yD);
-      pb.load(1, pb.arr(f0.p, ldy), my);      // d/dy f
-      pb.to_ortho(1, yD);
-      pb.cdiff(1, 1, ny, 1.0 / sy_);
-      pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
-      if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
-      pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-      if (by) pb.load(1, pb.arr(by->p, ldy), ny, 1.0, true);
-      pb.loadmul(1, pb.arr(VP_.p, ldy), ny);
-      pb.axpby(0, 0, 1.0, 1, 1.0, ny);
-      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
-      add_line(pb, tag);
-      return;
-    }
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+    pb.load(1, pb.arr(f0.p, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+    pb.pair_last_loads();
     pb.stash(0);
-    pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
-    pb.to_ortho(0, yD);
+    pb.to_ortho_from(0, 1, yD);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.dct(0, ny, yD.bwd_pre.p, nullptr);
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
+    if (by) pb.pair_last_loads();
     pb.unstash_axpy(0, 1.0, 1.0, ny);
     pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     add_line(pb, tag);
@@ -1166,6 +1137,10 @@ void Navier2DEngine::build_confined() {
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
     pb.dct(0, nx, nullptr, postcut_x_.p, cut_x);                 // forward transform + 2/3 rule in x
     pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
+    if (which == 2) {   // dt ka lap(tempbc) rides with the convection term: slot 0 = conv - ka lap(tempbc), scaled by -dt below
+      pb.load(0, pb.arr(yx(TBC2_), ldx), nx, -ka_, true);
+      pb.pair_last_loads();
+    }
     pb.to_ortho(1, ax);                                       // S_x
     pb.axpby(0, 0, -dt, 1, 1.0, nx);
     if (which == 0) {
@@ -1173,13 +1148,12 @@ void Navier2DEngine::build_confined() {
       pb.cdiff(1, 1, nx, 1.0 / sx_);
       pb.axpby(0, 0, 1.0, 1, -dt, nx);
     } else if (which == 1) {
-      pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
       pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
+      pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
+      pb.pair_last_loads();
       pb.to_ortho(1, xN);
       pb.load(1, pb.arr(yx(TBC_), ldx), nx, 1.0, true);
       pb.axpby(0, 0, 1.0, 1, dt, nx);
-    } else {
-      pb.load(0, pb.arr(yx(TBC2_), ldx), nx, dt * ka_, true);
     }
     pb.pinv_matvec(0, ax);
     pb.fdma_solve(0, mx, hh.fdma[0]);
@@ -1231,9 +1205,10 @@ void Navier2DEngine::build_confined() {
     ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(xD);
     pb.loadx(0, pb.arr(yx(U_), ldx), mx, my, yD.low.p);
+    pb.load(1, pb.arr(yx(Y_[0]), ldx), mx);
+    pb.pair_last_loads();
     pb.to_ortho(0, xD);
     pb.cdiff(0, 0, nx, 1.0 / sx_);
-    pb.load(1, pb.arr(yx(Y_[0]), ldx), mx);
     pb.to_ortho(1, xD);
     pb.axpby(0, 0, 1.0, 1, 1.0, nx);
     pb.store(0, pb.arr(yx(DIV_), ldx), nx);
@@ -1309,20 +1284,22 @@ void Navier2DEngine::build_confined() {
   add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   // ---- S8: x part of the velocity correction
   {
-    ProgramBuilder pb = ypb(1, my);
+    ProgramBuilder pb = ypb(2, my);   // the two velocity components side by side: their loads travel in pairs
     pb.set_fft(xD);
     pb.load(0, pb.arr(yx(Y_[2]), ldx), mx);
+    pb.load(1, pb.arr(yx(Y_[3]), ldx), mx);
+    pb.pair_last_loads();
     pb.to_ortho(0, xN);
     pb.cdiff(0, 0, nx, -1.0 / sx_);
     pb.from_ortho(0, xD);
+    pb.to_ortho(1, xN);
+    pb.from_ortho(1, xD);
     pb.load(0, pb.arr(yx(U_), ldx), mx, 1.0, true);
+    pb.load(1, pb.arr(yx(V_), ldx), mx, 1.0, true);
+    pb.pair_last_loads();
     pb.store(0, pb.arr(yx(U_), ldx), mx);
     pb.guard_last_store(flagp());
-    pb.load(0, pb.arr(yx(Y_[3]), ldx), mx);
-    pb.to_ortho(0, xN);
-    pb.from_ortho(0, xD);
-    pb.load(0, pb.arr(yx(V_), ldx), mx, 1.0, true);
-    pb.store(0, pb.arr(yx(V_), ldx), mx);
+    pb.store(1, pb.arr(yx(V_), ldx), mx);
     pb.guard_last_store(flagp());
     add_line(pb, "S8 x: correction-x");
   }
@@ -1334,6 +1311,7 @@ void Navier2DEngine::build_confined() {
     pb.to_ortho(0, xN);
     pb.load(0, pb.arr(yx(DIV_), ldx), nx, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nx, 1.0, true);
+    pb.pair_last_loads();
     pb.store(0, pb.arr(yx(P_), ldx), nx);
     pb.guard_last_store(flagp());
     add_line(pb, "S9 x: pressure update");
@@ -1370,7 +1348,6 @@ void Navier2DEngine::build_periodic() {
   AxisTables& yD = sp_vel_->axis(1);             // Dirichlet(ny)
   AxisTables& yN = sp_pseu_->axis(1);            // Neumann(ny)
   const int slx = xF.slot_len, sly = yD.slot_len;
-  const bool pair = dct_pair_ && yD.pair_dct_ok();   // OP_DCT2 where two lines go together
   const long ldx = ldx_, ldy = ldy_;
   const double dt = dt_;
   const int cut_x = kx * 2 / 3, cut_y = ny * 2 / 3;
@@ -1411,18 +1388,6 @@ void Navier2DEngine::build_periodic() {
   for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
-  if (pair) {   // u and v of an x-row are transformed together (dct_pair.h)
-    ProgramBuilder pb = xpb(2, nx, false);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(X_[0].p, ldy), my);
-    pb.to_ortho(0, yD);
-    pb.load(1, pb.arr(X_[2].p, ldy), my);
-    pb.to_ortho(1, yD);
-    pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
-    pb.store(0, pb.arr(UP_.p, ldy), ny);
-    pb.store(1, pb.arr(VP_.p, ldy), ny);
-    add_line(pb, "S2 y: velx, vely -> phys");
-  } else
   for (int w = 0; w < 2; ++w) {
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
@@ -1435,34 +1400,19 @@ void Navier2DEngine::build_periodic() {
     // waits in the register stash
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
-    if (pair) {
-      // d/dx f and d/dy f of the x-row go to physical space together; no register stash needed
-      pb.load(0, pb.arr(fx.p, ldy), my);      // d/dx f (x-derivative taken in S1)
-      pb.to_ortho(0, yD);
-      pb.load(1, pb.arr(f0.p, ldy), my);      // d/dy f
-      pb.to_ortho(1, yD);
-      pb.cdiff(1, 1, ny, 1.0 / sy_);
-      pb.dct_pair(0, ny, yD.bwd_pre.p, nullptr);
-      if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
-      pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-      if (by) pb.load(1, pb.arr(by->p, ldy), ny, 1.0, true);
-      pb.loadmul(1, pb.arr(VP_.p, ldy), ny);
-      pb.axpby(0, 0, 1.0, 1, 1.0, ny);
-      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
-      add_line(pb, tag);
-      return;
-    }
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
     if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
+    pb.load(1, pb.arr(f0.p, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+    pb.pair_last_loads();
     pb.stash(0);
-    pb.load(0, pb.arr(f0.p, ldy), my);        // d/dy f
-    pb.to_ortho(0, yD);
+    pb.to_ortho_from(0, 1, yD);
     pb.cdiff(0, 0, ny, 1.0 / sy_);
     pb.dct(0, ny, yD.bwd_pre.p, nullptr);
     if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
     pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
+    if (by) pb.pair_last_loads();
     pb.unstash_axpy(0, 1.0, 1.0, ny);
     pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     add_line(pb, tag);
@@ -1488,10 +1438,13 @@ void Navier2DEngine::build_periodic() {
       pb.load_cik(0, pb.arr(yx(P_), ldx), nc, -dt / sx_, true);         // - dt d/dx pres
     } else if (which == 1) {
       pb.load(0, pb.arr(yx(GY_), ldx), nc, -dt, true);
+      pb.pair_last_loads();                                             // with the state rows
       pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(TBC_), ldx), nc, dt, true);
+      pb.pair_last_loads();
     } else {
       pb.load(0, pb.arr(yx(TBC2_), ldx), nc, dt * ka_, true);
+      pb.pair_last_loads();                                             // with the state rows
     }
     pb.tabdiv(0, 0, nc, hh.diag0.p, 1);
     pb.store(0, pb.arr(yx(Y_[3 + which]), ldx), nc);
@@ -1588,6 +1541,7 @@ void Navier2DEngine::build_periodic() {
     pb.guard_last_store(flagp());
     pb.load(0, pb.arr(yx(Y_[3]), ldx), nc);
     pb.load(0, pb.arr(yx(V_), ldx), nc, 1.0, true);
+    pb.pair_last_loads();
     pb.store(0, pb.arr(yx(V_), ldx), nc);
     pb.guard_last_store(flagp());
     add_line(pb, "S8 x: correction-x");
@@ -1599,6 +1553,7 @@ void Navier2DEngine::build_periodic() {
     pb.loadx(0, pb.arr(yx(Y_[4]), ldx), nc, my, yN.low.p, 1.0 / dt);
     pb.load(0, pb.arr(yx(DIV_), ldx), nc, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nc, 1.0, true);
+    pb.pair_last_loads();
     pb.store(0, pb.arr(yx(P_), ldx), nc);
     pb.guard_last_store(flagp());
     add_line(pb, "S9 x: pressure update");

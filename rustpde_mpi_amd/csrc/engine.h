@@ -200,7 +200,6 @@ class Navier2DEngine {
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;   // brackets of update(), created once
 #endif
   bool use_graph_ = true;
-  bool dct_pair_ = true;   // backward DCTs of two lines of a row as one complex transform (dct_pair.h); RPDE_DCT_PAIR=0: one by one
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);

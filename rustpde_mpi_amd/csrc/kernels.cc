@@ -58,7 +58,9 @@ RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long l
 // Three kernels per configuration (line_vm.h kVar*): light, with the second-order back-substitution
 // scan, with the register stash.  All are held to 128 VGPRs (4 waves per SIMD) so that two
 // workgroups of a two-slot program share a CU; none spills more than a few dwords.
-template <class Cfg, int VAR>
+// TRACE: the instrumented twin (Program::trace, tools/trace_ops.py), built for the 512-thread configuration
+// only; in the product kernels the record pointer is a compile-time null and every RPDE_MARK folds away
+template <class Cfg, int VAR, bool TRACE = false>
 __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
   // XCD-aware line map: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
@@ -67,12 +69,17 @@ __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= pg.nlines) return;
-  Blk blk{line, (int)blockIdx.y, Cfg::T, rpde_lds};
+  Blk blk{line, (int)blockIdx.y, Cfg::T, rpde_lds,
+          TRACE ? pg.trace + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride : nullptr, 0};
   run_line_program<Cfg, VAR>(blk, pg);
 }
 
-template <class Cfg, int VAR>
+template <class Cfg, int VAR, bool TRACE = false>
 static void launch_kernel(const Program& pg, size_t bytes, Stream& st) {
+  if constexpr (!TRACE && Cfg::T == 512) {
+    if (pg.trace) { launch_kernel<Cfg, VAR, true>(pg, bytes, st); return; }
+  }
+  RPDE_REQUIRE(TRACE || pg.trace == nullptr, "Program::trace: only the 512-thread configuration has the instrumented kernels");
   // the dynamic-LDS permission of a kernel is raised lazily, per device (several handles on
   // several devices / host threads in one process stay correct)
   static std::atomic<size_t> configured[32];
@@ -80,12 +87,12 @@ static void launch_kernel(const Program& pg, size_t bytes, Stream& st) {
   RPDE_HIP(hipGetDevice(&dev));
   std::atomic<size_t>& have = configured[dev & 31];
   if (bytes > have.load(std::memory_order_acquire)) {
-    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg, VAR>),
+    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_kernel<Cfg, VAR, TRACE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     have.store(bytes, std::memory_order_release);
   }
   dim3 grid(8 * ((pg.nlines + 7) / 8), pg.ncomp), block(Cfg::T);   // 8 bands of ceil(nlines / 8) lines
-  hipLaunchKernelGGL((line_kernel<Cfg, VAR>), grid, block, bytes, st.s, pg);
+  hipLaunchKernelGGL((line_kernel<Cfg, VAR, TRACE>), grid, block, bytes, st.s, pg);
   RPDE_HIP(hipGetLastError());
 }
 

@@ -52,6 +52,7 @@ using lds2_t = __attribute__((address_space(3))) dbl2*;
 enum OpCode : int {
   OP_END = 0,
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;
+               // b = 1 (OP_LOAD / OP_LOADX): the NEXT op is a plain OP_LOAD executed together with this one (both lines' loads in flight at once)
                // i0 = 2: interleaved complex line times i*kappa (kappa = pair index): d[2j] (+)= -s0 j Im A_j, d[2j+1] (+)= s0 j Re A_j
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1;
@@ -63,8 +64,6 @@ enum OpCode : int {
   OP_REC2,     // descending second-order: x_k = p_k b_k + q_k x_{k+2} + r_k x_{k+4}; p = tab, q = i0, r = i1; slot b (the last one) = scratch
   OP_DCT,      // slot d (scratch d+1): x <- DCT-I(x * pre) * post ; n = N+1; direct path: pre = table tab (-1 none), post = table i0;
                // FFT path: tab / i0 >= 0 = standard backward pre / forward post scaling on, a = first zeroed coefficient, s1 = 1/N
-  OP_DCT2,     // FFT path only: the lines in slots d and d + 1 (n = N + 1 reals each) are transformed TOGETHER as one
-               // complex sequence (dct_pair.h); tab / i0 / a / s1 as the FFT-path flags of OP_DCT
   OP_MUL,      // d[k] = (acc ? d[k] : 0) + s0 * a[k] * b[k]
   OP_AXPBY,    // d[k] = s0 * a[k] + s1 * b[k]
   OP_ZERO,     // d[k] = 0 for i0 <= k < i1
@@ -97,7 +96,6 @@ struct Op {
 };
 
 constexpr int kMaxOps = 40;
-constexpr int kTraceStride = kMaxOps + 4;   // [0], [1]: 100 MHz wall clock at entry / exit; [2 + ip]: shader clock when thread 0 reaches op ip; [2 + nops]: at exit
 constexpr int kMaxArr = 16;
 constexpr int kMaxTab = 24;
 
@@ -112,7 +110,7 @@ struct Program {
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
   int tw2;        // table index of the split twiddles (cos, sin)(pi k / N) resp. (2 pi k / nx)
   int* nanflag;   // device flag raised by guarded stores (OP_STORE with acc = 1); may be null
-  long long* trace;   // diagnostics (tools/trace_ops.py): kTraceStride stamps per workgroup, see run_line_program; normally null
+  long long* trace;   // diagnostics (tools/trace_ops.py): kTraceStride words per workgroup (platform.h RPDE_MARK); normally null
   Op ops[kMaxOps];
   ArrayRef arr[kMaxArr];
   const double* tabs[kMaxTab];
@@ -359,8 +357,12 @@ RPDE_DEVN void fft_pass(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
   RPDE_SYNC(blk);
 }
 
-template <class Cfg, int N, class Src = LdsSrc>
-RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
+struct NoHook { RPDE_DEV void operator()() const {} };
+
+// hook(): called between the last two passes -- the caller's chance to put global loads in flight that
+// its next phase needs (the DCT's split twiddles: an L2 round trip otherwise exposed after the last barrier)
+template <class Cfg, int N, class Src = LdsSrc, class Hook = NoHook>
+RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw, const Src src = Src(), const Hook hook = Hook()) {
   // radix schedule: one of {2,4,8} first (if log2 N is not a multiple of 4), then 16s
   constexpr int L = (N >= 8192) ? 13 : (N >= 4096) ? 12 : (N >= 2048) ? 11 : (N >= 1024) ? 10
                   : (N >= 512) ? 9 : (N >= 256) ? 8 : (N >= 128) ? 7 : (N >= 64) ? 6
@@ -370,23 +372,25 @@ RPDE_DEVN void fft_lds(Blk& blk, lds_t w, tab_t tw, const Src src = Src()) {
   constexpr int LG = (RM == 16) ? 4 : 3;
   constexpr int nm = L / LG;
   constexpr int rem = L % LG;
+  if constexpr (nm == 0) hook();
   if constexpr (rem == 1) fft_pass<Cfg, N, 2, 0, Src>(blk, w, tw, src);
   if constexpr (rem == 2) fft_pass<Cfg, N, 4, 0, Src>(blk, w, tw, src);
   if constexpr (rem == 3) fft_pass<Cfg, N, 8, 0, Src>(blk, w, tw, src);
   if constexpr (nm >= 1) {
+    if constexpr (nm == 1) hook();
     if constexpr (rem == 0) fft_pass<Cfg, N, RM, 0, Src>(blk, w, tw, src);
     else fft_pass<Cfg, N, RM, rem>(blk, w, tw);
   }
-  if constexpr (nm >= 2) fft_pass<Cfg, N, RM, rem + LG>(blk, w, tw);
-  if constexpr (nm >= 3) fft_pass<Cfg, N, RM, rem + 2 * LG>(blk, w, tw);
-  if constexpr (nm >= 4) fft_pass<Cfg, N, RM, rem + 3 * LG>(blk, w, tw);
+  if constexpr (nm >= 2) { if constexpr (nm == 2) hook(); fft_pass<Cfg, N, RM, rem + LG>(blk, w, tw); }
+  if constexpr (nm >= 3) { if constexpr (nm == 3) hook(); fft_pass<Cfg, N, RM, rem + 2 * LG>(blk, w, tw); }
+  if constexpr (nm >= 4) { if constexpr (nm == 4) hook(); fft_pass<Cfg, N, RM, rem + 3 * LG>(blk, w, tw); }
 }
 
-template <class Cfg, class Src = LdsSrc>
-RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw, const Src src = Src()) {
+template <class Cfg, class Src = LdsSrc, class Hook = NoHook>
+RPDE_DEV void fft_dispatch(Blk& blk, lds_t w, int n, tab_t tw, const Src src = Src(), const Hook hook = Hook()) {
   switch (n) {
 #define RPDE_FFT_CASE(NN) \
-  case NN: if constexpr (NN >= Cfg::FMIN && NN <= Cfg::FMAX) fft_lds<Cfg, NN, Src>(blk, w, tw, src); break;
+  case NN: if constexpr (NN >= Cfg::FMIN && NN <= Cfg::FMAX) fft_lds<Cfg, NN, Src, Hook>(blk, w, tw, src, hook); break;
     RPDE_FFT_CASE(2) RPDE_FFT_CASE(4) RPDE_FFT_CASE(8) RPDE_FFT_CASE(16) RPDE_FFT_CASE(32)
     RPDE_FFT_CASE(64) RPDE_FFT_CASE(128) RPDE_FFT_CASE(256) RPDE_FFT_CASE(512)
     RPDE_FFT_CASE(1024) RPDE_FFT_CASE(2048) RPDE_FFT_CASE(4096) RPDE_FFT_CASE(8192)
@@ -405,14 +409,26 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, 
   constexpr int T = Cfg::T;
   // FFT with the pack step fused into the reads of its first pass (the work area overlaps x: every
   // pass reads everything before the barrier that precedes its writes)
-  if (sten == 2) fft_dispatch<Cfg, DctSrc<2>>(blk, x, N, tw, DctSrc<2>{x, N, pre, low});
-  else if (sten == 1) fft_dispatch<Cfg, DctSrc<1>>(blk, x, N, tw, DctSrc<1>{x, N, pre, low});
-  else fft_dispatch<Cfg, DctSrc<0>>(blk, x, N, tw, DctSrc<0>{x, N, pre, low});
+  constexpr int QH = Cfg::FMAX / 2 / T + 1;
+  static_assert(2 * QH <= Cfg::EPT + 2, "pair split needs 2 QH registers");
+  const int H = N >> 1;
+  // the split twiddles (cos, sin)(pi k / N) of this thread's pairs go in flight before the last FFT pass
+  RPDE_TLS(blk, double, cs, 2 * QH);
+  auto fetch_split = [&]() {
+    RPDE_PHASE(blk, tid) {
+#pragma unroll
+      for (int q = 0; q < QH; ++q) {
+        const int k = tid + q * T, kk = (k <= H) ? k : 0;
+        RPDE_T(cs)[2 * q] = tw2[2 * kk];
+        RPDE_T(cs)[2 * q + 1] = tw2[2 * kk + 1];
+      }
+    }
+  };
+  if (sten == 2) fft_dispatch<Cfg, DctSrc<2>>(blk, x, N, tw, DctSrc<2>{x, N, pre, low}, fetch_split);
+  else if (sten == 1) fft_dispatch<Cfg, DctSrc<1>>(blk, x, N, tw, DctSrc<1>{x, N, pre, low}, fetch_split);
+  else fft_dispatch<Cfg, DctSrc<0>>(blk, x, N, tw, DctSrc<0>{x, N, pre, low}, fetch_split);
   {  // split: E_k = A + B, E_{N-k} = A - B with A = (Zr_k + Zr_{N-k})/2,
      // B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2: one thread per pair (k, N-k)
-    constexpr int QH = Cfg::FMAX / 2 / T + 1;
-    static_assert(2 * QH <= Cfg::EPT + 2, "pair split needs 2 QH registers");
-    const int H = N >> 1;
     RPDE_TLS(blk, double, e, 2 * QH);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
@@ -423,7 +439,7 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, 
           const dbl2 za = ((lds2_t)x)[pidx(k)];
           const dbl2 zb = ((lds2_t)x)[pidx((k == 0) ? 0 : kn)];
           const double ar = za.x, ai = za.y, br = zb.x, bi = zb.y;
-          const double c = tw2[2 * k], s = tw2[2 * k + 1];
+          const double c = RPDE_T(cs)[2 * q], s = RPDE_T(cs)[2 * q + 1];
           const double A = 0.5 * (ar + br), B = 0.5 * (c * (ai + bi) - s * (ar - br));
           double ek = A + B, en = A - B;
           if (post) {   // forward scaling (-1)^k / N (ends: half), zero from `cut` on; N even: k, N-k share the sign
@@ -454,10 +470,6 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, 
     }
   }
 }
-
-}  // namespace rpde
-#include "dct_pair.h"
-namespace rpde {
 
 // direct O(n^2) DCT-I for line lengths without an FFT plan (small / odd sizes); costab[m] = cos(pi m / N), m < 2N
 template <class Cfg>
@@ -935,20 +947,20 @@ template <class Cfg, int VAR = kVarAll>
 RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   constexpr int T = Cfg::T, EPT = Cfg::EPT;
   constexpr bool FULL = (VAR & kVarRec2) != 0, STASH = (VAR & kVarStash) != 0;
+  // paired loads hold two or three rows in registers: not in the 1024-thread configuration (18 elements per
+  // thread would spill); there the ops of a pair simply run one after the other
+  constexpr bool kPairs = EPT <= 12;
   RPDE_TLS(blk, double, stash, STASH ? EPT : 1);
   const int line = blk.line, comp = blk.comp;
   const int SL = pg.slot_len;
   lds_t lds = (lds_t)blk.lds;
   lds_t carry = lds + pg.nslots * SL + (T * EPT - SL) + 8;
 #ifndef RPDE_EMU
-  long long* const trc = pg.trace ? pg.trace + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride : nullptr;
-  if (trc && threadIdx.x == 0) trc[0] = (long long)wall_clock64();
+  if (blk.trc && threadIdx.x == 0) blk.trc[0] = (long long)wall_clock64();
 #endif
   for (int ip = 0; ip < pg.nops; ++ip) {
     const Op& op = pg.ops[ip];
-#ifndef RPDE_EMU
-    if (trc && threadIdx.x == 0) trc[2 + ip] = (long long)clock64();
-#endif
+    RPDE_MARK(blk, ip);
     lds_t d = lds + op.d * SL;
     clds_t a = lds + op.a * SL;
     clds_t b = lds + op.b * SL;
@@ -961,6 +973,45 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         cgmem_t src = (cgmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         const int es = A.es;
         const bool plain = !op.i0 && es == 1;       // contiguous line: no 64-bit index arithmetic
+        if (kPairs && op.b == 1) {
+          // pair of plain loads (ProgramBuilder::pair_last_loads): the loads of this op and of the next one are in
+          // flight together -- one HBM round trip instead of two; the second may target the same slot (applied in order)
+          const Op& o2 = pg.ops[ip + 1];
+          const ArrayRef& A2 = pg.arr[o2.arr];
+          cgmem_t src2 = (cgmem_t)(A2.p + comp * A2.coff + (long)line * A2.ld);
+          lds_t d2 = lds + o2.d * SL;
+          const int n2 = o2.n;
+          const bool same = o2.d == op.d;
+          RPDE_PHASE(blk, tid) {
+            double v[EPT], w[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              v[q] = (k < n) ? src[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              w[q] = (k < n2) ? src2[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const double x = op.s0 * v[q], y = o2.s0 * w[q];
+              const double old = d[k];
+              const double r = (op.acc == 2) ? (k < n ? old * x : old) : (op.acc ? (old + x) : x);
+              const double old2 = same ? r : d2[k];
+              const double r2 = (o2.acc == 2) ? (k < n2 ? old2 * y : old2) : (o2.acc ? (old2 + y) : y);
+              if (k < SL) {
+                if (same) d[k] = r2;
+                else { d[k] = r; d2[k] = r2; }
+              }
+            }
+          }
+          RPDE_SYNC(blk);
+          ++ip;                                       // the second op of the pair is done
+          break;
+        }
         RPDE_PHASE(blk, tid) {
           double v[EPT];
           if (plain) {
@@ -999,6 +1050,43 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         cgmem_t s2p = (cgmem_t)(A.p + comp * A.coff + (long)(line - 2) * A.ld);
         const double c2 = has2 ? ((tab_t)pg.tabs[op.tab])[gline - 2] : 0.0;
         const int es = A.es;
+        if (kPairs && op.b == 1) {   // paired with the plain load that follows (see OP_LOAD): three rows in flight together
+          const Op& o2 = pg.ops[ip + 1];
+          const ArrayRef& A2 = pg.arr[o2.arr];
+          cgmem_t src2 = (cgmem_t)(A2.p + comp * A2.coff + (long)line * A2.ld);
+          lds_t d2 = lds + o2.d * SL;
+          const int n2 = o2.n;
+          const bool same = o2.d == op.d;
+          RPDE_PHASE(blk, tid) {
+            double v0[EPT], v2[EPT], w[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              v0[q] = (has0 && k < n) ? s0p[(long)k * es] : 0.0;
+              v2[q] = (has2 && k < n) ? s2p[(long)k * es] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              w[q] = (k < n2) ? src2[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const double x = op.s0 * (v0[q] + c2 * v2[q]), y = o2.s0 * w[q];
+              const double r = op.acc ? (d[k] + x) : x;
+              const double old2 = same ? r : d2[k];
+              const double r2 = (o2.acc == 2) ? (k < n2 ? old2 * y : old2) : (o2.acc ? (old2 + y) : y);
+              if (k < SL) {
+                if (same) d[k] = r2;
+                else { d[k] = r; d2[k] = r2; }
+              }
+            }
+          }
+          RPDE_SYNC(blk);
+          ++ip;
+          break;
+        }
         RPDE_PHASE(blk, tid) {
           double v0[EPT], v2[EPT];
 #pragma unroll
@@ -1048,6 +1136,21 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       } break;
       case OP_STEN: if constexpr (Cfg::kCheb) {
         tab_t low = (tab_t)(pg.tabs[op.tab] + toff);
+        if (op.d != op.a) {   // out of place: no thread overwrites what another one still reads -- one phase
+          RPDE_PHASE(blk, tid) {
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+              const int k = tid + q * T;
+              const int k2 = (k >= 2) ? k - 2 : 0;
+              const double a0 = a[k], a2 = a[k2], l2 = low[k2];
+              double x = (k < n - 2) ? a0 : 0.0;
+              x += (k >= 2) ? l2 * a2 : 0.0;
+              if (k < n) d[k] = x;
+            }
+          }
+          RPDE_SYNC(blk);
+          break;
+        }
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
 #pragma unroll
@@ -1135,10 +1238,6 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
           dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
         }
-      } break;
-      case OP_DCT2: if constexpr (Cfg::kCheb) {
-        dct1_pair_lds<Cfg>(blk, d, SL, n - 1, op.tab >= 0, op.i0 >= 0, op.a, op.s1, (tab_t)pg.tabs[pg.tw],
-                           (tab_t)pg.tabs[pg.tw2]);
       } break;
       case OP_MUL: {
         RPDE_PHASE(blk, tid) {
@@ -1236,8 +1335,9 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       default: break;
     }
   }
+  RPDE_MARK(blk, pg.nops);
 #ifndef RPDE_EMU
-  if (trc && threadIdx.x == 0) { trc[2 + pg.nops] = (long long)clock64(); trc[1] = (long long)wall_clock64(); }
+  if (blk.trc && threadIdx.x == 0) { blk.trc[1] = (long long)wall_clock64(); blk.trc[2] = blk.nm; }
 #endif
 }
 

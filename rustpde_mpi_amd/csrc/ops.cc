@@ -106,6 +106,18 @@ void ProgramBuilder::loadmul(int d, int a, int n, double s0) {
 void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, double s0, bool acc) {
   Op& o = push(OP_LOADX); o.d = d; o.arr = a; o.n = n; o.i1 = rows; o.tab = tab(lowtab); o.s0 = s0; o.acc = acc;
 }
+void ProgramBuilder::pair_last_loads() {
+  RPDE_REQUIRE(pg.nops >= 2, "pair_last_loads: two load ops expected");
+  Op& o1 = pg.ops[pg.nops - 2];
+  const Op& o2 = pg.ops[pg.nops - 1];
+  RPDE_REQUIRE(o2.code == OP_LOAD && o2.i0 == 0 && pg.arr[o2.arr].es == 1, "pair_last_loads: the second op must be a plain load");
+  RPDE_REQUIRE((o1.code == OP_LOAD && o1.i0 == 0 && pg.arr[o1.arr].es == 1 && o1.b == 0) ||
+                   (o1.code == OP_LOADX && o1.b == 0),
+               "pair_last_loads: the first op must be a plain load or a cross-line load");
+  RPDE_REQUIRE(pg.nops < 3 || pg.ops[pg.nops - 3].b == 0 || (pg.ops[pg.nops - 3].code != OP_LOAD && pg.ops[pg.nops - 3].code != OP_LOADX),
+               "pair_last_loads: the first op already belongs to a pair");
+  o1.b = 1;
+}
 void ProgramBuilder::store(int a, int ar, int n, double s0, int half) {
   Op& o = push(OP_STORE); o.a = a; o.arr = ar; o.n = n; o.s0 = s0; o.i0 = half > 0; o.i1 = half;
 }
@@ -175,17 +187,6 @@ void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const do
   dct_flags(o, n, pre, post, cut);
   o.arr = store_arr; o.b = nstore; o.s0 = scale;
 }
-void ProgramBuilder::dct_pair(int d, int n, const double* pre, const double* post, int cut) {
-  RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT2 transforms slots d and d + 1");
-  if (pg.fft_n == 0) {   // direct O(n^2) transform: in place, one line after the other
-    Op& o1 = push(OP_DCT); o1.d = d; o1.n = n; o1.i1 = -1; o1.arr = -1; o1.tab = pre ? tab(pre) : -1; o1.i0 = post ? tab(post) : -1;
-    Op& o2 = push(OP_DCT); o2.d = d + 1; o2.n = n; o2.i1 = -1; o2.arr = -1; o2.tab = pre ? tab(pre) : -1; o2.i0 = post ? tab(post) : -1;
-    return;
-  }
-  RPDE_REQUIRE(pg.fft_n >= 8 && pg.fft_n <= 4096, "OP_DCT2: lines of 9 .. 4097 points (AxisTables::pair_dct_ok)");
-  Op& o = push(OP_DCT2); o.d = d; o.n = n; o.i1 = -1; o.arr = -1;
-  dct_flags(o, n, pre, post, cut);
-}
 void ProgramBuilder::mul(int d, int a, int b, int n, double s0, bool acc) {
   Op& o = push(OP_MUL); o.d = d; o.a = a; o.b = b; o.n = n; o.s0 = s0; o.acc = acc;
 }
@@ -209,6 +210,10 @@ void ProgramBuilder::cik(int d, int a, int nc, double s0, int power) {
 }
 void ProgramBuilder::to_ortho(int d, const AxisTables& ax) {
   if (ax.base.is_composite()) sten(d, d, ax.base.n, ax.low.p);
+}
+void ProgramBuilder::to_ortho_from(int d, int a, const AxisTables& ax) {
+  if (ax.base.is_composite()) sten(d, a, ax.base.n, ax.low.p);
+  else axpby(d, a, 1.0, a, 0.0, ax.base.n);
 }
 void ProgramBuilder::from_ortho(int d, const AxisTables& ax) {
   if (!ax.base.is_composite()) return;

@@ -25,8 +25,6 @@ struct AxisTables {
   DBuf fo_t0, fo_t1, fo_t2, fo_pup, fo_qup, fo_qdn;  // from_ortho
   DBuf pv0, pv1, pv2;                           // B2 pseudo-inverse rows (Chebyshev family)
   explicit AxisTables(const Base& b);
-  // OP_DCT2 (two lines per transform, dct_pair.h) handles the direct path and FFT lines of 9 .. 4097 points
-  bool pair_dct_ok() const { return base.is_cheb() && (fft_n == 0 || (fft_n >= 8 && fft_n <= 4096)); }
   int n_phys() const { return base.n; }
   int n_ortho() const { return base.n_ortho(); }   // complex count for Fourier
   int n_spec() const { return base.m; }
@@ -57,6 +55,9 @@ class ProgramBuilder {
   // ops (slot indices d, a, b)
   void load(int d, int arr, int n, double s0 = 1.0, bool acc = false, int interleave_half = 0);
   void loadmul(int d, int arr, int n, double s0 = 1.0);   // d[k] *= s0 * A[line][k]
+  // the last two ops (load / loadmul of contiguous lines; the first may be a loadx) run as ONE
+  // op: both lines' global loads are in flight together, one HBM round trip instead of two
+  void pair_last_loads();
   // interleaved complex line (n doubles) times i*kappa while loading: d (+)= s0 * (i kappa) * A
   void load_cik(int d, int arr, int n, double s0 = 1.0, bool acc = false);
   void set_line0(int line0) { pg.line0 = line0; }
@@ -80,9 +81,6 @@ class ProgramBuilder {
   // values, scaled).  Fall back to separate ops when the line uses the direct (non-FFT) transform.
   void dct_fused(int d, const AxisTables& ax, bool sten, const double* pre, const double* post,
                  int store_arr = -1, int nstore = 0, double scale = 1.0, int cut = -1);
-  // the lines in slots d and d + 1 transformed together (two DCT-I for the price of one: dct_pair.h);
-  // same `pre` / `post` / `cut` meaning as dct().  Lines without an FFT plan get two direct transforms.
-  void dct_pair(int d, int n, const double* pre, const double* post, int cut = -1);
   void mul(int d, int a, int b, int n, double s0 = 1.0, bool acc = false);
   void axpby(int d, int a, double s0, int b, double s1, int n);
   // per-thread register copy of slot a (kept until the end of the program), and
@@ -96,6 +94,7 @@ class ProgramBuilder {
   void cik(int d, int a, int ncomplex, double s0, int power);
   // composites
   void to_ortho(int d, const AxisTables& ax);                 // slot d: composite -> ortho (in place)
+  void to_ortho_from(int d, int a, const AxisTables& ax);     // slot d = composite -> ortho of slot a (d != a: one phase)
   void from_ortho(int d, const AxisTables& ax);               // slot d: ortho -> composite (in place)
   void fdma_solve(int d, int n, const FdmaDev& f);            // slot d in place
   void pinv_matvec(int d, const AxisTables& ax);              // slot d: ortho (n) -> (n-2), in place

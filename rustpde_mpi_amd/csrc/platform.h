@@ -59,8 +59,7 @@ struct Blk {          // one workgroup
 };
 #define RPDE_PHASE(blk, tid) for (int tid = 0; tid < (blk).T; ++tid)
 #define RPDE_SYNC(blk) ((void)0)
-#define RPDE_WSYNC() ((void)0)
-#define RPDE_CLZ(x) __builtin_clz((unsigned)(x))
+#define RPDE_MARK(blk, id) ((void)0)
 #define RPDE_TLS(blk, type, name, K) std::vector<type> name##_st((size_t)(blk).T * (K)); const int name##_K = (K)
 #define RPDE_T(name) (&name##_st[(size_t)tid * name##_K])
 #else
@@ -70,7 +69,14 @@ struct Blk {          // one workgroup
 struct Blk {
   int line, comp, T;
   double* lds;
+  long long* trc;   // diagnostics: this workgroup's record of Program::trace (null: no tracing)
+  int nm;           // marks written so far
 };
+// one (id, shader clock) pair per mark: id >= 0 = thread 0 reaches op id of the program, -1 = thread 0 leaves a barrier
+constexpr int kTraceMarks = 126;
+constexpr int kTraceStride = 4 + 2 * kTraceMarks;   // [0], [1]: 100 MHz wall clock at entry / exit, [2]: marks, then the pairs from [4]
+#define RPDE_MARK(blk, id) do { if ((blk).trc) { if (threadIdx.x == 0 && (blk).nm < kTraceMarks) { \
+    (blk).trc[4 + 2 * (blk).nm] = (id); (blk).trc[5 + 2 * (blk).nm] = (long long)clock64(); } ++(blk).nm; } } while (0)
 // The thread index is laundered through an empty volatile asm in every phase: otherwise the
 // compiler hoists the per-thread index arithmetic of ALL ops out of the interpreter loop, keeps it
 // live across the whole program and spills it in the prologue (160 B/lane of scratch writes per
@@ -82,12 +88,7 @@ __device__ __forceinline__ int rpde_tid() {
   return t;
 }
 #define RPDE_PHASE(blk, tid) for (int tid = rpde_tid(), _once = 1; _once; _once = 0)
-#define RPDE_SYNC(blk) __syncthreads()
-// ordering point for LDS traffic INSIDE one wavefront (lanes of a wave run in lockstep and the LDS serves
-// a wave's accesses in order): the compiler must not move LDS accesses across it, the hardware needs nothing
-#define RPDE_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
-                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#define RPDE_CLZ(x) __clz((int)(x))
+#define RPDE_SYNC(blk) do { __syncthreads(); RPDE_MARK(blk, -1); } while (0)
 #define RPDE_TLS(blk, type, name, K) type name[K]
 #define RPDE_T(name) name
 #endif

@@ -157,11 +157,3 @@ def test_column_scans_several_blocks(emu_lib, periodic, nx, ny):
     """The Helmholtz-y solve and the y-derivatives as column scans (colscan.h) with more than one block of
     64 rows: block carries, partial last block (127 = 64 + 63 rows, 255 = 3 x 64 + 63)."""
     K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 4, check_at=[1, 4])
-
-
-@pytest.mark.parametrize("periodic,nx,ny", [(False, 4097, 9), (False, 9, 4097), (False, 257, 129), (True, 64, 2049)])
-def test_pair_dct_long_lines(emu_lib, periodic, nx, ny):
-    """The two-lines-at-once DCT (csrc/dct_pair.h) on lines up to the headline length: S1 (x), S2-phys
-    and the convection programs (y) use it.  Shared eigen-decomposition: at 4097 two LAPACK runs of the
-    reference's Poisson setup differ by more than the bar."""
-    K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 2, check_at=[1, 2], eig_mode="shared")

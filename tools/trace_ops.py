@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where the time of a line program goes: per-op shader-clock durations inside the kernel
+"""Where the time of a line program goes: shader clocks per op and per barrier phase inside the kernel
 (Program::trace, rpde_navier2d_trace_launch).  tools/trace_ops.py [nx ny] [tag ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,8 +18,18 @@ for tag in tags:
     except Exception as e:   # tag not in this configuration
         print(f"-- {tag}: {e}")
         continue
-    tot = rows[-1][4]
+    tot = rows[0][4]
     print(f"== {t}: {n} workgroups, kernel span {span:.3f} ms, program median {tot:.0f} clk")
-    print(f"   {'ip':>2s} {'op':8s} {'mean':>8s} {'p10':>8s} {'median':>8s} {'p90':>8s} {'share':>6s}")
-    for ip, op, mean, p10, med, p90 in rows:
-        print(f"   {ip:2d} {op:8s} {mean:8.0f} {p10:8.0f} {med:8.0f} {p90:8.0f} {med / max(tot, 1):6.3f}")
+    # group the marks by op: a row with id >= 0 closes the previous op
+    ops, cur = [], None
+    for id_, name, mean, p10, med, p90 in rows[1:]:
+        if cur is not None:
+            cur["phases"].append((med, p10, p90))
+        if id_ >= 0:
+            cur = {"ip": id_, "name": name, "phases": []}
+            ops.append(cur)
+    # rows[1] is the first op's start mark (delta from nothing): the loop above handles it because cur is None there
+    for op in ops[:-1]:
+        tot_op = sum(p[0] for p in op["phases"])
+        ph = " ".join(f"{p[0]:.0f}" for p in op["phases"])
+        print(f"   {op['ip']:2d} {op['name']:8s} {tot_op:8.0f} {tot_op / max(tot, 1):6.3f}   phases: {ph}")
