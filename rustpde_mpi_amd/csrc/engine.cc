@@ -1141,8 +1141,7 @@ void Navier2DEngine::build_confined() {
       pb.load(0, pb.arr(yx(TBC2_), ldx), nx, -ka_, true);
       pb.pair_last_loads();
     }
-    pb.to_ortho(1, ax);                                       // S_x
-    pb.axpby(0, 0, -dt, 1, 1.0, nx);
+    pb.to_ortho_axpby(0, -dt, 1, 1.0, ax);                    // slot 0 = -dt * conv + S_x S_y state
     if (which == 0) {
       pb.load(1, pb.arr(yx(P_), ldx), nx);
       pb.cdiff(1, 1, nx, 1.0 / sx_);
@@ -1151,9 +1150,8 @@ void Navier2DEngine::build_confined() {
       pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
       pb.pair_last_loads();
-      pb.to_ortho(1, xN);
-      pb.load(1, pb.arr(yx(TBC_), ldx), nx, 1.0, true);
-      pb.axpby(0, 0, 1.0, 1, dt, nx);
+      pb.to_ortho_axpby(0, 1.0, 1, dt, xN);
+      pb.load(0, pb.arr(yx(TBC_), ldx), nx, dt, true);
     }
     pb.pinv_matvec(0, ax);
     pb.fdma_solve(0, mx, hh.fdma[0]);
@@ -1209,8 +1207,7 @@ void Navier2DEngine::build_confined() {
     pb.pair_last_loads();
     pb.to_ortho(0, xD);
     pb.cdiff(0, 0, nx, 1.0 / sx_);
-    pb.to_ortho(1, xD);
-    pb.axpby(0, 0, 1.0, 1, 1.0, nx);
+    pb.to_ortho_axpby(0, 1.0, 1, 1.0, xD);
     pb.store(0, pb.arr(yx(DIV_), ldx), nx);
     pb.pinv_matvec(0, xN);
     pb.store(0, pb.arr(yx(Y_[1]), ldx), mx, 1.0, po.half);

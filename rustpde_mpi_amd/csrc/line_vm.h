@@ -57,7 +57,8 @@ enum OpCode : int {
   OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1;
                // acc = 1: NaN guard -- a stored NaN raises *Program::nanflag (Integrate::exit, navier.rs:482-489)
-  OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length)
+  OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length);
+               // acc = 1 (d != a only): d[k] = s1 * d[k] + s0 * (that)
   OP_MV3,      // d[k] = t0[k] a[k] + t1[k] a[k+2] + t2[k] a[k+4]             k < n  (tables tab, tab+1, tab+2)
   OP_CDIFF,    // d = s0 * d/dx of the Chebyshev series a (length n)
   OP_REC1,     // first-order stride-2 recurrence, x_k = p_k b_k + q_k x_{k-2 dir}; p = tab (-1: ones), q = i0, dir = i1
@@ -675,6 +676,48 @@ __device__ __forceinline__ Affine<ORDER> affine_shfl_up(const Affine<ORDER>& a, 
   }
   return r;
 }
+// cross-lane moves of the in-wave scans as DPP (VALU data path; no trip through the LDS crossbar like
+// ds_bpermute).  Lanes without a source (row edge, masked row) receive `old` -- the identity of the scan,
+// so no select follows.  Controls (CDNA ISA, wave64): row_shr:n = 0x110 + n, wave_shr:1 = 0x138,
+// row_bcast:15 = 0x142 (lane 15 of a row to the next row), row_bcast:31 = 0x143 (lane 31 to rows 2, 3)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+  const long long xb = __double_as_longlong(x), ob = __double_as_longlong(old);
+  const int lo = __builtin_amdgcn_update_dpp((int)ob, (int)xb, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(ob >> 32), (int)(xb >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+template <int ORDER, int CTRL, int ROW_MASK>
+__device__ __forceinline__ Affine<ORDER> affine_dpp(const Affine<ORDER>& a) {
+  Affine<ORDER> r = affine_identity<ORDER>();
+  r.m11 = dpp_f64<CTRL, ROW_MASK>(1.0, a.m11);
+  r.v1 = dpp_f64<CTRL, ROW_MASK>(0.0, a.v1);
+  if constexpr (ORDER == 2) {
+    r.m12 = dpp_f64<CTRL, ROW_MASK>(0.0, a.m12); r.m21 = dpp_f64<CTRL, ROW_MASK>(0.0, a.m21);
+    r.m22 = dpp_f64<CTRL, ROW_MASK>(1.0, a.m22); r.v2 = dpp_f64<CTRL, ROW_MASK>(0.0, a.v2);
+  }
+  return r;
+}
+// inclusive scan over the 64 lanes: Kogge-Stone inside the rows of 16, then the row totals travel on
+template <int ORDER>
+__device__ __forceinline__ Affine<ORDER> affine_wave_scan(Affine<ORDER> inc) {
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x111, 0xF>(inc));
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x112, 0xF>(inc));
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x114, 0xF>(inc));
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x118, 0xF>(inc));
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x142, 0xA>(inc));
+  inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x143, 0xC>(inc));
+  return inc;
+}
+__device__ __forceinline__ double sum_wave_scan(double v) {
+  v += dpp_f64<0x111, 0xF>(0.0, v);
+  v += dpp_f64<0x112, 0xF>(0.0, v);
+  v += dpp_f64<0x114, 0xF>(0.0, v);
+  v += dpp_f64<0x118, 0xF>(0.0, v);
+  v += dpp_f64<0x142, 0xA>(0.0, v);
+  v += dpp_f64<0x143, 0xC>(0.0, v);
+  return v;
+}
 template <int ORDER>
 __device__ __forceinline__ Affine<ORDER> affine_shfl_idx(const Affine<ORDER>& a, int src) {
   Affine<ORDER> r = affine_identity<ORDER>();
@@ -765,16 +808,9 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
       inc[par] = Affine<ORDER>{m[0], m[1], m[2], m[3], m[4], m[5]};
     }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {   // the two parities give two independent chains
-        const Affine<ORDER> prev = affine_shfl_up<ORDER>(inc[par], off);
-        inc[par] = affine_select<ORDER>(lane >= off, affine_compose<ORDER>(inc[par], prev), inc[par]);
-      }
-    }
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      exc[par] = affine_select<ORDER>(lane == 0, affine_identity<ORDER>(), affine_shfl_up<ORDER>(inc[par], 1));
+    for (int par = 0; par < 2; ++par) {     // the two parities give two independent chains
+      inc[par] = affine_wave_scan<ORDER>(inc[par]);
+      exc[par] = affine_dpp<ORDER, 0x138, 0xF>(inc[par]);   // wave_shr:1, lane 0 gets the identity
     }
     if constexpr (NW > 1) {
       if (lane == 63) {
@@ -885,13 +921,8 @@ RPDE_DEVN void scan_cheb_diff(Blk& blk, lds_t dst, clds_t src, int n, lds_t carr
   {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double v[2] = {vv[0], vv[1]};
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const double u = __shfl_up(v[par], o);
-        v[par] += (lane >= o) ? u : 0.0;
-      }
+    v[0] = sum_wave_scan(v[0]);
+    v[1] = sum_wave_scan(v[1]);
     double S[2] = {0.0, 0.0};
     if constexpr (NW > 1) {
       if (lane == 63) { carry[wave] = v[0]; carry[NW + wave] = v[1]; }
@@ -899,10 +930,7 @@ RPDE_DEVN void scan_cheb_diff(Blk& blk, lds_t dst, clds_t src, int n, lds_t carr
       for (int u = 0; u < wave; ++u) { S[0] += carry[u]; S[1] += carry[NW + u]; }
     }
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const double e = __shfl_up(v[par], 1);
-      vv[par] = ((lane == 0) ? 0.0 : e) + S[par];
-    }
+    for (int par = 0; par < 2; ++par) vv[par] = dpp_f64<0x138, 0xF>(0.0, v[par]) + S[par];   // wave_shr:1
   }
 #endif
   RPDE_SYNC(blk);   // every thread has consumed its inputs (in-place operation is allowed)
@@ -1145,6 +1173,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
               const double a0 = a[k], a2 = a[k2], l2 = low[k2];
               double x = (k < n - 2) ? a0 : 0.0;
               x += (k >= 2) ? l2 * a2 : 0.0;
+              if (op.acc) x = op.s1 * d[k] + op.s0 * x;   // fused axpby: d = s1 d + s0 S a
               if (k < n) d[k] = x;
             }
           }

@@ -211,6 +211,16 @@ void ProgramBuilder::cik(int d, int a, int nc, double s0, int power) {
 void ProgramBuilder::to_ortho(int d, const AxisTables& ax) {
   if (ax.base.is_composite()) sten(d, d, ax.base.n, ax.low.p);
 }
+void ProgramBuilder::to_ortho_axpby(int d, double sd, int a, double sa, const AxisTables& ax) {
+  RPDE_REQUIRE(d != a, "to_ortho_axpby: out of place only");
+  if (ax.base.is_composite()) {
+    sten(d, a, ax.base.n, ax.low.p);
+    Op& o = pg.ops[pg.nops - 1];
+    o.acc = 1; o.s1 = sd; o.s0 = sa;
+  } else {
+    axpby(d, d, sd, a, sa, ax.base.n);
+  }
+}
 void ProgramBuilder::to_ortho_from(int d, int a, const AxisTables& ax) {
   if (ax.base.is_composite()) sten(d, a, ax.base.n, ax.low.p);
   else axpby(d, a, 1.0, a, 0.0, ax.base.n);

@@ -94,6 +94,7 @@ class ProgramBuilder {
   void cik(int d, int a, int ncomplex, double s0, int power);
   // composites
   void to_ortho(int d, const AxisTables& ax);                 // slot d: composite -> ortho (in place)
+  void to_ortho_axpby(int d, double sd, int a, double sa, const AxisTables& ax);   // d = sd * d + sa * (composite -> ortho of slot a), d != a
   void to_ortho_from(int d, int a, const AxisTables& ax);     // slot d = composite -> ortho of slot a (d != a: one phase)
   void from_ortho(int d, const AxisTables& ax);               // slot d: ortho -> composite (in place)
   void fdma_solve(int d, int n, const FdmaDev& f);            // slot d in place
