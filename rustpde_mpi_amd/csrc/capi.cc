@@ -559,8 +559,9 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
     Stream st;
 #ifndef RPDE_EMU
     // non-line kernels: "gemm_nt" / "gemm_nn" (n x n x n, the Poisson GEMM shapes), "transpose"
-    // (n x nlines), "mfma_peak" (register-only MFMA loop; returns ms, flops = blocks*4*iters*8*2048)
-    if (w == "gemm_nt" || w == "gemm_nn" || w == "transpose" || w == "mfma_peak") {
+    // (n x nlines), "mfma_peak" / "mfma_peak_a" (register-only MFMA loop, accumulators in VGPRs / AGPRs;
+    // returns ms, flops = blocks*4*iters*16*2048)
+    if (w == "gemm_nt" || w == "gemm_nn" || w == "transpose" || w == "mfma_peak" || w == "mfma_peak_a") {
       const long ld = pitch(n), ld2 = pitch(nlines);
       DBuf A((size_t)std::max(n, nlines) * std::max(ld, ld2)), B((size_t)std::max(n, nlines) * std::max(ld, ld2)),
           Cc((size_t)std::max(n, nlines) * std::max(ld, ld2));
@@ -574,7 +575,7 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
         if (w == "gemm_nt") launch_gemm_nt(n, nlines, n, A.p, ld, B.p, ld, Cc.p, ld2, st);
         else if (w == "gemm_nn") launch_gemm_nn(n, nlines, n, A.p, ld, B.p, ld2, Cc.p, ld2, st);
         else if (w == "transpose") launch_transpose(A.p, ld, Cc.p, ld2, nlines, n, 1, st);
-        else launch_mfma_peak(Cc.p, n, nlines, st);   // n = workgroups, nlines = iterations
+        else launch_mfma_peak(Cc.p, n, nlines, st, w == "mfma_peak_a" ? 1 : 0);   // n = workgroups, nlines = iterations
       };
       once();
       dev_sync(st);

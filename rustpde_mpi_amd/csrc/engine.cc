@@ -509,6 +509,17 @@ void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, lon
   l.bytes = 8.0 * ((double)M * K + (double)N * K + (double)M * N);
   step_.push_back(l);
 }
+void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
+  Launch l;
+  l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
+  l.gp[0] = p0; l.gp[1] = p1;
+  l.tag = tag;
+  for (const GemmProblem& g : l.gp) {
+    l.flops += 2.0 * g.M * (double)g.N * g.K;
+    l.bytes += 8.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N);
+  }
+  step_.push_back(l);
+}
 void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols,
                                     const char* tag) {
   Launch l;
@@ -561,6 +572,8 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kHalo: halo(l.out, ldx_, l.cols); break;
     case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
+    case Launch::kGemmPairNT: launch_gemm_pair(false, l.gp[0], l.gp[1], st_); break;
+    case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
     case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
     case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
@@ -1218,9 +1231,10 @@ void Navier2DEngine::build_confined() {
     // ---- G1: eigen-space transform along x (NT GEMM absorbs the YX -> XY transpose).
     // only the first my = ny - 2 columns are needed: the B2 preconditioner of the next stage never
     // reads the last two orthonormal coefficients (matvec.rs:215-226), and 4095 = 32 x 128 tiles
-    add_gemm(false, po.me, my, po.me, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[1]), ldx, X_[0].p, ldy, "G1 even");
-    add_gemm(false, po.mo, my, po.mo, po.fwd_o.p(), po.fwd_o.ld, yx(Y_[1]) + po.half, ldx,
-             X_[0].p + (size_t)po.me * ldy, ldy, "G1 odd");
+    // the even and the odd block are independent: one launch of 2 x 512 tiles (kernels.cc gemm_f64_pair_kernel)
+    add_gemm_pair(false, GemmProblem{po.me, my, po.me, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[1]), ldx, X_[0].p, ldy},
+                  GemmProblem{po.mo, my, po.mo, po.fwd_o.p(), po.fwd_o.ld, yx(Y_[1]) + po.half, ldx,
+                              X_[0].p + (size_t)po.me * ldy, ldy}, "G1 even + odd");
   } else {
     // sharded: x is complete on every rank in YX layout, so both GEMMs are local there
     // (src/solver_mpi/poisson.rs:166,186): C[j, k] = sum_i R[j, i] fwd[k, i], then exchange
@@ -1241,9 +1255,9 @@ void Navier2DEngine::build_confined() {
   }
   if (P == 1) {
     // ---- G2: back to coefficient space (rows of one parity are 2 ldy apart)
-    add_gemm(true, po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy, "G2 even");
-    add_gemm(true, po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
-             PS_.p + ldy, 2 * ldy, "G2 odd");
+    add_gemm_pair(true, GemmProblem{po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy},
+                  GemmProblem{po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
+                              PS_.p + ldy, 2 * ldy}, "G2 even + odd");
     { Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.tag = "pseu[0,0]=0"; step_.push_back(l); }
   } else {
     T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");

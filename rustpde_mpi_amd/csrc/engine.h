@@ -176,7 +176,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
+    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
+    GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
     ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;
@@ -201,6 +202,7 @@ class Navier2DEngine {
 #endif
   bool use_graph_ = true;
   void add_line(const ProgramBuilder& pb, const char* tag);
+  void add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);
   void add_halo(double* base, int ncols, const char* tag);

@@ -154,23 +154,31 @@ void launch_transpose(const double* in, long ldi, double* out, long ldo, int row
 // fragment read one contiguous 512-byte ds_read_b64 per wave (conflict free).
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 typedef double dbl2v __attribute__((ext_vector_type(2)));
-constexpr int kGemmDefaultVariant = 0;   // see gemm_f64_kernel: 0 = BK 16, 1 = + s_setprio, 2 = BK 32, 3 = BK 32 + s_setprio
+// D = A B + D with the accumulator PINNED TO VGPRs.  Measured on MI355X (rpde_microbench mfma_peak /
+// mfma_peak_a): v_mfma_f64_16x16x4_f64 runs at 77.4 TFLOP/s with a VGPR accumulator and at 38.3 with an
+// AGPR one; left to itself the register allocator parks part of the 128 accumulator registers in AGPRs.
+// Inline asm is opaque to the hazard recognizer: readers of the accumulators outside the MFMA stream wait
+// explicitly (mfma_drain).
+__device__ __forceinline__ void mfma_f64_vgpr(dbl4& acc, double a, double b) {
+  asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+constexpr int kGemmDefaultVariant = 4;   // 0 = one LDS stage of BK 16, 1 = + s_setprio, 2 = BK 32, 3 = BK 32 + s_setprio, 4 = two stages, pipeline written out (gemm_f64_db_tile)
 
 // BK: k-depth of one LDS stage (16: 32 KB of LDS, 32: 64 KB and half as many barriers per flop);
 // PRIO: raise the wave priority around the MFMA bursts (s_setprio) so that the partner wave's memory
 // phase does not delay them.  The variant is chosen by the launcher (RPDE_GEMM_VARIANT, default below).
 template <bool NN, int BK, bool PRIO>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
-                                                       const double* __restrict__ A, long lda,
-                                                       const double* __restrict__ B, long ldb,
-                                                       double* __restrict__ C, long ldc) {
+__device__ __forceinline__ void gemm_f64_tile(int M, int N, int K, const double* __restrict__ A, long lda,
+                                              const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
+                                              int tile_m, int tile_n) {
   constexpr int KS = BK / 4;      // k sub-steps (one MFMA k-depth each) per stage
   constexpr int KT = BK / 2;      // doubles per thread and operand per stage
   __shared__ __attribute__((aligned(16))) double As[KS][128][4];
   __shared__ __attribute__((aligned(16))) double Bs[KS][128][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
   const int l15 = lane & 15, l4 = lane >> 4;
 
   dbl4 acc[4][4];
@@ -184,32 +192,34 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
   const int bn = tid & 127, bkp = tid >> 7;               // B when NN: column n, k pair (k = 4e + 2 bkp + {0,1})
   // interior tiles (every row / column of the 128 x 128 block and all BK k exist) load without
   // bounds checks and with 16-byte accesses; `vec16` = the operands allow aligned 16-byte loads
-  const bool tile_full = (m0 + 128 <= M) && (n0 + 128 <= N);
+  // edge tiles read the last valid row / column again instead of predicating every load (their results are
+  // never stored), so only the last, partial k-stage takes the guarded path
+  const int arow_a = min(m0 + arow, M - 1), arow_b = min(n0 + arow, N - 1), bcol = min(n0 + bn, N - 1);
   const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
 
   auto gload = [&](int k0) {
-    if (tile_full && k0 + BK <= K) {
+    if (k0 + BK <= K) {
       if (vec16) {
-        const dbl2v* p = reinterpret_cast<const dbl2v*>(A + (long)(m0 + arow) * lda + k0 + akk);
+        const dbl2v* p = reinterpret_cast<const dbl2v*>(A + (long)arow_a * lda + k0 + akk);
 #pragma unroll
         for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
       } else {
-        const double* p = A + (long)(m0 + arow) * lda + k0 + akk;
+        const double* p = A + (long)arow_a * lda + k0 + akk;
 #pragma unroll
         for (int e = 0; e < KT; ++e) ra[e] = p[e];
       }
       if constexpr (!NN) {
         if (vec16) {
-          const dbl2v* p = reinterpret_cast<const dbl2v*>(B + (long)(n0 + arow) * ldb + k0 + akk);
+          const dbl2v* p = reinterpret_cast<const dbl2v*>(B + (long)arow_b * ldb + k0 + akk);
 #pragma unroll
           for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
         } else {
-          const double* p = B + (long)(n0 + arow) * ldb + k0 + akk;
+          const double* p = B + (long)arow_b * ldb + k0 + akk;
 #pragma unroll
           for (int e = 0; e < KT; ++e) rb[e] = p[e];
         }
       } else {
-        const double* p = B + (long)(k0 + 2 * bkp) * ldb + n0 + bn;
+        const double* p = B + (long)(k0 + 2 * bkp) * ldb + bcol;
 #pragma unroll
         for (int e = 0; e < KS; ++e) { rb[2 * e] = p[(long)(4 * e) * ldb]; rb[2 * e + 1] = p[(long)(4 * e + 1) * ldb]; }
       }
@@ -277,11 +287,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          mfma_f64_vgpr(acc[i][j], a[i], b[j]);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
   }
+  mfma_drain();
   // D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -296,6 +307,170 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
     }
 }
 
+template <bool NN, int BK, bool PRIO>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
+                                                       const double* __restrict__ A, long lda,
+                                                       const double* __restrict__ B, long ldb,
+                                                       double* __restrict__ C, long ldc) {
+  gemm_f64_tile<NN, BK, PRIO>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
+}
+// two independent products in one launch (blockIdx.z picks): the even and the odd block of the Poisson
+// eigen-transforms.  512 tiles are exactly one round on 256 CUs with two workgroups each -- prologue, epilogue
+// and the store burst of a round are not hidden; 1024 tiles give every CU a second round to overlap them with
+struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; };
+template <bool NN, bool DB>
+__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1);
+
+// Variant 4: the same tiling with the pipeline written out.  Two LDS stages (64 KB): the operands of stage
+// t + 1 are written while stage t feeds the MFMAs, so one barrier per stage instead of two; the fragments of
+// k sub-step s + 1 are read from LDS before the 16 MFMAs of sub-step s issue; the global loads of stage t + 2
+// are in flight during all of stage t + 1.
+template <bool NN>
+__device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
+                                                 const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
+                                                 int tile_m, int tile_n) {
+  constexpr int BK = 16, KS = 4, KT = 8;
+  __shared__ __attribute__((aligned(16))) double As[2][KS][128][4];
+  __shared__ __attribute__((aligned(16))) double Bs[2][KS][128][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  dbl4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+  double ra[KT], rb[KT];
+  const int arow = tid >> 1, akk = (tid & 1) * KT;
+  const int bn = tid & 127, bkp = tid >> 7;
+  const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
+  // edge tiles read the last valid row / column again (results never stored): no predicated loads
+  const double* pa = A + (long)min(m0 + arow, M - 1) * lda + akk;
+  const double* pbt = B + (long)min(n0 + arow, N - 1) * ldb + akk;          // !NN
+  const double* pbn = B + (long)(2 * bkp) * ldb + min(n0 + bn, N - 1);       // NN
+
+  auto gload = [&](int k0) {
+    if (k0 + BK <= K && vec16) {
+      const dbl2v* p = reinterpret_cast<const dbl2v*>(pa + k0);
+#pragma unroll
+      for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
+      if constexpr (!NN) {
+        const dbl2v* q = reinterpret_cast<const dbl2v*>(pbt + k0);
+#pragma unroll
+        for (int e = 0; e < KT / 2; ++e) { const dbl2v v = q[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
+      } else {
+        const double* q = pbn + (long)k0 * ldb;
+#pragma unroll
+        for (int e = 0; e < KS; ++e) { rb[2 * e] = q[(long)(4 * e) * ldb]; rb[2 * e + 1] = q[(long)(4 * e + 1) * ldb]; }
+      }
+      return;
+    }
+    {
+      const int r = m0 + arow;
+#pragma unroll
+      for (int e = 0; e < KT; ++e) ra[e] = (r < M && k0 + akk + e < K) ? pa[k0 + e] : 0.0;
+    }
+    if constexpr (!NN) {
+      const int r = n0 + arow;
+#pragma unroll
+      for (int e = 0; e < KT; ++e) rb[e] = (r < N && k0 + akk + e < K) ? pbt[k0 + e] : 0.0;
+    } else {
+      const int n = n0 + bn;
+#pragma unroll
+      for (int e = 0; e < KS; ++e) {
+        const int k = k0 + 4 * e + 2 * bkp;
+        rb[2 * e] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
+        rb[2 * e + 1] = (k + 1 < K && n < N) ? B[(long)(k + 1) * ldb + n] : 0.0;
+      }
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int h = 0; h < KT / 4; ++h) {
+      dbl2v* d = reinterpret_cast<dbl2v*>(&As[st][(akk >> 2) + h][arow][0]);
+      d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
+      d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
+    }
+    if constexpr (!NN) {
+#pragma unroll
+      for (int h = 0; h < KT / 4; ++h) {
+        dbl2v* d = reinterpret_cast<dbl2v*>(&Bs[st][(akk >> 2) + h][arow][0]);
+        d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
+        d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < KS; ++e)
+        *reinterpret_cast<dbl2v*>(&Bs[st][e][bn][2 * bkp]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
+    }
+  };
+  auto frag = [&](int st, int s, double (&a)[4], double (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = As[st][s][wm * 64 + i * 16 + l15][l4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = Bs[st][s][wn * 64 + j * 16 + l15][l4];
+  };
+  auto mma = [&](const double (&a)[4], const double (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        mfma_f64_vgpr(acc[i][j], a[i], b[j]);
+  };
+
+  gload(0);
+  lstore(0);
+  if (BK < K) gload(BK);
+  __syncthreads();
+  int st = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, st ^= 1) {
+    const bool more = k0 + BK < K;
+    double a0[4], b0[4], a1[4], b1[4];
+    frag(st, 0, a0, b0);
+    frag(st, 1, a1, b1);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore(st ^ 1);                 // stage t + 1 (its global loads were issued a full stage ago)
+    frag(st, 2, a0, b0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + 2 * BK < K) gload(k0 + 2 * BK);  // stage t + 2
+    frag(st, 3, a1, b1);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __syncthreads();
+  }
+  mfma_drain();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r];
+      }
+    }
+}
+
+template <bool NN>
+__global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
+                                                          const double* __restrict__ A, long lda,
+                                                          const double* __restrict__ B, long ldb,
+                                                          double* __restrict__ C, long ldc) {
+  gemm_f64_db_tile<NN>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
+}
+template <bool NN, bool DB>
+__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1) {
+  const GemmArgs& g = blockIdx.z ? g1 : g0;
+  if ((int)blockIdx.y * 128 >= g.M || (int)blockIdx.x * 128 >= g.N) return;
+  if constexpr (DB) gemm_f64_db_tile<NN>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
+  else gemm_f64_tile<NN, 16, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
+}
+
 template <bool NN>
 static void launch_gemm(int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                         Stream& st) {
@@ -306,7 +481,29 @@ static void launch_gemm(int M, int N, int K, const double* A, long lda, const do
     case 1: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     case 2: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     case 3: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+    case 4: hipLaunchKernelGGL((gemm_f64_db_kernel<NN>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+  }
+  RPDE_HIP(hipGetLastError());
+}
+void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
+  if (p0.M <= 0 || p0.N <= 0 || p1.M <= 0 || p1.N <= 0) {
+    for (const GemmProblem* p : {&p0, &p1}) {
+      if (nn) launch_gemm<true>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
+      else launch_gemm<false>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
+    }
+    return;
+  }
+  static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
+  const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc};
+  dim3 grid((std::max(p0.N, p1.N) + 127) / 128, (std::max(p0.M, p1.M) + 127) / 128, 2);
+  const bool db = variant == 4;
+  if (nn) {
+    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, true>), grid, dim3(256), 0, st.s, g0, g1);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, false>), grid, dim3(256), 0, st.s, g0, g1);
+  } else {
+    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, true>), grid, dim3(256), 0, st.s, g0, g1);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, false>), grid, dim3(256), 0, st.s, g0, g1);
   }
   RPDE_HIP(hipGetLastError());
 }
@@ -411,22 +608,29 @@ void launch_col_diff(const ColDiffArgs& a, Stream& st) {
 // sustained f64 MFMA rate of the chip (no memory traffic): 4 waves per workgroup, 8 independent
 // accumulator chains per wave, `iters` x 8 v_mfma_f64_16x16x4_f64 per wave.  The achievable peak a
 // GEMM can be priced against once the clock has settled under the matrix load.
+// KIND 0: accumulators pinned to VGPRs, 1: to AGPRs (inline asm, in-place accumulate: the compiler adds no
+// register moves).  16 independent chains per wave, `iters` x 16 v_mfma_f64_16x16x4_f64 per wave.
+template <int KIND>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
-  dbl4 acc[8];
+  dbl4 acc[16];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = dbl4{0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < 16; ++i) acc[i] = dbl4{0.0, 0.0, 0.0, 0.0};
   const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 16; ++i) {
+      if constexpr (KIND == 0) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+    }
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (s == 12345.678) out[0] = s;   // keep the chains alive
 }
-void launch_mfma_peak(double* out, int blocks, int iters, Stream& st) {
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st.s, out, iters);
+void launch_mfma_peak(double* out, int blocks, int iters, Stream& st, int kind) {
+  if (kind == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(256), 0, st.s, out, iters);
+  else hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, st.s, out, iters);
   RPDE_HIP(hipGetLastError());
 }
 
@@ -579,6 +783,12 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
       for (int n = 0; n < N; ++n) row[n] += a * b[n];
     }
     for (int n = 0; n < N; ++n) C[(long)m * ldc + n] = row[n];
+  }
+}
+void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
+  for (const GemmProblem* p : {&p0, &p1}) {
+    if (nn) launch_gemm_nn(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
+    else launch_gemm_nt(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
   }
 }
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream&) {

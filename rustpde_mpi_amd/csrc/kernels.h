@@ -37,6 +37,10 @@ void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double
 // C[m, n] = sum_k A[m, k] * B[k, n]   (A: M x K lda, B: K x N ldb, C: M x N ldc), f64
 void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream& st);
+// two independent products of the same kind (nn: both as launch_gemm_nn, else as launch_gemm_nt) in ONE launch
+struct GemmProblem { int M = 0, N = 0, K = 0; const double* A = nullptr; long lda = 0; const double* B = nullptr; long ldb = 0;
+                     double* C = nullptr; long ldc = 0; };
+void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st);
 
 // out[r * ldo + c] = in[r * ldi + c], r < rows, c < cols (doubles)
 void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, int cols, Stream& st);
@@ -73,7 +77,7 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
                         double* partial, double* out4, Stream& st);
 
 // measurement only: `blocks` workgroups x 4 waves x `iters` x 8 independent v_mfma_f64_16x16x4_f64 chains
-void launch_mfma_peak(double* out, int blocks, int iters, Stream& st);
+void launch_mfma_peak(double* out, int blocks, int iters, Stream& st, int kind = 0);
 
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
