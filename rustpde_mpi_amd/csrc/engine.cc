@@ -499,16 +499,6 @@ void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
   l.out = base; l.cols = ncols; l.tag = tag;
   step_.push_back(l);
 }
-void Navier2DEngine::add_gemm(bool nn, int M, int N, int K, const double* A, long lda,
-                              const double* B, long ldb, double* C, long ldc, const char* tag) {
-  Launch l;
-  l.type = nn ? Launch::kGemmNN : Launch::kGemmNT;
-  l.in = A; l.ldi = lda; l.b = B; l.ldb = ldb; l.out = C; l.ldo = ldc; l.M = M; l.N = N; l.K = K;
-  l.tag = tag;
-  l.flops = 2.0 * M * (double)N * K;
-  l.bytes = 8.0 * ((double)M * K + (double)N * K + (double)M * N);
-  step_.push_back(l);
-}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -570,8 +560,6 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kLine: launch_line_program(l.pg, st_); break;
     case Launch::kTranspose: exchange(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, l.to_xy, l.spec); break;
     case Launch::kHalo: halo(l.out, ldx_, l.cols); break;
-    case Launch::kGemmNT: launch_gemm_nt(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
-    case Launch::kGemmNN: launch_gemm_nn(l.M, l.N, l.K, l.in, l.ldi, l.b, l.ldb, l.out, l.ldo, st_); break;
     case Launch::kGemmPairNT: launch_gemm_pair(false, l.gp[0], l.gp[1], st_); break;
     case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
@@ -1238,9 +1226,9 @@ void Navier2DEngine::build_confined() {
   } else {
     // sharded: x is complete on every rank in YX layout, so both GEMMs are local there
     // (src/solver_mpi/poisson.rs:166,186): C[j, k] = sum_i R[j, i] fwd[k, i], then exchange
-    add_gemm(false, myl, po.me, po.me, yx(Y_[1]), ldx, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[2]), ldx, "G1 even");
-    add_gemm(false, myl, po.mo, po.mo, yx(Y_[1]) + po.half, ldx, po.fwd_o.p(), po.fwd_o.ld,
-             yx(Y_[2]) + po.me, ldx, "G1 odd");
+    add_gemm_pair(false, GemmProblem{myl, po.me, po.me, yx(Y_[1]), ldx, po.fwd_e.p(), po.fwd_e.ld, yx(Y_[2]), ldx},
+                  GemmProblem{myl, po.mo, po.mo, yx(Y_[1]) + po.half, ldx, po.fwd_o.p(), po.fwd_o.ld, yx(Y_[2]) + po.me, ldx},
+                  "G1 even + odd");
     T(yx(Y_[2]), X_[0].p, my, mx, true, "T4b");
   }
   // ---- S6: y preconditioner + per-eigenvalue banded solves (line index = eigen index)
@@ -1262,9 +1250,9 @@ void Navier2DEngine::build_confined() {
   } else {
     T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");
     // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land de-interleaved in x
-    add_gemm(false, myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[3]), ldx, "G2 even");
-    add_gemm(false, myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld,
-             yx(Y_[3]) + po.half, ldx, "G2 odd");
+    add_gemm_pair(false, GemmProblem{myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[3]), ldx},
+                  GemmProblem{myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld, yx(Y_[3]) + po.half, ldx},
+                  "G2 even + odd");
     {
       ProgramBuilder pb = ypb(1, my);
       pb.set_fft(xN);

@@ -176,17 +176,16 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmNT, kGemmNN, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
     ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;
     Program pg;                  // kLine
-    const double* in = nullptr;  // transposes / gemm A
-    const double* b = nullptr;   // gemm B
+    const double* in = nullptr;  // transposes
     double* out = nullptr;
-    long ldi = 0, ldb = 0, ldo = 0;
-    int rows = 0, cols = 0, elem = 1, M = 0, N = 0, K = 0;
+    long ldi = 0, ldo = 0;
+    int rows = 0, cols = 0, elem = 1;
     const char* tag = "";
     double bytes = 0.0;          // algorithmic HBM bytes of one launch (reads + writes)
     double flops = 0.0;          // floating point operations of one launch (GEMMs)
@@ -210,8 +209,6 @@ class Navier2DEngine {
   // (single GPU: column scans instead of transpose -> line program -> transpose)
   void add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols, const char* tag);
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
-  void add_gemm(bool nn, int M, int N, int K, const double* A, long lda, const double* B, long ldb,
-                double* C, long ldc, const char* tag);
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

@@ -163,6 +163,7 @@ __device__ __forceinline__ void mfma_f64_vgpr(dbl4& acc, double a, double b) {
   asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+constexpr long kGemmSmallTileBelow = 512;   // fewer 128 x 128 tiles than this (two per CU): use 64 x 64 tiles
 constexpr int kGemmDefaultVariant = 4;   // 0 = one LDS stage of BK 16, 1 = + s_setprio, 2 = BK 32, 3 = BK 32 + s_setprio, 4 = two stages, pipeline written out (gemm_f64_db_tile)
 
 // BK: k-depth of one LDS stage (16: 32 KB of LDS, 32: 64 KB and half as many barriers per flop);
@@ -318,37 +319,45 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
 // eigen-transforms.  512 tiles are exactly one round on 256 CUs with two workgroups each -- prologue, epilogue
 // and the store burst of a round are not hidden; 1024 tiles give every CU a second round to overlap them with
 struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; };
-template <bool NN, bool DB>
+template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1);
 
 // Variant 4: the same tiling with the pipeline written out.  Two LDS stages (64 KB): the operands of stage
 // t + 1 are written while stage t feeds the MFMAs, so one barrier per stage instead of two; the fragments of
 // k sub-step s + 1 are read from LDS before the 16 MFMAs of sub-step s issue; the global loads of stage t + 2
 // are in flight during all of stage t + 1.
-template <bool NN>
+// TM x TM block tile (128 or 64), 4 waves in a 2 x 2 grid, each wave MT x MT MFMA tiles (MT = TM / 32).  The
+// 64-tile serves problems that would not give every CU a 128-tile (small grids; the local products of a
+// pencil-sharded run, 512 x 2048 x 2048 per GPU at 4097^2 on 8 GPUs).
+template <bool NN, int TM>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
                                                  int tile_m, int tile_n) {
-  constexpr int BK = 16, KS = 4, KT = 8;
-  __shared__ __attribute__((aligned(16))) double As[2][KS][128][4];
-  __shared__ __attribute__((aligned(16))) double Bs[2][KS][128][4];
+  constexpr int BK = 16, KS = 4;
+  constexpr int MT = TM / 32;          // MFMA tiles per wave and dimension
+  constexpr int TPR = 256 / TM;        // threads per operand row (k contiguous)
+  constexpr int KT = BK / TPR;         // doubles per thread and operand per stage (8 or 4)
+  constexpr int VPE = TM / 64;         // NN: k-values per thread and k sub-step (2 or 1)
+  static_assert(TM == 128 || TM == 64, "tile sizes 128 and 64");
+  __shared__ __attribute__((aligned(16))) double As[2][KS][TM][4];
+  __shared__ __attribute__((aligned(16))) double Bs[2][KS][TM][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int m0 = tile_m * TM, n0 = tile_n * TM;
   const int l15 = lane & 15, l4 = lane >> 4;
-  dbl4 acc[4][4];
+  dbl4 acc[MT][MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < MT; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
   double ra[KT], rb[KT];
-  const int arow = tid >> 1, akk = (tid & 1) * KT;
-  const int bn = tid & 127, bkp = tid >> 7;
+  const int arow = tid / TPR, akk = (tid % TPR) * KT;
+  const int bn = tid % TM, bkg = tid / TM;                                   // NN: column n, k group
   const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
   // edge tiles read the last valid row / column again (results never stored): no predicated loads
   const double* pa = A + (long)min(m0 + arow, M - 1) * lda + akk;
   const double* pbt = B + (long)min(n0 + arow, N - 1) * ldb + akk;          // !NN
-  const double* pbn = B + (long)(2 * bkp) * ldb + min(n0 + bn, N - 1);       // NN
+  const double* pbn = B + (long)(VPE * bkg) * ldb + min(n0 + bn, N - 1);     // NN: k = 4 e + VPE bkg + v
 
   auto gload = [&](int k0) {
     if (k0 + BK <= K && vec16) {
@@ -362,7 +371,9 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
       } else {
         const double* q = pbn + (long)k0 * ldb;
 #pragma unroll
-        for (int e = 0; e < KS; ++e) { rb[2 * e] = q[(long)(4 * e) * ldb]; rb[2 * e + 1] = q[(long)(4 * e + 1) * ldb]; }
+        for (int e = 0; e < KS; ++e)
+#pragma unroll
+          for (int v = 0; v < VPE; ++v) rb[VPE * e + v] = q[(long)(4 * e + v) * ldb];
       }
       return;
     }
@@ -378,11 +389,12 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
     } else {
       const int n = n0 + bn;
 #pragma unroll
-      for (int e = 0; e < KS; ++e) {
-        const int k = k0 + 4 * e + 2 * bkp;
-        rb[2 * e] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
-        rb[2 * e + 1] = (k + 1 < K && n < N) ? B[(long)(k + 1) * ldb + n] : 0.0;
-      }
+      for (int e = 0; e < KS; ++e)
+#pragma unroll
+        for (int v = 0; v < VPE; ++v) {
+          const int k = k0 + 4 * e + VPE * bkg + v;
+          rb[VPE * e + v] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
+        }
     }
   };
   auto lstore = [&](int st) {
@@ -401,21 +413,23 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < KS; ++e)
-        *reinterpret_cast<dbl2v*>(&Bs[st][e][bn][2 * bkp]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
+      for (int e = 0; e < KS; ++e) {
+        if constexpr (VPE == 2) *reinterpret_cast<dbl2v*>(&Bs[st][e][bn][2 * bkg]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
+        else Bs[st][e][bn][bkg] = rb[e];
+      }
     }
   };
-  auto frag = [&](int st, int s, double (&a)[4], double (&b)[4]) {
+  auto frag = [&](int st, int s, double (&a)[MT], double (&b)[MT]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = As[st][s][wm * 64 + i * 16 + l15][l4];
+    for (int i = 0; i < MT; ++i) a[i] = As[st][s][wm * (TM / 2) + i * 16 + l15][l4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = Bs[st][s][wn * 64 + j * 16 + l15][l4];
+    for (int j = 0; j < MT; ++j) b[j] = Bs[st][s][wn * (TM / 2) + j * 16 + l15][l4];
   };
-  auto mma = [&](const double (&a)[4], const double (&b)[4]) {
+  auto mma = [&](const double (&a)[MT], const double (&b)[MT]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < MT; ++j)
         mfma_f64_vgpr(acc[i][j], a[i], b[j]);
   };
 
@@ -426,7 +440,7 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   int st = 0;
   for (int k0 = 0; k0 < K; k0 += BK, st ^= 1) {
     const bool more = k0 + BK < K;
-    double a0[4], b0[4], a1[4], b1[4];
+    double a0[MT], b0[MT], a1[MT], b1[MT];
     frag(st, 0, a0, b0);
     frag(st, 1, a1, b1);
     mma(a0, b0);
@@ -444,30 +458,33 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   }
   mfma_drain();
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + l15;
+    for (int j = 0; j < MT; ++j) {
+      const int n = n0 + wn * (TM / 2) + j * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        const int m = m0 + wm * (TM / 2) + i * 16 + l4 + 4 * r;
         if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r];
       }
     }
 }
 
-template <bool NN>
+template <bool NN, int TM>
 __global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
                                                           const double* __restrict__ A, long lda,
                                                           const double* __restrict__ B, long ldb,
                                                           double* __restrict__ C, long ldc) {
-  gemm_f64_db_tile<NN>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
+  gemm_f64_db_tile<NN, TM>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
 }
-template <bool NN, bool DB>
+// DB: 0 = one-stage 128-tile, 1 = two-stage 128-tile, 2 = two-stage 64-tile
+template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
-  if ((int)blockIdx.y * 128 >= g.M || (int)blockIdx.x * 128 >= g.N) return;
-  if constexpr (DB) gemm_f64_db_tile<NN>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
+  constexpr int TM = DB == 2 ? 64 : 128;
+  if ((int)blockIdx.y * TM >= g.M || (int)blockIdx.x * TM >= g.N) return;
+  if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
+  else if constexpr (DB == 1) gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
   else gemm_f64_tile<NN, 16, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
 }
 
@@ -477,11 +494,17 @@ static void launch_gemm(int M, int N, int K, const double* A, long lda, const do
   if (M <= 0 || N <= 0) return;
   static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
   dim3 grid((N + 127) / 128, (M + 127) / 128);
+  if (variant == 4 && (long)grid.x * grid.y < kGemmSmallTileBelow) {   // too few 128-tiles for the chip
+    dim3 g64((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 64>), g64, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
+    RPDE_HIP(hipGetLastError());
+    return;
+  }
   switch (variant) {
     case 1: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     case 2: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     case 3: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-    case 4: hipLaunchKernelGGL((gemm_f64_db_kernel<NN>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
+    case 4: hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
     default: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
   }
   RPDE_HIP(hipGetLastError());
@@ -496,14 +519,19 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
   }
   static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
   const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc};
-  dim3 grid((std::max(p0.N, p1.N) + 127) / 128, (std::max(p0.M, p1.M) + 127) / 128, 2);
+  const int Mx = std::max(p0.M, p1.M), Nx = std::max(p0.N, p1.N);
+  dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, 2);
   const bool db = variant == 4;
-  if (nn) {
-    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, true>), grid, dim3(256), 0, st.s, g0, g1);
-    else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, false>), grid, dim3(256), 0, st.s, g0, g1);
+  if (db && (long)grid.x * grid.y * 2 < kGemmSmallTileBelow) {
+    dim3 g64((Nx + 63) / 64, (Mx + 63) / 64, 2);
+    if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1);
+  } else if (nn) {
+    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 0>), grid, dim3(256), 0, st.s, g0, g1);
   } else {
-    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, true>), grid, dim3(256), 0, st.s, g0, g1);
-    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, false>), grid, dim3(256), 0, st.s, g0, g1);
+    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 1>), grid, dim3(256), 0, st.s, g0, g1);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 0>), grid, dim3(256), 0, st.s, g0, g1);
   }
   RPDE_HIP(hipGetLastError());
 }
