@@ -468,18 +468,6 @@ void Navier2DEngine::add_line(const ProgramBuilder& pb, const char* tag) {
   l.type = Launch::kLine;
   l.pg = pb.pg;
   l.tag = tag;
-  static const bool touch = [] { const char* e = std::getenv("RPDE_TOUCH"); return e && std::atoi(e) != 0; }();
-  static const int stagger = [] { const char* e = std::getenv("RPDE_STAGGER"); return e ? std::atoi(e) : 0; }();
-  l.pg.stagger = stagger;
-  if (touch && comm_.size == 1) {
-    const int nh = add_touches(l.pg);
-    if (std::getenv("RPDE_TOUCH_VERBOSE")) {
-      fprintf(stderr, "%-36s %d hints:", tag, nh);
-      for (int i = 0; i < l.pg.nops; ++i)
-        if (l.pg.ops[i].code == OP_TOUCH) fprintf(stderr, " [before op %d: arr %d line+%d n=%d]", i + 1, l.pg.ops[i].arr, l.pg.ops[i].i0, l.pg.ops[i].n);
-      fprintf(stderr, "\n");
-    }
-  }
   for (int i = 0; i < l.pg.nops; ++i) {
     const Op& o = l.pg.ops[i];
     if (o.code == OP_LOAD || o.code == OP_LOADX || o.code == OP_STORE)
@@ -716,7 +704,7 @@ std::string Navier2DEngine::describe_step() const {
 
 std::string Navier2DEngine::trace_launch(const std::string& tag) {
   static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct",
-                                         "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy", "touch"};
+                                         "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy"};
   size_t which = step_.size();
   for (size_t i = 0; i < step_.size(); ++i)
     if (step_[i].type == Launch::kLine && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }

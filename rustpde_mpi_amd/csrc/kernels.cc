@@ -69,12 +69,6 @@ __global__ __launch_bounds__(Cfg::T, 4) void line_kernel(const Program pg) {
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= pg.nlines) return;
-  if (pg.stagger > 0) {
-    // the k-th workgroup a CU receives in the first round (32 CUs per XCD) waits k * stagger sleeps
-    const int slot = ((int)blockIdx.x >> 3) / 32;
-    if (slot > 0 && slot < 1024 / Cfg::T)
-      for (int i = 0; i < slot * pg.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   Blk blk{line, (int)blockIdx.y, Cfg::T, rpde_lds,
           TRACE ? pg.trace + ((long)blockIdx.y * gridDim.x + blockIdx.x) * kTraceStride : nullptr, 0};
   run_line_program<Cfg, VAR>(blk, pg);
@@ -913,16 +907,6 @@ LineClass line_class_for(int slot_len) {
     case 2: return {CfgL::T, CfgL::C};
     case 3: return {CfgX::T, CfgX::C};
     default: fail("line too long for one workgroup: slot length " + std::to_string(slot_len));
-  }
-}
-size_t line_program_lds_bytes(const Program& pg) {
-  auto bytes = [&](int max_slot, int carry) { return line_lds_doubles(pg.nslots, pg.slot_len, max_slot, carry) * sizeof(double); };
-  switch (class_index(pg.slot_len)) {
-    case 0: return bytes(CfgS::kMaxSlotLen, CfgS::kCarryLen);
-    case 1: return bytes(CfgM::kMaxSlotLen, CfgM::kCarryLen);
-    case 2: return bytes(CfgL::kMaxSlotLen, CfgL::kCarryLen);
-    case 3: return bytes(CfgX::kMaxSlotLen, CfgX::kCarryLen);
-    default: fail("line too long for one workgroup: slot length " + std::to_string(pg.slot_len));
   }
 }
 std::vector<double> chunk_major(const std::vector<double>& tab, LineClass lc, int dir, double pad) {

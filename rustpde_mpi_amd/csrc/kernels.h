@@ -19,8 +19,6 @@ inline int slot_len_for(int maxlen) {
 // kernel configuration (threads per line, scan chunk per thread) used for a given slot length
 struct LineClass { int T, C; };
 LineClass line_class_for(int slot_len);
-// dynamic LDS bytes a workgroup of this program is launched with
-size_t line_program_lds_bytes(const Program& pg);
 
 // Re-order a recurrence table for the chunked scans: out[i * T + t] = tab[tau(t) * C + i] with
 // tau(t) = t (dir > 0) or T - 1 - t (dir < 0); entries past the end of `tab` are `pad`.

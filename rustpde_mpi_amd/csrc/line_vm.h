@@ -74,10 +74,6 @@ enum OpCode : int {
   OP_CIK,      // complex line: d = (i k s0)^i0 * a  for k < n (complex count)
   OP_PUSH,     // per-thread register stash <- a[k]   (one stash per program run; saves an LDS slot)
   OP_POPAXPY,  // d[k] = s0 * d[k] + s1 * stash[k]    k < n
-  OP_TOUCH,    // cache hint, no result: pull the n doubles of A[line + i0] towards the XCD's L2 (one 4-byte LDS-DMA read per
-               // 128-byte cache line into a scratch area nobody reads; no VGPR, no wait).  i0 != 0: only inside the band of
-               // i1 consecutive lines this XCD sweeps.  Issued ahead of a transform, so that the HBM round trip of a later
-               // load of this line -- or of the first load of the workgroup that takes this slot next -- overlaps with it
 };
 
 // kernel variants: which register-hungry features a program needs (each is compiled out of the
@@ -115,7 +111,6 @@ struct Program {
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
   int tw2;        // table index of the split twiddles (cos, sin)(pi k / N) resp. (2 pi k / nx)
   int* nanflag;   // device flag raised by guarded stores (OP_STORE with acc = 1); may be null
-  int stagger;    // experiment (RPDE_STAGGER): workgroups of the first round that share a CU start `stagger` x 8128 clocks apart
   long long* trace;   // diagnostics (tools/trace_ops.py): kTraceStride words per workgroup (platform.h RPDE_MARK); normally null
   Op ops[kMaxOps];
   ArrayRef arr[kMaxArr];
@@ -139,13 +134,12 @@ struct LineCfg {
   // workgroup, so no DCT (needs two slots) and no banded scans (a Fourier axis has none)
   static constexpr bool kCheb = (T_ <= 512);
   static constexpr int kCarryLen = 2 * ((T_ + 63) / 64) * 6 + 4;  // doubles: wave totals of a scan
-  static constexpr int kTouchLen = 32;                 // doubles: landing area of OP_TOUCH (256 B, one LDS-DMA dword per lane)
 };
 
 // slots are slot_len apart; the last one is padded to T*EPT doubles so that unguarded reads of
 // k = tid + q T < T*EPT (+4 for the stencil taps) stay inside the allocation
 RPDE_HD inline size_t line_lds_doubles(int nslots, int slot_len, int t_ept, int carry_len) {
-  return (size_t)nslots * slot_len + (t_ept - slot_len) + 8 + carry_len + 32;   // 32 = LineCfg::kTouchLen
+  return (size_t)nslots * slot_len + (t_ept - slot_len) + 8 + carry_len;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1318,27 +1312,6 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           }
           RPDE_SYNC(blk);
         }
-      } break;
-      case OP_TOUCH: {
-#ifndef RPDE_EMU
-        const ArrayRef& A = pg.arr[op.arr];
-        const int l2 = line + op.i0;
-        const bool ok = op.i0 == 0 || (l2 < pg.nlines && l2 / op.i1 == line / op.i1);
-        if (ok) {
-          const __attribute__((address_space(1))) char* src =
-              (const __attribute__((address_space(1))) char*)(A.p + comp * A.coff + (long)l2 * A.ld);
-          // M0 = LDS byte address of the landing area (wave-uniform); saved and restored inside the statement
-          const unsigned land = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(carry + Cfg::kCarryLen));
-          RPDE_PHASE(blk, tid) {
-            if (tid * 16 < n) {
-              const __attribute__((address_space(1))) char* q = src + (long)tid * 128;
-              unsigned keep;
-              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                           : "=&s"(keep) : "v"(q), "s"(land));
-            }
-          }
-        }
-#endif
       } break;
       case OP_ZERO: {
         RPDE_PHASE(blk, tid) {

@@ -92,57 +92,6 @@ Op& ProgramBuilder::push(int code) {
   o.s0 = 1.0;
   return o;
 }
-int add_touches(Program& pg) {
-  auto is_anchor = [&](const Op& o) {
-    return (o.code == OP_DCT && pg.fft_n > 0) || o.code == OP_RFFT_F || o.code == OP_RFFT_B;
-  };
-  auto is_plain = [&](const Op& o) {
-    return (o.code == OP_LOAD && o.i0 == 0 && pg.arr[o.arr].es == 1) || (o.code == OP_LOADX && pg.arr[o.arr].es == 1);
-  };
-  std::vector<int> anchors;
-  for (int i = 0; i < pg.nops; ++i) {
-    if (pg.ops[i].code == OP_TOUCH) return 0;                      // already hinted
-    if (is_anchor(pg.ops[i])) anchors.push_back(i);
-  }
-  if (anchors.empty()) return 0;
-  // workgroups in flight: 128 VGPRs = 16 waves per CU, 160 KiB of LDS, 256 CUs dealt round-robin over 8 XCDs
-  const LineClass lc = line_class_for(pg.slot_len);
-  const size_t lds = line_program_lds_bytes(pg);
-  const int per_cu = std::max(1, std::min<int>(1024 / lc.T, (int)(160 * 1024 / lds)));
-  const int succ = 256 * per_cu / 8, band = (pg.nlines + 7) / 8;
-  struct Hint { int before, arr, n, delta; };
-  std::vector<Hint> hints;
-  auto add = [&](int before, const Op& o, int delta) {
-    for (const Hint& h : hints)
-      if (h.before == before && h.arr == o.arr && h.delta == delta) return;
-    hints.push_back(Hint{before, o.arr, o.n, delta});
-  };
-  for (int i = 0; i < pg.nops; ++i) {
-    const Op& o = pg.ops[i];
-    if (!is_plain(o)) continue;
-    if (i < anchors.front()) { if (succ < band) add(anchors.back(), o, succ); continue; }
-    int a = anchors.front();
-    for (int k : anchors) if (k < i) a = k;
-    add(a, o, 0);
-  }
-  while (!hints.empty() && pg.nops + (int)hints.size() > kMaxOps) hints.pop_back();
-  if (hints.empty()) return 0;
-  Op out[kMaxOps];
-  int n = 0;
-  for (int i = 0; i < pg.nops; ++i) {
-    for (const Hint& h : hints)
-      if (h.before == i) {
-        Op t{};
-        t.code = OP_TOUCH; t.arr = h.arr; t.n = h.n; t.i0 = h.delta; t.i1 = band; t.tab = -1; t.s0 = 1.0;
-        out[n++] = t;
-      }
-    out[n++] = pg.ops[i];
-  }
-  for (int i = 0; i < n; ++i) pg.ops[i] = out[i];
-  pg.nops = n;
-  return (int)hints.size();
-}
-
 void ProgramBuilder::load(int d, int a, int n, double s0, bool acc, int half) {
   RPDE_REQUIRE(n <= pg.slot_len, "line longer than the slot");
   Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = acc; o.i0 = half > 0; o.i1 = half;

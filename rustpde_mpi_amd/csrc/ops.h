@@ -108,13 +108,6 @@ class ProgramBuilder {
   void dct_flags(Op& o, int n, const double* pre, const double* post, int cut);
 };
 
-// Cache hints for a finished line program (OP_TOUCH, line_vm.h): ahead of every transform op, the lines that the
-// plain loads behind it will read; ahead of the last transform, the first loads of the line that the workgroup
-// taking this slot next will start with (same XCD band, `resident workgroups / 8` lines further).  A line program
-// alternates between waiting for HBM and a long LDS-bound transform; the hints move the HBM round trips of the
-// next waits under the transform.  Programs without a transform op are left alone.  Returns the number of hints.
-int add_touches(Program& pg);
-
 // ------------------------------------------------------------------------------------------
 // a 2-D device array in canonical (XY) layout: rows x cols elements of `elem` doubles, pitch ld doubles
 struct Arr2 {
