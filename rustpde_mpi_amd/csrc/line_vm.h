@@ -533,6 +533,11 @@ RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) 
   RPDE_TLS(blk, double, yr, QM);
   RPDE_TLS(blk, double, yi, QM);
   RPDE_PHASE(blk, tid) {
+    double tc[QM], ts[QM];   // split twiddles: all fetched before the first use
+#pragma unroll
+    for (int q = 0; q < QM; ++q) { const int kc = min(tid + q * T, M); tc[q] = tw2[2 * kc]; ts[q] = tw2[2 * kc + 1]; }
+#pragma unroll
+    for (int q = 0; q < QM; ++q) { RPDE_PIN(tc[q]); RPDE_PIN(ts[q]); }
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
       const int k = tid + q * T;
@@ -541,7 +546,7 @@ RPDE_DEVN void rfft_forward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2) 
         const int kb = 2 * pidx((k == 0) ? 0 : M - k);
         const double ar = x[ka], ai = x[ka + 1];
         const double br = x[kb], bi = x[kb + 1];
-        const double c = tw2[2 * k], s = tw2[2 * k + 1];
+        const double c = tc[q], s = ts[q];
         const double sr = ar + br, si = ai - bi, dr = ar - br, di = ai + bi;
         RPDE_T(yr)[q] = 0.5 * (sr + c * di - s * dr);
         RPDE_T(yi)[q] = 0.5 * (si - c * dr - s * di);
@@ -570,6 +575,11 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
     RPDE_TLS(blk, double, zr, QM);
     RPDE_TLS(blk, double, zi, QM);
     RPDE_PHASE(blk, tid) {
+      double tc[QM], ts[QM];   // split twiddles: all fetched before the first use
+#pragma unroll
+      for (int q = 0; q < QM; ++q) { const int kc = min(tid + q * T, M); tc[q] = tw2[2 * kc]; ts[q] = tw2[2 * kc + 1]; }
+#pragma unroll
+      for (int q = 0; q < QM; ++q) { RPDE_PIN(tc[q]); RPDE_PIN(ts[q]); }
 #pragma unroll
       for (int q = 0; q < QM; ++q) {
         const int k = tid + q * T;
@@ -578,7 +588,7 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
           double ar = x[2 * k], ai = x[2 * k + 1];
           double br = x[2 * kb], bi = -x[2 * kb + 1];  // conj X_{M-k}
           if (k == 0) { ai = 0.0; bi = 0.0; }
-          const double c = tw2[2 * k], s = tw2[2 * k + 1];  // conj(W^k) = c + i s
+          const double c = tc[q], s = ts[q];  // conj(W^k) = c + i s
           const double sr = ar + br, si = ai + bi, dr = ar - br, di = ai - bi;
           // Z_k = ( S + i (c + i s) D ) / 2 ;  store conj(Z_k) for the conjugate-FFT inverse
           const double er = sr + (-(c * di) - s * dr);
@@ -1166,11 +1176,16 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         tab_t low = (tab_t)(pg.tabs[op.tab] + toff);
         if (op.d != op.a) {   // out of place: no thread overwrites what another one still reads -- one phase
           RPDE_PHASE(blk, tid) {
+            double lw[EPT];   // stencil coefficients: all fetched before the first use
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) lw[q] = low[max(tid + q * T - 2, 0)];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) RPDE_PIN(lw[q]);
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
               const int k = tid + q * T;
               const int k2 = (k >= 2) ? k - 2 : 0;
-              const double a0 = a[k], a2 = a[k2], l2 = low[k2];
+              const double a0 = a[k], a2 = a[k2], l2 = lw[q];
               double x = (k < n - 2) ? a0 : 0.0;
               x += (k >= 2) ? l2 * a2 : 0.0;
               if (op.acc) x = op.s1 * d[k] + op.s0 * x;   // fused axpby: d = s1 d + s0 S a
@@ -1182,11 +1197,16 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         }
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
+          double lw[EPT];
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) lw[q] = low[max(tid + q * T - 2, 0)];
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) RPDE_PIN(lw[q]);
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
             const int k2 = (k >= 2) ? k - 2 : 0;
-            const double a0 = a[k], a2 = a[k2], l2 = low[k2];
+            const double a0 = a[k], a2 = a[k2], l2 = lw[q];
             double x = (k < n - 2) ? a0 : 0.0;
             x += (k >= 2) ? l2 * a2 : 0.0;
             RPDE_T(v)[q] = x;
@@ -1205,14 +1225,27 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         tab_t t2 = (tab_t)(pg.tabs[op.tab + 2] + toff);
         RPDE_TLS(blk, double, v, EPT);
         RPDE_PHASE(blk, tid) {
+          // the three band coefficients of half of this thread's rows are in flight together (with per-line
+          // tables they come from HBM); tables carry slack, so the reads need no predicate
+          constexpr int H0 = EPT / 2;
 #pragma unroll
-          for (int q = 0; q < EPT; ++q) {
-            const int k = tid + q * T;
-            // input line has n + 2 entries; the +4 tap exists for k < n - 2 only (matvec.rs:215-226)
-            const double a0 = a[k], a2 = a[k + 2], a4 = a[k + 4];
-            double x = a0 * t0[k] + a2 * t1[k];
-            x += (k < n - 2) ? a4 * t2[k] : 0.0;
-            RPDE_T(v)[q] = x;
+          for (int h = 0; h < 2; ++h) {
+            constexpr int HN = EPT - H0 > H0 ? EPT - H0 : H0;
+            const int q0 = h ? H0 : 0, q1 = h ? EPT : H0;
+            double c0[HN], c1[HN], c2[HN];
+#pragma unroll
+            for (int q = q0; q < q1; ++q) { const int k = tid + q * T; c0[q - q0] = t0[k]; c1[q - q0] = t1[k]; c2[q - q0] = t2[k]; }
+#pragma unroll
+            for (int q = q0; q < q1; ++q) { RPDE_PIN(c0[q - q0]); RPDE_PIN(c1[q - q0]); RPDE_PIN(c2[q - q0]); }
+#pragma unroll
+            for (int q = q0; q < q1; ++q) {
+              const int k = tid + q * T;
+              // input line has n + 2 entries; the +4 tap exists for k < n - 2 only (matvec.rs:215-226)
+              const double a0 = a[k], a2 = a[k + 2], a4 = a[k + 4];
+              double x = a0 * c0[q - q0] + a2 * c1[q - q0];
+              x += (k < n - 2) ? a4 * c2[q - q0] : 0.0;
+              RPDE_T(v)[q] = x;
+            }
           }
         }
         RPDE_SYNC(blk);
@@ -1326,11 +1359,15 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
       case OP_TABDIV: {
         tab_t t = (tab_t)(pg.tabs[op.tab] + toff);
         RPDE_PHASE(blk, tid) {
+          double den[EPT];   // unpredicated table reads, all issued before the first use; lanes past the end are not stored
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) den[q] = t[min(tid + q * T, n - 1) >> op.i0];
+#pragma unroll
+          for (int q = 0; q < EPT; ++q) RPDE_PIN(den[q]);
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            const double den = (k < n) ? t[k >> op.i0] : 1.0;
-            const double v = a[k] / den;
+            const double v = a[k] / den[q];
             if (k < n) d[k] = v;
           }
         }

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #ifndef RPDE_EMU
@@ -22,6 +23,10 @@
 #endif
 
 namespace rpde {
+#ifdef RPDE_EMU
+using std::min;   // device code has HIP's min(int, int)
+using std::max;
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // error handling (host)
@@ -58,6 +63,7 @@ struct Blk {          // one workgroup
   double* lds;        // base of the workgroup's LDS
 };
 #define RPDE_PHASE(blk, tid) for (int tid = 0; tid < (blk).T; ++tid)
+#define RPDE_PIN(x) ((void)0)
 #define RPDE_SYNC(blk) ((void)0)
 #define RPDE_MARK(blk, id) ((void)0)
 #define RPDE_TLS(blk, type, name, K) std::vector<type> name##_st((size_t)(blk).T * (K)); const int name##_K = (K)
@@ -88,6 +94,10 @@ __device__ __forceinline__ int rpde_tid() {
   return t;
 }
 #define RPDE_PHASE(blk, tid) for (int tid = rpde_tid(), _once = 1; _once; _once = 0)
+// A value loaded from global memory is pinned where all loads of the phase have been issued: the compiler
+// may not sink the load into the (per-lane predicated) block of its only user, where it would be followed by
+// an s_waitcnt vmcnt(0) -- one dependent memory round trip per element (tools/check_load_issue.py)
+#define RPDE_PIN(x) asm volatile("" : "+v"(x))
 #define RPDE_SYNC(blk) do { __syncthreads(); RPDE_MARK(blk, -1); } while (0)
 #define RPDE_TLS(blk, type, name, K) type name[K]
 #define RPDE_T(name) name
