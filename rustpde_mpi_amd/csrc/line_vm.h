@@ -48,6 +48,15 @@ using lds2_t = dbl2*;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 using lds2_t = __attribute__((address_space(3))) dbl2*;
 #endif
+#ifdef RPDE_EMU
+using cgmem2_t = const dbl2*;   // two consecutive doubles of a global line moved with one 16-byte access
+using gmem2_t = dbl2*;
+using clds2_t = const dbl2*;
+#else
+using clds2_t = const __attribute__((address_space(3))) dbl2*;
+using cgmem2_t = const __attribute__((address_space(1))) dbl2*;
+using gmem2_t = __attribute__((address_space(1))) dbl2*;
+#endif
 
 enum OpCode : int {
   OP_END = 0,
@@ -981,6 +990,13 @@ constexpr int kTableSlack = 5200;
 // VAR selects what is compiled in: the second-order scan (OP_REC2) and the register stash
 // (OP_PUSH / OP_POPAXPY, 2 EPT VGPRs live across the whole program) are each left out of the
 // variants that do not need them
+// A contiguous line of n doubles can be moved as 16-byte pairs (k, k + 1), k even, when its first element is
+// 16-byte aligned and element n exists whenever n is odd (the pitch of an array is a multiple of 16 doubles).
+// Thread t then owns the pairs k = 2 t + 2 T j -- half as many vector-memory and LDS instructions per line.
+RPDE_HD inline bool line_vec16(const double* p, int n, long ld) {
+  return (((size_t)p) & 15) == 0 && ((n & 1) == 0 || n < ld);
+}
+
 template <class Cfg, int VAR = kVarAll>
 RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   constexpr int T = Cfg::T, EPT = Cfg::EPT;
@@ -988,6 +1004,7 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
   // paired loads hold two or three rows in registers: not in the 1024-thread configuration (18 elements per
   // thread would spill); there the ops of a pair simply run one after the other
   constexpr bool kPairs = EPT <= 12;
+  constexpr bool kVec = (EPT % 2) == 0;   // 16-byte line moves (line_vec16)
   RPDE_TLS(blk, double, stash, STASH ? EPT : 1);
   const int line = blk.line, comp = blk.comp;
   const int SL = pg.slot_len;
@@ -1020,6 +1037,44 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           lds_t d2 = lds + o2.d * SL;
           const int n2 = o2.n;
           const bool same = o2.d == op.d;
+          if (kVec && (SL & 1) == 0 && line_vec16(A.p + comp * A.coff + (long)line * A.ld, n, A.ld) &&
+              line_vec16(A2.p + comp * A2.coff + (long)line * A2.ld, n2, A2.ld)) {
+            cgmem2_t s1 = (cgmem2_t)src, s2 = (cgmem2_t)src2;
+            lds2_t dd = (lds2_t)d, dd2 = (lds2_t)d2;
+            RPDE_PHASE(blk, tid) {
+              dbl2 v[EPT / 2], w[EPT / 2];
+#pragma unroll
+              for (int j = 0; j < EPT / 2; ++j) {
+                const int k = 2 * tid + 2 * T * j;
+                v[j] = (k < n) ? s1[k >> 1] : dbl2{0.0, 0.0};
+              }
+#pragma unroll
+              for (int j = 0; j < EPT / 2; ++j) {
+                const int k = 2 * tid + 2 * T * j;
+                w[j] = (k < n2) ? s2[k >> 1] : dbl2{0.0, 0.0};
+              }
+#pragma unroll
+              for (int j = 0; j < EPT / 2; ++j) {
+                const int k = 2 * tid + 2 * T * j;
+                const double x0 = op.s0 * v[j].x, x1 = (k + 1 < n) ? op.s0 * v[j].y : 0.0;
+                const double y0 = o2.s0 * w[j].x, y1 = (k + 1 < n2) ? o2.s0 * w[j].y : 0.0;
+                const dbl2 old = dd[k >> 1];
+                dbl2 r, r2;
+                r.x = (op.acc == 2) ? (k < n ? old.x * x0 : old.x) : (op.acc ? (old.x + x0) : x0);
+                r.y = (op.acc == 2) ? (k + 1 < n ? old.y * x1 : old.y) : (op.acc ? (old.y + x1) : x1);
+                const dbl2 old2 = same ? r : dd2[k >> 1];
+                r2.x = (o2.acc == 2) ? (k < n2 ? old2.x * y0 : old2.x) : (o2.acc ? (old2.x + y0) : y0);
+                r2.y = (o2.acc == 2) ? (k + 1 < n2 ? old2.y * y1 : old2.y) : (o2.acc ? (old2.y + y1) : y1);
+                if (k < SL) {
+                  if (same) dd[k >> 1] = r2;
+                  else { dd[k >> 1] = r; dd2[k >> 1] = r2; }
+                }
+              }
+            }
+            RPDE_SYNC(blk);
+            ++ip;
+            break;
+          }
           RPDE_PHASE(blk, tid) {
             double v[EPT], w[EPT];
 #pragma unroll
@@ -1050,6 +1105,30 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
           ++ip;                                       // the second op of the pair is done
           break;
         }
+        if (kVec && plain && (SL & 1) == 0 && line_vec16(A.p + comp * A.coff + (long)line * A.ld, n, A.ld)) {
+          cgmem2_t src2 = (cgmem2_t)src;
+          lds2_t dd = (lds2_t)d;
+          RPDE_PHASE(blk, tid) {
+            dbl2 v[EPT / 2];
+#pragma unroll
+            for (int j = 0; j < EPT / 2; ++j) {
+              const int k = 2 * tid + 2 * T * j;
+              v[j] = (k < n) ? src2[k >> 1] : dbl2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int j = 0; j < EPT / 2; ++j) {
+              const int k = 2 * tid + 2 * T * j;
+              const double x0 = op.s0 * v[j].x, x1 = (k + 1 < n) ? op.s0 * v[j].y : 0.0;
+              const dbl2 old = dd[k >> 1];
+              dbl2 r;
+              r.x = (op.acc == 2) ? (k < n ? old.x * x0 : old.x) : (op.acc ? (old.x + x0) : x0);
+              r.y = (op.acc == 2) ? (k + 1 < n ? old.y * x1 : old.y) : (op.acc ? (old.y + x1) : x1);
+              if (k < SL) dd[k >> 1] = r;
+            }
+          }
+          RPDE_SYNC(blk);
+          break;
+        }
         RPDE_PHASE(blk, tid) {
           double v[EPT];
           if (plain) {
@@ -1062,9 +1141,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
               const int k = tid + q * T;
-              if (op.i0 == 2) {   // (i kappa) * complex: swap re/im inside the pair, sign and wavenumber
-                const double w = (k & 1) ? (double)(k >> 1) : -(double)(k >> 1);
-                v[q] = (k < n) ? w * src[(long)(k ^ 1) * es] : 0.0;
+              if (op.i0 == 2) {   // (i kappa) * complex: swap re/im inside the pair; sign and wavenumber are applied below (a
+                v[q] = (k < n) ? src[(long)(k ^ 1) * es] : 0.0;   // product here would put a wait behind every load)
               } else {
                 const long kk = op.i0 ? ((long)(k & 1) * op.i1 + (k >> 1)) : k;   // i0: parity de-interleaved source
                 v[q] = (k < n) ? src[kk * es] : 0.0;
@@ -1074,7 +1152,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            const double x = op.s0 * v[q];
+            const double wk = (op.i0 == 2) ? ((k & 1) ? (double)(k >> 1) : -(double)(k >> 1)) : 1.0;
+            const double x = op.s0 * (wk * v[q]);
             const double old = d[k];
             if (k < SL) d[k] = (op.acc == 2) ? (k < n ? old * x : old) : (op.acc ? (old + x) : x);
           }
@@ -1147,6 +1226,24 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         gmem_t dstp = (gmem_t)(A.p + comp * A.coff + (long)line * A.ld);
         const bool plain = !op.i0 && A.es == 1;
         const bool guard = op.acc != 0 && pg.nanflag != nullptr;
+        if (kVec && plain && (SL & 1) == 0 && line_vec16(A.p + comp * A.coff + (long)line * A.ld, n, A.ld)) {
+          gmem2_t dst2 = (gmem2_t)dstp;
+          clds2_t aa = (clds2_t)a;
+          RPDE_PHASE(blk, tid) {
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < EPT / 2; ++j) {
+              const int k = 2 * tid + 2 * T * j;
+              const dbl2 x = aa[k >> 1];
+              const double x0 = op.s0 * x.x, x1 = op.s0 * x.y;
+              if (k + 1 < n) { dst2[k >> 1] = dbl2{x0, x1}; bad |= (x0 != x0) | (x1 != x1); }
+              else if (k < n) { dstp[k] = x0; bad |= (x0 != x0); }
+            }
+            if (guard && bad) *pg.nanflag = 1;
+          }
+          RPDE_SYNC(blk);
+          break;
+        }
         RPDE_PHASE(blk, tid) {
           if (plain) {
             bool bad = false;
