@@ -5,7 +5,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/r02
 rm -rf $O; mkdir -p $O
-(timeout 1500 python -m pytest tests -m gpu -q --durations=10 2>&1 | tail -25) > $O/pytest_gpu.txt
+# PYTEST_K: optional -k expression (the last call of round 2 had 12 GPU-minutes left: the tests not run earlier on the same code)
+(timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --durations=10 ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -25) > $O/pytest_gpu.txt
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_write.log 2>&1
@@ -14,7 +15,7 @@ cd $R
 python tools/pmc_traffic.py --fetch $O/fetch --write $O/write --schedule $O/schedule.json --out $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
 python tools/pmc_counters.py $O/sq $O/schedule.json > $O/sq_counters.txt 2>&1
 cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json     # bench.py picks roofline.traffic up from here
-python bench.py --parity-independent > $O/bench.json 2> $O/bench.err
+python bench.py ${BENCH_FLAGS---parity-independent} > $O/bench.json 2> $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
 cd $R
