@@ -19,6 +19,8 @@
 // its chunk with the exact inflow.  Arithmetic per element is identical to the sequential
 // recurrence; only the inflow is obtained through affine-map composition.
 #pragma once
+#include <type_traits>
+
 #include "platform.h"
 
 namespace rpde {
@@ -437,8 +439,79 @@ RPDE_DEVN void dct1_lds(Blk& blk, lds_t x, int N, bool pre, bool post, int cut, 
   if (sten == 2) fft_dispatch<Cfg, DctSrc<2>>(blk, x, N, tw, DctSrc<2>{x, N, pre, low}, fetch_split);
   else if (sten == 1) fft_dispatch<Cfg, DctSrc<1>>(blk, x, N, tw, DctSrc<1>{x, N, pre, low}, fetch_split);
   else fft_dispatch<Cfg, DctSrc<0>>(blk, x, N, tw, DctSrc<0>{x, N, pre, low}, fetch_split);
-  {  // split: E_k = A + B, E_{N-k} = A - B with A = (Zr_k + Zr_{N-k})/2,
-     // B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2: one thread per pair (k, N-k)
+  // split: E_k = A + B, E_{N-k} = A - B with A = (Zr_k + Zr_{N-k})/2,
+  // B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k}))/2: one thread per pair (k, N-k)
+  //
+  // Fast form for the two largest lengths of a configuration (compile-time N; the whole line stored, contiguous):
+  // thread t owns the pairs k = t + q T, q < H / T -- every LDS and global address is one per-thread base plus a
+  // constant (pidx(t + q T) = pidx(t) + q (T + T/16); pidx(N - q T - t) = pidx(-t) + (N - q T) (1 + 1/16), T a
+  // multiple of 16) -- and thread 0 also owns k = H.  The generic form below spends 280 vector instructions per
+  // thread on 60 of arithmetic, and with two waves per SIMD every instruction is 8 clocks of the line's latency.
+  auto split_fast = [&](auto NC, auto STORE) {
+    constexpr int NN = decltype(NC)::value;
+    constexpr bool kStore = decltype(STORE)::value;
+    constexpr int HH = NN / 2, QF = HH / T;
+    static_assert(HH % T == 0 && T % 16 == 0 && QF >= 1 && QF < QH, "split_fast: line length / thread count");
+    lds2_t X = (lds2_t)x;
+    RPDE_TLS(blk, double, ek, QF + 1);
+    RPDE_TLS(blk, double, en, QF + 1);
+    RPDE_PHASE(blk, tid) {
+      const int pa = tid + (tid >> 4);          // pidx(tid)
+      const int pb = -tid + ((-tid) >> 4);      // pidx(-tid) (arithmetic shift: floor)
+      const double fs = (tid & 1) ? -inv_n : inv_n;   // T is even: k and N - k have the parity of tid
+#pragma unroll
+      for (int q = 0; q <= QF; ++q) {
+        if (q == QF && tid != 0) break;         // k = H: thread 0 only
+        const int k = tid + q * T;
+        const dbl2 za = X[pa + q * (T + T / 16)];
+        const int ib = (q == 0) ? (tid == 0 ? 0 : pb + NN + NN / 16) : pb + (NN - q * T) + (NN - q * T) / 16;
+        const dbl2 zb = X[ib];
+        const double c = RPDE_T(cs)[2 * q], sn = RPDE_T(cs)[2 * q + 1];
+        const double A = 0.5 * (za.x + zb.x), B = 0.5 * (c * (za.y + zb.y) - sn * (za.x - zb.x));
+        double e0 = A + B, e1 = A - B;
+        if (post) {   // forward scaling (-1)^k / N (ends: half), zero from `cut` on
+          const double f = (q == 0 && tid == 0) ? 0.5 * fs : fs;
+          e0 = (k < cut) ? e0 * f : 0.0;
+          e1 = (NN - k < cut) ? e1 * f : 0.0;
+        }
+        if constexpr (kStore) {
+          gdst[k] = gscale * e0;
+          gdst[NN - k] = gscale * e1;
+        } else {
+          RPDE_T(ek)[q] = e0;
+          RPDE_T(en)[q] = e1;
+        }
+      }
+    }
+    RPDE_SYNC(blk);
+    if constexpr (!kStore) {
+      RPDE_PHASE(blk, tid) {
+#pragma unroll
+        for (int q = 0; q <= QF; ++q) {
+          if (q == QF && tid != 0) break;
+          const int k = tid + q * T;
+          x[k] = RPDE_T(ek)[q];
+          x[NN - k] = RPDE_T(en)[q];
+        }
+      }
+      RPDE_SYNC(blk);
+    }
+  };
+  if constexpr (Cfg::FMAX / 4 >= T) {
+    const bool whole = gdst == nullptr || (ges == 1 && gn > N);
+    if (whole && (N == Cfg::FMAX || N == Cfg::FMAX / 2)) {
+      using std::integral_constant;
+      if (N == Cfg::FMAX) {
+        if (gdst) split_fast(integral_constant<int, Cfg::FMAX>{}, integral_constant<bool, true>{});
+        else split_fast(integral_constant<int, Cfg::FMAX>{}, integral_constant<bool, false>{});
+      } else {
+        if (gdst) split_fast(integral_constant<int, Cfg::FMAX / 2>{}, integral_constant<bool, true>{});
+        else split_fast(integral_constant<int, Cfg::FMAX / 2>{}, integral_constant<bool, false>{});
+      }
+      return;
+    }
+  }
+  {
     RPDE_TLS(blk, double, e, 2 * QH);
     RPDE_PHASE(blk, tid) {
 #pragma unroll
