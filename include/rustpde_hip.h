@@ -132,6 +132,21 @@ int rpde_navier2d_set_write_intervall(rpde_navier2d* h, double dt_save);
 int rpde_navier2d_callback(rpde_navier2d* h);
 int rpde_navier2d_callback_from_filename(rpde_navier2d* h, const char* flow_name, const char* info_name,
                                          int suppress_io, double write_flow_intervall);
+/* Statistics (src/navier_stokes/statistics.rs:11-108; `navier.statistics = Some(Statistics::new(&navier, save_stat,   *
+ * write_stat))`, navier.rs:88): four fields of the orthonormal `field` space kept on the device -- `temp` = running  *
+ * mean of temp.to_ortho(), `ux` / `uy` = the last velx / vely .to_ortho() (the reference assigns, statistics.rs:98-99), *
+ * `nusselt` = the Nusselt field of the last snapshot (statistics.rs:248-271) -- plus avg_time, tot_time, num_save.     *
+ * Once enabled, rpde_navier2d_callback* updates them on `save_stat` and writes data/statistics.h5 on `write_stat`     *
+ * (navier_io.rs:105-121).  _write: groups temp, ux, uy, nusselt (x, dx, y, dy, v, vhat) + tot_time, avg_time,          *
+ * num_save (unsigned 64-bit, a Rust usize) + ra, pr, nu, ka (statistics.rs:142-161); _read: statistics.rs:116-130.    *
+ * _get: name in {temp, ux, uy, nusselt}, coefficients of the `field` space (nx x ny doubles, or (nx/2+1) x ny          *
+ * complex interleaved when periodic).                                                                                 */
+int rpde_navier2d_statistics_enable(rpde_navier2d* h, double save_stat, double write_stat);
+int rpde_navier2d_statistics_update(rpde_navier2d* h);
+int rpde_navier2d_statistics_write(rpde_navier2d* h, const char* filename);
+int rpde_navier2d_statistics_read(rpde_navier2d* h, const char* filename);
+int rpde_navier2d_statistics_get(rpde_navier2d* h, const char* name, double* out, size_t len);
+int rpde_navier2d_statistics_scalars(rpde_navier2d* h, double* avg_time, double* tot_time, long long* num_save);
 /* the same HDF5 subset for hosts without libhdf5: contiguous f64 datasets of rank 1 or 2, one group level  *
  * (src/io/read_write_hdf5.rs:38-188: read_from_hdf5 / write_to_hdf5 "create or append, overwrite")          */
 int rpde_h5_shape(const char* filename, const char* path, int* rank, uint64_t* dims2);

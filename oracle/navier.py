@@ -343,3 +343,52 @@ class Navier2D:
         # `field` is never scaled in the reference (navier.rs:256-261): averages use the
         # unscaled grid of `field` itself; weights dx/length are scale invariant.
         return fld
+
+
+class Statistics:
+    """Oracle mirror of ``Statistics<T, S>`` (``src/navier_stokes/statistics.rs:11-108``): fields of the
+    orthonormal ``field`` space -- ``t_avg`` is a running mean, ``ux_avg`` / ``uy_avg`` and ``nusselt`` hold the
+    LAST snapshot (the reference assigns them, ``statistics.rs:98-103``)."""
+
+    def __init__(self, navier: Navier2D, save_stat, write_stat):   # Statistics::new, statistics.rs:50-76
+        self.params = dict(navier.params)
+        self.scale = list(navier.scale)
+        space = navier.field.space
+        self.field = Field2(space)
+        self.t_avg, self.ux_avg, self.uy_avg, self.nusselt = (Field2(space) for _ in range(4))
+        self.save_stat, self.write_stat = save_stat, write_stat
+        self.avg_time = 0.0
+        self.tot_time = navier.time
+        self.num_save = 0
+
+    def update(self, that, uxhat, uyhat, time):                     # statistics.rs:84-108
+        if time < self.tot_time:
+            print(f"Statistics time mismatch (navier < stat): {time!r} < {self.tot_time!r}")
+            return
+        weight = float(self.num_save)
+        self.t_avg.vhat = (self.t_avg.vhat * weight + that) / (weight + 1.0)
+        self.ux_avg.vhat = np.array(uxhat, copy=True)
+        self.uy_avg.vhat = np.array(uyhat, copy=True)
+        self._nusselt(that, uyhat, self.params["ka"])
+        self.nusselt.vhat = self.field.vhat.copy()
+        self.num_save += 1
+        self.avg_time += time - self.tot_time
+        self.tot_time = time
+
+    def _nusselt(self, that, uyhat, kappa):                         # fn nusselt, statistics.rs:248-271
+        field = self.field
+        field.vhat = np.array(uyhat, copy=True)
+        field.backward()
+        uy_v = field.v.copy()
+        field.vhat = np.array(that, copy=True)
+        field.backward()
+        uy_temp = field.v * uy_v
+        dtdz = field.gradient([0, 1], None) / (self.scale[1] * -1.0)
+        field.vhat = dtdz
+        field.backward()
+        field.v = (field.v + uy_temp / kappa) * 2.0 * self.scale[1]
+        field.forward()
+
+    def update_from(self, navier: Navier2D):
+        """The one call site of the reference (``navier_io.rs:110-115``)."""
+        self.update(navier.temp.to_ortho(), navier.velx.to_ortho(), navier.vely.to_ortho(), navier.time)

@@ -27,7 +27,7 @@ import numpy as np
 from ._capi import Lib, RpdeError, as_f64, ptr
 
 __all__ = ["Navier2D", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
-           "chebyshev", "cheb_dirichlet", "cheb_neumann", "fourier_r2c", "LIB_PATH"]
+           "chebyshev", "cheb_dirichlet", "cheb_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
 _lib = None
@@ -243,6 +243,17 @@ class Navier2D:
             print(f"Reading file {filename!r} was successfull.")
         except RpdeError as exc:
             print(f"Error while reading file {filename!r}. Error: {exc}")
+
+    # ---- statistics (`pub statistics: Option<Statistics<T, S>>`, navier.rs:88)
+    @property
+    def statistics(self):
+        return getattr(self, "_statistics", None)
+
+    @statistics.setter
+    def statistics(self, value):
+        if value is not None and value._nav is not self:
+            raise RpdeError("Statistics belong to the Navier2D they were created from")
+        self._statistics = value
 
     # ---- extras
     def div_norm(self):
@@ -487,6 +498,73 @@ class h5:
         a = as_f64(array)
         dims = (C.c_uint64 * 2)(*a.shape)
         library.call("rpde_h5_write", str(filename).encode(), path.encode(), a.ndim, dims, ptr(a))
+
+
+class _StatField:
+    """One member of `Statistics` (a `Field2` of the orthonormal `field` space): `.vhat` reads the coefficients."""
+
+    def __init__(self, stats, name):
+        self._stats, self._name = stats, name
+
+    @property
+    def vhat(self):
+        nav = self._stats._nav
+        rows = nav.nx // 2 + 1 if nav.periodic else nav.nx
+        out = np.empty((rows, nav.ny * (2 if nav.periodic else 1)))
+        nav._lib.call("rpde_navier2d_statistics_get", nav._h, self._name.encode(), ptr(out), out.size)
+        return out.view(np.complex128) if nav.periodic else out
+
+
+class Statistics:
+    """`Statistics<T, S>` (src/navier_stokes/statistics.rs:11-108) kept on the device of its `Navier2D`:
+    `t_avg` (running mean of temp.to_ortho()), `ux_avg` / `uy_avg` (the LAST velx / vely .to_ortho(): the
+    reference assigns), `nusselt` (Nusselt field of the last snapshot), `avg_time`, `tot_time`, `num_save`.
+
+        nav.statistics = Statistics.new(nav, save_stat=1.0, write_stat=10.0)   # then nav.callback() does the rest
+
+    `update()` takes no arrays: it reads the fields of its engine, which is what the only call site of the
+    reference passes (navier_io.rs:110-115)."""
+
+    def __init__(self, navier, save_stat, write_stat):
+        self._nav = navier
+        self.save_stat, self.write_stat = float(save_stat), float(write_stat)
+        navier._lib.call("rpde_navier2d_statistics_enable", navier._h, self.save_stat, self.write_stat)
+        self.t_avg, self.ux_avg, self.uy_avg, self.nusselt = (_StatField(self, n) for n in ("temp", "ux", "uy", "nusselt"))
+
+    @classmethod
+    def new(cls, navier, save_stat, write_stat):
+        return cls(navier, save_stat, write_stat)
+
+    def _scalars(self):
+        a, t, n = C.c_double(), C.c_double(), C.c_longlong()
+        self._nav._lib.call("rpde_navier2d_statistics_scalars", self._nav._h, C.byref(a), C.byref(t), C.byref(n))
+        return a.value, t.value, n.value
+
+    avg_time = property(lambda self: self._scalars()[0])
+    tot_time = property(lambda self: self._scalars()[1])
+    num_save = property(lambda self: self._scalars()[2])
+
+    def update(self):
+        self._nav._lib.call("rpde_navier2d_statistics_update", self._nav._h)
+
+    def write(self, filename):
+        self._nav._lib.call("rpde_navier2d_statistics_write", self._nav._h, str(filename).encode())
+
+    def read(self, filename):
+        self._nav._lib.call("rpde_navier2d_statistics_read", self._nav._h, str(filename).encode())
+
+    def write_unwrap(self, filename):
+        try:
+            self.write(filename)
+        except RpdeError as exc:
+            print(f"Error while writing file {filename!r}. Error: {exc}")
+
+    def read_unwrap(self, filename):
+        try:
+            self.read(filename)
+            print(f"Reading file {filename!r} was successfull.")
+        except RpdeError as exc:
+            print(f"Error while reading file {filename!r}. Error: {exc}")
 
 
 def microbench(what, n, nlines, reps=20, device=0, library=None):

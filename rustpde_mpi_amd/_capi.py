@@ -62,6 +62,12 @@ SIGNATURES = {
     "rpde_navier2d_set_write_intervall": (C.c_int, [_vp, C.c_double]),
     "rpde_navier2d_callback": (C.c_int, [_vp]),
     "rpde_navier2d_callback_from_filename": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
+    "rpde_navier2d_statistics_enable": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "rpde_navier2d_statistics_update": (C.c_int, [_vp]),
+    "rpde_navier2d_statistics_write": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_navier2d_statistics_read": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_navier2d_statistics_get": (C.c_int, [_vp, C.c_char_p, _dp, C.c_size_t]),
+    "rpde_navier2d_statistics_scalars": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_longlong)]),
     "rpde_h5_shape": (C.c_int, [C.c_char_p, C.c_char_p, _ip, C.POINTER(C.c_uint64)]),
     "rpde_h5_read": (C.c_int, [C.c_char_p, C.c_char_p, _dp, C.c_size_t]),
     "rpde_h5_write": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), _dp]),

@@ -306,6 +306,36 @@ int rpde_navier2d_callback_from_filename(rpde_navier2d* h, const char* flow_name
     h->e->callback_from_filename(flow_name, info_name, suppress_io != 0, write_flow_intervall);
   })
 }
+int rpde_navier2d_statistics_enable(rpde_navier2d* h, double save_stat, double write_stat) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(save_stat > 0.0 && write_stat > 0.0, "statistics: save_stat and write_stat are positive time intervals");
+    select_device(h->device);
+    h->e->statistics_enable(save_stat, write_stat);
+  })
+}
+int rpde_navier2d_statistics_update(rpde_navier2d* h) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->statistics_update(); })
+}
+int rpde_navier2d_statistics_write(rpde_navier2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->statistics_write(filename); })
+}
+int rpde_navier2d_statistics_read(rpde_navier2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->statistics_read(filename); })
+}
+int rpde_navier2d_statistics_get(rpde_navier2d* h, const char* name, double* out, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(name && out, "null pointer");
+    select_device(h->device);
+    h->e->statistics_get(name, out, len);
+  })
+}
+int rpde_navier2d_statistics_scalars(rpde_navier2d* h, double* avg_time, double* tot_time, long long* num_save) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(avg_time && tot_time && num_save, "null pointer");
+    h->e->statistics_scalars(avg_time, tot_time, num_save);
+  })
+}
 // h5lite access for hosts without libhdf5 (tests, Python mirror): datasets of rank 1 / 2, f64
 int rpde_h5_shape(const char* filename, const char* path, int* rank, uint64_t* dims2) {
   RPDE_TRY({

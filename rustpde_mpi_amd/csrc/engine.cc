@@ -12,6 +12,21 @@
 
 namespace rpde {
 
+// Statistics (src/navier_stokes/statistics.rs:11-37): defined here because the constructor and the destructor own one
+struct Navier2DEngine::Stats {
+  double save_stat = 0.0, write_stat = 0.0, avg_time = 0.0, tot_time = 0.0;
+  long long num_save = 0;
+  Arr2 t_avg, ux, uy, nus;   // coefficients in the orthonormal `field` space, canonical layout
+  Arr2& member(const std::string& name) {
+    if (name == "temp") return t_avg;
+    if (name == "ux") return ux;
+    if (name == "uy") return uy;
+    if (name == "nusselt") return nus;
+    fail("statistics: no member \"" + name + "\" (temp, ux, uy, nusselt)");
+  }
+};
+static const char* const kStatMembers[4] = {"temp", "ux", "uy", "nusselt"};   // statistics.rs:178-185
+
 struct Navier2DEngine::Field {
   std::string name;
   Space2Ops* sp = nullptr;
@@ -958,6 +973,15 @@ void Navier2DEngine::callback_from_filename(const std::string& flow_name, const 
       std::fprintf(stderr, "Error while writing file \"%s\". Error: %s\n", flow_name.c_str(), ex.what());
     }
   }
+  if (stats_) {   // navier_io.rs:105-121
+    if (std::fmod(time_ + dt_ / 2.0, stats_->save_stat) < dt_) statistics_update();
+    if (std::fmod(time_ + dt_ / 2.0, stats_->write_stat) < dt_) {
+      try { statistics_write("data/statistics.h5"); }
+      catch (const std::exception& ex) {
+        std::fprintf(stderr, "Error while writing file \"data/statistics.h5\". Error: %s\n", ex.what());
+      }
+    }
+  }
   if (suppress_io) return;
   const double div = div_norm();
   double nu, nuv, re;
@@ -975,6 +999,159 @@ void Navier2DEngine::callback_from_filename(const std::string& flow_name, const 
   } else {
     std::fprintf(stderr, "Couldn't write to file: %s\n", info_name.c_str());
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Statistics (src/navier_stokes/statistics.rs)
+
+void Navier2DEngine::statistics_enable(double save_stat, double write_stat) {
+  // Statistics::new (statistics.rs:50-76): zero fields, avg_time = 0, tot_time = navier.time, num_save = 0
+  stats_ = std::make_unique<Stats>();
+  Stats& s = *stats_;
+  s.save_stat = save_stat; s.write_stat = write_stat; s.tot_time = time_;
+  const int ro = sp_ortho_->ortho_rows();
+  for (const char* m : kStatMembers) s.member(m).alloc(ro, ny_, ex_);
+}
+
+void Navier2DEngine::statistics_update() {
+  RPDE_REQUIRE(stats_ != nullptr, "statistics_update: statistics are not enabled");
+  Stats& s = *stats_;
+  if (time_ < s.tot_time) {   // statistics.rs:87-93
+    if (comm_.rank == 0) { std::printf("Statistics time mismatch (navier < stat): %g < %g\n", time_, s.tot_time); std::fflush(stdout); }
+    return;
+  }
+  Space2Ops& so = *sp_ortho_;
+  const int ro = so.ortho_rows(), nx = nx_, ny = ny_;
+  Arr2 that(ro, ny, ex_);
+  {
+    Arr2 c(sp_temp_->spec_rows(), sp_temp_->spec_cols(), ex_);
+    state_to_canonical(field("temp"), c);
+    sp_temp_->to_ortho(c, that, st_);
+  }
+  {
+    Arr2 c(sp_vel_->spec_rows(), sp_vel_->spec_cols(), ex_);
+    state_to_canonical(field("velx"), c);
+    sp_vel_->to_ortho(c, s.ux, st_);       // ux_avg.vhat.assign(uxhat): the last field, not a mean (statistics.rs:98)
+    state_to_canonical(field("vely"), c);
+    sp_vel_->to_ortho(c, s.uy, st_);
+  }
+  const int comp_off = ex_ == 2 ? 1 : 0;
+  {  // t_avg = (t_avg * weight + that) / (weight + 1), weight = num_save (statistics.rs:94-97)
+    const double w = (double)s.num_save;
+    ProgramBuilder pb(2, so.axis(1).slot_len, ro, ex_);
+    const int a = pb.arr(s.t_avg.p(), s.t_avg.ld, ex_, comp_off), b = pb.arr(that.p(), that.ld, ex_, comp_off);
+    pb.load(0, a, ny, w); pb.load(0, b, ny, 1.0, true); pb.store(0, a, ny, 1.0 / (w + 1.0));
+    pb.run(st_);
+  }
+  {  // nusselt(field, that, uyhat, ka, scale) (statistics.rs:248-271)
+    Arr2 uyv(nx, ny, 1), tv(nx, ny, 1), g(ro, ny, ex_), dv(nx, ny, 1);
+    so.backward(s.uy, uyv, st_);
+    so.backward(that, tv, st_);
+    so.gradient(that, 0, 1, 1.0, 1.0, g, st_);    // gradient([0, 1], None); the division by (scale[1] * -1) rides below
+    so.backward(g, dv, st_);
+    // field.v = (dtdz + uy * T / kappa) * 2 * scale[1]
+    ProgramBuilder pb(2, so.axis(1).slot_len, nx, 1);
+    const int at = pb.arr(tv.p(), tv.ld), au = pb.arr(uyv.p(), uyv.ld), ad = pb.arr(dv.p(), dv.ld);
+    pb.load(0, at, ny);
+    pb.loadmul(0, au, ny, 1.0 / ka_);
+    pb.load(0, ad, ny, 1.0 / (sy_ * -1.0), true);
+    pb.store(0, ad, ny, 2.0 * sy_);
+    pb.run(st_);
+    so.forward(dv, s.nus, st_);
+  }
+  dev_sync(st_);
+  s.num_save += 1;
+  s.avg_time += time_ - s.tot_time;
+  s.tot_time = time_;
+}
+
+void Navier2DEngine::statistics_get(const std::string& name, double* host, size_t len) {
+  RPDE_REQUIRE(stats_ != nullptr, "statistics_get: statistics are not enabled");
+  Arr2& a = stats_->member(name);
+  RPDE_REQUIRE(len == (size_t)a.rows * a.cols * a.elem, "statistics_get: wrong length");
+  dev_sync(st_);
+  dev_download2d(host, a.p(), a.ld, a.rows, (long)a.cols * a.elem);
+}
+
+void Navier2DEngine::statistics_scalars(double* avg_time, double* tot_time, long long* num_save) const {
+  RPDE_REQUIRE(stats_ != nullptr, "statistics_scalars: statistics are not enabled");
+  *avg_time = stats_->avg_time; *tot_time = stats_->tot_time; *num_save = stats_->num_save;
+}
+
+void Navier2DEngine::statistics_write(const std::string& filename) {
+  // Statistics::write (statistics.rs:142-161): every member backward()-ed and written like a Field2
+  // (field/io.rs:95-103), then tot_time, avg_time, num_save (a usize: unsigned 64-bit integer) and the params
+  RPDE_REQUIRE(stats_ != nullptr, "statistics_write: statistics are not enabled");
+  Stats& s = *stats_;
+  h5::Tree t;
+  Vec x((size_t)nx_), y((size_t)ny_);
+  grid(0, x.data(), x.size());
+  grid(1, y.data(), y.size());
+  for (const char* m : kStatMembers) {
+    const std::string g = m;
+    Arr2& a = s.member(m);
+    t[g + "/x"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/dx"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/y"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[g + "/dy"] = h5::Dataset{{(uint64_t)ny_}, y};
+    Arr2 v(nx_, ny_, 1);
+    sp_ortho_->backward(a, v, st_);
+    dev_sync(st_);
+    h5::Dataset dv{{(uint64_t)nx_, (uint64_t)ny_}, Vec((size_t)nx_ * ny_)};
+    dev_download2d(dv.data.data(), v.p(), v.ld, nx_, ny_);
+    t[g + "/v"] = std::move(dv);
+    const int r = a.rows, c = a.cols, e = a.elem;
+    Vec vh((size_t)r * c * e);
+    dev_download2d(vh.data(), a.p(), a.ld, r, (long)c * e);
+    if (e == 1) {
+      t[g + "/vhat"] = h5::Dataset{{(uint64_t)r, (uint64_t)c}, std::move(vh)};
+    } else {
+      h5::Dataset re{{(uint64_t)r, (uint64_t)c}, Vec((size_t)r * c)}, im = re;
+      for (size_t k = 0; k < (size_t)r * c; ++k) { re.data[k] = vh[2 * k]; im.data[k] = vh[2 * k + 1]; }
+      t[g + "/vhat_re"] = std::move(re);
+      t[g + "/vhat_im"] = std::move(im);
+    }
+  }
+  t["tot_time"] = h5::Dataset{{1}, {s.tot_time}};
+  t["avg_time"] = h5::Dataset{{1}, {s.avg_time}};
+  h5::Dataset ns{{1}, {(double)s.num_save}};
+  ns.u64 = true;
+  t["num_save"] = std::move(ns);
+  for (const char* k : {"ra", "pr", "nu", "ka"}) t[k] = h5::Dataset{{1}, {param(k)}};
+  if (comm_.rank == 0) h5::update_file(filename, t);
+}
+
+void Navier2DEngine::statistics_read(const std::string& filename) {
+  // Statistics::read (statistics.rs:116-130): vhat of every member (other resolutions by spectral truncation /
+  // zero padding, field/io.rs:151-176), then tot_time, avg_time, num_save
+  RPDE_REQUIRE(stats_ != nullptr, "statistics_read: statistics are not enabled");
+  Stats& s = *stats_;
+  h5::Reader rd(filename);
+  for (const char* m : kStatMembers) {
+    const std::string g = m;
+    Arr2& a = s.member(m);
+    const int r = a.rows, c = a.cols, e = a.elem;
+    Vec neu((size_t)r * c * e, 0.0);
+    uint64_t ro = 0, co = 0;
+    auto place = [&](const h5::Dataset& d, int comp) {
+      RPDE_REQUIRE(d.dims.size() == 2, "statistics: " + g + "/vhat must be two-dimensional");
+      ro = d.dims[0]; co = d.dims[1];
+      const uint64_t rm = std::min<uint64_t>(ro, r), cm = std::min<uint64_t>(co, c);
+      for (uint64_t i = 0; i < rm; ++i)
+        for (uint64_t j = 0; j < cm; ++j) neu[(i * c + j) * e + comp] = d.data[i * co + j];
+    };
+    if (e == 1) place(rd.read(g + "/vhat"), 0);
+    else { place(rd.read(g + "/vhat_re"), 0); place(rd.read(g + "/vhat_im"), 1); }
+    if (((int)ro != r || (int)co != c) && periodic_) {
+      const double norm = (double)(r - 1) / (double)(ro - 1);
+      for (double& v : neu) v *= norm;
+    }
+    dev_upload2d(a.p(), a.ld, neu.data(), r, (long)c * e);
+  }
+  s.tot_time = rd.read("tot_time").data.at(0);
+  s.avg_time = rd.read("avg_time").data.at(0);
+  s.num_save = (long long)rd.read("num_save").data.at(0);
+  if (comm_.rank == 0) { std::printf(" <== \"%s\"\n", filename.c_str()); std::fflush(stdout); }
 }
 
 void Navier2DEngine::callback() {

@@ -73,6 +73,18 @@ class Navier2DEngine {
   void callback_from_filename(const std::string& flow_name, const std::string& info_name, bool suppress_io,
                               double write_flow_intervall);
   void callback();                       // Integrate::callback (navier.rs:476-480): data/flow{time:0>8.2}.h5, data/info.txt
+  // Statistics (src/navier_stokes/statistics.rs:11-108, hooked into the callback at navier_io.rs:105-121): four
+  // fields of the orthonormal `field` space kept on the device -- the running mean of temp.to_ortho() (`temp`), the
+  // LAST velx / vely .to_ortho() (`ux`, `uy`: the reference assigns, it does not average) and the Nusselt field of
+  // the last snapshot (`nusselt`, statistics.rs:248-271) -- plus avg_time, tot_time, num_save.
+  void statistics_enable(double save_stat, double write_stat);   // navier.statistics = Some(Statistics::new(&navier, ..))
+  bool statistics_enabled() const { return stats_ != nullptr; }
+  void statistics_update();                                       // Statistics::update(temp, velx, vely to_ortho, time)
+  void statistics_write(const std::string& filename);             // groups temp, ux, uy, nusselt + tot_time, avg_time, num_save (u64), params
+  void statistics_read(const std::string& filename);
+  // name in {temp, ux, uy, nusselt}: coefficients in the `field` space (nx x ny, or (nx/2+1) x ny complex interleaved)
+  void statistics_get(const std::string& name, double* host, size_t len);
+  void statistics_scalars(double* avg_time, double* tot_time, long long* num_save) const;
   void set_write_intervall(double v) { write_intervall_ = v; }   // `write_intervall: Option<f64>`; < 0 = None
   double time() const { return time_; }
   double dt() const { return dt_; }
@@ -167,6 +179,8 @@ class Navier2DEngine {
   int* hflag_ = nullptr;         // pinned host landing pad of the flag
   bool dirty_ = false;           // a field was written from the host since the last update()
   double write_intervall_ = -1.0;   // navier.rs:79 `write_intervall: Option<f64>` (None)
+  struct Stats;
+  std::unique_ptr<Stats> stats_;   // `statistics: Option<Statistics<T, S>>` (navier.rs:88)
   int* flagp() const { return reinterpret_cast<int*>(nanflag_.p); }
   bool read_nanflag();
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in

@@ -54,7 +54,10 @@ uint64_t dataset_header(Buf& f, const Dataset& d, uint64_t data_addr) {
     for (uint64_t v : d.dims) s.u64(v);
     message(m, 0x0001, s.b);
   }
-  {  // datatype: class 1 (floating point) version 1, IEEE binary64 little endian
+  if (d.u64) {  // datatype: class 0 (fixed point) version 1, unsigned, little endian, 8 bytes: bit offset 0, precision 64
+    const uint8_t t[12] = {0x10, 0x00, 0x00, 0x00, 8, 0, 0, 0, 0, 0, 64, 0};
+    message(m, 0x0003, std::vector<uint8_t>(t, t + 12), 0x01);
+  } else {  // datatype: class 1 (floating point) version 1, IEEE binary64 little endian
     const uint8_t t[20] = {0x11, 0x20, 0x3f, 0x00, 8, 0, 0, 0,    // class|version, bit fields (LE, msb implied, sign at 63), size 8
                            0, 0, 64, 0, 52, 11, 0, 52, 0xff, 0x03, 0, 0};   // offset 0, precision 64, exp at 52 (11 bits), mantissa at 0 (52 bits), bias 1023
     message(m, 0x0003, std::vector<uint8_t>(t, t + 20), 0x01);
@@ -158,7 +161,11 @@ void write_file(const std::string& filename, const Tree& tree) {
   for (const auto& kv : tree) {
     addr[&kv.second] = pos;
     const size_t nb = kv.second.data.size() * 8;
-    if (nb) RPDE_REQUIRE(std::fwrite(kv.second.data.data(), 1, nb, fp) == nb, "h5lite: short write");
+    if (nb && kv.second.u64) {
+      std::vector<uint64_t> iv(kv.second.data.size());
+      for (size_t i = 0; i < iv.size(); ++i) iv[i] = (uint64_t)kv.second.data[i];
+      RPDE_REQUIRE(std::fwrite(iv.data(), 1, nb, fp) == nb, "h5lite: short write");
+    } else if (nb) RPDE_REQUIRE(std::fwrite(kv.second.data.data(), 1, nb, fp) == nb, "h5lite: short write");
     pos += nb;
   }
   // metadata after the data, built at its absolute file addresses
@@ -326,9 +333,10 @@ void Reader::parse_object(uint64_t oh, const std::string& path, int depth) {
       for (int r = 0; r < rank; ++r) e.dims.push_back(le(&d[off + (size_t)r * 8], 8));
       has_space = true;
     }
-    if (m.type == 0x0003) {   // datatype: IEEE f64 little endian only
+    if (m.type == 0x0003) {   // datatype: IEEE f64 little endian, or a 64-bit little-endian integer (scalars such as num_save)
       RPDE_REQUIRE(d.size() >= 8, "h5lite: short datatype message");
       f64 = (d[0] & 0x0f) == 1 && (d[1] & 1) == 0 && le(&d[4], 4) == 8;
+      if ((d[0] & 0x0f) == 0 && (d[1] & 1) == 0 && le(&d[4], 4) == 8) { f64 = true; e.kind = (d[1] & 0x08) ? 2 : 1; }
     }
     if (m.type == 0x0008) {   // layout
       RPDE_REQUIRE(d.size() >= 2, "h5lite: short layout message");
@@ -372,6 +380,14 @@ Dataset Reader::read(const std::string& path) const {
   } else if (e.addr != kUndef && n) {   // an undefined address = never written: zeros
     RPDE_REQUIRE(e.bytes == n * 8, "h5lite: contiguous dataset size");
     pread_(d.data.data(), base_ + e.addr, n * 8);
+  }
+  if (e.kind != 0) {   // integers on disk: convert in place
+    d.u64 = e.kind == 1;
+    for (uint64_t i = 0; i < n; ++i) {
+      uint64_t raw;
+      std::memcpy(&raw, &d.data[i], 8);
+      d.data[i] = e.kind == 1 ? (double)raw : (double)(int64_t)raw;
+    }
   }
   return d;
 }

@@ -1,5 +1,5 @@
 // h5lite: a minimal reader / writer for the subset of HDF5 the reference's snapshots use
-// (src/io/read_write_hdf5.rs:38-188: contiguous, un-chunked f64 datasets of rank 1 or 2 inside
+// (src/io/read_write_hdf5.rs:38-188: contiguous, un-chunked f64 (and 64-bit integer scalar) datasets of rank 1 or 2 inside
 // one level of groups; src/navier_stokes/navier_io.rs:21-62, src/field/io.rs:74-110).
 // There is no libhdf5 in this image, so the on-disk structures are produced and parsed by hand,
 // following the HDF5 File Format Specification, "classic" layout -- the one libhdf5's default
@@ -23,6 +23,9 @@ namespace h5 {
 struct Dataset {
   std::vector<uint64_t> dims;   // rank 1 or 2
   std::vector<double> data;     // row-major
+  // stored on disk as unsigned 64-bit little-endian integers (H5T_STD_U64LE: what the hdf5 crate writes for a Rust
+  // `usize`, e.g. `num_save` of statistics.rs:153); the values are carried as doubles in memory
+  bool u64 = false;
 };
 
 // datasets by path: "time", "ux/v", "temp/vhat_re" ... (at most one group level)
@@ -45,7 +48,8 @@ class Reader {
   Dataset read(const std::string& path) const;
 
  private:
-  struct Entry { std::vector<uint64_t> dims; uint64_t addr = 0, bytes = 0; bool compact = false; std::vector<uint8_t> inline_data; };
+  struct Entry { std::vector<uint64_t> dims; uint64_t addr = 0, bytes = 0; bool compact = false; std::vector<uint8_t> inline_data;
+                 int kind = 0; };   // kind: 0 = f64, 1 = u64, 2 = i64
   void walk_group(uint64_t oh_addr, const std::string& prefix, int depth);
   void walk_btree(uint64_t node, uint64_t heap_data, const std::string& prefix, int depth);
   void parse_object(uint64_t oh_addr, const std::string& path, int depth);

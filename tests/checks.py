@@ -179,3 +179,27 @@ def check_step_parity(lib, periodic, nx, ny, ra, dt, steps, aspect=1.0, tol=1e-1
     for got, want in zip(nav.diagnostics(), (ora.eval_nu(), ora.eval_nuvol(), ora.eval_re())):
         assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (got, want)
     return worst
+
+
+def check_statistics(lib, periodic, nx, ny, ra=1e4, dt=0.01, tol=1e-11):
+    """Statistics (statistics.rs:84-108, 248-271) on the device vs the oracle's restatement: three updates at
+    different times; t_avg is a running mean, ux / uy / nusselt hold the last snapshot."""
+    from oracle import navier as N
+    nav, ora = make_pair(lib, periodic, nx, ny, ra, 1.0, dt, 1.0)
+    st = R.Statistics.new(nav, 0.02, 0.04)
+    so = N.Statistics(ora, 0.02, 0.04)
+    nav.statistics = st
+    assert st.num_save == 0 and st.avg_time == 0.0 and st.tot_time == nav.get_time()
+    for k, steps in enumerate((2, 3, 1)):
+        nav.update(steps)
+        for _ in range(steps):
+            ora.update()
+        st.update()
+        so.update_from(ora)
+        assert st.num_save == so.num_save == k + 1
+        assert abs(st.avg_time - so.avg_time) < 1e-12 and abs(st.tot_time - so.tot_time) < 1e-12
+        for got, want in ((st.t_avg, so.t_avg), (st.ux_avg, so.ux_avg), (st.uy_avg, so.uy_avg), (st.nusselt, so.nusselt)):
+            assert rel(got.vhat, want.vhat) < tol, (k, rel(got.vhat, want.vhat))
+    # the mean is a mean: after three saves t_avg differs from the last snapshot
+    assert rel(st.t_avg.vhat, ora.temp.to_ortho()) > 1e-6
+    return st, so

@@ -92,10 +92,16 @@ class File:
         rank = sp[1]
         dims = struct.unpack_from("<%dQ" % rank, sp, 8)
         dt = d[0x03]
-        assert dt[0] == 0x11 and dt[1] == 0x20 and dt[2] == 0x3f and struct.unpack_from("<I", dt, 4)[0] == 8
-        assert tuple(dt[8:20]) == (0, 0, 64, 0, 52, 11, 0, 52, 0xff, 0x03, 0, 0), "IEEE binary64 properties"
+        if dt[0] == 0x10:   # fixed point, version 1: H5T_STD_U64LE (a Rust usize such as `num_save`)
+            assert dt[1] == 0 and dt[2] == 0 and struct.unpack_from("<I", dt, 4)[0] == 8, "unsigned little-endian, 8 bytes"
+            assert tuple(dt[8:12]) == (0, 0, 64, 0), "bit offset 0, precision 64"
+            np_type = "<u8"
+        else:
+            assert dt[0] == 0x11 and dt[1] == 0x20 and dt[2] == 0x3f and struct.unpack_from("<I", dt, 4)[0] == 8
+            assert tuple(dt[8:20]) == (0, 0, 64, 0, 52, 11, 0, 52, 0xff, 0x03, 0, 0), "IEEE binary64 properties"
+            np_type = "<f8"
         lay = d[0x08]
         assert lay[0] == 3 and lay[1] == 1, "layout v3, contiguous"
         addr, size = struct.unpack_from("<QQ", lay, 2)
         assert size == 8 * int(np.prod(dims)) and addr % 8 == 0
-        self.datasets[path] = np.frombuffer(self.b, dtype="<f8", count=int(np.prod(dims)), offset=addr).reshape(dims)
+        self.datasets[path] = np.frombuffer(self.b, dtype=np_type, count=int(np.prod(dims)), offset=addr).reshape(dims)
