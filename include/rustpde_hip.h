@@ -192,6 +192,11 @@ int rpde_navier2d_poisson_eigenbasis(rpde_navier2d* h, double* lam, double* fwd,
 /* pencil transposes (single device: LDS-tiled kernel).  out[c][r] = in[r][c]; elem = 1 | 2        *
  * funspace Decomp2d::transpose_x_to_y / transpose_y_to_x     src/field_mpi.rs:456-477             */
 int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, int device);
+/* funspace `backward` along contiguous lines (src/field.rs:108-111) through the whole-line transform kernel   *
+ * (csrc/dct_line.h: n / 16 threads per line, data in registers, four workgroups per CU): `nlines` lines of     *
+ * n_in coefficients (kind 0 chebyshev: n_in = n, kind 1 cheb_dirichlet: n_in = n - 2) -> n physical values.    *
+ * n = 4097 (HIP and emulation builds) or 257 (emulation build); other shapes return an error.                 */
+int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double* out, int device);
 /* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
  * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);

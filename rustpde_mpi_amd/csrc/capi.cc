@@ -6,6 +6,7 @@
 #include <string>
 
 #include "engine.h"
+#include "dct_line.h"
 #include "h5lite.h"
 #include "rccl_transport.h"
 
@@ -563,6 +564,21 @@ int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, 
     launch_transpose(a.p(), a.ld, b.p(), b.ld, rows, cols, elem, st);
     dev_sync(st);
     dev_download2d(out, b.p(), b.ld, cols, (long)rows * elem);
+  })
+}
+int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double* out, int device) {
+  RPDE_TRY({
+    RPDE_REQUIRE(in && out && nlines > 0 && (kind == 0 || kind == 1), "bad argument");
+    select_device(device);
+    Stream st;
+    const Base b = make_base(kind == 1 ? kChebDirichlet : kChebyshev, n);
+    AxisTables ax(b);
+    Arr2 a(nlines, b.m), v(nlines, n);
+    dev_upload2d(a.p(), a.ld, in, nlines, b.m);
+    DctLineArgs d{a.p(), a.ld, b.m, v.p(), v.ld, nlines, n - 1, kind == 1 ? 2 : 0, ax.tw.p, ax.tw2.p, 1.0};
+    RPDE_REQUIRE(ax.fft_n == n - 1 && launch_dct_line(d, st), "rpde_dct_line_backward: line length not covered by the whole-line kernel");
+    dev_sync(st);
+    dev_download2d(out, v.p(), v.ld, nlines, n);
   })
 }
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device) {

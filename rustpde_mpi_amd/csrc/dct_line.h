@@ -1,0 +1,208 @@
+// Backward Chebyshev transform of contiguous lines as a kernel of its own (experiment of round 2):
+//
+//   out[line][k] = scale * DCT-I( f_m * (a_m - [sten] a_{m-2}) )_k ,   k = 0 .. N,   f_m = (-1)^m / 2 (ends: 1)
+//
+// i.e. composite (Dirichlet) or orthonormal Chebyshev coefficients of a line -> its N + 1 physical values: what the
+// line program  LOAD ; DCT(stencil, backward scaling, fused store)  computes (funspace `backward`, src/field.rs:108-111).
+//
+// Why a second form: a DCT line in the line VM is a latency chain of ONE workgroup (512 threads, 128 VGPRs, 76 KB of
+// LDS: two workgroups per CU and no room for a third).  Here a line belongs to N / 16 threads (256 for N = 4096:
+// one wave per SIMD) that keep their 16 complex points in registers through all radix-16 passes and use LDS only
+// as an exchange buffer for ONE real component at a time: N (1 + 1/16) doubles = 34.8 KB, so FOUR workgroups
+// share a CU at 128 VGPRs.  More barriers per line (an exchange costs four), twice the lines in flight.
+//
+// The arithmetic is that of dct1_lds: even extension packed two reals per complex, N-point complex FFT (Stockham
+// index pattern, radix 16), split step with the twiddles (cos, sin)(pi k / N).
+#pragma once
+#include "line_vm.h"
+
+namespace rpde {
+
+struct DctLineArgs {
+  const double* in; long ldi; int n_in;   // input lines: n_in <= N + 1 coefficients each (the rest counts as zero)
+  double* out; long ldo;                  // output lines: N + 1 values each
+  int nlines;
+  int N;                                  // 256 or 4096
+  int sten;                               // 0: orthonormal input; 2: Dirichlet composite input (c_m = a_m - a_{m-2})
+  const double* tw;                       // N complex FFT twiddles (cos, -sin)(2 pi k / N)      (AxisTables::tw)
+  const double* tw2;                      // split twiddles (cos, sin)(pi k / N), k = 0 .. N     (AxisTables::tw2)
+  double scale;
+};
+
+RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16; }
+// the 16-byte staging loads need an aligned line start and, for an odd count, one readable element behind the line
+RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
+  return (a.N == 256 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
+         ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2);
+}
+
+template <int N>
+RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
+  constexpr int T = N / 16;
+  static_assert(N == 4096 || N == 256, "N = 16^2 or 16^3");
+  static_assert(T % 16 == 0, "padded indices assume T a multiple of 16");
+  lds_t buf = (lds_t)blk.lds;
+  lds2_t buf2 = (lds2_t)blk.lds;
+  const int line = blk.line;
+  cgmem2_t src2 = (cgmem2_t)(a.in + (long)line * a.ldi);
+  gmem_t dst = (gmem_t)(a.out + (long)line * a.ldo);
+  tab_t tw = (tab_t)a.tw;
+  tab_t tw2 = (tab_t)a.tw2;
+  const int n_in = a.n_in;
+  const bool sten = a.sten == 2;
+  RPDE_TLS(blk, double, re, 16);
+  RPDE_TLS(blk, double, im, 16);
+
+  // ---- stage the line two doubles into the buffer: xs[m + 2] = x[m] (m < n_in), zeros in front and behind, so that
+  // the stencil tap x[m - 2] and the tail m >= n_in need no selects.  Pair p holds xs[2p], xs[2p + 1] = x[2p - 2], x[2p - 1].
+  RPDE_PHASE(blk, tid) {
+    constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);   // pairs per thread: 2 T QP >= N + 4
+    dbl2 v[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int p = tid + q * T, k = 2 * p - 2;
+      v[q] = (k >= 0 && k < n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int p = tid + q * T, k = 2 * p - 2;
+      dbl2 w = v[q];
+      if (k + 1 >= n_in) w.y = 0.0;
+      if (2 * p + 1 < N + 4) buf2[p] = w;
+    }
+  }
+  RPDE_SYNC(blk);
+
+  // ---- inputs of the first pass: z_i = (v_{2i}, v_{2i+1}) for i < N/2, (v_{2N-2i}, v_{2N-2i-1}) behind, i = tid + t T
+  RPDE_PHASE(blk, tid) {
+    clds2_t xs2 = (clds2_t)buf;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = tid + t * T;               // m0 = 2 i: x[m0], x[m0+1] = pair i + 1; x[m0-2], x[m0-1] = pair i
+      const dbl2 c = xs2[i + 1], p = xs2[i];
+      const double v0 = sten ? c.x - p.x : c.x, v1 = sten ? c.y - p.y : c.y;
+      const double f0 = (t == 0 && tid == 0) ? 1.0 : 0.5;      // m = 0: the end of the line
+      RPDE_T(re)[t] = f0 * v0;
+      RPDE_T(im)[t] = -0.5 * v1;
+    }
+#pragma unroll
+    for (int t = 8; t < 16; ++t) {
+      const int m0 = 2 * N - 2 * (tid + t * T);                // even, 2 <= m0 <= N
+      const double x0 = buf[m0 + 2], x1 = buf[m0 + 1], t0 = buf[m0], t1 = buf[m0 - 1];   // x[m0], x[m0-1], x[m0-2], x[m0-3]
+      const double v0 = sten ? x0 - t0 : x0, v1 = sten ? x1 - t1 : x1;
+      const double f0 = (t == 8 && tid == 0) ? 1.0 : 0.5;      // m = N: the other end
+      RPDE_T(re)[t] = f0 * v0;
+      RPDE_T(im)[t] = -0.5 * v1;
+    }
+    SmallDft<16>::run(RPDE_T(re), RPDE_T(im));                 // first pass: no twiddles
+  }
+
+  // exchange after the pass with Ns = 2^LGNS: output t of butterfly j belongs to position j0 + t Ns, input t of
+  // butterfly j of the next pass is position j + t T; one real component at a time through the padded buffer
+  auto exchange = [&](auto LG) {
+    constexpr int LGNS = decltype(LG)::value, Ns = 1 << LGNS;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      RPDE_SYNC(blk);                                          // everybody has read what this overwrites
+      RPDE_PHASE(blk, tid) {
+        const int j0 = ((tid >> LGNS) << (LGNS + 4)) + (tid & (Ns - 1));
+        const int b0 = pidx(j0);
+        double* z = half ? RPDE_T(im) : RPDE_T(re);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int p = (Ns >= 16) ? b0 + t * Ns + (t * Ns) / 16 : pidx(j0 + t * Ns);
+          buf[p] = z[t];
+        }
+      }
+      RPDE_SYNC(blk);
+      RPDE_PHASE(blk, tid) {
+        const int b = pidx(tid);
+        double* z = half ? RPDE_T(im) : RPDE_T(re);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) z[t] = buf[b + t * T + (t * T) / 16];
+      }
+    }
+  };
+  // pass with twiddles W_N^(t k tstep), k = j mod Ns, tstep = N / (16 Ns): powers of the table entry for t = 1
+  auto pass = [&](auto LG) {
+    constexpr int LGNS = decltype(LG)::value, Ns = 1 << LGNS, tstep = N / (16 * Ns);
+    RPDE_PHASE(blk, tid) {
+      const int k = tid & (Ns - 1);
+      const double wc = tw[2 * (k * tstep)], ws = tw[2 * (k * tstep) + 1];
+      double cc = wc, cs = ws;
+      double* xr = RPDE_T(re);
+      double* xi = RPDE_T(im);
+#pragma unroll
+      for (int t = 1; t < 16; ++t) {
+        const double ar = xr[t], ai = xi[t];
+        xr[t] = ar * cc - ai * cs;
+        xi[t] = ar * cs + ai * cc;
+        if (t < 15) { const double nc = cc * wc - cs * ws, ns = cc * ws + cs * wc; cc = nc; cs = ns; }
+      }
+      SmallDft<16>::run(xr, xi);
+    }
+  };
+  exchange(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 4>{});
+  if constexpr (N == 4096) {
+    exchange(std::integral_constant<int, 4>{});
+    pass(std::integral_constant<int, 8>{});
+  }
+  // now thread j holds Z_k for k = j + t T (natural order)
+
+  // ---- split: E_k = A + B, E_{N-k} = A - B, A = (Zr_k + Zr_{N-k}) / 2, B = (c_k (Zi_k + Zi_{N-k}) - s_k (Zr_k - Zr_{N-k})) / 2.
+  // Thread j produces the pairs of k = j + t T, t < 8 (k < N/2); the partner Z_{N-k} comes through the buffer, again
+  // one real component at a time.  Thread 0 also owns k = 0 <-> N (its own partner) and k = N/2.
+  RPDE_TLS(blk, double, pr, 8);
+  RPDE_TLS(blk, double, cs8, 16);
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+    const int b = pidx(tid);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) buf[b + t * T + (t * T) / 16] = RPDE_T(re)[t];
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+    const int nb = -tid + ((-tid) >> 4);                       // pidx(-tid): N - k = (N - t T) - tid, N - t T a multiple of 16
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int p = (t == 0 && tid == 0) ? 0 : nb + (N - t * T) + (N - t * T) / 16;
+      RPDE_T(pr)[t] = buf[p];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {                              // split twiddles of this thread's k: in flight across the next barriers
+      const int k = tid + t * T;
+      RPDE_T(cs8)[2 * t] = tw2[2 * k];
+      RPDE_T(cs8)[2 * t + 1] = tw2[2 * k + 1];
+    }
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+    const int b = pidx(tid);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) buf[b + t * T + (t * T) / 16] = RPDE_T(im)[t];
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+    const int nb = -tid + ((-tid) >> 4);
+    const double sc = a.scale;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = tid + t * T;
+      const int p = (t == 0 && tid == 0) ? 0 : nb + (N - t * T) + (N - t * T) / 16;
+      const double pi = buf[p];
+      const double zr = RPDE_T(re)[t], zi = RPDE_T(im)[t], c = RPDE_T(cs8)[2 * t], s = RPDE_T(cs8)[2 * t + 1];
+      const double A = 0.5 * (zr + RPDE_T(pr)[t]), B = 0.5 * (c * (zi + pi) - s * (zr - RPDE_T(pr)[t]));
+      dst[k] = sc * (A + B);
+      dst[N - k] = sc * (A - B);
+    }
+    if (tid == 0) {   // k = N/2 = 8 T: its own partner
+      const double c = tw2[2 * (N / 2)], s = tw2[2 * (N / 2) + 1];
+      const double zr = RPDE_T(re)[8], zi = RPDE_T(im)[8];
+      const double A = 0.5 * (zr + zr), B = 0.5 * (c * (zi + zi) - s * (zr - zr));
+      dst[N / 2] = sc * (A + B);
+    }
+  }
+}
+
+}  // namespace rpde

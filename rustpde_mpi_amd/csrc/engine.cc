@@ -514,6 +514,23 @@ void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
   l.out = base; l.cols = ncols; l.tag = tag;
   step_.push_back(l);
 }
+bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
+  // RPDE_DCT_LINE=0 keeps the line-VM program (A/B measurements); the HIP build covers N = 4096 only
+  static const bool on = [] { const char* e = std::getenv("RPDE_DCT_LINE"); return !e || std::atoi(e) != 0; }();
+#ifdef RPDE_EMU
+  const bool covered = dct_line_ok(a);
+#else
+  const bool covered = a.N == 4096 && dct_line_ok(a);
+#endif
+  if (!on || !covered || comm_.size != 1) return false;
+  Launch l;
+  l.type = Launch::kDctLine;
+  l.dl = a;
+  l.tag = tag;
+  l.bytes = 8.0 * ((double)a.n_in + a.N + 1) * a.nlines;
+  step_.push_back(l);
+  return true;
+}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -579,6 +596,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
     case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
+    case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
   }
 }
@@ -1270,6 +1288,9 @@ void Navier2DEngine::build_confined() {
   // ---- S2: y-lines: physical products and forward y transform
   // physical velocities once per step (shared by the three convection programs)
   for (int w = 0; w < 2; ++w) {
+    // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
+    const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
+    if (yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys")) continue;
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
@@ -1565,6 +1586,9 @@ void Navier2DEngine::build_periodic() {
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
   for (int w = 0; w < 2; ++w) {
+    // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
+    const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
+    if (yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys")) continue;
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);

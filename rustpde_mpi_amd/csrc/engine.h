@@ -8,6 +8,7 @@
 #include <memory>
 #include <string>
 
+#include "dct_line.h"
 #include "ops.h"
 
 namespace rpde {
@@ -190,7 +191,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff } type;
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine } type;
+    DctLineArgs dl{};            // kDctLine
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
     ColDiffArgs cd{};            // kColDiff
@@ -223,6 +225,8 @@ class Navier2DEngine {
   // (single GPU: column scans instead of transpose -> line program -> transpose)
   void add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols, const char* tag);
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
+  // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
+  bool add_dct_line(const DctLineArgs& a, const char* tag);
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

@@ -3,6 +3,8 @@
 // loops that define the expected results of the HIP kernels.
 #include "kernels.h"
 
+#include "dct_line.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -633,6 +635,24 @@ void launch_col_diff(const ColDiffArgs& a, Stream& st) {
   RPDE_HIP(hipGetLastError());
 }
 
+// dct_line.h: one line per workgroup of N / 16 threads, 34.8 KB of LDS, 128 VGPRs: four workgroups per CU
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void dct_line_kernel(const DctLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  const int chunk = (int)gridDim.x >> 3;                     // XCD-aware line map, as in line_kernel
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  dct_bwd_line<N>(blk, a);
+}
+bool launch_dct_line(const DctLineArgs& a, Stream& st) {
+  if (a.N != 4096 || !dct_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  hipLaunchKernelGGL(dct_line_kernel<4096>, dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+
 // sustained f64 MFMA rate of the chip (no memory traffic): 4 waves per workgroup, 8 independent
 // accumulator chains per wave, `iters` x 8 v_mfma_f64_16x16x4_f64 per wave.  The achievable peak a
 // GEMM can be priced against once the clock has settled under the matrix load.
@@ -879,6 +899,17 @@ void launch_col_diff(const ColDiffArgs& a, Stream&) {
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
   for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i, par);
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
+}
+bool launch_dct_line(const DctLineArgs& a, Stream&) {
+  if (!dct_line_ok(a)) return false;
+  std::vector<double> lds(dct_line_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);   // 16-byte aligned like the device buffer
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) dct_bwd_line<4096>(blk, a); else dct_bwd_line<256>(blk, a);
+  }
+  return true;
 }
 
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream&) {

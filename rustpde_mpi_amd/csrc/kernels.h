@@ -66,6 +66,11 @@ void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 void launch_col_hholtz(const ColHhArgs& a, Stream& st);
 void launch_col_diff(const ColDiffArgs& a, Stream& st);
 
+// backward Chebyshev transform of whole lines with four workgroups per CU (dct_line.h); false: shape / alignment
+// not covered (the caller runs the line program instead)
+struct DctLineArgs;
+bool launch_dct_line(const DctLineArgs& a, Stream& st);
+
 // weighted averages of the callback diagnostics on the device (field/average.rs:26-59 applied to
 // eval_nu / eval_nuvol / eval_re, functions.rs:146-233).  Inputs are physical (nx x ny, pitch ld) arrays:
 // total temperature T, its unscaled y-derivative dT, ux, uy; wx / wy = dx / length of the two axes.

@@ -203,3 +203,15 @@ def check_statistics(lib, periodic, nx, ny, ra=1e4, dt=0.01, tol=1e-11):
     # the mean is a mean: after three saves t_avg differs from the last snapshot
     assert rel(st.t_avg.vhat, ora.temp.to_ortho()) > 1e-6
     return st, so
+
+
+def check_dct_line_backward(lib, n, nlines=5):
+    """The whole-line backward transform kernel (csrc/dct_line.h) against the oracle's `backward` along an axis."""
+    rng = np.random.default_rng(n)
+    for kind, base in ((1, B.cheb_dirichlet(n)), (0, B.chebyshev(n))):
+        m = n - 2 if kind == 1 else n
+        a = np.ascontiguousarray(rng.standard_normal((nlines, m)))
+        out = np.empty((nlines, n))
+        lib.call("rpde_dct_line_backward", kind, n, R._capi.ptr(a), nlines, R._capi.ptr(out), 0)
+        want = base.backward(a, 1)
+        assert rel(out, want) < 2e-12, (kind, n, rel(out, want))

@@ -34,8 +34,20 @@ def test_reference_known_answers(emu_lib):
     K.check_reference_known_answers(emu_lib)
 
 
+@pytest.mark.parametrize("n", [257, 4097])
+def test_dct_line_backward(emu_lib, n):
+    K.check_dct_line_backward(emu_lib, n)
+
+
+def test_whole_line_kernel_rejects_other_lengths(emu_lib):
+    a = np.zeros((1, 129)); out = np.zeros((1, 129))
+    with pytest.raises(R.RpdeError, match="not covered"):
+        emu_lib.call("rpde_dct_line_backward", 0, 129, R._capi.ptr(a), 1, R._capi.ptr(out), 0)
+
+
 @pytest.mark.parametrize("nx,ny,ra,dt,steps", [(17, 17, 1e4, 0.01, 5), (33, 33, 1e5, 0.01, 20),
-                                               (65, 33, 1e5, 0.01, 10), (33, 65, 1e5, 0.01, 10)])
+                                               (65, 33, 1e5, 0.01, 10), (33, 65, 1e5, 0.01, 10),
+                                               (17, 257, 1e5, 0.01, 4)])   # ny = 257: S2 runs the whole-line kernel
 def test_confined_step(emu_lib, nx, ny, ra, dt, steps):
     K.check_step_parity(emu_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
 
@@ -44,7 +56,8 @@ def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 
 
-@pytest.mark.parametrize("nx,ny,steps,aspect", [(16, 17, 5, 1.0), (32, 33, 10, 1.0), (64, 33, 10, 1.0), (32, 17, 5, 2.0)])
+@pytest.mark.parametrize("nx,ny,steps,aspect", [(16, 17, 5, 1.0), (32, 33, 10, 1.0), (64, 33, 10, 1.0), (32, 17, 5, 2.0),
+                                                (16, 257, 3, 1.0)])   # ny = 257: whole-line kernel in S2
 def test_periodic_step(emu_lib, nx, ny, steps, aspect):
     K.check_step_parity(emu_lib, True, nx, ny, 1e5, 0.01, steps, aspect=aspect, check_at=[1, 2, steps])
 

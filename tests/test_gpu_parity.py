@@ -192,6 +192,16 @@ def test_prandtl_number_not_one(hip_lib, periodic, nx, ny, pr):
     K.check_step_parity(hip_lib, periodic, nx, ny, 1e5, 0.01, 10, pr=pr, check_at=[1, 10])
 
 
+def test_dct_line_backward_4097(hip_lib):
+    K.check_dct_line_backward(hip_lib, 4097, nlines=37)
+
+
+def test_step_through_the_whole_line_kernel(hip_lib):
+    """ny = 4097: the physical velocities of S2 come from csrc/dct_line.h (four workgroups per CU)."""
+    K.check_step_parity(hip_lib, False, 17, 4097, 1e6, 1e-3, 3)
+    K.check_step_parity(hip_lib, True, 16, 4097, 1e6, 1e-3, 3)
+
+
 def test_exit_flag_device_side(hip_lib):
     """Integrate::exit (navier.rs:482-489): the device flag agrees with the reference's NaN test of
     the divergence norm -- clean run: False; NaN injected: True from the next step on."""
