@@ -194,9 +194,13 @@ int rpde_navier2d_poisson_eigenbasis(rpde_navier2d* h, double* lam, double* fwd,
 int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, int device);
 /* funspace `backward` along contiguous lines (src/field.rs:108-111) through the whole-line transform kernel   *
  * (csrc/dct_line.h: n / 16 threads per line, data in registers, four workgroups per CU): `nlines` lines of     *
- * n_in coefficients (kind 0 chebyshev: n_in = n, kind 1 cheb_dirichlet: n_in = n - 2) -> n physical values.    *
+ * n_in coefficients (kind 0 chebyshev: n_in = n, kind 1 cheb_dirichlet: n_in = n - 2) -> n physical values.     *
  * n = 4097 (HIP and emulation builds) or 257 (emulation build); other shapes return an error.                 */
 int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double* out, int device);
+/* the same with the derivative along the line in between: out = backward_ortho(scale * d/dx to_ortho(in))       *
+ * (funspace `gradient` + `backward` of the orthonormal space, src/field.rs:127-129); kind 2 = cheb_neumann      *
+ * (n_in = n - 2) is accepted by both entries                                                                    */
+int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double scale, double* out, int device);
 /* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
  * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "rpde_navier2d_poisson_eigenbasis": (C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
     "rpde_transpose": (C.c_int, [_dp, C.c_int, C.c_int, C.c_int, _dp, C.c_int]),
     "rpde_dct_line_backward": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int]),
+    "rpde_dct_line_gradient": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int]),
     "rpde_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]),
     "rpde_microbench": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }

@@ -566,20 +566,26 @@ int rpde_transpose(const double* in, int rows, int cols, int elem, double* out, 
     dev_download2d(out, b.p(), b.ld, cols, (long)rows * elem);
   })
 }
+static void dct_line_entry(int kind, int n, const double* in, int nlines, int deriv, double scale, double* out) {
+  RPDE_REQUIRE(in && out && nlines > 0 && kind >= 0 && kind <= 2, "bad argument");
+  Stream st;
+  const Base b = make_base(kind == 1 ? kChebDirichlet : (kind == 2 ? kChebNeumann : kChebyshev), n);
+  AxisTables ax(b);
+  Arr2 a(nlines, b.m), v(nlines, n);
+  dev_upload2d(a.p(), a.ld, in, nlines, b.m);
+  DctLineArgs d{a.p(), a.ld, b.m, v.p(), v.ld, nlines, n - 1, kind == 1 ? 2 : (kind == 2 ? 1 : 0), ax.tw.p, ax.tw2.p, 1.0};
+  d.low = kind == 2 ? ax.low.p : nullptr;
+  d.deriv = deriv;
+  d.dscale = scale;
+  RPDE_REQUIRE(ax.fft_n == n - 1 && launch_dct_line(d, st), "whole-line transform kernel: line length not covered");
+  dev_sync(st);
+  dev_download2d(out, v.p(), v.ld, nlines, n);
+}
 int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double* out, int device) {
-  RPDE_TRY({
-    RPDE_REQUIRE(in && out && nlines > 0 && (kind == 0 || kind == 1), "bad argument");
-    select_device(device);
-    Stream st;
-    const Base b = make_base(kind == 1 ? kChebDirichlet : kChebyshev, n);
-    AxisTables ax(b);
-    Arr2 a(nlines, b.m), v(nlines, n);
-    dev_upload2d(a.p(), a.ld, in, nlines, b.m);
-    DctLineArgs d{a.p(), a.ld, b.m, v.p(), v.ld, nlines, n - 1, kind == 1 ? 2 : 0, ax.tw.p, ax.tw2.p, 1.0};
-    RPDE_REQUIRE(ax.fft_n == n - 1 && launch_dct_line(d, st), "rpde_dct_line_backward: line length not covered by the whole-line kernel");
-    dev_sync(st);
-    dev_download2d(out, v.p(), v.ld, nlines, n);
-  })
+  RPDE_TRY({ select_device(device); dct_line_entry(kind, n, in, nlines, 0, 1.0, out); })
+}
+int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double scale, double* out, int device) {
+  RPDE_TRY({ select_device(device); dct_line_entry(kind, n, in, nlines, 1, scale, out); })
 }
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device) {
   RPDE_TRY({

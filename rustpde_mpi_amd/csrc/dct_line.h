@@ -23,17 +23,21 @@ struct DctLineArgs {
   double* out; long ldo;                  // output lines: N + 1 values each
   int nlines;
   int N;                                  // 256 or 4096
-  int sten;                               // 0: orthonormal input; 2: Dirichlet composite input (c_m = a_m - a_{m-2})
+  int sten;                               // 0: orthonormal input; 2: Dirichlet composite input (c_m = a_m - a_{m-2});
+                                          // 1: composite input with the stencil table `low` (c_m = a_m + low[m-2] a_{m-2})
   const double* tw;                       // N complex FFT twiddles (cos, -sin)(2 pi k / N)      (AxisTables::tw)
   const double* tw2;                      // split twiddles (cos, sin)(pi k / N), k = 0 .. N     (AxisTables::tw2)
   double scale;
+  const double* low = nullptr;            // sten == 1: AxisTables::low (length >= N - 1)
+  int deriv = 0;                          // 1: transform dscale * d/dx of the orthonormal series instead of the series
+  double dscale = 1.0;                    //    (funspace `gradient` along the line, src/field.rs:127-129)
 };
 
 RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16; }
 // the 16-byte staging loads need an aligned line start and, for an odd count, one readable element behind the line
 RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
   return (a.N == 256 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
-         ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2);
+         ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2 || (a.sten == 1 && a.low != nullptr));
 }
 
 template <int N>
@@ -73,8 +77,96 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
   }
   RPDE_SYNC(blk);
 
+  // ---- table stencil and / or derivative: the orthonormal coefficients (then their derivative) replace the staged
+  // line, thread t owning the contiguous chunk k = 16 t .. 16 t + 15 (the last thread also k = N)
+  bool sten_in_read = sten;
+  if (a.sten == 1 || a.deriv) {
+    sten_in_read = false;
+    if (a.sten != 0) {
+      tab_t low = (tab_t)a.low;
+      RPDE_TLS(blk, double, c, 17);
+      RPDE_PHASE(blk, tid) {
+        const int k0 = 16 * tid;
+        double xs[19], lw[17];
+#pragma unroll
+        for (int i = 0; i < 19; ++i) xs[i] = buf[k0 + i];                       // xs[i] = a_{k0 + i - 2}
+#pragma unroll
+        for (int i = 0; i < 17; ++i) lw[i] = (a.sten == 2) ? -1.0 : low[max(k0 + i - 2, 0)];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) RPDE_T(c)[i] = xs[i + 2] + lw[i] * xs[i];  // c_k = a_k + low_{k-2} a_{k-2}; zeros outside
+      }
+      RPDE_SYNC(blk);
+      RPDE_PHASE(blk, tid) {
+        const int k0 = 16 * tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) buf[k0 + i + 2] = RPDE_T(c)[i];
+        if (tid == T - 1) buf[N + 2] = RPDE_T(c)[16];
+      }
+      RPDE_SYNC(blk);
+    }
+    if (a.deriv) {
+      // d_k = dscale * sum_{j > k, j + k odd} 2 j c_j, d_0 halved (the suffix sums of scan_cheb_diff, line_vm.h): thread t
+      // owns the chunk lo = 16 (T - 1 - t), so that the carry flows from thread t - 1 to thread t
+      RPDE_TLS(blk, double, zz, 16);
+      RPDE_TLS(blk, double, vv, 2);
+      lds_t carry = buf + N + 8;
+      RPDE_PHASE(blk, tid) {
+        const int lo = (T - 1 - tid) * 16;
+        double bb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[lo + i + 3];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          double z = 0.0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int e = 14 + par - 2 * i;
+            z += bb[e];
+            RPDE_T(zz)[e] = z;
+          }
+          RPDE_T(vv)[par] = z;
+        }
+      }
+#ifdef RPDE_EMU
+      for (int par = 0; par < 2; ++par) {
+        double run = 0.0;
+        for (int t = 0; t < T; ++t) { const double mine = vv_st[(size_t)t * 2 + par]; vv_st[(size_t)t * 2 + par] = run; run += mine; }
+      }
+      (void)carry;
+#else
+      {
+        constexpr int NW = (T + 63) / 64;
+        const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        double v[2] = {vv[0], vv[1]};
+        v[0] = sum_wave_scan(v[0]);
+        v[1] = sum_wave_scan(v[1]);
+        double S[2] = {0.0, 0.0};
+        if constexpr (NW > 1) {
+          if (lane == 63) { carry[wave] = v[0]; carry[NW + wave] = v[1]; }
+          __syncthreads();
+          for (int u = 0; u < wave; ++u) { S[0] += carry[u]; S[1] += carry[NW + u]; }
+        }
+#pragma unroll
+        for (int par = 0; par < 2; ++par) vv[par] = dpp_f64<0x138, 0xF>(0.0, v[par]) + S[par];   // wave_shr:1
+      }
+#endif
+      RPDE_SYNC(blk);
+      RPDE_PHASE(blk, tid) {
+        const int lo = (T - 1 - tid) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = lo + i;
+          buf[k + 2] = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+        }
+        if (tid == 0) buf[N + 2] = 0.0;          // d_N = 0
+      }
+      RPDE_SYNC(blk);
+    }
+  }
+
   // ---- inputs of the first pass: z_i = (v_{2i}, v_{2i+1}) for i < N/2, (v_{2N-2i}, v_{2N-2i-1}) behind, i = tid + t T
   RPDE_PHASE(blk, tid) {
+    const bool sten = sten_in_read;
     clds2_t xs2 = (clds2_t)buf;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {

@@ -531,6 +531,25 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag) {
+  // RPDE_S1_LINE=1: value and x-derivative of a state line through the whole-line kernel (read per engine, so that a
+  // test can switch it); off by default until it has been timed on the GPU
+  const char* e = std::getenv("RPDE_S1_LINE");
+  const bool on = e && std::atoi(e) != 0;
+#ifdef RPDE_EMU
+  const bool covered = dct_line_ok(a0) && dct_line_ok(a1);
+#else
+  const bool covered = a0.N == 4096 && dct_line_ok(a0) && dct_line_ok(a1);
+#endif
+  if (!on || !covered || comm_.size != 1) return false;
+  Launch l;
+  l.type = Launch::kDctLine2;
+  l.dl = a0; l.dl2 = a1;
+  l.tag = tag;
+  l.bytes = 8.0 * ((double)a0.n_in + 2.0 * (a0.N + 1)) * a0.nlines;
+  step_.push_back(l);
+  return true;
+}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -597,6 +616,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
     case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
     case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
+    case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
   }
 }
@@ -1251,6 +1271,14 @@ void Navier2DEngine::build_confined() {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
   static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
   for (auto& f : s1) {
+    {   // whole-line kernel, two transforms per line (RPDE_S1_LINE=1): Dirichlet stencil in x for the velocities, the Neumann table for T
+      const bool dir = f.ax == &xD;
+      DctLineArgs v{yx(*f.st), ldx, mx, yx(*f.w0), ldx, ylines(my), nx - 1, dir ? 2 : 1, f.ax->tw.p, f.ax->tw2.p, 1.0};
+      v.low = dir ? nullptr : f.ax->low.p;
+      DctLineArgs d = v;
+      d.out = yx(*f.w1); d.deriv = 1; d.dscale = 1.0 / sx_;
+      if (f.ax->fft_n == nx - 1 && add_dct_line2(v, d, "S1 x: state -> phys-x + d/dx")) continue;
+    }
     if (s1_merge) {
       // one program per field: the orthonormal coefficients wait in the register stash while the value is
       // transformed, then come back for the derivative -- the state line is read once instead of twice

@@ -191,8 +191,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine } type;
-    DctLineArgs dl{};            // kDctLine
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2 } type;
+    DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
     ColDiffArgs cd{};            // kColDiff
@@ -227,6 +227,7 @@ class Navier2DEngine {
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
+  bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

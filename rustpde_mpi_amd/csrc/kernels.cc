@@ -652,6 +652,24 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st) {
   RPDE_HIP(hipGetLastError());
   return true;
 }
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void dct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  dct_bwd_line<N>(blk, a0);
+  __syncthreads();
+  dct_bwd_line<N>(blk, a1);
+}
+bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
+  if (a0.N != 4096 || a1.N != 4096 || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
+  if (a0.nlines <= 0) return true;
+  hipLaunchKernelGGL(dct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
 
 // sustained f64 MFMA rate of the chip (no memory traffic): 4 waves per workgroup, 8 independent
 // accumulator chains per wave, `iters` x 8 v_mfma_f64_16x16x4_f64 per wave.  The achievable peak a
@@ -899,6 +917,10 @@ void launch_col_diff(const ColDiffArgs& a, Stream&) {
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
   for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i, par);
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
+}
+bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
+  if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
+  return launch_dct_line(a0, st) && launch_dct_line(a1, st);
 }
 bool launch_dct_line(const DctLineArgs& a, Stream&) {
   if (!dct_line_ok(a)) return false;

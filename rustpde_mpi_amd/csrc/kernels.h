@@ -70,6 +70,9 @@ void launch_col_diff(const ColDiffArgs& a, Stream& st);
 // not covered (the caller runs the line program instead)
 struct DctLineArgs;
 bool launch_dct_line(const DctLineArgs& a, Stream& st);
+// two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
+// the second read of a line comes from L2
+bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
 
 // weighted averages of the callback diagnostics on the device (field/average.rs:26-59 applied to
 // eval_nu / eval_nuvol / eval_re, functions.rs:146-233).  Inputs are physical (nx x ny, pitch ld) arrays:

@@ -206,12 +206,17 @@ def check_statistics(lib, periodic, nx, ny, ra=1e4, dt=0.01, tol=1e-11):
 
 
 def check_dct_line_backward(lib, n, nlines=5):
-    """The whole-line backward transform kernel (csrc/dct_line.h) against the oracle's `backward` along an axis."""
+    """The whole-line transform kernel (csrc/dct_line.h) against the oracle: `backward` along an axis for the three
+    Chebyshev bases, and backward_ortho(scale * d/dx to_ortho(.)) (the physical x-derivative S1 of the step needs)."""
     rng = np.random.default_rng(n)
-    for kind, base in ((1, B.cheb_dirichlet(n)), (0, B.chebyshev(n))):
-        m = n - 2 if kind == 1 else n
+    ortho = B.chebyshev(n)
+    for kind, base in ((1, B.cheb_dirichlet(n)), (0, B.chebyshev(n)), (2, B.cheb_neumann(n))):
+        m = n if kind == 0 else n - 2
         a = np.ascontiguousarray(rng.standard_normal((nlines, m)))
         out = np.empty((nlines, n))
         lib.call("rpde_dct_line_backward", kind, n, R._capi.ptr(a), nlines, R._capi.ptr(out), 0)
         want = base.backward(a, 1)
         assert rel(out, want) < 2e-12, (kind, n, rel(out, want))
+        lib.call("rpde_dct_line_gradient", kind, n, R._capi.ptr(a), nlines, 0.5, R._capi.ptr(out), 0)
+        want = ortho.backward_ortho(0.5 * ortho.differentiate(base.to_ortho(a, 1), 1, 1), 1)
+        assert rel(out, want) < 2e-12, ("gradient", kind, n, rel(out, want))

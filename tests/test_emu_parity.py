@@ -52,6 +52,22 @@ def test_confined_step(emu_lib, nx, ny, ra, dt, steps):
     K.check_step_parity(emu_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
 
 
+def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch):
+    """RPDE_S1_LINE=1: value and x-derivative of the state lines (Dirichlet stencil for u, v; Neumann table for T;
+    suffix-sum derivative) through csrc/dct_line.h -- nx = 257 is a length the emulation build covers."""
+    monkeypatch.setenv("RPDE_S1_LINE", "1")
+    K.check_step_parity(emu_lib, False, 257, 17, 1e5, 0.01, 4, check_at=[1, 4])
+    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    with pytest.raises(R.RpdeError, match="no line program"):    # S1 is not a line program any more
+        nav.trace_launch("S1 x")
+    monkeypatch.setenv("RPDE_S1_LINE", "0")
+    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    try:
+        nav.trace_launch("S1 x")          # found (the emulation build returns a stub the parser does not take)
+    except ValueError:
+        pass
+
+
 def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 

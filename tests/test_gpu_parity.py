@@ -202,6 +202,21 @@ def test_step_through_the_whole_line_kernel(hip_lib):
     K.check_step_parity(hip_lib, True, 16, 4097, 1e6, 1e-3, 3)
 
 
+@pytest.mark.xfail(strict=False, reason="RPDE_S1_LINE=1 (off by default) was timed on the GPU and its kernel passed the operator "
+                   "parity there, but round 2 had no GPU minutes left for this engine-level comparison: first hardware run")
+def test_s1_whole_line_equals_line_program_4097(hip_lib, monkeypatch):
+    """RPDE_S1_LINE=1 against the default line program at nx = 4097 (no oracle needed: same engine, same setup data)."""
+    fields = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RPDE_S1_LINE", flag)
+        nav = R.Navier2D.new_confined(4097, 65, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(3)
+        fields[flag] = nav.physical_fields()
+    for k in fields["0"]:
+        assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, k
+
+
 def test_exit_flag_device_side(hip_lib):
     """Integrate::exit (navier.rs:482-489): the device flag agrees with the reference's NaN test of
     the divergence norm -- clean run: False; NaN injected: True from the next step on."""
