@@ -201,6 +201,10 @@ int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double
  * (funspace `gradient` + `backward` of the orthonormal space, src/field.rs:127-129); kind 2 = cheb_neumann      *
  * (n_in = n - 2) is accepted by both entries                                                                    */
 int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double scale, double* out, int device);
+/* funspace `forward` of the orthonormal Chebyshev base along contiguous lines (src/field.rs:103-106) through the same  *
+ * kernel: n physical values -> n coefficients, zero from index `cut` on (cut < 0: keep all; the 2/3 rule of            *
+ * src/navier_stokes/functions.rs:56-82 is cut = 2 n / 3)                                                               */
+int rpde_dct_line_forward(int n, const double* in, int nlines, int cut, double* out, int device);
 /* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
  * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);

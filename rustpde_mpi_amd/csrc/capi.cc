@@ -584,6 +584,22 @@ static void dct_line_entry(int kind, int n, const double* in, int nlines, int de
 int rpde_dct_line_backward(int kind, int n, const double* in, int nlines, double* out, int device) {
   RPDE_TRY({ select_device(device); dct_line_entry(kind, n, in, nlines, 0, 1.0, out); })
 }
+int rpde_dct_line_forward(int n, const double* in, int nlines, int cut, double* out, int device) {
+  RPDE_TRY({
+    RPDE_REQUIRE(in && out && nlines > 0, "bad argument");
+    select_device(device);
+    Stream st;
+    AxisTables ax(make_base(kChebyshev, n));
+    Arr2 v(nlines, n), c(nlines, n);
+    dev_upload2d(v.p(), v.ld, in, nlines, n);
+    DctLineArgs d{v.p(), v.ld, n, c.p(), c.ld, nlines, n - 1, 0, ax.tw.p, ax.tw2.p, 1.0};
+    d.fwd = 1;
+    d.cut = cut < 0 ? n : cut;
+    RPDE_REQUIRE(ax.fft_n == n - 1 && launch_dct_line(d, st), "whole-line transform kernel: line length not covered");
+    dev_sync(st);
+    dev_download2d(out, c.p(), c.ld, nlines, n);
+  })
+}
 int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double scale, double* out, int device) {
   RPDE_TRY({ select_device(device); dct_line_entry(kind, n, in, nlines, 1, scale, out); })
 }

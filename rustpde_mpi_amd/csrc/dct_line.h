@@ -31,6 +31,8 @@ struct DctLineArgs {
   const double* low = nullptr;            // sten == 1: AxisTables::low (length >= N - 1)
   int deriv = 0;                          // 1: transform dscale * d/dx of the orthonormal series instead of the series
   double dscale = 1.0;                    //    (funspace `gradient` along the line, src/field.rs:127-129)
+  int fwd = 0;                            // 1: forward transform (funspace `forward` of the orthonormal base, src/field.rs:103-106):
+  int cut = 1 << 30;                      //    N + 1 physical values in, coefficients (-1)^k E_k / N (ends halved) out, zero from `cut` on
 };
 
 RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16; }
@@ -174,8 +176,8 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
       const dbl2 c = xs2[i + 1], p = xs2[i];
       const double v0 = sten ? c.x - p.x : c.x, v1 = sten ? c.y - p.y : c.y;
       const double f0 = (t == 0 && tid == 0) ? 1.0 : 0.5;      // m = 0: the end of the line
-      RPDE_T(re)[t] = f0 * v0;
-      RPDE_T(im)[t] = -0.5 * v1;
+      RPDE_T(re)[t] = a.fwd ? v0 : f0 * v0;
+      RPDE_T(im)[t] = a.fwd ? v1 : -0.5 * v1;
     }
 #pragma unroll
     for (int t = 8; t < 16; ++t) {
@@ -183,8 +185,8 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
       const double x0 = buf[m0 + 2], x1 = buf[m0 + 1], t0 = buf[m0], t1 = buf[m0 - 1];   // x[m0], x[m0-1], x[m0-2], x[m0-3]
       const double v0 = sten ? x0 - t0 : x0, v1 = sten ? x1 - t1 : x1;
       const double f0 = (t == 8 && tid == 0) ? 1.0 : 0.5;      // m = N: the other end
-      RPDE_T(re)[t] = f0 * v0;
-      RPDE_T(im)[t] = -0.5 * v1;
+      RPDE_T(re)[t] = a.fwd ? v0 : f0 * v0;
+      RPDE_T(im)[t] = a.fwd ? v1 : -0.5 * v1;
     }
     SmallDft<16>::run(RPDE_T(re), RPDE_T(im));                 // first pass: no twiddles
   }
@@ -285,14 +287,23 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
       const double pi = buf[p];
       const double zr = RPDE_T(re)[t], zi = RPDE_T(im)[t], c = RPDE_T(cs8)[2 * t], s = RPDE_T(cs8)[2 * t + 1];
       const double A = 0.5 * (zr + RPDE_T(pr)[t]), B = 0.5 * (c * (zi + pi) - s * (zr - RPDE_T(pr)[t]));
-      dst[k] = sc * (A + B);
-      dst[N - k] = sc * (A - B);
+      double e0 = A + B, e1 = A - B;
+      if (a.fwd) {   // (-1)^k / N, both ends halved, the 2/3 rule; k and N - k have the parity of tid (T and N are even)
+        double f = (tid & 1) ? -1.0 / (double)N : 1.0 / (double)N;
+        if (t == 0 && tid == 0) f *= 0.5;
+        e0 = (k < a.cut) ? e0 * f : 0.0;
+        e1 = (N - k < a.cut) ? e1 * f : 0.0;
+      }
+      dst[k] = sc * e0;
+      dst[N - k] = sc * e1;
     }
     if (tid == 0) {   // k = N/2 = 8 T: its own partner
       const double c = tw2[2 * (N / 2)], s = tw2[2 * (N / 2) + 1];
       const double zr = RPDE_T(re)[8], zi = RPDE_T(im)[8];
       const double A = 0.5 * (zr + zr), B = 0.5 * (c * (zi + zi) - s * (zr - zr));
-      dst[N / 2] = sc * (A + B);
+      double e0 = A + B;
+      if (a.fwd) e0 = (N / 2 < a.cut) ? e0 * (1.0 / (double)N) : 0.0;       // N / 2 is even for N >= 4
+      dst[N / 2] = sc * e0;
     }
   }
 }

@@ -220,3 +220,12 @@ def check_dct_line_backward(lib, n, nlines=5):
         lib.call("rpde_dct_line_gradient", kind, n, R._capi.ptr(a), nlines, 0.5, R._capi.ptr(out), 0)
         want = ortho.backward_ortho(0.5 * ortho.differentiate(base.to_ortho(a, 1), 1, 1), 1)
         assert rel(out, want) < 2e-12, ("gradient", kind, n, rel(out, want))
+    v = np.ascontiguousarray(rng.standard_normal((nlines, n)))
+    for cut in (-1, 2 * n // 3):
+        lib.call("rpde_dct_line_forward", n, R._capi.ptr(v), nlines, cut, R._capi.ptr(out), 0)
+        want = ortho.forward_ortho(v, 1)
+        if cut >= 0:
+            want[:, cut:] = 0.0
+        assert rel(out, want) < 2e-12, ("forward", n, cut, rel(out, want))
+    lib.call("rpde_dct_line_backward", 0, n, R._capi.ptr(out), nlines, R._capi.ptr(v), 0)   # forward then backward of a dealiased line
+    assert rel(ortho.forward_ortho(v, 1)[:, :2 * n // 3], want[:, :2 * n // 3]) < 1e-11
