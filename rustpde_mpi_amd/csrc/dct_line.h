@@ -42,8 +42,16 @@ RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
          ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2 || (a.sten == 1 && a.low != nullptr));
 }
 
-template <int N>
-RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
+// what the split phase does with a result: emit(tid, slot, k, E_k) -- slot 2 t / 2 t + 1 for the pair (k, N - k) of a thread's
+// t-th point, slot 16 for k = N / 2 (thread 0).  The plain transform stores to the output line.
+struct DctStoreEmit {
+  gmem_t dst; double sc;
+  RPDE_DEV void operator()(int, int, int k, double v) const { dst[k] = sc * v; }
+};
+
+// staged: the input line is already in the buffer (x[m] at buf[m + 2], zeros around it) and a barrier has been passed
+template <int N, class Emit>
+RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const Emit& emit) {
   constexpr int T = N / 16;
   static_assert(N == 4096 || N == 256, "N = 16^2 or 16^3");
   static_assert(T % 16 == 0, "padded indices assume T a multiple of 16");
@@ -51,7 +59,6 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
   lds2_t buf2 = (lds2_t)blk.lds;
   const int line = blk.line;
   cgmem2_t src2 = (cgmem2_t)(a.in + (long)line * a.ldi);
-  gmem_t dst = (gmem_t)(a.out + (long)line * a.ldo);
   tab_t tw = (tab_t)a.tw;
   tab_t tw2 = (tab_t)a.tw2;
   const int n_in = a.n_in;
@@ -61,6 +68,7 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
 
   // ---- stage the line two doubles into the buffer: xs[m + 2] = x[m] (m < n_in), zeros in front and behind, so that
   // the stencil tap x[m - 2] and the tail m >= n_in need no selects.  Pair p holds xs[2p], xs[2p + 1] = x[2p - 2], x[2p - 1].
+  if (!staged) {
   RPDE_PHASE(blk, tid) {
     constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);   // pairs per thread: 2 T QP >= N + 4
     dbl2 v[QP];
@@ -78,6 +86,7 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
     }
   }
   RPDE_SYNC(blk);
+  }
 
   // ---- table stencil and / or derivative: the orthonormal coefficients (then their derivative) replace the staged
   // line, thread t owning the contiguous chunk k = 16 t .. 16 t + 15 (the last thread also k = N)
@@ -279,7 +288,6 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
   RPDE_SYNC(blk);
   RPDE_PHASE(blk, tid) {
     const int nb = -tid + ((-tid) >> 4);
-    const double sc = a.scale;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int k = tid + t * T;
@@ -294,8 +302,8 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
         e0 = (k < a.cut) ? e0 * f : 0.0;
         e1 = (N - k < a.cut) ? e1 * f : 0.0;
       }
-      dst[k] = sc * e0;
-      dst[N - k] = sc * e1;
+      emit(tid, 2 * t, k, e0);
+      emit(tid, 2 * t + 1, N - k, e1);
     }
     if (tid == 0) {   // k = N/2 = 8 T: its own partner
       const double c = tw2[2 * (N / 2)], s = tw2[2 * (N / 2) + 1];
@@ -303,9 +311,69 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
       const double A = 0.5 * (zr + zr), B = 0.5 * (c * (zi + zi) - s * (zr - zr));
       double e0 = A + B;
       if (a.fwd) e0 = (N / 2 < a.cut) ? e0 * (1.0 / (double)N) : 0.0;       // N / 2 is even for N >= 4
-      dst[N / 2] = sc * e0;
+      emit(tid, 16, N / 2, e0);
     }
   }
+}
+
+template <int N>
+RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
+  dct_line_core<N>(blk, a, false, DctStoreEmit{(gmem_t)(a.out + (long)blk.line * a.ldo), a.scale});
+}
+
+// One y-line of a convection term (src/navier_stokes/functions.rs:56-72, navier_eq.rs conv_velx / conv_vely / conv_temp):
+//   out = forward_y[ u (A + bx) + v (B + by) ] with the 2/3 rule,  A = backward_y(fx),  B = backward_y(dscale d/dy f0),
+// fx = d/dx f and f0 = f in (physical x, Dirichlet-composite y), u / v / bx / by physical along the line.  Three transforms
+// per line in registers; the first product waits in 17 registers per thread while the second transform runs (136 VGPRs:
+// three workgroups per CU); the sum is staged in the exchange buffer as the input of the forward transform.
+struct ConvLineArgs {
+  const double* fx; const double* f0; const double* up; const double* vp; const double* bx; const double* by;   // bx / by may be null
+  long ld; int n_in;              // all inputs share the pitch; n_in composite coefficients, N + 1 physical values
+  double* out; long ldo;
+  int nlines, N;
+  const double* tw; const double* tw2;
+  double dscale; int cut;
+};
+RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
+  const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
+  DctLineArgs b = a;
+  b.in = c.f0;
+  return dct_line_ok(a) && dct_line_ok(b);
+}
+
+template <int N>
+RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
+  constexpr int T = N / 16;
+  lds_t buf = (lds_t)blk.lds;
+  const long off = (long)blk.line * c.ld;
+  cgmem_t up = (cgmem_t)(c.up + off), vp = (cgmem_t)(c.vp + off);
+  cgmem_t bx = (cgmem_t)(c.bx ? c.bx + off : nullptr), by = (cgmem_t)(c.by ? c.by + off : nullptr);
+  const bool lift = c.bx != nullptr;
+  RPDE_TLS(blk, double, acc, 17);
+  DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
+  dct_line_core<N>(blk, a1, false, [&](int tid, int slot, int k, double v) {
+    RPDE_T(acc)[slot] = up[k] * (lift ? v + bx[k] : v);
+  });
+  RPDE_SYNC(blk);
+  DctLineArgs a2 = a1;
+  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
+  dct_line_core<N>(blk, a2, false, [&](int tid, int slot, int k, double v) {
+    RPDE_T(acc)[slot] += vp[k] * (lift ? v + by[k] : v);
+  });
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {   // the sum as the staged input line of the forward transform
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = tid + t * T;
+      buf[k + 2] = RPDE_T(acc)[2 * t];
+      buf[N - k + 2] = RPDE_T(acc)[2 * t + 1];
+    }
+    if (tid == 0) { buf[N / 2 + 2] = RPDE_T(acc)[16]; buf[0] = 0.0; buf[1] = 0.0; buf[N + 3] = 0.0; }
+  }
+  RPDE_SYNC(blk);
+  DctLineArgs a3{nullptr, 0, N + 1, nullptr, 0, c.nlines, N, 0, c.tw, c.tw2, 1.0};
+  a3.fwd = 1; a3.cut = c.cut;
+  dct_line_core<N>(blk, a3, true, DctStoreEmit{(gmem_t)(c.out + (long)blk.line * c.ldo), 1.0});
 }
 
 }  // namespace rpde

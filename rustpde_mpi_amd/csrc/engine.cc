@@ -550,6 +550,25 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
+  // RPDE_CONV_LINE=1: the convection terms through the whole-line kernel (three transforms per line in registers);
+  // prepared in round 2 on the emulation build, neither timed nor run on hardware yet: off by default
+  const char* e = std::getenv("RPDE_CONV_LINE");
+  const bool on = e && std::atoi(e) != 0;
+#ifdef RPDE_EMU
+  const bool covered = conv_line_ok(c);
+#else
+  const bool covered = c.N == 4096 && conv_line_ok(c);
+#endif
+  if (!on || !covered || comm_.size != 1) return false;
+  Launch l;
+  l.type = Launch::kConvLine;
+  l.cl = c;
+  l.tag = tag;
+  l.bytes = 8.0 * (2.0 * c.n_in + (c.bx ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by), out
+  step_.push_back(l);
+  return true;
+}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -616,6 +635,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
     case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
     case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
+    case Launch::kConvLine: RPDE_REQUIRE(launch_conv_line(l.cl, st_), "internal: conv line shape"); break;
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
   }
@@ -1328,6 +1348,11 @@ void Navier2DEngine::build_confined() {
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash, so two workgroups share a CU
+    {
+      const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                            xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+      if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
+    }
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
@@ -1626,6 +1651,11 @@ void Navier2DEngine::build_periodic() {
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash
+    {
+      const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                            xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+      if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
+    }
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)

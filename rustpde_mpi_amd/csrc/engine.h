@@ -191,7 +191,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2 } type;
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine } type;
+    ConvLineArgs cl{};           // kConvLine
     DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
@@ -228,6 +229,7 @@ class Navier2DEngine {
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
+  bool add_conv_line(const ConvLineArgs& c, const char* tag);
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

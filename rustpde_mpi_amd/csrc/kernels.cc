@@ -663,6 +663,22 @@ __global__ __launch_bounds__(N / 16, 4) void dct_line2_kernel(const DctLineArgs 
   __syncthreads();
   dct_bwd_line<N>(blk, a1);
 }
+template <int N>
+__global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs c) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= c.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  conv_line<N>(blk, c);
+}
+bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
+  if (c.N != 4096 || !conv_line_ok(c)) return false;
+  if (c.nlines <= 0) return true;
+  hipLaunchKernelGGL(conv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != 4096 || a1.N != 4096 || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   if (a0.nlines <= 0) return true;
@@ -917,6 +933,17 @@ void launch_col_diff(const ColDiffArgs& a, Stream&) {
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
   for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i, par);
   for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
+}
+bool launch_conv_line(const ConvLineArgs& c, Stream&) {
+  if (!conv_line_ok(c)) return false;
+  std::vector<double> lds(dct_line_lds_doubles(c.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < c.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, c.N / 16, base};
+    if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);
+  }
+  return true;
 }
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;

@@ -73,6 +73,10 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st);
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
+// one y-line of a convection term: two backward transforms, the physical products, the forward transform with the
+// 2/3 rule, all in registers + one exchange buffer (dct_line.h conv_line; three workgroups per CU)
+struct ConvLineArgs;
+bool launch_conv_line(const ConvLineArgs& c, Stream& st);
 
 // weighted averages of the callback diagnostics on the device (field/average.rs:26-59 applied to
 // eval_nu / eval_nuvol / eval_re, functions.rs:146-233).  Inputs are physical (nx x ny, pitch ld) arrays:

@@ -68,6 +68,24 @@ def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch):
         pass
 
 
+@pytest.mark.parametrize("periodic", [False, True])
+def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, monkeypatch, periodic):
+    """RPDE_CONV_LINE=1: conv_velx / conv_vely / conv_temp as three transforms per y-line in registers
+    (csrc/dct_line.h conv_line); ny = 257 is a length the emulation build covers."""
+    monkeypatch.setenv("RPDE_CONV_LINE", "1")
+    K.check_step_parity(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 0.01, 4, check_at=[1, 4])
+    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
+    with pytest.raises(R.RpdeError, match="no line program"):
+        nav.trace_launch("conv_temp")
+
+
+def test_step_with_every_whole_line_path(emu_lib, monkeypatch):
+    """257 x 257 confined: S1, the pure transforms of S2 and the convection terms all run csrc/dct_line.h."""
+    monkeypatch.setenv("RPDE_CONV_LINE", "1")
+    monkeypatch.setenv("RPDE_S1_LINE", "1")
+    K.check_step_parity(emu_lib, False, 257, 257, 1e6, 2e-3, 3, check_at=[1, 3])
+
+
 def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 
