@@ -352,12 +352,14 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   dct_line_core<N>(blk, a1, false, [&](int tid, int slot, int k, double v) {
+    (void)tid;
     RPDE_T(acc)[slot] = up[k] * (lift ? v + bx[k] : v);
   });
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   dct_line_core<N>(blk, a2, false, [&](int tid, int slot, int k, double v) {
+    (void)tid;
     RPDE_T(acc)[slot] += vp[k] * (lift ? v + by[k] : v);
   });
   RPDE_SYNC(blk);
