@@ -36,6 +36,9 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         got["pseu"] = nav.pseu.vhat
         divn = nav.div_norm()
         stats = nav.comm_stats()
+        st = R.Statistics.new(nav, 1.0, 1.0)   # collective too: every rank gathers, reduces and keeps the same statistics
+        st.update()
+        got["stat_temp"], got["stat_nusselt"] = st.t_avg.vhat, st.nusselt.vhat
         if rank == 0 and nx * ny > 1500 * 1500:
             # big grids: compare with the single-device engine instead of the (slow) oracle
             one = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", library=lib)
@@ -44,6 +47,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
             one.update(steps)
             want = one.physical_fields()
             want["pseu"] = one.pseu.vhat
+            got.pop("stat_temp"); got.pop("stat_nusselt")   # statistics are compared with the oracle on the small cases
             err = {k: float(np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-300)) for k in want}
             results.append({"case": [periodic, nx, ny, steps], "err": err, "div": [divn, one.div_norm()],
                             "comm": stats, "calls": comm.calls})
@@ -56,6 +60,9 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
                 ora.update()
             want = ora.physical_fields()
             want["pseu"] = ora.pseu.vhat
+            so = N.Statistics(ora, 1.0, 1.0)
+            so.update_from(ora)
+            want["stat_temp"], want["stat_nusselt"] = so.t_avg.vhat, so.nusselt.vhat
             err = {k: float(np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-300)) for k in want}
             results.append({"case": [periodic, nx, ny, steps], "err": err, "div": [divn, ora.div_norm()],
                             "comm": stats, "calls": comm.calls})
