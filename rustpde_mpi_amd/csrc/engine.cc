@@ -531,17 +531,73 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::s1_line_selfcheck(const DctLineArgs& a0, const DctLineArgs& a1, int slot_len,
+                                       const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program) {
+  // 64 lines of pseudo-random coefficients with a decaying spectrum; outputs of the line program (r0, r1) and of the
+  // whole-line kernel (w0, w1); ||r - w||^2 against ||r||^2 through the existing reduction
+  const int nl = std::min(a0.nlines, 64), n = a0.N + 1;
+  if (nl <= 0 || std::getenv("RPDE_S1_SELFCHECK_FAIL")) return false;   // the variable: test hook for the fallback
+  const long ld = a0.ldi;
+  DBuf in((size_t)nl * ld), r0((size_t)nl * ld), r1((size_t)nl * ld), w0((size_t)nl * ld), w1((size_t)nl * ld), red(4);
+  {
+    Vec h((size_t)nl * ld, 0.0);
+    unsigned long long z = 0x9E3779B97F4A7C15ull;
+    for (int l = 0; l < nl; ++l)
+      for (int k = 0; k < a0.n_in; ++k) {
+        z = z * 6364136223846793005ull + 1442695040888963407ull;
+        h[(size_t)l * ld + k] = ((double)(z >> 11) / 9007199254740992.0 - 0.5) / (1.0 + 1e-3 * k);
+      }
+    dev_upload(in.p, h.data(), h.size() * sizeof(double));
+  }
+  ProgramBuilder pb(2, slot_len, nl);
+  program(pb, in.p, r0.p, r1.p);
+  pb.run(st_);
+  DctLineArgs b0 = a0, b1 = a1;
+  b0.in = b1.in = in.p; b0.nlines = b1.nlines = nl;
+  b0.out = w0.p; b1.out = w1.p; b0.ldo = b1.ldo = ld;
+  if (!launch_dct_line2(b0, b1, st_)) return false;
+  double worst = 0.0;
+  for (int which = 0; which < 2; ++which) {
+    DBuf& r = which ? r1 : r0;
+    DBuf& w = which ? w1 : w0;
+    launch_sumsq(r.p, ld, nl, n, red.p, st_);
+    ProgramBuilder pd(2, slot_len, nl);
+    const int ar = pd.arr(r.p, ld), aw = pd.arr(w.p, ld);
+    pd.load(0, ar, n); pd.load(0, aw, n, -1.0, true); pd.store(0, ar, n);
+    pd.run(st_);
+    launch_sumsq(r.p, ld, nl, n, red.p + 2, st_);
+    dev_sync(st_);
+    double h[4];
+    dev_download(h, red.p, sizeof(h));
+    if (!(h[0] > 0.0) || h[1] > 0.0 || h[3] > 0.0) return false;      // empty or NaN
+    worst = std::max(worst, h[2] / h[0]);
+  }
+  return worst < 1e-24;
+}
+
 bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag) {
-  // RPDE_S1_LINE=1: value and x-derivative of a state line through the whole-line kernel (read per engine, so that a
-  // test can switch it); off by default until it has been timed on the GPU
+  // Value and x-derivative of a state line through the whole-line kernel (0.207 against 0.24 ms per launch at 4097^2).
+  // RPDE_S1_LINE: 0 = never, 1 = always, auto = after this engine has compared it with the line program on this
+  // device (s1_line_selfcheck); unset = auto in the HIP build, never in the emulation build.  Read per engine.
   const char* e = std::getenv("RPDE_S1_LINE");
-  const bool on = e && std::atoi(e) != 0;
 #ifdef RPDE_EMU
+  const std::string mode = e ? e : "0";
   const bool covered = dct_line_ok(a0) && dct_line_ok(a1);
 #else
+  const std::string mode = e ? e : "auto";
   const bool covered = a0.N == 4096 && dct_line_ok(a0) && dct_line_ok(a1);
 #endif
-  if (!on || !covered || comm_.size != 1) return false;
+  if (mode == "0" || !covered || comm_.size != 1) return false;
+  if (mode == "auto") {
+    bool ok = false;
+    try { ok = s1_program_ && s1_line_selfcheck(a0, a1, sp_vel_->axis(0).slot_len, s1_program_); }
+    catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: whole-line S1 self-check failed to run: %s\n", ex.what()); }
+    if (!ok) {
+      std::fprintf(stderr, "rustpde_hip: the whole-line S1 kernel does not reproduce the line program on this device; "
+                           "using the line program\n");
+      return false;
+    }
+  }
   Launch l;
   l.type = Launch::kDctLine2;
   l.dl = a0; l.dl2 = a1;
@@ -1291,7 +1347,18 @@ void Navier2DEngine::build_confined() {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
   static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
   for (auto& f : s1) {
-    {   // whole-line kernel, two transforms per line (RPDE_S1_LINE=1): Dirichlet stencil in x for the velocities, the Neumann table for T
+    // the line program of S1 for arbitrary input / output lines (the step's own arrays below; scratch lines in the self-check)
+    s1_program_ = [&, ax = f.ax](ProgramBuilder& pb, const double* in, double* o0, double* o1) {
+      pb.set_fft(*ax);
+      pb.load(0, pb.arr(in, ldx), mx);
+      pb.to_ortho(0, *ax);
+      pb.stash(0);
+      pb.dct_fused(0, *ax, false, ax->bwd_pre.p, nullptr, pb.arr(o0, ldx), nx);
+      pb.unstash_axpy(0, 0.0, 1.0, nx);
+      pb.cdiff(0, 0, nx, 1.0 / sx_);
+      pb.dct_fused(0, *ax, false, ax->bwd_pre.p, nullptr, pb.arr(o1, ldx), nx);
+    };
+    {   // whole-line kernel, two transforms per line: Dirichlet stencil in x for the velocities, the Neumann table for T
       const bool dir = f.ax == &xD;
       DctLineArgs v{yx(*f.st), ldx, mx, yx(*f.w0), ldx, ylines(my), nx - 1, dir ? 2 : 1, f.ax->tw.p, f.ax->tw2.p, 1.0};
       v.low = dir ? nullptr : f.ax->low.p;
@@ -1303,14 +1370,7 @@ void Navier2DEngine::build_confined() {
       // one program per field: the orthonormal coefficients wait in the register stash while the value is
       // transformed, then come back for the derivative -- the state line is read once instead of twice
       ProgramBuilder pb = ypb(2, my);
-      pb.set_fft(*f.ax);
-      pb.load(0, pb.arr(yx(*f.st), ldx), mx);
-      pb.to_ortho(0, *f.ax);
-      pb.stash(0);
-      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
-      pb.unstash_axpy(0, 0.0, 1.0, nx);
-      pb.cdiff(0, 0, nx, 1.0 / sx_);
-      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
+      s1_program_(pb, yx(*f.st), yx(*f.w0), yx(*f.w1));
       add_line(pb, "S1 x: state -> phys-x + d/dx");
       continue;
     }
@@ -1331,6 +1391,7 @@ void Navier2DEngine::build_confined() {
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
   }
+  s1_program_ = nullptr;
   // ---- T1: to XY
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform

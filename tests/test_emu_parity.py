@@ -52,7 +52,7 @@ def test_confined_step(emu_lib, nx, ny, ra, dt, steps):
     K.check_step_parity(emu_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
 
 
-def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch):
+def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch, capfd):
     """RPDE_S1_LINE=1: value and x-derivative of the state lines (Dirichlet stencil for u, v; Neumann table for T;
     suffix-sum derivative) through csrc/dct_line.h -- nx = 257 is a length the emulation build covers."""
     monkeypatch.setenv("RPDE_S1_LINE", "1")
@@ -60,6 +60,16 @@ def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch):
     nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
     with pytest.raises(R.RpdeError, match="no line program"):    # S1 is not a line program any more
         nav.trace_launch("S1 x")
+    # auto (the default of the HIP build): the engine first compares the two forms on pseudo-random lines on its device
+    monkeypatch.setenv("RPDE_S1_LINE", "auto")
+    K.check_step_parity(emu_lib, False, 257, 17, 1e5, 0.01, 2)
+    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    with pytest.raises(R.RpdeError, match="no line program"):
+        nav.trace_launch("S1 x")
+    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")       # a failing comparison keeps the line program
+    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    assert "does not reproduce the line program" in capfd.readouterr().err
+    monkeypatch.delenv("RPDE_S1_SELFCHECK_FAIL")
     monkeypatch.setenv("RPDE_S1_LINE", "0")
     nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
     try:
