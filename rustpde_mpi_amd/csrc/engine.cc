@@ -515,14 +515,32 @@ void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
   step_.push_back(l);
 }
 bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
-  // RPDE_DCT_LINE=0 keeps the line-VM program (A/B measurements); the HIP build covers N = 4096 only
-  static const bool on = [] { const char* e = std::getenv("RPDE_DCT_LINE"); return !e || std::atoi(e) != 0; }();
+  // RPDE_DCT_LINE (read per engine): 0 = line program; 1 = whole-line kernel; 2 or, in the HIP build, unset = whole-line kernel
+  // after this engine has compared it with the line program on its own device.  The HIP build covers N = 4096 only.
+  const char* env = std::getenv("RPDE_DCT_LINE");
+  const int mode = env ? std::atoi(env) : -1;
+  const bool on = mode != 0;
 #ifdef RPDE_EMU
   const bool covered = dct_line_ok(a);
 #else
   const bool covered = a.N == 4096 && dct_line_ok(a);
 #endif
   if (!on || !covered || comm_.size != 1) return false;
+#ifndef RPDE_EMU
+  const bool forced = mode == 1;
+#else
+  const bool forced = mode != 2;      // the emulation build compares only when asked to
+#endif
+  if (!forced) {   // the engine compares the kernel with the line program on its own device before it relies on it
+    bool ok = false;
+    try { ok = s1_program_ && line_selfcheck(a, nullptr, sp_vel_->axis(1).slot_len, s1_program_); }
+    catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: whole-line transform self-check failed to run: %s\n", ex.what()); }
+    if (!ok) {
+      std::fprintf(stderr, "rustpde_hip: the whole-line transform kernel does not reproduce the line program on this device; "
+                           "using the line program\n");
+      return false;
+    }
+  }
   Launch l;
   l.type = Launch::kDctLine;
   l.dl = a;
@@ -531,8 +549,9 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   step_.push_back(l);
   return true;
 }
-bool Navier2DEngine::s1_line_selfcheck(const DctLineArgs& a0, const DctLineArgs& a1, int slot_len,
-                                       const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program) {
+bool Navier2DEngine::line_selfcheck(const DctLineArgs& a0, const DctLineArgs* a1p, int slot_len,
+                                    const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program) {
+  const DctLineArgs& a1 = a1p ? *a1p : a0;
   // 64 lines of pseudo-random coefficients with a decaying spectrum; outputs of the line program (r0, r1) and of the
   // whole-line kernel (w0, w1); ||r - w||^2 against ||r||^2 through the existing reduction
   const int nl = std::min(a0.nlines, 64), n = a0.N + 1;
@@ -555,9 +574,9 @@ bool Navier2DEngine::s1_line_selfcheck(const DctLineArgs& a0, const DctLineArgs&
   DctLineArgs b0 = a0, b1 = a1;
   b0.in = b1.in = in.p; b0.nlines = b1.nlines = nl;
   b0.out = w0.p; b1.out = w1.p; b0.ldo = b1.ldo = ld;
-  if (!launch_dct_line2(b0, b1, st_)) return false;
+  if (a1p ? !launch_dct_line2(b0, b1, st_) : !launch_dct_line(b0, st_)) return false;
   double worst = 0.0;
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < (a1p ? 2 : 1); ++which) {
     DBuf& r = which ? r1 : r0;
     DBuf& w = which ? w1 : w0;
     launch_sumsq(r.p, ld, nl, n, red.p, st_);
@@ -578,7 +597,7 @@ bool Navier2DEngine::s1_line_selfcheck(const DctLineArgs& a0, const DctLineArgs&
 bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag) {
   // Value and x-derivative of a state line through the whole-line kernel (0.207 against 0.24 ms per launch at 4097^2).
   // RPDE_S1_LINE: 0 = never, 1 = always, auto = after this engine has compared it with the line program on this
-  // device (s1_line_selfcheck); unset = auto in the HIP build, never in the emulation build.  Read per engine.
+  // device (line_selfcheck); unset = auto in the HIP build, never in the emulation build.  Read per engine.
   const char* e = std::getenv("RPDE_S1_LINE");
 #ifdef RPDE_EMU
   const std::string mode = e ? e : "0";
@@ -590,7 +609,7 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   if (mode == "0" || !covered || comm_.size != 1) return false;
   if (mode == "auto") {
     bool ok = false;
-    try { ok = s1_program_ && s1_line_selfcheck(a0, a1, sp_vel_->axis(0).slot_len, s1_program_); }
+    try { ok = s1_program_ && line_selfcheck(a0, &a1, sp_vel_->axis(0).slot_len, s1_program_); }
     catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: whole-line S1 self-check failed to run: %s\n", ex.what()); }
     if (!ok) {
       std::fprintf(stderr, "rustpde_hip: the whole-line S1 kernel does not reproduce the line program on this device; "
@@ -1399,7 +1418,14 @@ void Navier2DEngine::build_confined() {
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
-    if (yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys")) continue;
+    s1_program_ = [&](ProgramBuilder& q, const double* in, double* o0, double*) {   // the same transform as a line program
+      q.set_fft(yD);
+      q.load(0, q.arr(in, ldy), my);
+      q.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, q.arr(o0, ldy), ny);
+    };
+    const bool whole = yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
+    s1_program_ = nullptr;
+    if (whole) continue;
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);
@@ -1702,7 +1728,14 @@ void Navier2DEngine::build_periodic() {
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
-    if (yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys")) continue;
+    s1_program_ = [&](ProgramBuilder& q, const double* in, double* o0, double*) {   // the same transform as a line program
+      q.set_fft(yD);
+      q.load(0, q.arr(in, ldy), my);
+      q.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, q.arr(o0, ldy), ny);
+    };
+    const bool whole = yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
+    s1_program_ = nullptr;
+    if (whole) continue;
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
     pb.load(0, pb.arr(X_[2 * w].p, ldy), my);

@@ -230,11 +230,11 @@ class Navier2DEngine {
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
-  // the whole-line S1 pair against the line program on the same pseudo-random lines, on this device (`program` fills a
-  // builder with the line program for the given input / outputs); true when they agree to 1e-12
-  bool s1_line_selfcheck(const DctLineArgs& a0, const DctLineArgs& a1, int slot_len,
-                         const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program);
-  std::function<void(ProgramBuilder&, const double*, double*, double*)> s1_program_;   // set while build_confined runs
+  // a whole-line transform (a0) or pair (a0, a1) against the line program on the same pseudo-random lines, on this device
+  // (`program` fills a builder with the line program for the given input / outputs); true when they agree to 1e-12
+  bool line_selfcheck(const DctLineArgs& a0, const DctLineArgs* a1, int slot_len,
+                      const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program);
+  std::function<void(ProgramBuilder&, const double*, double*, double*)> s1_program_;   // the line-program form, set while a step is built
   bool add_conv_line(const ConvLineArgs& c, const char* tag);
   void build_confined();
   void build_periodic();

@@ -89,6 +89,24 @@ def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, m
         nav.trace_launch("conv_temp")
 
 
+def test_s2_whole_line_self_check(emu_lib, monkeypatch, capfd):
+    """RPDE_DCT_LINE=2 (what the HIP build does when the variable is unset): the engine compares the whole-line
+    transform with the line program on pseudo-random lines before it relies on it; a failing comparison keeps the
+    line program."""
+    monkeypatch.setenv("RPDE_DCT_LINE", "2")
+    K.check_step_parity(emu_lib, False, 17, 257, 1e5, 0.01, 2)
+    nav, _ = K.make_pair(emu_lib, True, 16, 257, 1e5, 1.0, 0.01, 1.0)
+    with pytest.raises(R.RpdeError, match="no line program"):
+        nav.trace_launch("S2 y: velx")
+    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")
+    nav, _ = K.make_pair(emu_lib, False, 17, 257, 1e5, 1.0, 0.01, 1.0)
+    assert "does not reproduce the line program" in capfd.readouterr().err
+    try:
+        nav.trace_launch("S2 y: velx")     # a line program again
+    except ValueError:
+        pass
+
+
 def test_step_with_every_whole_line_path(emu_lib, monkeypatch):
     """257 x 257 confined: S1, the pure transforms of S2 and the convection terms all run csrc/dct_line.h."""
     monkeypatch.setenv("RPDE_CONV_LINE", "1")
