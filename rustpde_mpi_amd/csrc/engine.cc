@@ -625,17 +625,94 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   step_.push_back(l);
   return true;
 }
-bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
-  // RPDE_CONV_LINE=1: the convection terms through the whole-line kernel (three transforms per line in registers);
-  // prepared in round 2 on the emulation build, neither timed nor run on hardware yet: off by default
+bool Navier2DEngine::conv_line_selfcheck(const ConvLineArgs& c, int slot_len, const ConvProgram& program) {
+  const int nl = std::min(c.nlines, 64), n = c.N + 1;
+  if (nl <= 0 || std::getenv("RPDE_S1_SELFCHECK_FAIL")) return false;
+  const long ld = c.ld;
+  const size_t sz = (size_t)nl * ld;
+  DBuf fx(sz), f0(sz), up(sz), vp(sz), bx(sz), by(sz), r(sz), w(sz), red(4);
+  {
+    unsigned long long z = 0xD1B54A32D192ED03ull;
+    auto fill = [&](DBuf& d, int count, bool decay) {
+      Vec h(sz, 0.0);
+      for (int l = 0; l < nl; ++l)
+        for (int k = 0; k < count; ++k) {
+          z = z * 6364136223846793005ull + 1442695040888963407ull;
+          const double u = (double)(z >> 11) / 9007199254740992.0 - 0.5;
+          h[(size_t)l * ld + k] = decay ? u / (1.0 + 1e-3 * k) : u;
+        }
+      dev_upload(d.p, h.data(), h.size() * sizeof(double));
+    };
+    fill(fx, c.n_in, true); fill(f0, c.n_in, true);
+    fill(up, n, false); fill(vp, n, false); fill(bx, n, false); fill(by, n, false);
+  }
+  ConvLineArgs t = c;
+  t.fx = fx.p; t.f0 = f0.p; t.up = up.p; t.vp = vp.p;
+  t.bx = c.bx ? bx.p : nullptr; t.by = c.by ? by.p : nullptr;
+  t.nlines = nl; t.ldo = ld;
+  t.out = r.p;
+  ProgramBuilder pb(2, slot_len, nl);
+  program(pb, t);
+  pb.run(st_);
+  t.out = w.p;
+  if (!launch_conv_line(t, st_)) return false;
+  launch_sumsq(r.p, ld, nl, n, red.p, st_);
+  ProgramBuilder pd(2, slot_len, nl);
+  const int ar = pd.arr(r.p, ld), aw = pd.arr(w.p, ld);
+  pd.load(0, ar, n); pd.load(0, aw, n, -1.0, true); pd.store(0, ar, n);
+  pd.run(st_);
+  launch_sumsq(r.p, ld, nl, n, red.p + 2, st_);
+  dev_sync(st_);
+  double h[4];
+  dev_download(h, red.p, sizeof(h));
+  return h[0] > 0.0 && h[1] == 0.0 && h[3] == 0.0 && h[2] / h[0] < 1e-24;
+}
+
+bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag, const ConvProgram& program) {
+  // The convection terms through the whole-line kernel (dct_line.h conv_line: three transforms per line in registers).
+  // RPDE_CONV_LINE (read per engine): 0 = never, 1 = always, auto = the engine compares both forms on pseudo-random
+  // lines on its own device and, when they agree, times both on the step's own arrays and keeps the faster one.
+  // Unset = 0: the kernel was written after round 2's GPU minutes were spent and has not run on hardware.
   const char* e = std::getenv("RPDE_CONV_LINE");
-  const bool on = e && std::atoi(e) != 0;
+  const std::string mode = e ? e : "0";
 #ifdef RPDE_EMU
   const bool covered = conv_line_ok(c);
 #else
   const bool covered = c.N == 4096 && conv_line_ok(c);
 #endif
-  if (!on || !covered || comm_.size != 1) return false;
+  if (mode == "0" || !covered || comm_.size != 1) return false;
+  if (mode == "auto") {
+    if (conv_choice_ < 0) {
+      conv_choice_ = 0;
+      bool ok = false;
+      const int slot_len = sp_vel_->axis(1).slot_len;
+      try { ok = conv_line_selfcheck(c, slot_len, program); }
+      catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: convection self-check failed to run: %s\n", ex.what()); }
+      if (!ok) {
+        std::fprintf(stderr, "rustpde_hip: the whole-line convection kernel does not reproduce the line program on this device; "
+                             "using the line program\n");
+      } else {
+#ifdef RPDE_EMU
+        conv_choice_ = 1;               // nothing to time on the host
+#else
+        // both forms on the step's own arrays (their content does not change the time): one warm-up, three timed runs each
+        ProgramBuilder pb(2, slot_len, c.nlines);
+        program(pb, c);
+        float ms[2] = {0.f, 0.f};
+        for (int form = 0; form < 2; ++form)
+          for (int rep = 0; rep < 4; ++rep) {
+            if (rep == 1) RPDE_HIP(hipEventRecord(ev0_, st_.s));
+            if (form == 0) pb.run(st_); else launch_conv_line(c, st_);
+            if (rep == 3) { RPDE_HIP(hipEventRecord(ev1_, st_.s)); RPDE_HIP(hipEventSynchronize(ev1_)); RPDE_HIP(hipEventElapsedTime(&ms[form], ev0_, ev1_)); }
+          }
+        conv_choice_ = ms[1] < 0.97f * ms[0] ? 1 : 0;
+        std::fprintf(stderr, "rustpde_hip: convection term per launch: line program %.3f ms, whole-line kernel %.3f ms -> %s\n",
+                     ms[0] / 3.f, ms[1] / 3.f, conv_choice_ ? "whole-line kernel" : "line program");
+#endif
+      }
+    }
+    if (conv_choice_ != 1) return false;
+  }
   Launch l;
   l.type = Launch::kConvLine;
   l.cl = c;
@@ -1435,28 +1512,30 @@ void Navier2DEngine::build_confined() {
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash, so two workgroups share a CU
-    {
-      const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
-                            xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
-      if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
-    }
+    const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                          xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    // the line-program form, for the step's arrays or for the scratch lines of the self-check
+    const ConvProgram program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
+      pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
+      if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(c.up, ldy), ny);
+      pb.load(1, pb.arr(c.f0, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+      pb.pair_last_loads();
+      pb.stash(0);
+      pb.to_ortho_from(0, 1, yD);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+      if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(c.vp, ldy), ny);
+      if (c.by) pb.pair_last_loads();
+      pb.unstash_axpy(0, 1.0, 1.0, ny);
+      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+    };
+    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag, program)) return;
     ProgramBuilder pb = xpb(2, nx);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
-    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
-    if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
-    pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-    pb.load(1, pb.arr(f0.p, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
-    pb.pair_last_loads();
-    pb.stash(0);
-    pb.to_ortho_from(0, 1, yD);
-    pb.cdiff(0, 0, ny, 1.0 / sy_);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
-    if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
-    pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
-    if (by) pb.pair_last_loads();
-    pb.unstash_axpy(0, 1.0, 1.0, ny);
-    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+    program(pb, cl);
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
@@ -1745,28 +1824,30 @@ void Navier2DEngine::build_periodic() {
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash
-    {
-      const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
-                            xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
-      if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
-    }
+    const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                          xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    // the line-program form, for the step's arrays or for the scratch lines of the self-check
+    const ConvProgram program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
+      pb.set_fft(yD);
+      pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
+      pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
+      if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(c.up, ldy), ny);
+      pb.load(1, pb.arr(c.f0, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+      pb.pair_last_loads();
+      pb.stash(0);
+      pb.to_ortho_from(0, 1, yD);
+      pb.cdiff(0, 0, ny, 1.0 / sy_);
+      pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+      if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
+      pb.loadmul(0, pb.arr(c.vp, ldy), ny);
+      if (c.by) pb.pair_last_loads();
+      pb.unstash_axpy(0, 1.0, 1.0, ny);
+      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+    };
+    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag, program)) return;
     ProgramBuilder pb = xpb(2, nx, false);
-    pb.set_fft(yD);
-    pb.load(0, pb.arr(fx.p, ldy), my);        // d/dx f (x-derivative taken in S1)
-    pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
-    if (bx) pb.load(0, pb.arr(bx->p, ldy), ny, 1.0, true);
-    pb.loadmul(0, pb.arr(UP_.p, ldy), ny);
-    pb.load(1, pb.arr(f0.p, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
-    pb.pair_last_loads();
-    pb.stash(0);
-    pb.to_ortho_from(0, 1, yD);
-    pb.cdiff(0, 0, ny, 1.0 / sy_);
-    pb.dct(0, ny, yD.bwd_pre.p, nullptr);
-    if (by) pb.load(0, pb.arr(by->p, ldy), ny, 1.0, true);
-    pb.loadmul(0, pb.arr(VP_.p, ldy), ny);
-    if (by) pb.pair_last_loads();
-    pb.unstash_axpy(0, 1.0, 1.0, ny);
-    pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(out.p, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+    program(pb, cl);
     add_line(pb, tag);
   };
   conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");

@@ -87,6 +87,18 @@ def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, m
     nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
     with pytest.raises(R.RpdeError, match="no line program"):
         nav.trace_launch("conv_temp")
+    # auto: both forms on pseudo-random lines first (on the GPU also timed against each other)
+    monkeypatch.setenv("RPDE_CONV_LINE", "auto")
+    K.check_step_parity(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 0.01, 2)
+    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
+    with pytest.raises(R.RpdeError, match="no line program"):
+        nav.trace_launch("conv_velx")
+    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")
+    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
+    try:
+        nav.trace_launch("conv_velx")      # a failing comparison keeps the line program
+    except ValueError:
+        pass
 
 
 def test_s2_whole_line_self_check(emu_lib, monkeypatch, capfd):
