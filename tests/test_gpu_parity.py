@@ -217,23 +217,6 @@ def test_s1_whole_line_equals_line_program_4097(hip_lib, monkeypatch):
         assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, k
 
 
-@pytest.mark.xfail(strict=False, reason="RPDE_CONV_LINE=1 (off by default) was written and checked on the emulation build after "
-                   "the round's GPU minutes were spent: first hardware run")
-@pytest.mark.parametrize("periodic", [False, True])
-def test_conv_whole_line_equals_line_program_4097(hip_lib, monkeypatch, periodic):
-    """RPDE_CONV_LINE=1 against the default convection programs at ny = 4097 (same engine, same setup data)."""
-    fields = {}
-    ctor = R.Navier2D.new_periodic if periodic else R.Navier2D.new_confined
-    for flag in ("0", "auto"):   # auto: on-device comparison, then the faster of the two forms
-        monkeypatch.setenv("RPDE_CONV_LINE", flag)
-        nav = ctor(16 if periodic else 33, 4097, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
-        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
-        nav.update(3)
-        fields[flag] = nav.physical_fields()
-    for k in fields["0"]:
-        assert K.rel(fields["auto"][k], fields["0"][k]) < 1e-11, k
-
-
 def test_exit_flag_device_side(hip_lib):
     """Integrate::exit (navier.rs:482-489): the device flag agrees with the reference's NaN test of
     the divergence norm -- clean run: False; NaN injected: True from the next step on."""
