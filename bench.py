@@ -222,6 +222,7 @@ def main():
     nav.update(args.warmup)
     # which kernel dominates?  (per-launch HIP events, outside the timed region)
     prof = nav.profile(args.profile_steps)
+    sched = nav.schedule()
     tot = sum(r["ms_total"] for r in prof)
     # roofline kernel: the dominant compute kernel (line programs "S*", GEMMs "G*"); when sharded the
     # exchanges ("T*", halos "H*") are xGMI-bound and reported in `exchange` instead
@@ -340,6 +341,10 @@ def main():
         "roofline": roof,
         "phases": phases,
         "transform_pass": transform_pass,
+        # which form of each stage this engine chose at construction (whole-line kernels are taken after an on-device
+        # comparison with the line program: RPDE_DCT_LINE / RPDE_S1_LINE / RPDE_CONV_LINE)
+        "step_kernels": {k: sorted({t for t, _, _, _, kind in sched if kind == k})
+                         for k in sorted({kind for _, _, _, _, kind in sched}) if k.startswith("whole-line")},
     }
     if args.dry_run_emu:
         out["dry_run"] = True

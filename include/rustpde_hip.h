@@ -95,8 +95,9 @@ int rpde_navier2d_last_update_ms(rpde_navier2d* h, double* ms);
  * the launches whose tag contains `tag` inside rpde_navier2d_update (pass "" to switch it off)  */
 int rpde_navier2d_profile(rpde_navier2d* h, int nsteps, char* buf, size_t len);
 int rpde_navier2d_set_timed_tag(rpde_navier2d* h, const char* tag);
-/* the launches of one step in issue order, "tag\talgorithmic_bytes\tflops\tkernels\n" per launch (used to *
- * attribute rocprofv3 per-dispatch counters to the step's kernels, tools/pmc_traffic.py)          */
+/* the launches of one step in issue order, "tag\talgorithmic_bytes\tflops\tkernels\tkind\n" per launch (used *
+ * to attribute rocprofv3 per-dispatch counters to the step's kernels, tools/pmc_traffic.py; kind = "line      *
+ * program", "whole-line transform" ...: which form of a stage this engine chose at construction)            */
 int rpde_navier2d_describe_step(rpde_navier2d* h, char* buf, size_t len);
 int rpde_navier2d_get_timed(rpde_navier2d* h, double* ms_total, long* launches);
 /* diagnostics (tools/trace_ops.py): runs one step with the first line program whose tag contains `tag`     *

@@ -289,10 +289,11 @@ class Navier2D:
 
     def schedule(self):
         """The launches of one step in issue order: list of (tag, algorithmic bytes, flops, kernel
-        dispatches behind the launch -- a column scan is 5 or 3 kernels)."""
+        dispatches behind the launch -- a column scan is 5 or 3 kernels --, kind of kernel: "line program",
+        "whole-line transform" ... -- which form of a stage this engine chose, see RPDE_S1_LINE / RPDE_DCT_LINE)."""
         buf = C.create_string_buffer(1 << 16)
         self._lib.call("rpde_navier2d_describe_step", self._h, buf, len(buf))
-        return [(t, float(b), float(f), int(n)) for t, b, f, n in
+        return [(t, float(b), float(f), int(n), kind) for t, b, f, n, kind in
                 (line.split("\t") for line in buf.value.decode().splitlines())]
 
     def trace_launch(self, tag: str):

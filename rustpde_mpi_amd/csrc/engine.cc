@@ -921,7 +921,9 @@ std::string Navier2DEngine::describe_step() const {
   for (const Launch& l : step_) {
     char buf[512];
     const int ndisp = l.type == Launch::kColHholtz ? 5 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
-    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\n", l.tag, l.bytes, l.flops, ndisp);
+    static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
+                                        "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term"};
+    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", l.tag, l.bytes, l.flops, ndisp, kKind[(int)l.type]);
     out += buf;
   }
   return out;

@@ -35,5 +35,5 @@ nav.profile(1)                       # warm-up step, launch by launch
 rows = nav.profile(a.steps)          # the LAST steps * len(schedule) dispatches of the process
 sched = nav.schedule()
 json.dump({"workload": f"{'periodic' if a.periodic else 'confined'} {a.nx}x{a.ny}", "steps": a.steps,
-           "schedule": [{"tag": t, "bytes": b, "flops": f, "dispatches": n} for t, b, f, n in sched],
+           "schedule": [{"tag": t, "bytes": b, "flops": f, "dispatches": n, "kind": kind} for t, b, f, n, kind in sched],
            "event_ms": {r["tag"]: r["ms_total"] / r["launches"] for r in rows}}, open(a.out, "w"))
