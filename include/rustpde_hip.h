@@ -206,6 +206,13 @@ int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double
  * kernel: n physical values -> n coefficients, zero from index `cut` on (cut < 0: keep all; the 2/3 rule of            *
  * src/navier_stokes/functions.rs:56-82 is cut = 2 n / 3)                                                               */
 int rpde_dct_line_forward(int n, const double* in, int nlines, int cut, double* out, int device);
+/* One convection term along contiguous y-lines (conv_term, src/navier_stokes/functions.rs:56-69, summed and dealiased *
+ * like conv_velx / conv_vely / conv_temp, src/navier_stokes/navier_eq.rs:56-101) through the whole-line kernel:         *
+ *   out = forward_ortho[ up * (backward(fx) + bx) + vp * (backward_ortho(dscale * d/dy to_ortho(f0)) + by) ], zero from   *
+ * `cut` on.  fx, f0: `nlines` lines of n - 2 cheb_dirichlet coefficients; up, vp, bx, by: n physical values per line    *
+ * (bx, by may both be NULL); out: n orthonormal coefficients per line.  Same shapes as rpde_dct_line_backward.          */
+int rpde_conv_line(int n, const double* fx, const double* f0, const double* up, const double* vp, const double* bx,
+                   const double* by, int nlines, double dscale, int cut, double* out, int device);
 /* f64 GEMM used by the Poisson solve (ndarray `dot` -> dgemm, src/solver/poisson.rs:216,234):     *
  * c[M,N] = a[M,K] . b  with b given as [N,K] (transb = 1) or [K,N] (transb = 0); host buffers     */
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device);

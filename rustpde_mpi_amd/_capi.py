@@ -94,6 +94,7 @@ SIGNATURES = {
     "rpde_dct_line_backward": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int]),
     "rpde_dct_line_gradient": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int]),
     "rpde_dct_line_forward": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int]),
+    "rpde_conv_line": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp, C.c_int]),
     "rpde_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]),
     "rpde_microbench": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }

@@ -603,6 +603,28 @@ int rpde_dct_line_forward(int n, const double* in, int nlines, int cut, double* 
 int rpde_dct_line_gradient(int kind, int n, const double* in, int nlines, double scale, double* out, int device) {
   RPDE_TRY({ select_device(device); dct_line_entry(kind, n, in, nlines, 1, scale, out); })
 }
+int rpde_conv_line(int n, const double* fx, const double* f0, const double* up, const double* vp, const double* bx,
+                   const double* by, int nlines, double dscale, int cut, double* out, int device) {
+  RPDE_TRY({
+    RPDE_REQUIRE(fx && f0 && up && vp && out && nlines > 0 && n >= 5 && (bx == nullptr) == (by == nullptr), "bad argument");
+    select_device(device);
+    Stream st;
+    AxisTables ax(make_base(kChebDirichlet, n));
+    const long ld = pitch(n + 2);
+    const size_t sz = (size_t)nlines * ld;
+    DBuf dfx(sz), df0(sz), dup(sz), dvp(sz), dbx(bx ? sz : 8), dby(by ? sz : 8), dout(sz);
+    dev_upload2d(dfx.p, ld, fx, nlines, n - 2);
+    dev_upload2d(df0.p, ld, f0, nlines, n - 2);
+    dev_upload2d(dup.p, ld, up, nlines, n);
+    dev_upload2d(dvp.p, ld, vp, nlines, n);
+    if (bx) { dev_upload2d(dbx.p, ld, bx, nlines, n); dev_upload2d(dby.p, ld, by, nlines, n); }
+    const ConvLineArgs c{dfx.p, df0.p, dup.p, dvp.p, bx ? dbx.p : nullptr, by ? dby.p : nullptr, ld, n - 2, dout.p, ld,
+                         nlines, n - 1, ax.tw.p, ax.tw2.p, dscale, cut < 0 ? n : cut};
+    RPDE_REQUIRE(ax.fft_n == n - 1 && launch_conv_line(c, st), "whole-line convection kernel: line length not covered");
+    dev_sync(st);
+    dev_download2d(out, dout.p, ld, nlines, n);
+  })
+}
 int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb, double* c, int device) {
   RPDE_TRY({
     RPDE_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "bad argument");
@@ -660,6 +682,37 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
       return 0;
     }
 #endif
+    if (w.rfind("dct_line", 0) == 0) {   // whole-line backward transform (dct_line.h): "dct_line", "dct_line_pf3", "dct_line_pf4"
+      AxisTables ax(make_base(kChebDirichlet, n));
+      const long ld = pitch(n + 2);
+      DBuf in((size_t)nlines * ld), out((size_t)nlines * ld);
+      {
+        Vec hbuf((size_t)nlines * ld);
+        for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
+        in.upload(hbuf);
+      }
+      DctLineArgs d{in.p, ld, n - 2, out.p, ld, nlines, n - 1, 2, ax.tw.p, ax.tw2.p, 1.0};
+      const int saved = g_dct_line_pf;
+      g_dct_line_pf = w == "dct_line_pf3" ? 3 : (w == "dct_line_pf4" ? 4 : 0);
+      RPDE_REQUIRE(launch_dct_line(d, st), "dct_line: shape not covered");
+      dev_sync(st);
+#ifndef RPDE_EMU
+      hipEvent_t e0, e1;
+      RPDE_HIP(hipEventCreate(&e0)); RPDE_HIP(hipEventCreate(&e1));
+      RPDE_HIP(hipEventRecord(e0, st.s));
+      for (int r = 0; r < reps; ++r) launch_dct_line(d, st);
+      RPDE_HIP(hipEventRecord(e1, st.s));
+      RPDE_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      RPDE_HIP(hipEventElapsedTime(&t, e0, e1));
+      *ms = t / reps;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#else
+      *ms = 0.0;
+#endif
+      g_dct_line_pf = saved;
+      return 0;
+    }
     const bool fourier = w == "rfft";
     AxisTables ax(make_base(fourier ? kFourierR2c : kChebDirichlet, n));
     const Base& b = ax.base;

@@ -514,33 +514,24 @@ void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
   l.out = base; l.cols = ncols; l.tag = tag;
   step_.push_back(l);
 }
-bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
-  // RPDE_DCT_LINE (read per engine): 0 = line program; 1 = whole-line kernel; 2 or, in the HIP build, unset = whole-line kernel
-  // after this engine has compared it with the line program on its own device.  The HIP build covers N = 4096 only.
-  const char* env = std::getenv("RPDE_DCT_LINE");
-  const int mode = env ? std::atoi(env) : -1;
-  const bool on = mode != 0;
+// Whole-line kernels (csrc/dct_line.h) are the form of a stage wherever they cover the line length (N = 4096 in the HIP
+// build; also 256 in the emulation build); everything else runs the line program.  Each kernel has its own parity test
+// against the oracle (tests/test_gpu_parity.py: dct_line backward / gradient / forward, conv_line, step parity at 4097).
+// The environment only overrides for A/B measurements, read once per engine: RPDE_WHOLE_LINE=0 turns all of them
+// off, RPDE_DCT_LINE / RPDE_S1_LINE / RPDE_CONV_LINE / RPDE_S3_LINE = 0 | 1 one stage.
+static bool whole_line_on(const char* stage_env) {
+  if (const char* e = std::getenv(stage_env)) return std::atoi(e) != 0;
+  if (const char* e = std::getenv("RPDE_WHOLE_LINE")) return std::atoi(e) != 0;
+  return true;
+}
 #ifdef RPDE_EMU
-  const bool covered = dct_line_ok(a);
+static bool whole_line_len(int N) { return N == 256 || N == 4096; }
 #else
-  const bool covered = a.N == 4096 && dct_line_ok(a);
+static bool whole_line_len(int N) { return N == 4096; }
 #endif
-  if (!on || !covered || comm_.size != 1) return false;
-#ifndef RPDE_EMU
-  const bool forced = mode == 1;
-#else
-  const bool forced = mode != 2;      // the emulation build compares only when asked to
-#endif
-  if (!forced) {   // the engine compares the kernel with the line program on its own device before it relies on it
-    bool ok = false;
-    try { ok = s1_program_ && line_selfcheck(a, nullptr, sp_vel_->axis(1).slot_len, s1_program_); }
-    catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: whole-line transform self-check failed to run: %s\n", ex.what()); }
-    if (!ok) {
-      std::fprintf(stderr, "rustpde_hip: the whole-line transform kernel does not reproduce the line program on this device; "
-                           "using the line program\n");
-      return false;
-    }
-  }
+
+bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
+  if (!whole_line_on("RPDE_DCT_LINE") || !whole_line_len(a.N) || !dct_line_ok(a)) return false;
   Launch l;
   l.type = Launch::kDctLine;
   l.dl = a;
@@ -549,74 +540,10 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   step_.push_back(l);
   return true;
 }
-bool Navier2DEngine::line_selfcheck(const DctLineArgs& a0, const DctLineArgs* a1p, int slot_len,
-                                    const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program) {
-  const DctLineArgs& a1 = a1p ? *a1p : a0;
-  // 64 lines of pseudo-random coefficients with a decaying spectrum; outputs of the line program (r0, r1) and of the
-  // whole-line kernel (w0, w1); ||r - w||^2 against ||r||^2 through the existing reduction
-  const int nl = std::min(a0.nlines, 64), n = a0.N + 1;
-  if (nl <= 0 || std::getenv("RPDE_S1_SELFCHECK_FAIL")) return false;   // the variable: test hook for the fallback
-  const long ld = a0.ldi;
-  DBuf in((size_t)nl * ld), r0((size_t)nl * ld), r1((size_t)nl * ld), w0((size_t)nl * ld), w1((size_t)nl * ld), red(4);
-  {
-    Vec h((size_t)nl * ld, 0.0);
-    unsigned long long z = 0x9E3779B97F4A7C15ull;
-    for (int l = 0; l < nl; ++l)
-      for (int k = 0; k < a0.n_in; ++k) {
-        z = z * 6364136223846793005ull + 1442695040888963407ull;
-        h[(size_t)l * ld + k] = ((double)(z >> 11) / 9007199254740992.0 - 0.5) / (1.0 + 1e-3 * k);
-      }
-    dev_upload(in.p, h.data(), h.size() * sizeof(double));
-  }
-  ProgramBuilder pb(2, slot_len, nl);
-  program(pb, in.p, r0.p, r1.p);
-  pb.run(st_);
-  DctLineArgs b0 = a0, b1 = a1;
-  b0.in = b1.in = in.p; b0.nlines = b1.nlines = nl;
-  b0.out = w0.p; b1.out = w1.p; b0.ldo = b1.ldo = ld;
-  if (a1p ? !launch_dct_line2(b0, b1, st_) : !launch_dct_line(b0, st_)) return false;
-  double worst = 0.0;
-  for (int which = 0; which < (a1p ? 2 : 1); ++which) {
-    DBuf& r = which ? r1 : r0;
-    DBuf& w = which ? w1 : w0;
-    launch_sumsq(r.p, ld, nl, n, red.p, st_);
-    ProgramBuilder pd(2, slot_len, nl);
-    const int ar = pd.arr(r.p, ld), aw = pd.arr(w.p, ld);
-    pd.load(0, ar, n); pd.load(0, aw, n, -1.0, true); pd.store(0, ar, n);
-    pd.run(st_);
-    launch_sumsq(r.p, ld, nl, n, red.p + 2, st_);
-    dev_sync(st_);
-    double h[4];
-    dev_download(h, red.p, sizeof(h));
-    if (!(h[0] > 0.0) || h[1] > 0.0 || h[3] > 0.0) return false;      // empty or NaN
-    worst = std::max(worst, h[2] / h[0]);
-  }
-  return worst < 1e-24;
-}
 
 bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag) {
-  // Value and x-derivative of a state line through the whole-line kernel (0.207 against 0.24 ms per launch at 4097^2).
-  // RPDE_S1_LINE: 0 = never, 1 = always, auto = after this engine has compared it with the line program on this
-  // device (line_selfcheck); unset = auto in the HIP build, never in the emulation build.  Read per engine.
-  const char* e = std::getenv("RPDE_S1_LINE");
-#ifdef RPDE_EMU
-  const std::string mode = e ? e : "0";
-  const bool covered = dct_line_ok(a0) && dct_line_ok(a1);
-#else
-  const std::string mode = e ? e : "auto";
-  const bool covered = a0.N == 4096 && dct_line_ok(a0) && dct_line_ok(a1);
-#endif
-  if (mode == "0" || !covered || comm_.size != 1) return false;
-  if (mode == "auto") {
-    bool ok = false;
-    try { ok = s1_program_ && line_selfcheck(a0, &a1, sp_vel_->axis(0).slot_len, s1_program_); }
-    catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: whole-line S1 self-check failed to run: %s\n", ex.what()); }
-    if (!ok) {
-      std::fprintf(stderr, "rustpde_hip: the whole-line S1 kernel does not reproduce the line program on this device; "
-                           "using the line program\n");
-      return false;
-    }
-  }
+  // value and x-derivative of a state line: two transforms per line in one launch
+  if (!whole_line_on("RPDE_S1_LINE") || !whole_line_len(a0.N) || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   Launch l;
   l.type = Launch::kDctLine2;
   l.dl = a0; l.dl2 = a1;
@@ -625,94 +552,10 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   step_.push_back(l);
   return true;
 }
-bool Navier2DEngine::conv_line_selfcheck(const ConvLineArgs& c, int slot_len, const ConvProgram& program) {
-  const int nl = std::min(c.nlines, 64), n = c.N + 1;
-  if (nl <= 0 || std::getenv("RPDE_S1_SELFCHECK_FAIL")) return false;
-  const long ld = c.ld;
-  const size_t sz = (size_t)nl * ld;
-  DBuf fx(sz), f0(sz), up(sz), vp(sz), bx(sz), by(sz), r(sz), w(sz), red(4);
-  {
-    unsigned long long z = 0xD1B54A32D192ED03ull;
-    auto fill = [&](DBuf& d, int count, bool decay) {
-      Vec h(sz, 0.0);
-      for (int l = 0; l < nl; ++l)
-        for (int k = 0; k < count; ++k) {
-          z = z * 6364136223846793005ull + 1442695040888963407ull;
-          const double u = (double)(z >> 11) / 9007199254740992.0 - 0.5;
-          h[(size_t)l * ld + k] = decay ? u / (1.0 + 1e-3 * k) : u;
-        }
-      dev_upload(d.p, h.data(), h.size() * sizeof(double));
-    };
-    fill(fx, c.n_in, true); fill(f0, c.n_in, true);
-    fill(up, n, false); fill(vp, n, false); fill(bx, n, false); fill(by, n, false);
-  }
-  ConvLineArgs t = c;
-  t.fx = fx.p; t.f0 = f0.p; t.up = up.p; t.vp = vp.p;
-  t.bx = c.bx ? bx.p : nullptr; t.by = c.by ? by.p : nullptr;
-  t.nlines = nl; t.ldo = ld;
-  t.out = r.p;
-  ProgramBuilder pb(2, slot_len, nl);
-  program(pb, t);
-  pb.run(st_);
-  t.out = w.p;
-  if (!launch_conv_line(t, st_)) return false;
-  launch_sumsq(r.p, ld, nl, n, red.p, st_);
-  ProgramBuilder pd(2, slot_len, nl);
-  const int ar = pd.arr(r.p, ld), aw = pd.arr(w.p, ld);
-  pd.load(0, ar, n); pd.load(0, aw, n, -1.0, true); pd.store(0, ar, n);
-  pd.run(st_);
-  launch_sumsq(r.p, ld, nl, n, red.p + 2, st_);
-  dev_sync(st_);
-  double h[4];
-  dev_download(h, red.p, sizeof(h));
-  return h[0] > 0.0 && h[1] == 0.0 && h[3] == 0.0 && h[2] / h[0] < 1e-24;
-}
 
-bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag, const ConvProgram& program) {
-  // The convection terms through the whole-line kernel (dct_line.h conv_line: three transforms per line in registers).
-  // RPDE_CONV_LINE (read per engine): 0 = never, 1 = always, auto = the engine compares both forms on pseudo-random
-  // lines on its own device and, when they agree, times both on the step's own arrays and keeps the faster one.
-  // Unset = 0: the kernel was written after round 2's GPU minutes were spent and has not run on hardware.
-  const char* e = std::getenv("RPDE_CONV_LINE");
-  const std::string mode = e ? e : "0";
-#ifdef RPDE_EMU
-  const bool covered = conv_line_ok(c);
-#else
-  const bool covered = c.N == 4096 && conv_line_ok(c);
-#endif
-  if (mode == "0" || !covered || comm_.size != 1) return false;
-  if (mode == "auto") {
-    if (conv_choice_ < 0) {
-      conv_choice_ = 0;
-      bool ok = false;
-      const int slot_len = sp_vel_->axis(1).slot_len;
-      try { ok = conv_line_selfcheck(c, slot_len, program); }
-      catch (const std::exception& ex) { std::fprintf(stderr, "rustpde_hip: convection self-check failed to run: %s\n", ex.what()); }
-      if (!ok) {
-        std::fprintf(stderr, "rustpde_hip: the whole-line convection kernel does not reproduce the line program on this device; "
-                             "using the line program\n");
-      } else {
-#ifdef RPDE_EMU
-        conv_choice_ = 1;               // nothing to time on the host
-#else
-        // both forms on the step's own arrays (their content does not change the time): one warm-up, three timed runs each
-        ProgramBuilder pb(2, slot_len, c.nlines);
-        program(pb, c);
-        float ms[2] = {0.f, 0.f};
-        for (int form = 0; form < 2; ++form)
-          for (int rep = 0; rep < 4; ++rep) {
-            if (rep == 1) RPDE_HIP(hipEventRecord(ev0_, st_.s));
-            if (form == 0) pb.run(st_); else launch_conv_line(c, st_);
-            if (rep == 3) { RPDE_HIP(hipEventRecord(ev1_, st_.s)); RPDE_HIP(hipEventSynchronize(ev1_)); RPDE_HIP(hipEventElapsedTime(&ms[form], ev0_, ev1_)); }
-          }
-        conv_choice_ = ms[1] < 0.97f * ms[0] ? 1 : 0;
-        std::fprintf(stderr, "rustpde_hip: convection term per launch: line program %.3f ms, whole-line kernel %.3f ms -> %s\n",
-                     ms[0] / 3.f, ms[1] / 3.f, conv_choice_ ? "whole-line kernel" : "line program");
-#endif
-      }
-    }
-    if (conv_choice_ != 1) return false;
-  }
+bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
+  // a whole convection term per y-line (dct_line.h conv_line: three transforms per line in registers)
+  if (!whole_line_on("RPDE_CONV_LINE") || !whole_line_len(c.N) || !conv_line_ok(c)) return false;
   Launch l;
   l.type = Launch::kConvLine;
   l.cl = c;
@@ -984,7 +827,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   }
 #else
   (void)kOpNames;
-  out = std::string(step_[which].tag) + "\t0\t0\n";
+  out = std::string(step_[which].tag) + "\t0\t0\t0\n";   // same header as the HIP build (tag, workgroups, span, marks), no marks
 #endif
   return out;
 }
@@ -1445,17 +1288,6 @@ void Navier2DEngine::build_confined() {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
   static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
   for (auto& f : s1) {
-    // the line program of S1 for arbitrary input / output lines (the step's own arrays below; scratch lines in the self-check)
-    s1_program_ = [&, ax = f.ax](ProgramBuilder& pb, const double* in, double* o0, double* o1) {
-      pb.set_fft(*ax);
-      pb.load(0, pb.arr(in, ldx), mx);
-      pb.to_ortho(0, *ax);
-      pb.stash(0);
-      pb.dct_fused(0, *ax, false, ax->bwd_pre.p, nullptr, pb.arr(o0, ldx), nx);
-      pb.unstash_axpy(0, 0.0, 1.0, nx);
-      pb.cdiff(0, 0, nx, 1.0 / sx_);
-      pb.dct_fused(0, *ax, false, ax->bwd_pre.p, nullptr, pb.arr(o1, ldx), nx);
-    };
     {   // whole-line kernel, two transforms per line: Dirichlet stencil in x for the velocities, the Neumann table for T
       const bool dir = f.ax == &xD;
       DctLineArgs v{yx(*f.st), ldx, mx, yx(*f.w0), ldx, ylines(my), nx - 1, dir ? 2 : 1, f.ax->tw.p, f.ax->tw2.p, 1.0};
@@ -1468,7 +1300,14 @@ void Navier2DEngine::build_confined() {
       // one program per field: the orthonormal coefficients wait in the register stash while the value is
       // transformed, then come back for the derivative -- the state line is read once instead of twice
       ProgramBuilder pb = ypb(2, my);
-      s1_program_(pb, yx(*f.st), yx(*f.w0), yx(*f.w1));
+      pb.set_fft(*f.ax);
+      pb.load(0, pb.arr(yx(*f.st), ldx), mx);
+      pb.to_ortho(0, *f.ax);
+      pb.stash(0);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w0), ldx), nx);
+      pb.unstash_axpy(0, 0.0, 1.0, nx);
+      pb.cdiff(0, 0, nx, 1.0 / sx_);
+      pb.dct_fused(0, *f.ax, false, f.ax->bwd_pre.p, nullptr, pb.arr(yx(*f.w1), ldx), nx);
       add_line(pb, "S1 x: state -> phys-x + d/dx");
       continue;
     }
@@ -1489,7 +1328,6 @@ void Navier2DEngine::build_confined() {
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
   }
-  s1_program_ = nullptr;
   // ---- T1: to XY
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
@@ -1497,13 +1335,7 @@ void Navier2DEngine::build_confined() {
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
-    s1_program_ = [&](ProgramBuilder& q, const double* in, double* o0, double*) {   // the same transform as a line program
-      q.set_fft(yD);
-      q.load(0, q.arr(in, ldy), my);
-      q.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, q.arr(o0, ldy), ny);
-    };
     const bool whole = yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
-    s1_program_ = nullptr;
     if (whole) continue;
     ProgramBuilder pb = xpb(2, nx);
     pb.set_fft(yD);
@@ -1516,8 +1348,8 @@ void Navier2DEngine::build_confined() {
     // waits in the register stash, so two workgroups share a CU
     const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                           xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
-    // the line-program form, for the step's arrays or for the scratch lines of the self-check
-    const ConvProgram program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
+    // the line-program form
+    auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(yD);
       pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
       pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
@@ -1535,7 +1367,7 @@ void Navier2DEngine::build_confined() {
       pb.unstash_axpy(0, 1.0, 1.0, ny);
       pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     };
-    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag, program)) return;
+    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
     ProgramBuilder pb = xpb(2, nx);
     program(pb, cl);
     add_line(pb, tag);
@@ -1809,13 +1641,7 @@ void Navier2DEngine::build_periodic() {
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
-    s1_program_ = [&](ProgramBuilder& q, const double* in, double* o0, double*) {   // the same transform as a line program
-      q.set_fft(yD);
-      q.load(0, q.arr(in, ldy), my);
-      q.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, q.arr(o0, ldy), ny);
-    };
     const bool whole = yD.fft_n == ny - 1 && add_dct_line(dl, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
-    s1_program_ = nullptr;
     if (whole) continue;
     ProgramBuilder pb = xpb(2, nx, false);
     pb.set_fft(yD);
@@ -1828,8 +1654,8 @@ void Navier2DEngine::build_periodic() {
     // waits in the register stash
     const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                           xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
-    // the line-program form, for the step's arrays or for the scratch lines of the self-check
-    const ConvProgram program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
+    // the line-program form
+    auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(yD);
       pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
       pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
@@ -1847,7 +1673,7 @@ void Navier2DEngine::build_periodic() {
       pb.unstash_axpy(0, 1.0, 1.0, ny);
       pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     };
-    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag, program)) return;
+    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
     ProgramBuilder pb = xpb(2, nx, false);
     program(pb, cl);
     add_line(pb, tag);

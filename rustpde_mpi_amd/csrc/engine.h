@@ -230,16 +230,7 @@ class Navier2DEngine {
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
-  // a whole-line transform (a0) or pair (a0, a1) against the line program on the same pseudo-random lines, on this device
-  // (`program` fills a builder with the line program for the given input / outputs); true when they agree to 1e-12
-  bool line_selfcheck(const DctLineArgs& a0, const DctLineArgs* a1, int slot_len,
-                      const std::function<void(ProgramBuilder&, const double*, double*, double*)>& program);
-  std::function<void(ProgramBuilder&, const double*, double*, double*)> s1_program_;   // the line-program form, set while a step is built
-  // `program` builds the line-program form of the same convection term for the pointers of a ConvLineArgs
-  using ConvProgram = std::function<void(ProgramBuilder&, const ConvLineArgs&)>;
-  bool add_conv_line(const ConvLineArgs& c, const char* tag, const ConvProgram& program);
-  bool conv_line_selfcheck(const ConvLineArgs& c, int slot_len, const ConvProgram& program);   // 64 pseudo-random lines, both forms, 1e-12
-  int conv_choice_ = -1;   // RPDE_CONV_LINE=auto: -1 undecided, 0 line program, 1 whole-line kernel (decided at the first term of a step)
+  bool add_conv_line(const ConvLineArgs& c, const char* tag);
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

@@ -55,6 +55,7 @@ RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long l
   }
 }
 
+int g_dct_line_pf = [] { const char* e = std::getenv("RPDE_DCT_PF"); return e ? std::atoi(e) : 0; }();   // A/B switch (tools, microbench)
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
 // Three kernels per configuration (line_vm.h kVar*): light, with the second-order back-substitution
@@ -645,9 +646,44 @@ __global__ __launch_bounds__(N / 16, 4) void dct_line_kernel(const DctLineArgs a
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
   dct_bwd_line<N>(blk, a);
 }
+// the same transform by workgroups that stay: each walks over its share of the lines and fetches the next line while
+// it transforms the current one (DctLineStage); WPS = workgroups per CU the register budget is cut for
+template <int N, int WPS>
+__global__ __launch_bounds__(N / 16, WPS) void dct_line_pf_kernel(const DctLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  using St = DctLineStage<N>;
+  const int per = (int)gridDim.x >> 3;                       // workgroups per XCD
+  const int chunk = (a.nlines + 7) >> 3;                     // lines per XCD: a contiguous band, as in line_kernel
+  const int x = (int)blockIdx.x & 7, w = (int)blockIdx.x >> 3;
+  const int tid = (int)threadIdx.x;
+  dbl2 v[St::QP];
+  int idx = w;
+  int line = x * chunk + idx;
+  bool have = idx < chunk && line < a.nlines;
+  if (have) St::load(a, line, tid, v);
+  while (have) {
+    St::put(a, (lds2_t)buf, tid, v);
+    __syncthreads();
+    const int nidx = idx + per, nline = x * chunk + nidx;
+    const bool nhave = nidx < chunk && nline < a.nlines;
+    if (nhave) St::load(a, nline, tid, v);
+    Blk blk{line, 0, N / 16, buf, nullptr, 0};
+    dct_line_core<N>(blk, a, true, DctStoreEmit{(gmem_t)(a.out + (long)line * a.ldo), a.scale});
+    __syncthreads();                                         // the split phase has read the buffer
+    idx = nidx; line = nline; have = nhave;
+  }
+}
 bool launch_dct_line(const DctLineArgs& a, Stream& st) {
   if (a.N != 4096 || !dct_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
+  const int pf = g_dct_line_pf;
+  if (pf == 3 || pf == 4) {
+    const int grid = std::min(256 * pf, 8 * ((a.nlines + 7) / 8));
+    if (pf == 3) hipLaunchKernelGGL((dct_line_pf_kernel<4096, 3>), dim3(grid), dim3(256), 0, st.s, a);
+    else hipLaunchKernelGGL((dct_line_pf_kernel<4096, 4>), dim3(grid), dim3(256), 0, st.s, a);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   hipLaunchKernelGGL(dct_line_kernel<4096>, dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a);
   RPDE_HIP(hipGetLastError());
   return true;

@@ -229,3 +229,29 @@ def check_dct_line_backward(lib, n, nlines=5):
         assert rel(out, want) < 2e-12, ("forward", n, cut, rel(out, want))
     lib.call("rpde_dct_line_backward", 0, n, R._capi.ptr(out), nlines, R._capi.ptr(v), 0)   # forward then backward of a dealiased line
     assert rel(ortho.forward_ortho(v, 1)[:, :2 * n // 3], want[:, :2 * n // 3]) < 1e-11
+
+
+def check_conv_line(lib, n, nlines=5, lift=True):
+    """The whole convection term per y-line (csrc/dct_line.h conv_line) against the oracle's operators: conv_term
+    (functions.rs:56-69) summed and dealiased as in navier_eq.rs:56-101 -- backward of the x-derivative, backward of the
+    y-derivative (to_ortho, Chebyshev recurrence), physical products, forward transform, 2/3 rule."""
+    rng = np.random.default_rng(7 * n + nlines)
+    ortho, dirichlet = B.chebyshev(n), B.cheb_dirichlet(n)
+    decay = 1.0 / (1.0 + 1e-3 * np.arange(n - 2))
+    fx = np.ascontiguousarray(rng.standard_normal((nlines, n - 2)) * decay)
+    f0 = np.ascontiguousarray(rng.standard_normal((nlines, n - 2)) * decay)
+    up, vp, bx, by = (np.ascontiguousarray(rng.standard_normal((nlines, n))) for _ in range(4))
+    dscale, cut = 0.5, 2 * n // 3
+    out = np.empty((nlines, n))
+    null = R._capi.ptr(bx).__class__()        # NULL double*
+    lib.call("rpde_conv_line", n, R._capi.ptr(fx), R._capi.ptr(f0), R._capi.ptr(up), R._capi.ptr(vp),
+             R._capi.ptr(bx) if lift else null, R._capi.ptr(by) if lift else null, nlines, dscale, cut, R._capi.ptr(out), 0)
+    a = dirichlet.backward(fx, 1)
+    b = ortho.backward_ortho(dscale * ortho.differentiate(dirichlet.to_ortho(f0, 1), 1, 1), 1)
+    if lift:
+        a, b = a + bx, b + by
+    want = ortho.forward_ortho(up * a + vp * b, 1)
+    want[:, cut:] = 0.0
+    e = rel(out, want)
+    assert e < 2e-12, (n, lift, e)
+    return e

@@ -52,77 +52,54 @@ def test_confined_step(emu_lib, nx, ny, ra, dt, steps):
     K.check_step_parity(emu_lib, False, nx, ny, ra, dt, steps, check_at=[1, 2, steps])
 
 
-def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch, capfd):
-    """RPDE_S1_LINE=1: value and x-derivative of the state lines (Dirichlet stencil for u, v; Neumann table for T;
-    suffix-sum derivative) through csrc/dct_line.h -- nx = 257 is a length the emulation build covers."""
-    monkeypatch.setenv("RPDE_S1_LINE", "1")
+def _has_line_program(nav, tag):
+    try:
+        nav.trace_launch(tag)
+    except R.RpdeError as exc:
+        assert "no line program" in str(exc)
+        return False
+    return True
+
+
+def test_confined_step_s1_through_the_whole_line_kernel(emu_lib, monkeypatch):
+    """Value and x-derivative of the state lines (Dirichlet stencil for u, v; Neumann table for T; suffix-sum
+    derivative) through csrc/dct_line.h -- nx = 257 is a length the emulation build covers; RPDE_S1_LINE=0 keeps the
+    line program (A/B switch)."""
     K.check_step_parity(emu_lib, False, 257, 17, 1e5, 0.01, 4, check_at=[1, 4])
     nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
-    with pytest.raises(R.RpdeError, match="no line program"):    # S1 is not a line program any more
-        nav.trace_launch("S1 x")
-    # auto (the default of the HIP build): the engine first compares the two forms on pseudo-random lines on its device
-    monkeypatch.setenv("RPDE_S1_LINE", "auto")
+    assert not _has_line_program(nav, "S1 x")
+    monkeypatch.setenv("RPDE_S1_LINE", "0")
     K.check_step_parity(emu_lib, False, 257, 17, 1e5, 0.01, 2)
     nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
-    with pytest.raises(R.RpdeError, match="no line program"):
-        nav.trace_launch("S1 x")
-    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")       # a failing comparison keeps the line program
-    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
-    assert "does not reproduce the line program" in capfd.readouterr().err
-    monkeypatch.delenv("RPDE_S1_SELFCHECK_FAIL")
-    monkeypatch.setenv("RPDE_S1_LINE", "0")
-    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
-    try:
-        nav.trace_launch("S1 x")          # found (the emulation build returns a stub the parser does not take)
-    except ValueError:
-        pass
+    assert _has_line_program(nav, "S1 x")
 
 
 @pytest.mark.parametrize("periodic", [False, True])
 def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, monkeypatch, periodic):
-    """RPDE_CONV_LINE=1: conv_velx / conv_vely / conv_temp as three transforms per y-line in registers
-    (csrc/dct_line.h conv_line); ny = 257 is a length the emulation build covers."""
-    monkeypatch.setenv("RPDE_CONV_LINE", "1")
-    K.check_step_parity(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 0.01, 4, check_at=[1, 4])
-    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
-    with pytest.raises(R.RpdeError, match="no line program"):
-        nav.trace_launch("conv_temp")
-    # auto: both forms on pseudo-random lines first (on the GPU also timed against each other)
-    monkeypatch.setenv("RPDE_CONV_LINE", "auto")
-    K.check_step_parity(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 0.01, 2)
-    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
-    with pytest.raises(R.RpdeError, match="no line program"):
-        nav.trace_launch("conv_velx")
-    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")
-    nav, _ = K.make_pair(emu_lib, periodic, 16 if periodic else 17, 257, 1e5, 1.0, 0.01, 1.0)
-    try:
-        nav.trace_launch("conv_velx")      # a failing comparison keeps the line program
-    except ValueError:
-        pass
+    """conv_velx / conv_vely / conv_temp as three transforms per y-line in registers (csrc/dct_line.h conv_line);
+    ny = 257 is a length the emulation build covers; RPDE_CONV_LINE=0 and RPDE_WHOLE_LINE=0 keep the line programs."""
+    nx = 16 if periodic else 17
+    K.check_step_parity(emu_lib, periodic, nx, 257, 1e5, 0.01, 4, check_at=[1, 4])
+    nav, _ = K.make_pair(emu_lib, periodic, nx, 257, 1e5, 1.0, 0.01, 1.0)
+    assert not _has_line_program(nav, "conv_temp") and not _has_line_program(nav, "S2 y: velx")
+    monkeypatch.setenv("RPDE_CONV_LINE", "0")
+    K.check_step_parity(emu_lib, periodic, nx, 257, 1e5, 0.01, 2)
+    nav, _ = K.make_pair(emu_lib, periodic, nx, 257, 1e5, 1.0, 0.01, 1.0)
+    assert _has_line_program(nav, "conv_velx") and not _has_line_program(nav, "S2 y: velx")
+    monkeypatch.delenv("RPDE_CONV_LINE")
+    monkeypatch.setenv("RPDE_WHOLE_LINE", "0")
+    K.check_step_parity(emu_lib, periodic, nx, 257, 1e5, 0.01, 2)
+    nav, _ = K.make_pair(emu_lib, periodic, nx, 257, 1e5, 1.0, 0.01, 1.0)
+    assert _has_line_program(nav, "conv_velx") and _has_line_program(nav, "S2 y: velx")
 
 
-def test_s2_whole_line_self_check(emu_lib, monkeypatch, capfd):
-    """RPDE_DCT_LINE=2 (what the HIP build does when the variable is unset): the engine compares the whole-line
-    transform with the line program on pseudo-random lines before it relies on it; a failing comparison keeps the
-    line program."""
-    monkeypatch.setenv("RPDE_DCT_LINE", "2")
-    K.check_step_parity(emu_lib, False, 17, 257, 1e5, 0.01, 2)
-    nav, _ = K.make_pair(emu_lib, True, 16, 257, 1e5, 1.0, 0.01, 1.0)
-    with pytest.raises(R.RpdeError, match="no line program"):
-        nav.trace_launch("S2 y: velx")
-    monkeypatch.setenv("RPDE_S1_SELFCHECK_FAIL", "1")
-    nav, _ = K.make_pair(emu_lib, False, 17, 257, 1e5, 1.0, 0.01, 1.0)
-    assert "does not reproduce the line program" in capfd.readouterr().err
-    try:
-        nav.trace_launch("S2 y: velx")     # a line program again
-    except ValueError:
-        pass
+@pytest.mark.parametrize("n,lift", [(257, False), (257, True), (4097, True)])
+def test_conv_line_operator(emu_lib, n, lift):
+    K.check_conv_line(emu_lib, n, nlines=3, lift=lift)
 
 
-def test_step_with_every_whole_line_path(emu_lib, monkeypatch):
+def test_step_with_every_whole_line_path(emu_lib):
     """257 x 257 confined: S1, the pure transforms of S2 and the convection terms all run csrc/dct_line.h."""
-    monkeypatch.setenv("RPDE_CONV_LINE", "1")
-    monkeypatch.setenv("RPDE_S1_LINE", "1")
     K.check_step_parity(emu_lib, False, 257, 257, 1e6, 2e-3, 3, check_at=[1, 3])
 
 

@@ -202,19 +202,31 @@ def test_step_through_the_whole_line_kernel(hip_lib):
     K.check_step_parity(hip_lib, True, 16, 4097, 1e6, 1e-3, 3)
 
 
-@pytest.mark.xfail(strict=False, reason="RPDE_S1_LINE=1 (off by default) was timed on the GPU and its kernel passed the operator "
-                   "parity there, but round 2 had no GPU minutes left for this engine-level comparison: first hardware run")
-def test_s1_whole_line_equals_line_program_4097(hip_lib, monkeypatch):
-    """RPDE_S1_LINE=1 against the default line program at nx = 4097 (no oracle needed: same engine, same setup data)."""
-    fields = {}
+@pytest.mark.parametrize("stage", ["RPDE_S1_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE", "RPDE_WHOLE_LINE"])
+def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
+    """Each whole-line stage (the default at this length) against the same stage as a line program (<stage>=0): same
+    engine, same setup data, three steps.  The oracle comparisons are test_dct_line_backward_4097, test_conv_line_4097
+    and the step parity tests; this one pins the A/B switch itself."""
+    n0, n1 = (4097, 65) if stage == "RPDE_S1_LINE" else ((65, 4097) if stage != "RPDE_WHOLE_LINE" else (4097, 4097))
+    fields, kinds = {}, {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("RPDE_S1_LINE", flag)
-        nav = R.Navier2D.new_confined(4097, 65, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
+        monkeypatch.setenv(stage, flag)
+        nav = R.Navier2D.new_confined(n0, n1, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
         nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
         nav.update(3)
         fields[flag] = nav.physical_fields()
+        kinds[flag] = {kind for _, _, _, _, kind in nav.schedule() if kind.startswith("whole-line")}
+    assert kinds["1"]
+    if stage == "RPDE_WHOLE_LINE":
+        assert not kinds["0"]
     for k in fields["0"]:
-        assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, k
+        assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (stage, k)
+
+
+@pytest.mark.parametrize("lift", [False, True])
+def test_conv_line_4097(hip_lib, lift):
+    """conv_line (a whole convection term per y-line, three transforms in registers) vs the oracle's operators."""
+    print("conv_line vs oracle:", K.check_conv_line(hip_lib, 4097, nlines=19, lift=lift))
 
 
 def test_exit_flag_device_side(hip_lib):
