@@ -124,7 +124,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   RPDE_REQUIRE(P == 1 || (nyl_ >= 2 && nxl_ >= 2), "too many ranks for this grid (need >= 2 lines per rank)");
   const size_t nyx = (size_t)(nyl_ + 2) * ldx_;      // two halo rows in front (cross-line y stencil)
   const size_t nxy = (size_t)nxl_ * ldy_;
-  for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
+  for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &GX_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
@@ -564,6 +564,30 @@ bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::add_rhs_line(RhsLineArgs a, int which, const char* tag) {
+  // S3 (forward x transform, right-hand side, x part of the Helmholtz solve) as one kernel per field (rhs_line.h)
+  if (!whole_line_on("RPDE_S3_LINE") || !whole_line_len(a.N) || !rhs_line_ok(a)) return false;
+  RhsTabs& t = rhs_tabs_[which == 2 ? 1 : 0];
+  if (!t.t0.p) {   // chunk-major copies of the B2 rows and of the swept Helmholtz bands for 16 elements per thread
+    const int T = a.N / 16;
+    const Base& b = (which == 2 ? sp_temp_ : sp_vel_)->base(0);
+    const Mv3Tables pv = pinv_tables(b);
+    const FdmaTables& f = (which == 2 ? hh_temp_ : hh_vel_)->host[0];
+    t.t0.upload(chunk_major16(pv.t0, T, +1)); t.t1.upload(chunk_major16(pv.t1, T, +1)); t.t2.upload(chunk_major16(pv.t2, T, +1));
+    t.q1.upload(chunk_major16(f.q1, T, +1));
+    t.p2.upload(chunk_major16(f.p2, T, -1, 1.0)); t.q2.upload(chunk_major16(f.q2, T, -1)); t.r2.upload(chunk_major16(f.r2, T, -1));
+  }
+  a.t0 = t.t0.p; a.t1 = t.t1.p; a.t2 = t.t2.p; a.q1 = t.q1.p; a.p2 = t.p2.p; a.q2 = t.q2.p; a.r2 = t.r2.p;
+  Launch l;
+  l.type = Launch::kRhsLine;
+  l.rl = a;
+  l.tag = tag;
+  // conv + state + solution, plus d/dx p | T, d/dy p, T_bc | lap(T_bc)  (rows j - 2 are re-reads of a neighbour's row j)
+  const double n = a.N + 1, m = a.N - 1;
+  l.bytes = 8.0 * a.nlines * (n + 2.0 * m + (which == 0 ? n : which == 1 ? m + 2.0 * n : n));
+  step_.push_back(l);
+  return true;
+}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -633,6 +657,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kConvLine: RPDE_REQUIRE(launch_conv_line(l.cl, st_), "internal: conv line shape"); break;
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
+    case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
   }
 }
 
@@ -765,7 +790,8 @@ std::string Navier2DEngine::describe_step() const {
     char buf[512];
     const int ndisp = l.type == Launch::kColHholtz ? 5 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
-                                        "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term"};
+                                        "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
+                                        "whole-line rhs + hholtz-x"};
     snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", l.tag, l.bytes, l.flops, ndisp, kKind[(int)l.type]);
     out += buf;
   }
@@ -776,18 +802,27 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct",
                                          "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy"};
   size_t which = step_.size();
+  auto traceable = [](const Launch& l) { return l.type == Launch::kLine || l.type == Launch::kRhsLine || l.type == Launch::kDctLine; };
   for (size_t i = 0; i < step_.size(); ++i)
-    if (step_[i].type == Launch::kLine && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
+    if (traceable(step_[i]) && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
   RPDE_REQUIRE(which < step_.size(), "trace_launch: no line program with tag containing \"" + tag + "\"");
   std::string out;
 #ifndef RPDE_EMU
   Launch l = step_[which];
-  const long nblk = 8L * ((l.pg.nlines + 7) / 8) * l.pg.ncomp;
+  const bool prog = l.type == Launch::kLine;
+  const int tl = prog ? l.pg.nlines : (l.type == Launch::kRhsLine ? l.rl.nlines : l.dl.nlines);
+  const long nblk = 8L * ((tl + 7) / 8) * (prog ? l.pg.ncomp : 1);
   DBuf buf;
   buf.alloc((size_t)nblk * kTraceStride);            // doubles and long longs are both 8 bytes
   RPDE_HIP(hipMemsetAsync(buf.p, 0, (size_t)nblk * kTraceStride * 8, st_.s));
-  l.pg.trace = reinterpret_cast<long long*>(buf.p);
-  for (size_t i = 0; i < step_.size(); ++i) run_launch(i == which ? l : step_[i]);
+  long long* trec = reinterpret_cast<long long*>(buf.p);
+  l.pg.trace = trec;
+  for (size_t i = 0; i < step_.size(); ++i) {
+    if (i != which) { run_launch(step_[i]); continue; }
+    if (prog) run_launch(l);
+    else if (l.type == Launch::kRhsLine) RPDE_REQUIRE(launch_rhs_line(l.rl, st_, trec), "trace: rhs line");
+    else RPDE_REQUIRE(launch_dct_line(l.dl, st_, trec), "trace: dct line");
+  }
   dev_sync(st_);
   time_ += dt_;
   std::vector<long long> h((size_t)nblk * kTraceStride);
@@ -820,7 +855,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
     const double med = d.empty() ? 0 : d[d.size() / 2], p10 = d.empty() ? 0 : d[d.size() / 10], p90 = d.empty() ? 0 : d[d.size() * 9 / 10];
     const long long id = i == 0 ? -2 : ref[4 + 2 * i];   // -2: the whole program, -1: a barrier, >= 0: op ip starts (nops: end)
     const long long prev = i == 0 ? -2 : ref[4 + 2 * (i - 1)];
-    const char* name = id == -2 ? "program" : (id == -1 ? "sync" : (id < l.pg.nops ? kOpNames[l.pg.ops[id].code] : "end"));
+    const char* name = id == -2 ? "program" : (id == -1 ? "sync" : (!prog ? (id == 0 ? "begin" : "end") : (id < l.pg.nops ? kOpNames[l.pg.ops[id].code] : "end")));
     (void)prev;
     snprintf(line, sizeof line, "%lld\t%s\t%.0f\t%.0f\t%.0f\t%.0f\n", id, name, mean, p10, med, p90);
     out += line;
@@ -1223,6 +1258,13 @@ void Navier2DEngine::callback() {
 void Navier2DEngine::refresh_gy() {
   const bool spec = periodic_;
   const int rows_x = sp_ortho_->ortho_rows();
+  if (!periodic_) {   // d/dx p along the local x-lines: the same ops as the tail of S9
+    ProgramBuilder pb(1, sp_ortho_->axis(0).slot_len, ylines(ny_));
+    pb.set_fft(sp_ortho_->axis(0));
+    pb.set_line0(yb_);
+    pb.load(0, pb.arr(yx(P_), ldx_), nx_); pb.cdiff(0, 0, nx_, 1.0 / sx_); pb.store(0, pb.arr(yx(GX_), ldx_), nx_);
+    pb.run(st_);
+  }
   if (comm_.size == 1) {
     // the same column scan the step runs (C10): a restarted run continues bit-identically
     ColDiffArgs a{};
@@ -1384,6 +1426,17 @@ void Navier2DEngine::build_confined() {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
     // only the first my = ny - 2 orthonormal y-rows are needed: the B2-y preconditioner of S4 never
     // reads the last two (matvec.rs:215-226) -- and 4095 lines fill the CUs without a ragged tail
+    if (ax.fft_n == nx - 1) {   // one kernel per field (rhs_line.h)
+      RhsLineArgs r;
+      r.which = which; r.conv = yx(Y_[which]); r.st = yx(state); r.out = yx(Y_[3 + which]); r.ld = ldx;
+      r.nlines = ylines(my); r.line0 = yb_; r.N = nx - 1; r.cut = cut_x; r.dt = dt; r.ka = ka_;
+      r.lowy = yD.low.p; r.lowy2 = yD.low.p; r.stx = which == 2 ? 1 : 2; r.lowx = xN.low.p;
+      r.tw = ax.tw.p; r.tw2 = ax.tw2.p;
+      if (which == 0) r.grad = yx(GX_);
+      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(TBC_); }
+      if (which == 2) r.tbc = yx(TBC2_);
+      if (add_rhs_line(r, which, tag)) return;
+    }
     ProgramBuilder pb = ypb(2, my);
     pb.set_fft(ax);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
@@ -1395,9 +1448,7 @@ void Navier2DEngine::build_confined() {
     }
     pb.to_ortho_axpby(0, -dt, 1, 1.0, ax);                    // slot 0 = -dt * conv + S_x S_y state
     if (which == 0) {
-      pb.load(1, pb.arr(yx(P_), ldx), nx);
-      pb.cdiff(1, 1, nx, 1.0 / sx_);
-      pb.axpby(0, 0, 1.0, 1, -dt, nx);
+      pb.load(0, pb.arr(yx(GX_), ldx), nx, -dt, true);           // d/dx p, kept from the pressure update
     } else if (which == 1) {
       pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
@@ -1564,6 +1615,8 @@ void Navier2DEngine::build_confined() {
     pb.pair_last_loads();
     pb.store(0, pb.arr(yx(P_), ldx), nx);
     pb.guard_last_store(flagp());
+    pb.cdiff(0, 0, nx, 1.0 / sx_);                               // d/dx p for the next step's S3
+    pb.store(0, pb.arr(yx(GX_), ldx), nx);
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step

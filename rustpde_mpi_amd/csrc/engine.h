@@ -172,7 +172,7 @@ class Navier2DEngine {
   std::unique_ptr<PoissonOp> pois_;
 
   // state + constants (YX layout: row = y index, contiguous x)
-  DBuf U_, V_, T_, P_, GY_, TBC_, TBC2_, DIV_;
+  DBuf U_, V_, T_, P_, GY_, GX_, TBC_, TBC2_, DIV_;   // GX_, GY_: d/dx p, d/dy p kept from the pressure update
   DBuf Y_[6];
   // XY layout work arrays (row = x index, contiguous y)
   DBuf X_[9], BX_, BY_, PS_;
@@ -192,7 +192,8 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine } type;
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine } type;
+    RhsLineArgs rl{};            // kRhsLine
     ConvLineArgs cl{};           // kConvLine
     DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
     GemmProblem gp[2];           // kGemmPair*
@@ -231,6 +232,9 @@ class Navier2DEngine {
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
   bool add_conv_line(const ConvLineArgs& c, const char* tag);
+  bool add_rhs_line(RhsLineArgs a, int which, const char* tag);   // S3 as one kernel per field (rhs_line.h)
+  struct RhsTabs { DBuf t0, t1, t2, q1, p2, q2, r2; };            // chunk-major (16 per thread) tables of rhs_line, per field kind
+  RhsTabs rhs_tabs_[2];                                           // 0: velocities (Dirichlet x, nu), 1: temperature (Neumann x, ka)
   void build_confined();
   void build_periodic();
   void run_launch(const Launch& l);

@@ -4,6 +4,8 @@
 #include "kernels.h"
 
 #include "dct_line.h"
+#include "hdct_line.h"
+#include "rhs_line.h"
 
 #include <algorithm>
 #include <atomic>
@@ -55,6 +57,7 @@ RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long l
   }
 }
 
+int g_hdct = [] { const char* e = std::getenv("RPDE_HDCT"); return e ? std::atoi(e) : 1; }();   // which whole-line kernels run on the half-length core (hdct_line.h) instead of dct_line.h: bit 0 the pure transform, bit 1 the S1 pair, bit 2 the convection term (A/B switch)
 int g_dct_line_pf = [] { const char* e = std::getenv("RPDE_DCT_PF"); return e ? std::atoi(e) : 0; }();   // A/B switch (tools, microbench)
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
@@ -673,9 +676,77 @@ __global__ __launch_bounds__(N / 16, WPS) void dct_line_pf_kernel(const DctLineA
     idx = nidx; line = nline; have = nhave;
   }
 }
-bool launch_dct_line(const DctLineArgs& a, Stream& st) {
+// TRACE: instrumented twins (Navier2DEngine::trace_launch): thread 0 leaves a clock value behind every barrier
+#define RPDE_TRACE_BEGIN(trace) \
+  Blk blk{line, 0, N / 16, buf, TRACE ? (trace) + (long)blockIdx.x * kTraceStride : nullptr, 0}; \
+  if (TRACE && threadIdx.x == 0) { blk.trc[0] = (long long)wall_clock64(); } \
+  RPDE_MARK(blk, 0)
+#define RPDE_TRACE_END() \
+  do { RPDE_MARK(blk, 1); if (TRACE && threadIdx.x == 0) { blk.trc[1] = (long long)wall_clock64(); blk.trc[2] = blk.nm; } } while (0)
+// hdct_line.h: the same transforms through the half-length FFT (8 complex points per thread)
+template <int N, bool TRACE = false>
+__global__ __launch_bounds__(N / 16, 4) void hdct_line_kernel(const DctLineArgs a, long long* trace) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  RPDE_TRACE_BEGIN(trace);
+  hdct_bwd_line<N>(blk, a);
+  RPDE_TRACE_END();
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void hdct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  hdct_bwd_line<N>(blk, a0);
+  __syncthreads();
+  hdct_bwd_line<N>(blk, a1);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 3) void hconv_line_kernel(const ConvLineArgs c) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= c.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  hconv_line<N>(blk, c);
+}
+template <int N, int WHICH, bool TRACE = false>
+__global__ __launch_bounds__(N / 16, 4) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  RPDE_TRACE_BEGIN(trace);
+  rhs_line<N, WHICH>(blk, a);
+  RPDE_TRACE_END();
+}
+bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
+  if (a.N != 4096 || !rhs_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(256);
+  if (trace) {
+    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, true>), grid, block, 0, st.s, a, trace);
+    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, true>), grid, block, 0, st.s, a, trace);
+    else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, true>), grid, block, 0, st.s, a, trace);
+  } else if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0>), grid, block, 0, st.s, a, trace);
+  else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1>), grid, block, 0, st.s, a, trace);
+  else hipLaunchKernelGGL((rhs_line_kernel<4096, 2>), grid, block, 0, st.s, a, trace);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
   if (a.N != 4096 || !dct_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
+  if ((g_hdct & 1) || trace) {
+    if (trace) hipLaunchKernelGGL((hdct_line_kernel<4096, true>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
+    else hipLaunchKernelGGL((hdct_line_kernel<4096>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   const int pf = g_dct_line_pf;
   if (pf == 3 || pf == 4) {
     const int grid = std::min(256 * pf, 8 * ((a.nlines + 7) / 8));
@@ -711,6 +782,11 @@ __global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs
 bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   if (c.N != 4096 || !conv_line_ok(c)) return false;
   if (c.nlines <= 0) return true;
+  if (g_hdct & 4) {
+    hipLaunchKernelGGL(hconv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   hipLaunchKernelGGL(conv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
   RPDE_HIP(hipGetLastError());
   return true;
@@ -718,6 +794,11 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != 4096 || a1.N != 4096 || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   if (a0.nlines <= 0) return true;
+  if (g_hdct & 2) {
+    hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   hipLaunchKernelGGL(dct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
   RPDE_HIP(hipGetLastError());
   return true;
@@ -972,12 +1053,13 @@ void launch_col_diff(const ColDiffArgs& a, Stream&) {
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   if (!conv_line_ok(c)) return false;
-  std::vector<double> lds(dct_line_lds_doubles(c.N) + 2);
+  std::vector<double> lds(hdct_lds_doubles(c.N) + 2);
   double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
   for (int line = 0; line < c.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
-    if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);
+    if (g_hdct & 4) { if (c.N == 4096) hconv_line<4096>(blk, c); else hconv_line<256>(blk, c); }
+    else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);
   }
   return true;
 }
@@ -985,14 +1067,27 @@ bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) 
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   return launch_dct_line(a0, st) && launch_dct_line(a1, st);
 }
-bool launch_dct_line(const DctLineArgs& a, Stream&) {
+bool launch_rhs_line(const RhsLineArgs& a, Stream&, long long*) {
+  if (!rhs_line_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) { if (a.which == 0) rhs_line<4096, 0>(blk, a); else if (a.which == 1) rhs_line<4096, 1>(blk, a); else rhs_line<4096, 2>(blk, a); }
+    else { if (a.which == 0) rhs_line<256, 0>(blk, a); else if (a.which == 1) rhs_line<256, 1>(blk, a); else rhs_line<256, 2>(blk, a); }
+  }
+  return true;
+}
+bool launch_dct_line(const DctLineArgs& a, Stream&, long long*) {
   if (!dct_line_ok(a)) return false;
-  std::vector<double> lds(dct_line_lds_doubles(a.N) + 2);
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
   double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);   // 16-byte aligned like the device buffer
   for (int line = 0; line < a.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
-    if (a.N == 4096) dct_bwd_line<4096>(blk, a); else dct_bwd_line<256>(blk, a);
+    if (g_hdct & 1) { if (a.N == 4096) hdct_bwd_line<4096>(blk, a); else hdct_bwd_line<256>(blk, a); }
+    else if (a.N == 4096) dct_bwd_line<4096>(blk, a); else dct_bwd_line<256>(blk, a);
   }
   return true;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "colscan.h"
 #include "line_vm.h"
+#include "rhs_line.h"
 
 namespace rpde {
 
@@ -69,11 +70,13 @@ void launch_col_diff(const ColDiffArgs& a, Stream& st);
 // backward Chebyshev transform of whole lines with four workgroups per CU (dct_line.h); false: shape / alignment
 // not covered (the caller runs the line program instead)
 struct DctLineArgs;
-bool launch_dct_line(const DctLineArgs& a, Stream& st);
+bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace = nullptr);   // trace: diagnostics record (kTraceStride words per workgroup)
+extern int g_hdct;          // bit mask: which whole-line kernels run on the half-length core (hdct_line.h) -- 1 pure transform (default), 2 S1 pair, 4 convection term; RPDE_HDCT, A/B switch
 extern int g_dct_line_pf;   // 0: one line per workgroup; 3 / 4: persistent workgroups with a prefetched next line (A/B switch, RPDE_DCT_PF)
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
+bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace = nullptr);   // rhs_line.h: S3 of the confined step per x-line
 // one y-line of a convection term: two backward transforms, the physical products, the forward transform with the
 // 2/3 rule, all in registers + one exchange buffer (dct_line.h conv_line; three workgroups per CU)
 struct ConvLineArgs;

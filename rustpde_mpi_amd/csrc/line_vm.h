@@ -60,6 +60,62 @@ using cgmem2_t = const __attribute__((address_space(1))) dbl2*;
 using gmem2_t = __attribute__((address_space(1))) dbl2*;
 #endif
 
+// A row of doubles read or written in 16-byte pairs through a buffer descriptor: ONE 32-bit per-thread byte offset
+// serves every row and every array of a phase (the descriptor and the uniform part of the offset live in SGPRs), where
+// flat global addressing spends a 64-bit VGPR pair and the arithmetic for it on every load stream.  The descriptor covers
+// exactly `bytes` from the row's first element: an access outside (for instance the pair in front of the line, offset
+// -16) reads zero and is not stored.
+#ifdef RPDE_EMU
+// the emulation follows the hardware's rule: the per-thread offset alone is range-checked (as an unsigned number), the
+// uniform offset is simply added -- and it aborts on a final address outside the row, which the hardware would not notice
+struct RowBuf { const double* p; long bytes; };
+inline RowBuf row_buf(const double* p, long bytes) { return RowBuf{p, bytes}; }
+inline bool row_in(const RowBuf& r, int voff, int soff, int size) {
+  if (voff < 0 || (long)voff + size > r.bytes) return false;
+  const long o = (long)voff + soff;
+  if (soff < 0 || o + size > r.bytes) { std::fprintf(stderr, "row access outside its descriptor (%d + %d of %ld)\n", voff, soff, r.bytes); std::abort(); }
+  return true;
+}
+inline dbl2 row_ld2(const RowBuf& r, int voff, int soff) {
+  if (!row_in(r, voff, soff, 16)) return dbl2{0.0, 0.0};
+  const long o = ((long)voff + soff) / 8;
+  return dbl2{r.p[o], r.p[o + 1]};
+}
+inline double row_ld1(const RowBuf& r, int voff, int soff) {
+  if (!row_in(r, voff, soff, 8)) return 0.0;
+  return r.p[((long)voff + soff) / 8];
+}
+inline void row_st2(const RowBuf& r, int voff, int soff, dbl2 v) {
+  if (!row_in(r, voff, soff, 16)) return;
+  double* q = const_cast<double*>(r.p) + ((long)voff + soff) / 8;
+  q[0] = v.x; q[1] = v.y;
+}
+inline void row_st1(const RowBuf& r, int voff, int soff, double v) {
+  if (!row_in(r, voff, soff, 8)) return;
+  const_cast<double*>(r.p)[((long)voff + soff) / 8] = v;
+}
+#else
+typedef unsigned int rpde_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rpde_u32x2 __attribute__((ext_vector_type(2)));
+struct RowBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ RowBuf row_buf(const double* p, long bytes) {
+  // dword 3: DATA_FORMAT = 32-bit (the raw-buffer word of gfx9 / CDNA); stride 0; num_records = bytes
+  return RowBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ dbl2 row_ld2(const RowBuf& r, int voff, int soff) {
+  return __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(r.r, voff, soff, 0));
+}
+__device__ __forceinline__ double row_ld1(const RowBuf& r, int voff, int soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r.r, voff, soff, 0));
+}
+__device__ __forceinline__ void row_st2(const RowBuf& r, int voff, int soff, dbl2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rpde_u32x4, v), r.r, voff, soff, 0);
+}
+__device__ __forceinline__ void row_st1(const RowBuf& r, int voff, int soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rpde_u32x2, v), r.r, voff, soff, 0);
+}
+#endif
+
 enum OpCode : int {
   OP_END = 0,
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;

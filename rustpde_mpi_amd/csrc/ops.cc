@@ -416,7 +416,8 @@ HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
       RPDE_REQUIRE(b.is_composite(), "HholtzAdi: orthonormal Chebyshev base is not supported");
       Bands mtx = bands_axpy(hholtz_mat_a(b), -c[axis], hholtz_mat_b(b));
       fdma_sweep(mtx);
-      fdma[axis] = upload_fdma(fdma_tables(mtx), sp.axis(axis).slot_len);
+      host[axis] = fdma_tables(mtx);
+      fdma[axis] = upload_fdma(host[axis], sp.axis(axis).slot_len);
       if (axis == 1) col_y.upload(build_colhh_tables(pinv_tables(b), fdma_tables(mtx), kColBlockRows));
     } else {
       Vec d(b.m);

@@ -174,6 +174,7 @@ class HholtzAdiOp {
   HholtzAdiOp(Space2Ops& sp, double c0, double c1);
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
   FdmaDev fdma[2];      // Chebyshev axes
+  FdmaTables host[2];   // the same tables on the host, natural order (other kernels re-order them for their own chunking)
   ColHhDev col_y;       // axis 1 as a column scan over YX arrays (the fused step on one GPU)
   DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
   Space2Ops& sp;
