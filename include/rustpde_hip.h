@@ -104,7 +104,9 @@ int rpde_navier2d_get_timed(rpde_navier2d* h, double* ms_total, long* launches);
  * instrumented: thread 0 of every workgroup records the shader clock when it reaches an op and when it    *
  * leaves a barrier.  "tag\tworkgroups\tspan_ms\tmarks\n", then one row per mark in program order,          *
  * "id\tname\tmean\tp10\tmedian\tp90\n" = clocks since the previous mark over the workgroups (id >= 0: op  *
- * id starts, -1: a barrier inside the op, first row (-2) = the whole program)                            */
+ * id starts, -1: a barrier inside the op, first row (-2) = the whole program).  The traced step is a real *
+ * time step: the fields and the time advance by one dt.  The host-emulation build of the library (tests)  *
+ * returns the header line with zero workgroups and no rows.                                              */
 int rpde_navier2d_trace_launch(rpde_navier2d* h, const char* tag, char* buf, size_t len);
 /* Integrate::get_time / get_dt                               src/navier_stokes/navier.rs:468-474 */
 int rpde_navier2d_time(rpde_navier2d* h, double* t);
@@ -143,6 +145,9 @@ int rpde_navier2d_callback_from_filename(rpde_navier2d* h, const char* flow_name
  * _get: name in {temp, ux, uy, nusselt}, coefficients of the `field` space (nx x ny doubles, or (nx/2+1) x ny          *
  * complex interleaved when periodic).                                                                                 */
 int rpde_navier2d_statistics_enable(rpde_navier2d* h, double save_stat, double write_stat);
+/* `navier.statistics = Some(stats)` (on != 0) / `= None` (on == 0): the callback acts on attached statistics only     *
+ * (navier_io.rs:105 `if let Some(..)`); detaching keeps the accumulated fields.  _enable leaves them attached.        */
+int rpde_navier2d_statistics_attach(rpde_navier2d* h, int on);
 int rpde_navier2d_statistics_update(rpde_navier2d* h);
 int rpde_navier2d_statistics_write(rpde_navier2d* h, const char* filename);
 int rpde_navier2d_statistics_read(rpde_navier2d* h, const char* filename);

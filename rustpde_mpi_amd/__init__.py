@@ -253,6 +253,9 @@ class Navier2D:
     def statistics(self, value):
         if value is not None and value._nav is not self:
             raise RpdeError("Statistics belong to the Navier2D they were created from")
+        # the engine's callback acts on `Some(statistics)` only (navier_io.rs:105); None detaches, the data stays
+        if value is not None or getattr(self, "_statistics", None) is not None:
+            self._lib.call("rpde_navier2d_statistics_attach", self._h, 1 if value is not None else 0)
         self._statistics = value
 
     # ---- extras
@@ -530,6 +533,9 @@ class Statistics:
         self._nav = navier
         self.save_stat, self.write_stat = float(save_stat), float(write_stat)
         navier._lib.call("rpde_navier2d_statistics_enable", navier._h, self.save_stat, self.write_stat)
+        # Statistics::new does not touch the solver: the hook is `navier.statistics = Some(..)` (the setter above)
+        navier._lib.call("rpde_navier2d_statistics_attach", navier._h, 0)
+        navier._statistics = None
         self.t_avg, self.ux_avg, self.uy_avg, self.nusselt = (_StatField(self, n) for n in ("temp", "ux", "uy", "nusselt"))
 
     @classmethod

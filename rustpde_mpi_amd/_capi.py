@@ -63,6 +63,7 @@ SIGNATURES = {
     "rpde_navier2d_callback": (C.c_int, [_vp]),
     "rpde_navier2d_callback_from_filename": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
     "rpde_navier2d_statistics_enable": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "rpde_navier2d_statistics_attach": (C.c_int, [_vp, C.c_int]),
     "rpde_navier2d_statistics_update": (C.c_int, [_vp]),
     "rpde_navier2d_statistics_write": (C.c_int, [_vp, C.c_char_p]),
     "rpde_navier2d_statistics_read": (C.c_int, [_vp, C.c_char_p]),

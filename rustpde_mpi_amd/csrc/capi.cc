@@ -315,6 +315,13 @@ int rpde_navier2d_statistics_enable(rpde_navier2d* h, double save_stat, double w
     h->e->statistics_enable(save_stat, write_stat);
   })
 }
+int rpde_navier2d_statistics_attach(rpde_navier2d* h, int on) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(on == 0 || h->e->statistics_enabled(), "statistics_attach: statistics are not enabled");
+    h->e->statistics_attach(on != 0);
+  })
+}
 int rpde_navier2d_statistics_update(rpde_navier2d* h) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->statistics_update(); })
 }

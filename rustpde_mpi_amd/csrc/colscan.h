@@ -5,11 +5,15 @@
 // No LDS, no barriers, no transposes: the banded Helmholtz solve along y and the Chebyshev
 // y-derivatives stream at HBM speed instead of going XY -> line kernel -> YX.
 //
-// The sequential dependency along y is cut into NB blocks of BR rows: a block first runs from a ZERO
-// inflow state (pass A), a tiny per-column pass turns the block-end states into block inflow
-// states with the tabulated block transfer matrices (carry pass), and the last pass adds the
-// tabulated homogeneous response, x_j = x0_j + h1_j s1 + h2_j s2.  Per element the arithmetic is
-// that of the reference's sequential sweeps:
+// The sequential dependency along y is cut into NB blocks of BR rows.  The Helmholtz solve reads its
+// input TWICE and writes its output ONCE (round 2 made three read + write passes over a work array):
+//   summary pass   a thread loads its block of rows into registers, runs B2 rows, forward substitution and back
+//                  substitution from ZERO inflow states and keeps only the block-end states (no array is written);
+//   carry pass     per column and parity: the forward inflow of every block (ascending, tabulated block transfer
+//                  factors), then the backward inflow states (descending, tabulated 2 x 2 block transfer matrices;
+//                  the response of a block's backward end state to its own forward inflow is tabulated too: `g`);
+//   final pass     the same block again, now with its exact inflow states: the rows it stores are final.
+// Per element the arithmetic is that of the reference's sequential sweeps:
 //   MatVecFdma (B2 rows)      src/solver/matvec.rs:207-228
 //   Fdma::fdma fwd / bwd      src/solver/fdma.rs:101-118
 //   Chebyshev derivative      funspace gradient (src/field.rs:127-129), d_k = d_{k+2} + 2 (k+1) c_{k+1}
@@ -20,30 +24,39 @@
 namespace rpde {
 
 constexpr int kColMaxFields = 3;
+constexpr int kColBR = 32;             // rows per block: a thread keeps BR + 4 input rows in registers
 
-// per-row tables of one Helmholtz-y solver (device pointers; rows = n)
+// per-row tables of one Helmholtz-y solver (device pointers; every per-row table is zero-padded to NB * BR + 4
+// entries, so rows past the end of the system come out as zeros without a branch)
 struct ColHhTabs {
   const double *t0, *t1, *t2;          // B2 preconditioner rows: b_j = t0 w_j + t1 w_{j+2} + t2 w_{j+4}
-  const double *q1, *h1a;              // forward substitution y_j = b_j + q1_j y_{j-2}; response to a unit inflow
+  const double *q1;                    // forward substitution y_j = b_j + q1_j y_{j-2}
   const double *m1;                    // [NB][2]: block transfer of the forward chain, per parity
   const double *p2, *q2, *r2;          // back substitution x_j = p2_j y_j + q2_j x_{j+2} + r2_j x_{j+4}
-  const double *h1b, *h2b;             // responses to the unit inflow states (1,0) / (0,1)
   const double *m2;                    // [NB][2][4]: block transfer matrices of the backward chain
+  const double *g;                     // [NB][2][2]: backward end state of a block per unit of its forward inflow
+  // optional rank-one term (nullptr: none): out_j += kappa * h_j with kappa = sum over the input rows of w_row in_row,
+  // one number per column (the velocity correction: the Chebyshev derivative followed by the Dirichlet projection is
+  // local except for ONE entry of the right-hand side that carries a weighted sum of the whole column)
+  const double *w, *h;
 };
 
 struct ColHhArgs {
   int n;                 // rows of the banded system (composite size along y)
   int nin;               // valid rows of the input (rows >= nin read as zero)
   int ncols;             // columns (doubles per row that take part)
-  int BR, NB;            // rows per block (even), number of blocks
+  int NB;                // number of blocks of kColBR rows
   long ld;               // pitch of all arrays (doubles)
   int nf;                // fields solved in one launch (grid.z)
   const double* in[kColMaxFields];   // right-hand side after the x part (orthonormal rows)
-  double* z[kColMaxFields];          // work array (zero-inflow solutions), rows n
   double* out[kColMaxFields];        // solution rows n
+  int shift[kColMaxFields];          // tap 0 of row j is input row j - shift (rows < 0 read as zero)
+  int in_half;                       // > 0: the input columns are parity de-interleaved (column i of the output =
+                                     // input column (i & 1) * in_half + (i >> 1)); 0: same columns
   ColHhTabs tab[kColMaxFields];
   double *v1, *s1;       // [nf][NB][2][ld]     block-end values / block inflow of the forward chain
   double *v2, *s2;       // [nf][NB][2][2][ld]  block-end states / block inflow states of the backward chain
+  double *dotp, *kap;    // [nf][NB][ld] block parts of the rank-one sums, [nf][ld] the sums (fields with tab.w only)
   int* nanflag;          // raised when the final pass stores a NaN (Integrate::exit); may be null
 };
 
@@ -52,47 +65,86 @@ RPDE_HD inline long col_c2(const ColHhArgs& a, int f, int b, int par, int c) {
   return ((((long)f * a.NB + b) * 2 + par) * 2 + c) * a.ld;
 }
 
-// Rows are processed in batches of kColBatch: the loads of a batch are issued together (they do not
-// depend on the recurrence), then the batch is computed and stored.  One load in flight per thread
-// would leave the kernels latency bound (measured: 3.0 TB/s with 8192 resident waves x 512 B).
+// loads of the carry passes and of the derivative are issued in batches of kColBatch (they do not depend on
+// the recurrence); one load in flight per thread would leave the kernels latency bound
 constexpr int kColBatch = 8;
 
-// pass A: B2 rows + forward substitution from a zero inflow, ascending rows of block b
-RPDE_HD inline void colhh_fwd(const ColHhArgs& a, int f, int b, int i) {
+// one block of one column: FINAL = false keeps the block-end states of a run from zero inflow, FINAL = true
+// runs from the exact inflow states and stores the rows.  All BR + 4 row loads are in flight at once.
+template <bool FINAL>
+RPDE_HD inline void colhh_block(const ColHhArgs& a, int f, int b, int i) {
+  constexpr int BR = kColBR;
   const ColHhTabs& t = a.tab[f];
-  const double* __restrict__ w = a.in[f] + i;
-  double* __restrict__ z = a.z[f] + i;
-  const int j0 = b * a.BR, j1 = (j0 + a.BR < a.n) ? j0 + a.BR : a.n;
-  auto rd = [&](int j) { return j < a.nin ? w[(long)j * a.ld] : 0.0; };
-  double w0 = rd(j0), w1 = rd(j0 + 1), w2 = rd(j0 + 2), w3 = rd(j0 + 3);
-  double ze = 0.0, zo = 0.0;   // previous element of the even / odd chain (j0 is even)
-  for (int jb = j0; jb < j1; jb += kColBatch) {
-    double wn[kColBatch], zz[kColBatch];
+  const int ci = a.in_half ? (i & 1) * a.in_half + (i >> 1) : i;
+  const double* __restrict__ w = a.in[f] + ci;
+  const int j0 = b * BR, jr = j0 - a.shift[f];
+  double r[BR + 4];
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) wn[u] = rd(jb + 4 + u);
+  for (int u = 0; u < BR + 4; ++u) r[u] = (jr + u >= 0 && jr + u < a.nin) ? w[(long)(jr + u) * a.ld] : 0.0;
+  if (t.w) {
+    if (!FINAL) {                        // this block's part of the column sum: its own rows, the last block also the tail
+      double dot = 0.0;
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) {
-      const int j = jb + u;
-      const int jc = j < j1 ? j : j1 - 1;               // clamped table index; rows past the block are not stored
-      double bj = t.t0[jc] * w0 + t.t1[jc] * w2;
-      bj += (j < a.n - 2) ? t.t2[jc] * wn[u] : 0.0;
-      double& zp = (u & 1) ? zo : ze;
-      const double zj = bj + t.q1[jc] * zp;
-      zp = (j < j1) ? zj : zp;
-      zz[u] = zj;
-      w0 = w1; w1 = w2; w2 = w3; w3 = wn[u];
+      for (int u = 0; u < BR + 4; ++u)
+        if (u < BR || b == a.NB - 1) dot += t.w[(jr + u > 0) ? jr + u : 0] * r[u];
+      a.dotp[((long)f * a.NB + b) * a.ld + i] = dot;
     }
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u)
-      if (jb + u < j1) z[(long)(jb + u) * a.ld] = zz[u];
   }
-  a.v1[col_c1(a, f, b, 0) + i] = ze;
-  a.v1[col_c1(a, f, b, 1) + i] = zo;
+  double ye = 0.0, yo = 0.0;             // previous element of the even / odd forward chain (j0 is even)
+  double e1 = 0.0, e2 = 0.0, o1 = 0.0, o2 = 0.0;   // (most recent, the one before) of the even / odd backward chain
+  if (FINAL) {
+    ye = a.s1[col_c1(a, f, b, 0) + i]; yo = a.s1[col_c1(a, f, b, 1) + i];
+    e1 = a.s2[col_c2(a, f, b, 0, 0) + i]; e2 = a.s2[col_c2(a, f, b, 0, 1) + i];
+    o1 = a.s2[col_c2(a, f, b, 1, 0) + i]; o2 = a.s2[col_c2(a, f, b, 1, 1) + i];
+  }
+#pragma unroll
+  for (int u = 0; u < BR; ++u) {         // B2 row + forward substitution, ascending, in place
+    const int j = j0 + u;
+    const double bj = t.t0[j] * r[u] + t.t1[j] * r[u + 2] + t.t2[j] * r[u + 4];
+    double& yp = (u & 1) ? yo : ye;
+    yp = bj + t.q1[j] * yp;
+    r[u] = yp;
+  }
+  if (!FINAL) {
+    a.v1[col_c1(a, f, b, 0) + i] = ye;
+    a.v1[col_c1(a, f, b, 1) + i] = yo;
+  }
+#pragma unroll
+  for (int u = BR - 1; u >= 0; --u) {    // back substitution, descending, in place
+    const int j = j0 + u;
+    double& x1 = (u & 1) ? o1 : e1;
+    double& x2 = (u & 1) ? o2 : e2;
+    const double xj = t.p2[j] * r[u] + t.q2[j] * x1 + t.r2[j] * x2;
+    x2 = x1; x1 = xj;
+    r[u] = xj;
+  }
+  if (!FINAL) {
+    a.v2[col_c2(a, f, b, 0, 0) + i] = e1; a.v2[col_c2(a, f, b, 0, 1) + i] = e2;
+    a.v2[col_c2(a, f, b, 1, 0) + i] = o1; a.v2[col_c2(a, f, b, 1, 1) + i] = o2;
+  } else {
+    double* __restrict__ out = a.out[f] + i;
+    const double kap = t.w ? a.kap[(long)f * a.ld + i] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < BR; ++u)
+      if (j0 + u < a.n) {
+        const double x = t.w ? r[u] + kap * t.h[j0 + u] : r[u];
+        out[(long)(j0 + u) * a.ld] = x;
+        bad |= (x != x);
+      }
+    if (bad && a.nanflag) *a.nanflag = 1;
+  }
 }
 
-// carry of the forward chain: inflow of every block, ascending; thread = (column, parity)
-RPDE_HD inline void colhh_carry1(const ColHhArgs& a, int f, int i, int par) {
+// carry pass; thread = (column, parity).  Forward chain ascending, then the backward chain descending: the state a
+// block hands down is its zero-inflow end state + g * (its forward inflow) + M * (its backward inflow state).
+RPDE_HD inline void colhh_carry(const ColHhArgs& a, int f, int i, int par) {
   const ColHhTabs& t = a.tab[f];
+  if (t.w && par == 0) {                 // the column sum of the rank-one term
+    double k = 0.0;
+    for (int b = 0; b < a.NB; ++b) k += a.dotp[((long)f * a.NB + b) * a.ld + i];
+    a.kap[(long)f * a.ld + i] = k;
+  }
   double s = 0.0;
   for (int bb = 0; bb < a.NB; bb += kColBatch) {
     double v[kColBatch];
@@ -105,50 +157,14 @@ RPDE_HD inline void colhh_carry1(const ColHhArgs& a, int f, int i, int par) {
         s = t.m1[(bb + u) * 2 + par] * s + v[u];
       }
   }
-}
-
-// pass B: finish the forward chain, back substitution from a zero inflow, descending rows of block b
-RPDE_HD inline void colhh_mid(const ColHhArgs& a, int f, int b, int i) {
-  const ColHhTabs& t = a.tab[f];
-  double* __restrict__ z = a.z[f] + i;
-  const int j0 = b * a.BR, j1 = (j0 + a.BR < a.n) ? j0 + a.BR : a.n;
-  const double se = a.s1[col_c1(a, f, b, 0) + i], so = a.s1[col_c1(a, f, b, 1) + i];
-  double e1 = 0.0, e2 = 0.0, o1 = 0.0, o2 = 0.0;   // (most recent, the one before) of the even / odd chain
-  for (int jt = j1 - 1; jt >= j0; jt -= kColBatch) {
-    double zv[kColBatch];
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u) zv[u] = (jt - u >= j0) ? z[(long)(jt - u) * a.ld] : 0.0;
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u) {
-      const int j = jt - u;
-      if (j >= j0) {
-        const bool odd = j & 1;
-        const double y = zv[u] + t.h1a[j] * (odd ? so : se);
-        double& x1 = odd ? o1 : e1;
-        double& x2 = odd ? o2 : e2;
-        const double xj = t.p2[j] * y + t.q2[j] * x1 + t.r2[j] * x2;
-        x2 = x1; x1 = xj;
-        zv[u] = xj;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u)
-      if (jt - u >= j0) z[(long)(jt - u) * a.ld] = zv[u];
-  }
-  a.v2[col_c2(a, f, b, 0, 0) + i] = e1; a.v2[col_c2(a, f, b, 0, 1) + i] = e2;
-  a.v2[col_c2(a, f, b, 1, 0) + i] = o1; a.v2[col_c2(a, f, b, 1, 1) + i] = o2;
-}
-
-// carry of the backward chain: inflow state of every block, descending; thread = (column, parity)
-RPDE_HD inline void colhh_carry2(const ColHhArgs& a, int f, int i, int par) {
-  const ColHhTabs& t = a.tab[f];
   double s0 = 0.0, s1 = 0.0;
   for (int bt = a.NB - 1; bt >= 0; bt -= kColBatch) {
-    double v0[kColBatch], v1[kColBatch];
+    double v0[kColBatch], v1[kColBatch], fi[kColBatch];
 #pragma unroll
     for (int u = 0; u < kColBatch; ++u) {
       v0[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 0) + i] : 0.0;
       v1[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 1) + i] : 0.0;
+      fi[u] = (bt - u >= 0) ? a.s1[col_c1(a, f, bt - u, par) + i] : 0.0;   // written above by this thread
     }
 #pragma unroll
     for (int u = 0; u < kColBatch; ++u) {
@@ -157,39 +173,13 @@ RPDE_HD inline void colhh_carry2(const ColHhArgs& a, int f, int i, int par) {
         a.s2[col_c2(a, f, b, par, 0) + i] = s0;
         a.s2[col_c2(a, f, b, par, 1) + i] = s1;
         const double* m = t.m2 + (b * 2 + par) * 4;
-        const double n0 = m[0] * s0 + m[1] * s1 + v0[u];
-        const double n1 = m[2] * s0 + m[3] * s1 + v1[u];
+        const double* g = t.g + (b * 2 + par) * 2;
+        const double n0 = m[0] * s0 + m[1] * s1 + (v0[u] + g[0] * fi[u]);
+        const double n1 = m[2] * s0 + m[3] * s1 + (v1[u] + g[1] * fi[u]);
         s0 = n0; s1 = n1;
       }
     }
   }
-}
-
-// pass C: add the homogeneous response, store the solution
-RPDE_HD inline void colhh_fin(const ColHhArgs& a, int f, int b, int i) {
-  const ColHhTabs& t = a.tab[f];
-  const double* __restrict__ z = a.z[f] + i;
-  double* __restrict__ out = a.out[f] + i;
-  const int j0 = b * a.BR, j1 = (j0 + a.BR < a.n) ? j0 + a.BR : a.n;
-  const double e1 = a.s2[col_c2(a, f, b, 0, 0) + i], e2 = a.s2[col_c2(a, f, b, 0, 1) + i];
-  const double o1 = a.s2[col_c2(a, f, b, 1, 0) + i], o2 = a.s2[col_c2(a, f, b, 1, 1) + i];
-  bool bad = false;
-  for (int jb = j0; jb < j1; jb += kColBatch) {
-    double zv[kColBatch];
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u) zv[u] = (jb + u < j1) ? z[(long)(jb + u) * a.ld] : 0.0;
-#pragma unroll
-    for (int u = 0; u < kColBatch; ++u) {
-      const int j = jb + u;
-      if (j < j1) {
-        const bool odd = u & 1;   // j0 and the batch are even, so the parity of the row is that of u
-        const double x = zv[u] + t.h1b[j] * (odd ? o1 : e1) + t.h2b[j] * (odd ? o2 : e2);
-        out[(long)j * a.ld] = x;
-        bad |= (x != x);
-      }
-    }
-  }
-  if (bad && a.nanflag) *a.nanflag = 1;
 }
 
 // ---------------------------------------------------------------------------------------------

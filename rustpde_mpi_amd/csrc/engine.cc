@@ -135,6 +135,11 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     colv1_.alloc(3 * nb * 2 * ldx_); cols1_.alloc(3 * nb * 2 * ldx_);
     colv2_.alloc(3 * nb * 4 * ldx_); cols2_.alloc(3 * nb * 4 * ldx_);
     coldv_.alloc(nb * 2 * ldx_); colds_.alloc(nb * 2 * ldx_);
+    coldot_.alloc(3 * nb * ldx_); colkap_.alloc(3 * ldx_);
+    if (!periodic) {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables)
+      const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows);
+      colcorr_a_.upload(cc.a); colcorr_b_.upload(cc.b);
+    }
   }
   {  // dealias (functions.rs:72-82) folded into the post-scaling of the forward DCT
     Vec py = cheb_fwd_post(ny);
@@ -250,6 +255,15 @@ void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
+  if (f.buf == &PS_ && pseu_in_yx_) {
+    // the confined single-GPU step leaves the pseudo-pressure in YX layout with the x parity blocks side by side
+    // (build_confined, G2): bring it to the canonical array on demand
+    const PoissonOp& po = *pois_;
+    launch_transpose(yx(Y_[4]), ldx_, PS_.p, 2 * ldy_, my_, po.me, 1, st_);
+    launch_transpose(yx(Y_[4]) + pseu_half_, ldx_, PS_.p + ldy_, 2 * ldy_, my_, po.mo, 1, st_);
+    dev_sync(st_);
+    pseu_in_yx_ = false;
+  }
   const bool spec = periodic_;
   if (f.yx) {   // rows = y index (c of them), row length r * e doubles
     DBuf full((size_t)ny_ * ldx_);
@@ -277,6 +291,7 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
     scatter_rows_xy(in.p(), in.ld, *f.buf, r, c * e, periodic_);
   }
   dev_sync(st_);
+  if (f.buf == &PS_) pseu_in_yx_ = false;
   if (f.name == "pres") refresh_gy();
   // host write: the next exit() evaluates the divergence like the reference; the flag starts over
   dirty_ = true;
@@ -599,21 +614,37 @@ void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmPro
   }
   step_.push_back(l);
 }
-void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols,
-                                    const char* tag) {
+void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag) {
   Launch l;
   l.type = Launch::kColHholtz;
   l.tag = tag;
   ColHhArgs& a = l.ch;
   const ColHhDev& cv = hh_vel_->col_y;
-  a.n = my_; a.nin = my_; a.ncols = ncols; a.BR = cv.BR; a.NB = cv.NB; a.ld = ldx_; a.nf = 3;
+  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = cv.NB; a.ld = ldx_; a.nf = 3;
   for (int f = 0; f < 3; ++f) {
-    a.in[f] = in[f]; a.z[f] = z[f]; a.out[f] = out[f];
+    a.in[f] = in[f]; a.out[f] = out[f]; a.shift[f] = 0;
     a.tab[f] = (f == 2 ? hh_temp_->col_y : hh_vel_->col_y).tabs();
   }
-  a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p;
+  a.in_half = 0;
+  a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = flagp();
-  l.bytes = 3.0 * 6.0 * 8.0 * (double)my_ * ncols;   // three passes, each reads and writes the three arrays once
+  l.bytes = 3.0 * 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
+  step_.push_back(l);
+}
+void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag) {
+  // y part of correct_velocity (navier_eq.rs:117-125) on the YX pseudo-pressure: two banded column problems with
+  // the same input (hostmath.h build_colcorr_tables); the input columns are the parity blocks of the eigen-transform
+  Launch l;
+  l.type = Launch::kColHholtz;
+  l.tag = tag;
+  ColHhArgs& a = l.ch;
+  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = colcorr_a_.NB; a.ld = ldx_; a.nf = 2;
+  a.in[0] = ps; a.in[1] = ps; a.out[0] = outa; a.out[1] = outb; a.shift[0] = 2; a.shift[1] = 1;
+  a.tab[0] = colcorr_a_.tabs(); a.tab[1] = colcorr_b_.tabs();
+  a.in_half = half;
+  a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
+  a.nanflag = nullptr;
+  l.bytes = 3.0 * 8.0 * (double)my_ * ncols;          // algorithmic: the pseudo-pressure once, two arrays out
   step_.push_back(l);
 }
 void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale,
@@ -664,6 +695,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
 void Navier2DEngine::update(int nsteps) {
   RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
   if (nsteps > 0) dirty_ = false;
+  if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
 #ifndef RPDE_EMU
   hipEvent_t e0 = ev0_, e1 = ev1_;
   RPDE_HIP(hipEventRecord(e0, st_.s));
@@ -742,6 +774,7 @@ void Navier2DEngine::update(int nsteps) {
 
 std::string Navier2DEngine::profile(int nsteps) {
   struct Acc { long n = 0; double ms = 0, bytes = 0, flops = 0; };
+  if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
   std::vector<std::string> order;
   std::map<std::string, Acc> acc;
   for (int s = 0; s < nsteps; ++s) {
@@ -788,7 +821,7 @@ std::string Navier2DEngine::describe_step() const {
   std::string out;
   for (const Launch& l : step_) {
     char buf[512];
-    const int ndisp = l.type == Launch::kColHholtz ? 5 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
+    const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x"};
@@ -806,6 +839,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   for (size_t i = 0; i < step_.size(); ++i)
     if (traceable(step_[i]) && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
   RPDE_REQUIRE(which < step_.size(), "trace_launch: no line program with tag containing \"" + tag + "\"");
+  if (pseu_half_ > 0) pseu_in_yx_ = true;
   std::string out;
 #ifndef RPDE_EMU
   Launch l = step_[which];
@@ -1046,9 +1080,11 @@ static std::string rust_exp(double v, int prec) {   // Rust's {:.Ne}: d.dd..e[-]
   const int ex = std::atoi(s.c_str() + epos + 1);
   return s.substr(0, epos) + "e" + std::to_string(ex);
 }
-static std::string rust_display(double v) {          // shortest representation that round-trips
-  char buf[64];
-  auto res = std::to_chars(buf, buf + sizeof buf, v);
+static std::string rust_display(double v) {          // Rust's `{}` for f64: shortest digits that round-trip, NEVER an exponent
+  if (std::isnan(v)) return "NaN";
+  if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+  char buf[400];                                      // 1e-308 in fixed notation needs 326 characters
+  auto res = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
   return std::string(buf, res.ptr);
 }
 
@@ -1063,7 +1099,7 @@ void Navier2DEngine::callback_from_filename(const std::string& flow_name, const 
       std::fprintf(stderr, "Error while writing file \"%s\". Error: %s\n", flow_name.c_str(), ex.what());
     }
   }
-  if (stats_) {   // navier_io.rs:105-121
+  if (stats_ && stats_attached_) {   // navier_io.rs:105-121: `if let Some(ref mut statistics) = self.statistics`
     if (std::fmod(time_ + dt_ / 2.0, stats_->save_stat) < dt_) statistics_update();
     if (std::fmod(time_ + dt_ / 2.0, stats_->write_stat) < dt_) {
       try { statistics_write("data/statistics.h5"); }
@@ -1097,6 +1133,7 @@ void Navier2DEngine::callback_from_filename(const std::string& flow_name, const 
 void Navier2DEngine::statistics_enable(double save_stat, double write_stat) {
   // Statistics::new (statistics.rs:50-76): zero fields, avg_time = 0, tot_time = navier.time, num_save = 0
   stats_ = std::make_unique<Stats>();
+  stats_attached_ = true;
   Stats& s = *stats_;
   s.save_stat = save_stat; s.write_stat = write_stat; s.tot_time = time_;
   const int ro = sp_ortho_->ortho_rows();
@@ -1467,9 +1504,8 @@ void Navier2DEngine::build_confined() {
   if (P == 1) {
     // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays: no T3, no T4
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
-    double* cz[3] = {yx(Y_[0]), yx(Y_[1]), yx(Y_[2])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
-    add_col_hholtz(cin, cz, cout, mx, "C4 y: hholtz-y (column scan)");
+    add_col_hholtz(cin, cout, mx, "C4 y: hholtz-y (column scan)");
     // d/dy vely for the divergence (rows ny, composite x)
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, mx, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
   } else {
@@ -1544,11 +1580,18 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S6 y: poisson rows");
   }
   if (P == 1) {
-    // ---- G2: back to coefficient space (rows of one parity are 2 ldy apart)
-    add_gemm_pair(true, GemmProblem{po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, PS_.p, 2 * ldy},
-                  GemmProblem{po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy,
-                              PS_.p + ldy, 2 * ldy}, "G2 even + odd");
-    { Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.tag = "pseu[0,0]=0"; step_.push_back(l); }
+    // ---- G2: back to coefficient space, stored TRANSPOSED: the pseudo-pressure arrives in YX layout (row = y
+    // coefficient, the two parity blocks of x side by side -- the column scan below does not care about the order of
+    // its columns and hands them on interleaved), so the y part of the correction needs no transposes at all
+    GemmProblem g0{po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, yx(Y_[4]), ldx};
+    GemmProblem g1{po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy, yx(Y_[4]) + po.half, ldx};
+    g0.ct = g1.ct = true;
+    add_gemm_pair(true, g0, g1, "G2 even + odd");
+    { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
+    // ---- C7: y part of the velocity correction as column scans: from_ortho_y(to_ortho_y ps) and
+    // from_ortho_y(-d/dy to_ortho_y ps), columns interleaved on the way out (no S7, no T5)
+    add_col_corr(yx(Y_[4]), po.half, yx(Y_[2]), yx(Y_[3]), mx, "C7 y: correction-y (column scan)");
+    pseu_half_ = po.half;
   } else {
     T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");
     // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land de-interleaved in x
@@ -1564,25 +1607,24 @@ void Navier2DEngine::build_confined() {
     }
     if (yb_ == 0) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
     T(yx(Y_[4]), PS_.p, my, mx, true, "T4d");
+    // ---- S7: y part of the velocity correction
+    {
+      ProgramBuilder pb = xpb(2, mx);
+      pb.set_fft(yN);
+      pb.load(0, pb.arr(PS_.p, ldy), my);
+      pb.to_ortho(0, yN);
+      pb.cdiff(1, 0, ny, -1.0 / sy_);
+      pb.from_ortho(0, yD);
+      pb.store(0, pb.arr(X_[2].p, ldy), my);
+      pb.from_ortho(1, yD);
+      pb.store(1, pb.arr(X_[3].p, ldy), my);
+      add_line(pb, "S7 y: correction-y");
+    }
+    // ---- T5
+    T(X_[2].p, yx(Y_[2]), mx, my, false, "T5");
+    T(X_[3].p, yx(Y_[3]), mx, my, false, "T5");
+    add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   }
-  // ---- S7: y part of the velocity correction
-  {
-    ProgramBuilder pb = xpb(2, mx);
-    pb.set_fft(yN);
-    pb.load(0, pb.arr(PS_.p, ldy), my);
-    pb.to_ortho(0, yN);
-    pb.cdiff(1, 0, ny, -1.0 / sy_);
-    pb.from_ortho(0, yD);
-    pb.store(0, pb.arr(X_[2].p, ldy), my);
-    pb.from_ortho(1, yD);
-    pb.store(1, pb.arr(X_[3].p, ldy), my);
-    add_line(pb, "S7 y: correction-y");
-  }
-  // ---- T5
-  T(X_[2].p, yx(Y_[2]), mx, my, false, "T5");
-  T(X_[3].p, yx(Y_[3]), mx, my, false, "T5");
-  if (P == 1) T(PS_.p, yx(Y_[4]), mx, my, false, "T5");
-  add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   // ---- S8: x part of the velocity correction
   {
     ProgramBuilder pb = ypb(2, my);   // the two velocity components side by side: their loads travel in pairs
@@ -1608,7 +1650,7 @@ void Navier2DEngine::build_confined() {
   {
     ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xN);
-    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt);
+    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt, false, P == 1 ? po.half : 0);   // one GPU: parity blocks side by side
     pb.to_ortho(0, xN);
     pb.load(0, pb.arr(yx(DIV_), ldx), nx, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nx, 1.0, true);
@@ -1772,9 +1814,8 @@ void Navier2DEngine::build_periodic() {
     // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays (real-linear: the
     // interleaved re / im columns are independent columns)
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
-    double* cz[3] = {yx(Y_[0]), yx(Y_[1]), yx(Y_[2])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
-    add_col_hholtz(cin, cz, cout, nc, "C4 y: hholtz-y (column scan)");
+    add_col_hholtz(cin, cout, nc, "C4 y: hholtz-y (column scan)");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
   } else {
     for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, my, kx, true, "T3");

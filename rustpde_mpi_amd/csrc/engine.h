@@ -81,6 +81,9 @@ class Navier2DEngine {
   // the last snapshot (`nusselt`, statistics.rs:248-271) -- plus avg_time, tot_time, num_save.
   void statistics_enable(double save_stat, double write_stat);   // navier.statistics = Some(Statistics::new(&navier, ..))
   bool statistics_enabled() const { return stats_ != nullptr; }
+  // `navier.statistics = Some(stats)` / `= None` (navier_io.rs:105: the callback only acts on Some): the hook can be
+  // taken off and put back without dropping the accumulated fields.  statistics_enable() leaves it attached.
+  void statistics_attach(bool on) { stats_attached_ = on; }
   void statistics_update();                                       // Statistics::update(temp, velx, vely to_ortho, time)
   void statistics_write(const std::string& filename);             // groups temp, ux, uy, nusselt + tot_time, avg_time, num_save (u64), params
   void statistics_read(const std::string& filename);
@@ -183,6 +186,7 @@ class Navier2DEngine {
   double write_intervall_ = -1.0;   // navier.rs:79 `write_intervall: Option<f64>` (None)
   struct Stats;
   std::unique_ptr<Stats> stats_;   // `statistics: Option<Statistics<T, S>>` (navier.rs:88)
+  bool stats_attached_ = true;     // false: the Statistics exist but `navier.statistics` is None
   int* flagp() const { return reinterpret_cast<int*>(nanflag_.p); }
   bool read_nanflag();
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
@@ -226,8 +230,13 @@ class Navier2DEngine {
   void add_halo(double* base, int ncols, const char* tag);
   // Helmholtz solve along y of the three fields on YX arrays / Chebyshev y-derivative of a YX array
   // (single GPU: column scans instead of transpose -> line program -> transpose)
-  void add_col_hholtz(const double* const in[3], double* const z[3], double* const out[3], int ncols, const char* tag);
+  void add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag);
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
+  void add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag);
+  ColHhDev colcorr_a_, colcorr_b_;   // column problems of the velocity correction (confined, one GPU)
+  DBuf coldot_, colkap_;             // rank-one sums of the column scans
+  int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
+  bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);

@@ -1,5 +1,7 @@
 #include "h5lite.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -152,8 +154,15 @@ void write_file(const std::string& filename, const Tree& tree) {
   f.u64(0); f.u64(0); f.u32(1); f.u32(0); f.u64(0); f.u64(0);
   RPDE_REQUIRE(f.size() == 96, "h5lite: superblock layout");
 
-  FILE* fp = std::fopen(filename.c_str(), "wb");
-  RPDE_REQUIRE(fp != nullptr, "h5lite: cannot create " + filename);
+  // crash safety: everything goes to <filename>.tmp, which replaces the target by rename() only after a complete,
+  // flushed write -- an interrupted write never costs the previous snapshot / statistics file
+  const std::string tmpname = filename + ".tmp";
+  struct FileGuard {
+    FILE* fp; std::string tmp;
+    ~FileGuard() { if (fp) { std::fclose(fp); std::remove(tmp.c_str()); } }   // reached with fp set only on a throw
+  } guard{std::fopen(tmpname.c_str(), "wb"), tmpname};
+  FILE* fp = guard.fp;
+  RPDE_REQUIRE(fp != nullptr, "h5lite: cannot create " + tmpname);
   // raw data first (addresses are needed by the dataset headers); streamed, not buffered
   std::map<const Dataset*, uint64_t> addr;
   uint64_t pos = 96;
@@ -192,7 +201,14 @@ void write_file(const std::string& filename, const Tree& tree) {
   f.patch64(root_entry + 32, rhp);
   std::fseek(fp, 0, SEEK_SET);
   RPDE_REQUIRE(std::fwrite(f.b.data(), 1, 96, fp) == 96, "h5lite: short write");
-  std::fclose(fp);
+  RPDE_REQUIRE(std::fflush(fp) == 0, "h5lite: flush failed for " + tmpname);
+  (void)fsync(fileno(fp));
+  guard.fp = nullptr;
+  RPDE_REQUIRE(std::fclose(fp) == 0, "h5lite: close failed for " + tmpname);
+  if (std::rename(tmpname.c_str(), filename.c_str()) != 0) {
+    std::remove(tmpname.c_str());
+    RPDE_REQUIRE(false, "h5lite: cannot move " + tmpname + " over " + filename);
+  }
 }
 
 void update_file(const std::string& filename, const Tree& tree) {
@@ -218,6 +234,10 @@ Reader::Reader(const std::string& filename) {
   FILE* fp = std::fopen(filename.c_str(), "rb");
   RPDE_REQUIRE(fp != nullptr, "h5lite: cannot open " + filename);
   f_ = fp;
+  struct Closer {   // a throwing constructor never reaches ~Reader
+    void** f; bool armed = true;
+    ~Closer() { if (armed && *f) { std::fclose(static_cast<FILE*>(*f)); *f = nullptr; } }
+  } closer{&f_};
   std::fseek(fp, 0, SEEK_END);
   size_ = (uint64_t)std::ftell(fp);
   uint8_t sb[128] = {0};
@@ -234,12 +254,13 @@ Reader::Reader(const std::string& filename) {
   base_ = le(sb + 24 + o, 8);
   const uint64_t root_oh = le(sb + 56 + o + 8, 8);
   walk_group(base_ + root_oh, "", 0);
+  closer.armed = false;
 }
 
 Reader::~Reader() { if (f_) std::fclose(static_cast<FILE*>(f_)); }
 
 void Reader::pread_(void* dst, uint64_t off, uint64_t n) const {
-  RPDE_REQUIRE(off + n <= size_, "h5lite: read past the end of the file (corrupt address)");
+  RPDE_REQUIRE(n <= size_ && off <= size_ - n, "h5lite: read past the end of the file (corrupt address)");
   FILE* fp = static_cast<FILE*>(f_);
   std::fseek(fp, (long)off, SEEK_SET);
   RPDE_REQUIRE(std::fread(dst, 1, n, fp) == n, "h5lite: short read");

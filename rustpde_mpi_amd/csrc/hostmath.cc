@@ -207,36 +207,85 @@ ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR) {
   ColHhHost h;
   const int n = (int)f.p2.size();
   h.n = n; h.BR = BR; h.NB = (n + BR - 1) / BR;
-  auto padded = [&](const Vec& v) { Vec o(n, 0.0); std::copy(v.begin(), v.begin() + std::min<size_t>(v.size(), n), o.begin()); return o; };
+  const size_t np = (size_t)h.NB * BR + 4;   // zero padding: rows past the system come out as zeros without a branch
+  auto padded = [&](const Vec& v) { Vec o(np, 0.0); std::copy(v.begin(), v.begin() + std::min<size_t>(v.size(), n), o.begin()); return o; };
   h.t0 = padded(pv.t0); h.t1 = padded(pv.t1); h.t2 = padded(pv.t2);
   h.q1 = padded(f.q1); h.p2 = padded(f.p2); h.q2 = padded(f.q2); h.r2 = padded(f.r2);
-  h.h1a.assign(n, 0.0); h.h1b.assign(n, 0.0); h.h2b.assign(n, 0.0);
   h.m1.assign((size_t)h.NB * 2, 0.0);
   h.m2.assign((size_t)h.NB * 8, 0.0);
+  h.g.assign((size_t)h.NB * 4, 0.0);
+  std::vector<long double> ya(np, 0.0L);
   for (int b = 0; b < h.NB; ++b) {
     const int j0 = b * BR, j1 = std::min(j0 + BR, n);
     for (int par = 0; par < 2; ++par) {
       // forward chain (ascending): response to a unit inflow y_{j0+par-2} = 1
       long double y = 1.0L;
-      for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; h.h1a[j] = (double)y; }
+      for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; ya[j] = y; }
       h.m1[(size_t)b * 2 + par] = (double)y;   // an empty chain keeps the inflow (m = 1)
-      // backward chain (descending): runs from the inflow states (1,0) and (0,1)
-      long double x1[2] = {1.0L, 0.0L}, x2[2] = {0.0L, 1.0L};
+      // backward chain (descending): runs from the inflow states (1,0) and (0,1); third column: zero inflow state,
+      // driven by the forward response above (what a unit of forward inflow leaves at the block's lower end)
+      long double x1[3] = {1.0L, 0.0L, 0.0L}, x2[3] = {0.0L, 1.0L, 0.0L};
       int jt = j1 - 1;
       if ((jt & 1) != par) --jt;                // highest row of this parity in the block
       for (int j = jt; j >= j0; j -= 2) {
-        for (int c = 0; c < 2; ++c) {
-          const long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
+        for (int c = 0; c < 3; ++c) {
+          long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
+          if (c == 2) nw += (long double)h.p2[j] * ya[j];
           x2[c] = x1[c]; x1[c] = nw;
         }
-        h.h1b[j] = (double)x1[0];
-        h.h2b[j] = (double)x1[1];
       }
       double* m = &h.m2[((size_t)b * 2 + par) * 4];
       m[0] = (double)x1[0]; m[1] = (double)x1[1]; m[2] = (double)x2[0]; m[3] = (double)x2[1];
+      h.g[((size_t)b * 2 + par) * 2 + 0] = (double)x1[2];
+      h.g[((size_t)b * 2 + par) * 2 + 1] = (double)x2[2];
     }
   }
   return h;
+}
+
+ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR) {
+  RPDE_REQUIRE(bd.is_composite() && bn.is_composite() && bd.m == bn.m && bd.n == bn.n, "colcorr: two composite bases of one size");
+  const int m = bd.m, n = bd.n;
+  const Vec lowd = stencil_low(bd), lown = stencil_low(bn);
+  for (int k = 0; k < m; ++k) RPDE_REQUIRE(lowd[k] == -1.0, "colcorr: the target base must carry the Dirichlet stencil");
+  const FromOrthoTables fo = from_ortho_tables(bd);
+  FdmaTables f{fo.q_up, Vec(m, 1.0), fo.q_dn, Vec(m, 0.0)};
+  auto ln = [&](int k) { return (k >= 0 && k < m) ? lown[k] : 0.0; };
+  ColCorrHost out;
+  {   // a: rhs_k = c_k + lowd_k c_{k+2}, c = S_N ps
+    Mv3Tables t{Vec(m), Vec(m), Vec(m)};
+    for (int k = 0; k < m; ++k) {
+      t.t0[k] = fo.p_up[k] * ln(k - 2);
+      t.t1[k] = fo.p_up[k] * (1.0 + lowd[k] * ln(k));
+      t.t2[k] = fo.p_up[k] * lowd[k];
+    }
+    out.a = build_colhh_tables(t, f, BR);
+  }
+  {   // b: rhs_k = dscale 2 (k + 1) c_{k+1} (k >= 1), rhs_0 = dscale (c_1 - d_2 / 2)
+    Mv3Tables t{Vec(m), Vec(m), Vec(m, 0.0)};
+    for (int k = 0; k < m; ++k) {
+      const double sk = (k == 0) ? dscale : dscale * 2.0 * (double)(k + 1);
+      t.t0[k] = fo.p_up[k] * sk * ln(k - 1);
+      t.t1[k] = fo.p_up[k] * sk;
+    }
+    out.b = build_colhh_tables(t, f, BR);
+    const size_t np = out.b.t0.size();
+    // kappa = -dscale / 2 * d_2,  d_2 = sum_{odd j >= 3} 2 j c_j,  c_j = ps_j + lown_{j-2} ps_{j-2}
+    out.b.w.assign(np, 0.0);
+    for (int j = 1; j < m; j += 2) {
+      double wj = (j >= 3) ? 2.0 * j : 0.0;
+      if (j + 2 <= n - 1) wj += 2.0 * (j + 2) * lown[j];
+      out.b.w[j] = -0.5 * dscale * wj;
+    }
+    // response to a unit right-hand side in row 0 (even chain): g_0 = p_0, g_k = q_k g_{k-2}; x_k = g_k + qd_k x_{k+2}
+    out.b.h.assign(np, 0.0);
+    std::vector<long double> g(m, 0.0L);
+    long double y = 0.0L;
+    for (int k = 0; k < m; k += 2) { y = (k == 0) ? (long double)fo.p_up[0] : (long double)fo.q_up[k] * y; g[k] = y; }
+    long double x = 0.0L;
+    for (int k = ((m - 1) & ~1); k >= 0; k -= 2) { x = g[k] + (long double)fo.q_dn[k] * x; out.b.h[k] = (double)x; }
+  }
+  return out;
 }
 
 // ------------------------------------------------------------------------------------- LAPACK

@@ -64,13 +64,24 @@ struct FdmaTables { Vec q1, p2, q2, r2; };
 FdmaTables fdma_tables(const Bands& swept);
 
 // Tables of the column-scan Helmholtz solve (colscan.h) for one swept Fdma and its B2 preconditioner,
-// rows cut into blocks of BR: per-row coefficients, the responses to unit block inflows and the
-// block transfer matrices of the forward (first-order) and backward (second-order) chains.
+// rows cut into blocks of BR: per-row coefficients (zero-padded to NB * BR + 4), the block transfer
+// factors / matrices of the forward (first-order) and backward (second-order) chains, and `g`: the backward
+// end state a block reaches from a zero backward inflow per unit of its forward inflow.
 struct ColHhHost {
   int n = 0, BR = 0, NB = 0;
-  Vec t0, t1, t2, q1, h1a, m1, p2, q2, r2, h1b, h2b, m2;
+  Vec t0, t1, t2, q1, m1, p2, q2, r2, m2, g;
+  Vec w, h;   // optional rank-one term (colscan.h): weights of the column sum, response; empty: none
 };
 ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR);
+// y part of the velocity correction (navier_eq.rs:117-125) as two banded column problems on the pseudo-pressure
+// (Neumann-composite rows, base `bn`), results in the Dirichlet-composite base `bd` of the velocities:
+//   a = from_ortho_D( to_ortho_N(ps) )                          taps ps_{k-2}, ps_k, ps_{k+2}          (shift 2)
+//   b = from_ortho_D( dscale * d/dy to_ortho_N(ps) )            taps ps_{k-1}, ps_{k+1} + rank-one term (shift 1)
+// For the Dirichlet stencil (c_k = a_k - a_{k-2}) the right-hand side of the projection, S^T d = d_k - d_{k+2}, is the
+// LOCAL term 2 (k + 1) c_{k+1} of the derivative's recurrence d_k = d_{k+2} + 2 (k + 1) c_{k+1}; only row 0 (d_0 is
+// halved) keeps a sum over the column: rhs_0 = dscale (c_1 - d_2 / 2) -- the rank-one term.
+struct ColCorrHost { ColHhHost a, b; };
+ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR);
 
 // dense helpers (row-major) + LAPACK (loaded at run time from the OpenBLAS that ships with SciPy,
 // the same library family the reference links: Cargo.toml:39,45-46)

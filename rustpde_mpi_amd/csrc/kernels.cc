@@ -57,7 +57,8 @@ RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long l
   }
 }
 
-int g_hdct = [] { const char* e = std::getenv("RPDE_HDCT"); return e ? std::atoi(e) : 1; }();   // which whole-line kernels run on the half-length core (hdct_line.h) instead of dct_line.h: bit 0 the pure transform, bit 1 the S1 pair, bit 2 the convection term (A/B switch)
+int g_hdct = [] { const char* e = std::getenv("RPDE_HDCT"); return e ? std::atoi(e) : 3; }();   // which whole-line kernels run on the half-length core (hdct_line.h) instead of dct_line.h: bit 0 the pure transform, bit 1 the S1 pair, bit 2 the convection term (A/B switch)
+static const int g_rhs_wpc = [] { const char* e = std::getenv("RPDE_RHS_WPC"); return e ? std::atoi(e) : 3; }();   // workgroups per CU the register budget of rhs_line is cut for (measured: 3 without spills 0.215 / 0.267 / 0.214 ms, 4 with 70 - 90 spilled registers 0.258 / 0.315 / 0.275)
 int g_dct_line_pf = [] { const char* e = std::getenv("RPDE_DCT_PF"); return e ? std::atoi(e) : 0; }();   // A/B switch (tools, microbench)
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
@@ -324,9 +325,33 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
 // two independent products in one launch (blockIdx.z picks): the even and the odd block of the Poisson
 // eigen-transforms.  512 tiles are exactly one round on 256 CUs with two workgroups each -- prologue, epilogue
 // and the store burst of a round are not hidden; 1024 tiles give every CU a second round to overlap them with
-struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; };
+struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; bool ct; };
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: in the linear
+// order an XCD works on a few n-tiles of EVERY m-tile, so each of the 8 L2s pulls the whole A operand (measured:
+// 2.4 x the operand bytes).  With rx * ry = 8 rectangular regions of bw x bh tiles, one per XCD, the panels an L2
+// has to hold are bw + bh instead of gx / 8 + gy (32 x 16 tiles: 8 + 8 instead of 4 + 16).  bw == 0: linear order.
+struct GemmSwizzle { int rx = 0, bw = 0, bh = 0; };
+static GemmSwizzle gemm_swizzle(int gx, int gy) {
+  static const bool on = [] { const char* e = std::getenv("RPDE_GEMM_SWIZZLE"); return !e || std::atoi(e) != 0; }();
+  GemmSwizzle best;
+  if (!on || (gx * gy) % 8) return best;
+  int cost = 1 << 30;
+  for (int rx = 1; rx <= 8; rx *= 2) {
+    const int ry = 8 / rx;
+    if (gx % rx || gy % ry) continue;
+    if (gx / rx + gy / ry < cost) { cost = gx / rx + gy / ry; best = GemmSwizzle{rx, gx / rx, gy / ry}; }
+  }
+  return best;
+}
+__device__ __forceinline__ void gemm_tile_of_block(const GemmSwizzle& z, int& tx, int& ty) {
+  tx = (int)blockIdx.x; ty = (int)blockIdx.y;
+  if (z.bw == 0) return;
+  const int l = tx + (int)gridDim.x * ty, xcd = l & 7, s = l >> 3;
+  tx = (xcd % z.rx) * z.bw + s % z.bw;
+  ty = (xcd / z.rx) * z.bh + s / z.bw;
+}
 template <bool NN, int DB>
-__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1);
+__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z);
 
 // Variant 4: the same tiling with the pipeline written out.  Two LDS stages (64 KB): the operands of stage
 // t + 1 are written while stage t feeds the MFMAs, so one barrier per stage instead of two; the fragments of
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 template <bool NN, int TM>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
-                                                 int tile_m, int tile_n) {
+                                                 int tile_m, int tile_n, bool ct = false) {
   constexpr int BK = 16, KS = 4;
   constexpr int MT = TM / 32;          // MFMA tiles per wave and dimension
   constexpr int TPR = 256 / TM;        // threads per operand row (k contiguous)
@@ -471,7 +496,8 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM / 2) + i * 16 + l4 + 4 * r;
-        if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r];
+        // ct: C^T -- the four lanes of a column write 32 contiguous bytes of row n, the four registers the 128 bytes
+        if (m < M && n < N) C[ct ? (long)n * ldc + m : (long)m * ldc + n] = acc[i][j][r];
       }
     }
 }
@@ -485,13 +511,15 @@ __global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
 }
 // DB: 0 = one-stage 128-tile, 1 = two-stage 128-tile, 2 = two-stage 64-tile
 template <bool NN, int DB>
-__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1) {
+__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
   constexpr int TM = DB == 2 ? 64 : 128;
-  if ((int)blockIdx.y * TM >= g.M || (int)blockIdx.x * TM >= g.N) return;
-  if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
-  else if constexpr (DB == 1) gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
-  else gemm_f64_tile<NN, 16, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, (int)blockIdx.y, (int)blockIdx.x);
+  int tx, ty;
+  gemm_tile_of_block(z, tx, ty);
+  if (ty * TM >= g.M || tx * TM >= g.N) return;
+  if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+  else if constexpr (DB == 1) gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+  else gemm_f64_tile<NN, 16, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx);
 }
 
 template <bool NN>
@@ -517,6 +545,7 @@ static void launch_gemm(int M, int N, int K, const double* A, long lda, const do
 }
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
   if (p0.M <= 0 || p0.N <= 0 || p1.M <= 0 || p1.N <= 0) {
+    RPDE_REQUIRE(!(p0.ct || p1.ct), "transposed store: both problems must be non-empty");
     for (const GemmProblem* p : {&p0, &p1}) {
       if (nn) launch_gemm<true>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
       else launch_gemm<false>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
@@ -524,20 +553,25 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     return;
   }
   static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
-  const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc};
+  const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc, p0.ct}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.ct};
+  RPDE_REQUIRE(!(p0.ct || p1.ct) || variant == 4, "transposed store: two-stage GEMM variant only");
   const int Mx = std::max(p0.M, p1.M), Nx = std::max(p0.N, p1.N);
   dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, 2);
   const bool db = variant == 4;
   if (db && (long)grid.x * grid.y * 2 < kGemmSmallTileBelow) {
     dim3 g64((Nx + 63) / 64, (Mx + 63) / 64, 2);
-    if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1);
-    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1);
-  } else if (nn) {
-    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1);
-    else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 0>), grid, dim3(256), 0, st.s, g0, g1);
+    const GemmSwizzle z = gemm_swizzle((int)g64.x, (int)g64.y);
+    if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
   } else {
-    if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 1>), grid, dim3(256), 0, st.s, g0, g1);
-    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 0>), grid, dim3(256), 0, st.s, g0, g1);
+    const GemmSwizzle z = gemm_swizzle((int)grid.x, (int)grid.y);
+    if (nn) {
+      if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 0>), grid, dim3(256), 0, st.s, g0, g1, z);
+    } else {
+      if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 0>), grid, dim3(256), 0, st.s, g0, g1, z);
+    }
   }
   RPDE_HIP(hipGetLastError());
 }
@@ -606,11 +640,9 @@ template <int PASS>
 __global__ __launch_bounds__(256) void col_hholtz_kernel(const ColHhArgs a) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x), f = (int)blockIdx.z;
   if (i >= a.ncols) return;
-  if constexpr (PASS == 0) colhh_fwd(a, f, (int)blockIdx.y, i);
-  if constexpr (PASS == 1) colhh_carry1(a, f, i, (int)blockIdx.y);
-  if constexpr (PASS == 2) colhh_mid(a, f, (int)blockIdx.y, i);
-  if constexpr (PASS == 3) colhh_carry2(a, f, i, (int)blockIdx.y);
-  if constexpr (PASS == 4) colhh_fin(a, f, (int)blockIdx.y, i);
+  if constexpr (PASS == 0) colhh_block<false>(a, f, (int)blockIdx.y, i);
+  if constexpr (PASS == 1) colhh_carry(a, f, i, (int)blockIdx.y);
+  if constexpr (PASS == 2) colhh_block<true>(a, f, (int)blockIdx.y, i);
 }
 void launch_col_hholtz(const ColHhArgs& a, Stream& st) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0) return;
@@ -618,8 +650,6 @@ void launch_col_hholtz(const ColHhArgs& a, Stream& st) {
   hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, blk, 0, st.s, a);
   hipLaunchKernelGGL(col_hholtz_kernel<2>, gb, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_hholtz_kernel<3>, gc, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_hholtz_kernel<4>, gb, blk, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
 }
 template <int PASS>
@@ -694,8 +724,8 @@ __global__ __launch_bounds__(N / 16, 4) void hdct_line_kernel(const DctLineArgs 
   hdct_bwd_line<N>(blk, a);
   RPDE_TRACE_END();
 }
-template <int N>
-__global__ __launch_bounds__(N / 16, 4) void hdct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
+template <int N, int WPC = 4>
+__global__ __launch_bounds__(N / 16, WPC) void hdct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -705,8 +735,8 @@ __global__ __launch_bounds__(N / 16, 4) void hdct_line2_kernel(const DctLineArgs
   __syncthreads();
   hdct_bwd_line<N>(blk, a1);
 }
-template <int N>
-__global__ __launch_bounds__(N / 16, 3) void hconv_line_kernel(const ConvLineArgs c) {
+template <int N, int WPC = 3>
+__global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -714,8 +744,8 @@ __global__ __launch_bounds__(N / 16, 3) void hconv_line_kernel(const ConvLineArg
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
   hconv_line<N>(blk, c);
 }
-template <int N, int WHICH, bool TRACE = false>
-__global__ __launch_bounds__(N / 16, 4) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
+template <int N, int WHICH, bool TRACE = false, int WPC = 4>
+__global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -732,6 +762,10 @@ bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
     if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, true>), grid, block, 0, st.s, a, trace);
     else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, true>), grid, block, 0, st.s, a, trace);
     else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, true>), grid, block, 0, st.s, a, trace);
+  } else if (g_rhs_wpc == 3) {   // default: register budget of three workgroups per CU (no spills) instead of four
+    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, false, 3>), grid, block, 0, st.s, a, trace);
+    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, false, 3>), grid, block, 0, st.s, a, trace);
+    else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, false, 3>), grid, block, 0, st.s, a, trace);
   } else if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0>), grid, block, 0, st.s, a, trace);
   else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1>), grid, block, 0, st.s, a, trace);
   else hipLaunchKernelGGL((rhs_line_kernel<4096, 2>), grid, block, 0, st.s, a, trace);
@@ -783,7 +817,9 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   if (c.N != 4096 || !conv_line_ok(c)) return false;
   if (c.nlines <= 0) return true;
   if (g_hdct & 4) {
-    hipLaunchKernelGGL(hconv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+    static const int wpc = [] { const char* e = std::getenv("RPDE_CONV_WPC"); return e ? std::atoi(e) : 3; }();   // A/B switch
+    if (wpc == 2) hipLaunchKernelGGL((hconv_line_kernel<4096, 2>), dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+    else hipLaunchKernelGGL(hconv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
@@ -795,7 +831,9 @@ bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) 
   if (a0.N != 4096 || a1.N != 4096 || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   if (a0.nlines <= 0) return true;
   if (g_hdct & 2) {
-    hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+    static const int wpc = [] { const char* e = std::getenv("RPDE_S1_WPC"); return e ? std::atoi(e) : 4; }();   // A/B switch
+    if (wpc == 3) hipLaunchKernelGGL((hdct_line2_kernel<4096, 3>), dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+    else hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
     RPDE_HIP(hipGetLastError());
     return true;
   }
@@ -986,8 +1024,16 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 }
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
   for (const GemmProblem* p : {&p0, &p1}) {
-    if (nn) launch_gemm_nn(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
-    else launch_gemm_nt(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
+    if (p->M <= 0 || p->N <= 0) continue;
+    std::vector<double> tmp;
+    double* C = p->C;
+    long ldc = p->ldc;
+    if (p->ct) { tmp.resize((size_t)p->M * p->N); C = tmp.data(); ldc = p->N; }
+    if (nn) launch_gemm_nn(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, C, ldc, st);
+    else launch_gemm_nt(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, C, ldc, st);
+    if (p->ct)
+      for (int m = 0; m < p->M; ++m)
+        for (int n = 0; n < p->N; ++n) p->C[(long)n * p->ldc + m] = tmp[(size_t)m * p->N + n];
   }
 }
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream&) {
@@ -1039,11 +1085,9 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
 }
 void launch_col_hholtz(const ColHhArgs& a, Stream&) {
   for (int f = 0; f < a.nf; ++f) {
-    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fwd(a, f, b, i);
-    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry1(a, f, i, par);
-    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_mid(a, f, b, i);
-    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry2(a, f, i, par);
-    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_fin(a, f, b, i);
+    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<false>(a, f, b, i);
+    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry(a, f, i, par);
+    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<true>(a, f, b, i);
   }
 }
 void launch_col_diff(const ColDiffArgs& a, Stream&) {

@@ -40,7 +40,8 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
                     double* C, long ldc, Stream& st);
 // two independent products of the same kind (nn: both as launch_gemm_nn, else as launch_gemm_nt) in ONE launch
 struct GemmProblem { int M = 0, N = 0, K = 0; const double* A = nullptr; long lda = 0; const double* B = nullptr; long ldb = 0;
-                     double* C = nullptr; long ldc = 0; };
+                     double* C = nullptr; long ldc = 0;
+                     bool ct = false; };   // ct: store the product transposed, C[n * ldc + m] (launch_gemm_pair only)
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st);
 
 // out[r * ldo + c] = in[r * ldi + c], r < rows, c < cols (doubles)
@@ -71,7 +72,7 @@ void launch_col_diff(const ColDiffArgs& a, Stream& st);
 // not covered (the caller runs the line program instead)
 struct DctLineArgs;
 bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace = nullptr);   // trace: diagnostics record (kTraceStride words per workgroup)
-extern int g_hdct;          // bit mask: which whole-line kernels run on the half-length core (hdct_line.h) -- 1 pure transform (default), 2 S1 pair, 4 convection term; RPDE_HDCT, A/B switch
+extern int g_hdct;          // bit mask: which whole-line kernels run on the half-length core (hdct_line.h) -- 1 pure transform, 2 S1 pair (default: both), 4 convection term; RPDE_HDCT, A/B switch
 extern int g_dct_line_pf;   // 0: one line per workgroup; 3 / 4: persistent workgroups with a prefetched next line (A/B switch, RPDE_DCT_PF)
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2

@@ -121,7 +121,7 @@ enum OpCode : int {
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;
                // b = 1 (OP_LOAD / OP_LOADX): the NEXT op is a plain OP_LOAD executed together with this one (both lines' loads in flight at once)
                // i0 = 2: interleaved complex line times i*kappa (kappa = pair index): d[2j] (+)= -s0 j Im A_j, d[2j+1] (+)= s0 j Re A_j
-  OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][k] + [line>=2] tab[line-2] A[line-2][k])
+  OP_LOADX,    // d[k] = (acc ? d[k] : 0) + s0 * ([line<i1] A[line][map(k)] + [line>=2] tab[line-2] A[line-2][map(k)]); i0 = half > 0: parity map (unpaired form only)
   OP_STORE,    // A[line][map(k)] = s0 * a[k]   k < n ; i0 = 1: parity de-interleave, half = i1;
                // acc = 1: NaN guard -- a stored NaN raises *Program::nanflag (Integrate::exit, navier.rs:482-489)
   OP_STEN,     // d[k] = [k<n-2] a[k] + [k>=2] tab[k-2] * a[k-2]              k < n  (n = ortho length);
@@ -1338,8 +1338,9 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {
             const int k = tid + q * T;
-            v0[q] = (has0 && k < n) ? s0p[(long)k * es] : 0.0;
-            v2[q] = (has2 && k < n) ? s2p[(long)k * es] : 0.0;
+            const long kk = op.i0 ? ((long)(k & 1) * op.i0 + (k >> 1)) : (long)k;   // i0 = half: parity de-interleaved rows
+            v0[q] = (has0 && k < n) ? s0p[kk * es] : 0.0;
+            v2[q] = (has2 && k < n) ? s2p[kk * es] : 0.0;
           }
 #pragma unroll
           for (int q = 0; q < EPT; ++q) {

@@ -103,8 +103,8 @@ void ProgramBuilder::load_cik(int d, int a, int n, double s0, bool acc) {
 void ProgramBuilder::loadmul(int d, int a, int n, double s0) {
   Op& o = push(OP_LOAD); o.d = d; o.arr = a; o.n = n; o.s0 = s0; o.acc = 2;
 }
-void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, double s0, bool acc) {
-  Op& o = push(OP_LOADX); o.d = d; o.arr = a; o.n = n; o.i1 = rows; o.tab = tab(lowtab); o.s0 = s0; o.acc = acc;
+void ProgramBuilder::loadx(int d, int a, int n, int rows, const double* lowtab, double s0, bool acc, int half) {
+  Op& o = push(OP_LOADX); o.d = d; o.arr = a; o.n = n; o.i1 = rows; o.tab = tab(lowtab); o.s0 = s0; o.acc = acc; o.i0 = half;
 }
 void ProgramBuilder::pair_last_loads() {
   RPDE_REQUIRE(pg.nops >= 2, "pair_last_loads: two load ops expected");
@@ -112,7 +112,7 @@ void ProgramBuilder::pair_last_loads() {
   const Op& o2 = pg.ops[pg.nops - 1];
   RPDE_REQUIRE(o2.code == OP_LOAD && o2.i0 == 0 && pg.arr[o2.arr].es == 1, "pair_last_loads: the second op must be a plain load");
   RPDE_REQUIRE((o1.code == OP_LOAD && o1.i0 == 0 && pg.arr[o1.arr].es == 1 && o1.b == 0) ||
-                   (o1.code == OP_LOADX && o1.b == 0),
+                   (o1.code == OP_LOADX && o1.b == 0 && o1.i0 == 0),
                "pair_last_loads: the first op must be a plain load or a cross-line load");
   RPDE_REQUIRE(pg.nops < 3 || pg.ops[pg.nops - 3].b == 0 || (pg.ops[pg.nops - 3].code != OP_LOAD && pg.ops[pg.nops - 3].code != OP_LOADX),
                "pair_last_loads: the first op already belongs to a pair");
@@ -404,8 +404,9 @@ void Space2Ops::gradient(const Arr2& vhat, int d0, int d1, double s0, double s1,
 // ------------------------------------------------------------------------------------------
 void ColHhDev::upload(const ColHhHost& h) {
   n = h.n; BR = h.BR; NB = h.NB;
-  t0.upload(h.t0); t1.upload(h.t1); t2.upload(h.t2); q1.upload(h.q1); h1a.upload(h.h1a); m1.upload(h.m1);
-  p2.upload(h.p2); q2.upload(h.q2); r2.upload(h.r2); h1b.upload(h.h1b); h2b.upload(h.h2b); m2.upload(h.m2);
+  t0.upload(h.t0); t1.upload(h.t1); t2.upload(h.t2); q1.upload(h.q1); m1.upload(h.m1);
+  p2.upload(h.p2); q2.upload(h.q2); r2.upload(h.r2); m2.upload(h.m2); g.upload(h.g);
+  if (!h.w.empty()) { w.upload(h.w); hr.upload(h.h); }
 }
 
 HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {

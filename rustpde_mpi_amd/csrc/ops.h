@@ -61,7 +61,7 @@ class ProgramBuilder {
   // interleaved complex line (n doubles) times i*kappa while loading: d (+)= s0 * (i kappa) * A
   void load_cik(int d, int arr, int n, double s0 = 1.0, bool acc = false);
   void set_line0(int line0) { pg.line0 = line0; }
-  void loadx(int d, int arr, int n, int rows, const double* lowtab, double s0 = 1.0, bool acc = false);
+  void loadx(int d, int arr, int n, int rows, const double* lowtab, double s0 = 1.0, bool acc = false, int deinterleave_half = 0);
   void store(int a, int arr, int n, double s0 = 1.0, int deinterleave_half = 0);
   // the last op (a plain OP_STORE) raises *flag when it stores a NaN: the device-side form of
   // Integrate::exit (navier.rs:482-489) -- no extra pass over the fields, no allocation
@@ -161,12 +161,12 @@ class Space2Ops {
 
 // device tables of the column-scan form of one Helmholtz-y solve (colscan.h)
 struct ColHhDev {
-  DBuf t0, t1, t2, q1, h1a, m1, p2, q2, r2, h1b, h2b, m2;
+  DBuf t0, t1, t2, q1, m1, p2, q2, r2, m2, g, w, hr;
   int n = 0, BR = 0, NB = 0;
   void upload(const ColHhHost& h);
-  ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, h1a.p, m1.p, p2.p, q2.p, r2.p, h1b.p, h2b.p, m2.p}; }
+  ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, m1.p, p2.p, q2.p, r2.p, m2.p, g.p, w.p, hr.p}; }
 };
-constexpr int kColBlockRows = 32;   // multiple of colscan.h's kColBatch; 128 blocks at 4097: three full rounds of waves
+constexpr int kColBlockRows = kColBR; // rows per block of the column scans (colscan.h)
 
 // HholtzAdi (src/solver/hholtz_adi.rs:48-76,149-169) on canonical arrays
 class HholtzAdiOp {

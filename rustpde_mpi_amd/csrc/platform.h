@@ -187,20 +187,22 @@ inline void dev_sync(Stream& st) {
 struct DBuf {
   double* p = nullptr;
   size_t n = 0;
+  double* base = nullptr;   // what the allocator returned
   DBuf() = default;
   explicit DBuf(size_t count) { alloc(count); }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
-  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n), base(o.base) { o.p = nullptr; o.n = 0; o.base = nullptr; }
   DBuf& operator=(DBuf&& o) noexcept {
-    if (this != &o) { dev_free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { dev_free(base); p = o.p; n = o.n; base = o.base; o.p = nullptr; o.n = 0; o.base = nullptr; }
     return *this;
   }
-  ~DBuf() { dev_free(p); }
+  ~DBuf() { dev_free(base); }
   void alloc(size_t count) {
-    dev_free(p);
+    dev_free(base);
     n = count;
-    p = static_cast<double*>(dev_alloc(count * sizeof(double)));
+    base = static_cast<double*>(dev_alloc(count * sizeof(double)));
+    p = base;
   }
   // tables are uploaded with kUploadSlack zero doubles behind them: device code reads table
   // entries without bounds checks up to the per-thread capacity of a line kernel

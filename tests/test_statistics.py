@@ -76,6 +76,25 @@ def test_callback_updates_and_writes_statistics(emu_lib, tmp_path, monkeypatch):
         other.statistics = st                              # statistics belong to their engine
 
 
+def test_statistics_none_detaches_the_hook(emu_lib, tmp_path, monkeypatch):
+    """`statistics: Option<Statistics>` (navier.rs:88): the callback acts on Some only (navier_io.rs:105); creating a
+    Statistics does not hook it, assigning None takes the hook off and keeps the data, assigning it again resumes."""
+    monkeypatch.chdir(tmp_path)
+    nav, _ = K.make_pair(emu_lib, False, 17, 17, 1e4, 1.0, 0.01, 1.0)
+    st = R.Statistics.new(nav, 0.02, 0.04)                 # not assigned: Statistics::new alone changes nothing
+    R.integrate(nav, 0.04, save_intervall=0.01)
+    assert st.num_save == 0 and not os.path.exists("data/statistics.h5")
+    nav.statistics = st
+    R.integrate(nav, 0.08, save_intervall=0.01)
+    assert st.num_save == 2                                # t = 0.06, 0.08
+    nav.statistics = None
+    R.integrate(nav, 0.12, save_intervall=0.01)
+    assert nav.statistics is None and st.num_save == 2     # detached: no update, the data stays
+    nav.statistics = st
+    R.integrate(nav, 0.14, save_intervall=0.01)
+    assert st.num_save == 3
+
+
 @pytest.mark.gpu
 def test_statistics_on_the_gpu(hip_lib, tmp_path):
     st, so = K.check_statistics(hip_lib, False, 129, 65, ra=1e5)
