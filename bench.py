@@ -133,6 +133,43 @@ def parity_vs_oracle(make, ora, nsteps, shared):
             "ok": all(v < PARITY_TOL for v in rel.values())}
 
 
+def parity_independent_golden(make, args):
+    """The engine on its OWN setup (one dgeev per parity block, C++) against committed samples of the oracle run in the
+    REFERENCE's setup (ONE dgeev of the whole x operator, src/solver/utils.rs:67-99) -- tests/golden/make_headline_golden.py,
+    up to 200 steps of this workload.  Per snapshot and field: relative L2 over the sample points, next to the oracle's own
+    full-vs-parity difference at that step (the start-up transient of DESIGN.md section 4).  None when no golden file
+    exists for the workload."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", f"headline_{args.nx}_full.npz")
+    if args.periodic or args.nx != args.ny or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if abs(float(g["ra"]) - args.ra) > 0 or abs(float(g["dt"]) - args.dt) > 0 or abs(args.aspect - 1.0) > 0:
+        return None
+    stride = int(g["stride"])
+    nav = make(None)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    rows, done = [], 0
+    for s in [int(v) for v in g["snaps"]]:
+        if f"velx_{s}" not in g.files:
+            continue
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        rel = {k: float(np.linalg.norm(f[k][::stride, ::stride] - g[f"{k}_{s}"]) / np.linalg.norm(g[f"{k}_{s}"]))
+               for k in ("velx", "vely", "temp", "pres")}
+        fvp = {k: float(g[f"{k}_{s}_full_vs_parity"]) for k in rel}
+        rows.append({"steps": s, "rel_l2": rel, "oracle_full_vs_parity": fvp})
+    del nav
+    first = next((r["steps"] for r in rows if all(v < PARITY_TOL for v in r["rel_l2"].values())), None)
+    first_uvt = next((r["steps"] for r in rows if all(r["rel_l2"][k] < PARITY_TOL for k in ("velx", "vely", "temp"))), None)
+    return {"golden": os.path.relpath(path, ROOT), "sample_stride": stride,
+            "setup": "engine: own dgeev per parity block; golden: oracle with ONE dgeev of the whole operator (the reference's algorithm)",
+            "snapshots": rows, "first_snapshot_all_fields_below_tol": first, "first_snapshot_u_v_T_below_tol": first_uvt,
+            "tol": PARITY_TOL}
+
+
 def pmc_traffic(workload, tag):
     """HBM bytes per launch of kernel `tag` from the committed rocprofv3 --pmc passes
     (tools/pmc_step.py + tools/pmc_traffic.py -> profiles/*pmc_traffic*.json, FETCH_SIZE and
@@ -358,6 +395,9 @@ def main():
         del nav   # free the timed engine's HBM before the parity engine is built
         out["cpu_baseline"], ora, osteps = cpu_baseline(args, eig)
         out["parity"] = parity_vs_oracle(make, ora, osteps, shared=eig is not None)
+        gold = parity_independent_golden(make, args)
+        if gold is not None:
+            out["parity_independent_golden"] = gold
         if args.parity_independent and eig is not None:
             del ora, eig
             _, ora2, osteps = cpu_baseline(args, None)

@@ -111,7 +111,9 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   ldx_ = pitch(periodic ? nx + 2 : nx);
   ldy_ = pitch((long)ny * ex_);
   const int P = comm_.size;
-  ypart_ = split(ny, P);
+  // rows of YX arrays: every rank starts at an EVEN row (the column scans run one chain per parity, colscan.h)
+  ypart_ = split((ny + 1) / 2, P);
+  for (int& b : ypart_) b = std::min(2 * b, ny);
   xpart_ = split(nx, P);
   kpart_ = periodic ? split(kx_, P) : xpart_;
   // the factorised y-systems of the Poisson solve, one per x-row: a pencil-sharded rank keeps the rows
@@ -122,7 +124,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   nyl_ = ye_ - yb_;
   nxl_ = std::max(xpart_[comm_.rank + 1] - xpart_[comm_.rank], kpart_[comm_.rank + 1] - kpart_[comm_.rank]);
   RPDE_REQUIRE(P == 1 || (nyl_ >= 2 && nxl_ >= 2), "too many ranks for this grid (need >= 2 lines per rank)");
-  const size_t nyx = (size_t)(nyl_ + 2) * ldx_;      // two halo rows in front (cross-line y stencil)
+  const size_t nyx = (size_t)(nyl_ + 2 + 4) * ldx_;  // two halo rows in front (cross-line y stencil), four behind (column scans)
   const size_t nxy = (size_t)nxl_ * ldy_;
   for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &GX_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
@@ -130,15 +132,25 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   red_.alloc(2);
   nanflag_.alloc(2);
-  if (P == 1) {   // block carries of the column scans
-    const size_t nb = (size_t)((ny + kColBlockRows - 1) / kColBlockRows);
+  {   // column scans (colscan.h): block carries, tables of this rank's rows, summaries that travel between the ranks
+    const size_t nb = (size_t)((nyl_ + kColBlockRows - 1) / kColBlockRows) + 1;
     colv1_.alloc(3 * nb * 2 * ldx_); cols1_.alloc(3 * nb * 2 * ldx_);
     colv2_.alloc(3 * nb * 4 * ldx_); cols2_.alloc(3 * nb * 4 * ldx_);
     coldv_.alloc(nb * 2 * ldx_); colds_.alloc(nb * 2 * ldx_);
     coldot_.alloc(3 * nb * ldx_); colkap_.alloc(3 * ldx_);
+    const std::vector<int>* rk = P > 1 ? &ypart_ : nullptr;
+    const int jend = std::min(ye_, my_);
+    const Base& by = sp_vel_->base(1);
+    colhh_vel_.upload(build_colhh_tables(pinv_tables(by), hh_vel_->host[1], kColBlockRows, yb_, jend, rk));
+    colhh_temp_.upload(build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
     if (!periodic) {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables)
-      const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows);
+      const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows, yb_, jend, rk);
       colcorr_a_.upload(cc.a); colcorr_b_.upload(cc.b);
+    }
+    if (P > 1) {
+      const size_t cnt = (size_t)3 * kColSumm * ldx_;
+      colsumm_.alloc(cnt); colsend_.alloc(cnt * P); colgath_.alloc(cnt * P);
+      halo_s_.alloc((size_t)3 * 6 * ldx_); halo_r_.alloc((size_t)3 * 6 * ldx_);
     }
   }
   {  // dealias (functions.rs:72-82) folded into the post-scaling of the forward DCT
@@ -205,10 +217,12 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     dev_sync(st_);
   }
   if (periodic) build_periodic(); else build_confined();
-  if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos
+  if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos + column-scan summaries
     xchg_count_ = 0;
     for (size_t i = 0; i < step_.size();) {
-      if (step_[i].type == Launch::kHalo) { ++xchg_count_; ++i; continue; }
+      if (step_[i].type == Launch::kHalo || step_[i].type == Launch::kColHholtz || step_[i].type == Launch::kColDiff) {
+        ++xchg_count_; ++i; continue;   // halo rows; the summaries of a column scan
+      }
       if (step_[i].type != Launch::kTranspose) { ++i; continue; }
       size_t j = i; int n = 0;
       while (j < step_.size() && n < kMaxBatch && step_[j].type == Launch::kTranspose &&
@@ -256,11 +270,21 @@ void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
   if (f.buf == &PS_ && pseu_in_yx_) {
-    // the confined single-GPU step leaves the pseudo-pressure in YX layout with the x parity blocks side by side
+    // the confined step leaves the pseudo-pressure in YX layout with the x parity blocks side by side
     // (build_confined, G2): bring it to the canonical array on demand
     const PoissonOp& po = *pois_;
-    launch_transpose(yx(Y_[4]), ldx_, PS_.p, 2 * ldy_, my_, po.me, 1, st_);
-    launch_transpose(yx(Y_[4]) + pseu_half_, ldx_, PS_.p + ldy_, 2 * ldy_, my_, po.mo, 1, st_);
+    if (comm_.size == 1) {
+      launch_transpose(yx(Y_[4]), ldx_, PS_.p, 2 * ldy_, my_, po.me, 1, st_);
+      launch_transpose(yx(Y_[4]) + pseu_half_, ldx_, PS_.p + ldy_, 2 * ldy_, my_, po.mo, 1, st_);
+    } else {   // interleave the parity blocks, then the pencil exchange (collective: every rank calls get_field)
+      ProgramBuilder pb(1, sp_pseu_->axis(0).slot_len, ylines(my_));
+      pb.set_fft(sp_pseu_->axis(0));
+      pb.set_line0(yb_);
+      pb.load(0, pb.arr(yx(Y_[4]), ldx_), mx_, 1.0, false, pseu_half_);
+      pb.store(0, pb.arr(yx(Y_[3]), ldx_), mx_);
+      pb.run(st_);
+      exchange(yx(Y_[3]), ldx_, PS_.p, ldy_, my_, mx_, 1, true, false);
+    }
     dev_sync(st_);
     pseu_in_yx_ = false;
   }
@@ -381,14 +405,56 @@ void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int c
   launch_xchg_unpack(d, recvbuf_.p, st_);        // one launch: all sources, all arrays
 }
 
-void Navier2DEngine::halo(double* base, long ld, int ncols) {
-  (void)ncols;
+void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
+  // rows [-front, 0) of every array <- the last `front` local rows of rank - 1; rows [nyl, nyl + tail) <- the first
+  // `tail` rows of rank + 1: one exchange for all arrays and both directions (staged: the segments of an all-to-all
+  // are contiguous)
   const int P = comm_.size, me = comm_.rank;
-  if (P == 1) return;
+  if (P == 1 || n == 0) return;
+  RPDE_REQUIRE(n <= 3 && front <= 2 && tail <= 4, "halo_rows: staging holds three arrays of 2 + 4 rows");
+  const long ld = ldx_;
   std::vector<int64_t> sc(P, 0), rc(P, 0);
-  if (me + 1 < P) sc[me + 1] = 2 * ld;
-  if (me > 0) rc[me - 1] = 2 * ld;
-  alltoallv(base + (size_t)(nyl_ - 2) * ld, sc, base - 2 * ld, rc);
+  const bool up = me + 1 < P, dn = me > 0;
+  if (dn) { sc[me - 1] = (int64_t)n * tail * ld; rc[me - 1] = (int64_t)n * front * ld; }
+  if (up) { sc[me + 1] = (int64_t)n * front * ld; rc[me + 1] = (int64_t)n * tail * ld; }
+  double* snd = halo_s_.p;
+  if (dn && tail)  for (int a = 0; a < n; ++a) launch_copy2d(arr[a], ld, snd + (size_t)a * tail * ld, ld, tail, (int)ld, st_);
+  double* snd_up = snd + (dn ? (size_t)n * tail * ld : 0);
+  if (up && front) for (int a = 0; a < n; ++a) launch_copy2d(arr[a] + (size_t)(nyl_ - front) * ld, ld, snd_up + (size_t)a * front * ld, ld, front, (int)ld, st_);
+  alltoallv(snd, sc, halo_r_.p, rc);
+  const double* rcv = halo_r_.p;
+  if (dn && front) for (int a = 0; a < n; ++a) launch_copy2d(rcv + (size_t)a * front * ld, ld, arr[a] - (size_t)front * ld, ld, front, (int)ld, st_);
+  const double* rcv_up = rcv + (dn ? (size_t)n * front * ld : 0);
+  if (up && tail)  for (int a = 0; a < n; ++a) launch_copy2d(rcv_up + (size_t)a * tail * ld, ld, arr[a] + (size_t)nyl_ * ld, ld, tail, (int)ld, st_);
+}
+
+// Column scans when the rows are split over the ranks (colscan.h): block summaries, this rank's summary, ONE small
+// exchange that gives every rank everybody's summary, inflow of the own rows from them, final pass.
+void Navier2DEngine::run_col_hholtz(ColHhArgs a) {
+  const int P = comm_.size;
+  if (P == 1) { launch_col_hholtz(a, st_); return; }
+  const int64_t cnt = (int64_t)a.nf * kColSumm * ldx_;
+  a.summ = colsumm_.p; a.gath = colgath_.p;
+  launch_col_hholtz_phase(a, 0, st_);
+  launch_col_hholtz_phase(a, 1, st_);
+  for (int q = 0; q < P; ++q) launch_copy2d(colsumm_.p, cnt, colsend_.p + (size_t)q * cnt, cnt, 1, (int)cnt, st_);
+  std::vector<int64_t> sc(P, cnt), rc(P, cnt);
+  alltoallv(colsend_.p, sc, colgath_.p, rc);
+  launch_col_hholtz_phase(a, 2, st_);
+  launch_col_hholtz_phase(a, 3, st_);
+}
+void Navier2DEngine::run_col_diff(ColDiffArgs a) {
+  const int P = comm_.size;
+  if (P == 1) { launch_col_diff(a, st_); return; }
+  const int64_t cnt = 2 * ldx_;
+  a.summ = colsumm_.p; a.gath = colgath_.p;
+  launch_col_diff_phase(a, 0, st_);
+  launch_col_diff_phase(a, 1, st_);
+  for (int q = 0; q < P; ++q) launch_copy2d(colsumm_.p, cnt, colsend_.p + (size_t)q * cnt, cnt, 1, (int)cnt, st_);
+  std::vector<int64_t> sc(P, cnt), rc(P, cnt);
+  alltoallv(colsend_.p, sc, colgath_.p, rc);
+  launch_col_diff_phase(a, 2, st_);
+  launch_col_diff_phase(a, 3, st_);
 }
 
 void Navier2DEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
@@ -522,11 +588,13 @@ void Navier2DEngine::add_transpose(const double* in, long ldi, double* out, long
   }
   step_.push_back(l);
 }
-void Navier2DEngine::add_halo(double* base, int ncols, const char* tag) {
+void Navier2DEngine::add_halo(std::initializer_list<double*> arrays, int front, int tail, const char* tag) {
   if (comm_.size == 1) return;
   Launch l;
   l.type = Launch::kHalo;
-  l.out = base; l.cols = ncols; l.tag = tag;
+  l.nhal = 0;
+  for (double* a : arrays) l.hal[l.nhal++] = a;
+  l.front = front; l.tail = tail; l.tag = tag;
   step_.push_back(l);
 }
 // Whole-line kernels (csrc/dct_line.h) are the form of a stage wherever they cover the line length (N = 4096 in the HIP
@@ -619,16 +687,16 @@ void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const out
   l.type = Launch::kColHholtz;
   l.tag = tag;
   ColHhArgs& a = l.ch;
-  const ColHhDev& cv = hh_vel_->col_y;
-  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = cv.NB; a.ld = ldx_; a.nf = 3;
+  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = colhh_vel_.NB; a.ld = ldx_; a.nf = 3;
+  a.row0 = yb_; a.jend = std::min(ye_, my_); a.nranks = comm_.size; a.rank = comm_.rank;
   for (int f = 0; f < 3; ++f) {
     a.in[f] = in[f]; a.out[f] = out[f]; a.shift[f] = 0;
-    a.tab[f] = (f == 2 ? hh_temp_->col_y : hh_vel_->col_y).tabs();
+    a.tab[f] = (f == 2 ? colhh_temp_ : colhh_vel_).tabs();
   }
   a.in_half = 0;
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = flagp();
-  l.bytes = 3.0 * 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
+  l.bytes = 3.0 * 2.0 * 8.0 * (double)ylines(my_) * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
   step_.push_back(l);
 }
 void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag) {
@@ -639,12 +707,13 @@ void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, doub
   l.tag = tag;
   ColHhArgs& a = l.ch;
   a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = colcorr_a_.NB; a.ld = ldx_; a.nf = 2;
+  a.row0 = yb_; a.jend = std::min(ye_, my_); a.nranks = comm_.size; a.rank = comm_.rank;
   a.in[0] = ps; a.in[1] = ps; a.out[0] = outa; a.out[1] = outb; a.shift[0] = 2; a.shift[1] = 1;
   a.tab[0] = colcorr_a_.tabs(); a.tab[1] = colcorr_b_.tabs();
   a.in_half = half;
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = nullptr;
-  l.bytes = 3.0 * 8.0 * (double)my_ * ncols;          // algorithmic: the pseudo-pressure once, two arrays out
+  l.bytes = 3.0 * 8.0 * (double)ylines(my_) * ncols;  // algorithmic: the pseudo-pressure once, two arrays out
   step_.push_back(l);
 }
 void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale,
@@ -653,10 +722,11 @@ void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const
   l.type = Launch::kColDiff;
   l.tag = tag;
   ColDiffArgs& a = l.cd;
-  a.nout = ny_; a.m = m_in; a.ncols = ncols; a.BR = kColBlockRows; a.NB = (ny_ + kColBlockRows - 1) / kColBlockRows;
+  a.nout = ny_; a.m = m_in; a.ncols = ncols; a.BR = kColBlockRows; a.NB = (nyl_ + kColBlockRows - 1) / kColBlockRows;
   a.ldi = ldx_; a.ldo = ldx_; a.in = in; a.out = out; a.low = low; a.scale = scale;
   a.vd = coldv_.p; a.sd = colds_.p;
-  l.bytes = 8.0 * ncols * (2.0 * m_in + ny_);          // the input twice (block sums, final pass), the output once
+  a.row0 = yb_; a.jend = ye_; a.nranks = comm_.size; a.rank = comm_.rank;
+  l.bytes = 8.0 * ncols * (2.0 * ylines(m_in) + nyl_);   // the input twice (block sums, final pass), the output once
   step_.push_back(l);
 }
 size_t Navier2DEngine::run_from(size_t i) {
@@ -679,15 +749,15 @@ void Navier2DEngine::run_launch(const Launch& l) {
   switch (l.type) {
     case Launch::kLine: launch_line_program(l.pg, st_); break;
     case Launch::kTranspose: exchange(l.in, l.ldi, l.out, l.ldo, l.rows, l.cols, l.elem, l.to_xy, l.spec); break;
-    case Launch::kHalo: halo(l.out, ldx_, l.cols); break;
+    case Launch::kHalo: halo_rows(l.hal, l.nhal, l.front, l.tail); break;
     case Launch::kGemmPairNT: launch_gemm_pair(false, l.gp[0], l.gp[1], st_); break;
     case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
-    case Launch::kColHholtz: launch_col_hholtz(l.ch, st_); break;
+    case Launch::kColHholtz: run_col_hholtz(l.ch); break;
     case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
     case Launch::kConvLine: RPDE_REQUIRE(launch_conv_line(l.cl, st_), "internal: conv line shape"); break;
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
-    case Launch::kColDiff: launch_col_diff(l.cd, st_); break;
+    case Launch::kColDiff: run_col_diff(l.cd); break;
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
   }
 }
@@ -1302,25 +1372,18 @@ void Navier2DEngine::refresh_gy() {
     pb.load(0, pb.arr(yx(P_), ldx_), nx_); pb.cdiff(0, 0, nx_, 1.0 / sx_); pb.store(0, pb.arr(yx(GX_), ldx_), nx_);
     pb.run(st_);
   }
-  if (comm_.size == 1) {
+  {
     // the same column scan the step runs (C10): a restarted run continues bit-identically
+    double* pa[1] = {yx(P_)};
+    halo_rows(pa, 1, 2, 4);
     ColDiffArgs a{};
-    a.nout = ny_; a.m = ny_; a.ncols = rows_x * ex_; a.BR = kColBlockRows; a.NB = (ny_ + kColBlockRows - 1) / kColBlockRows;
+    a.nout = ny_; a.m = ny_; a.ncols = rows_x * ex_; a.BR = kColBlockRows; a.NB = (nyl_ + kColBlockRows - 1) / kColBlockRows;
     a.ldi = ldx_; a.ldo = ldx_; a.in = yx(P_); a.out = yx(GY_); a.low = nullptr; a.scale = 1.0 / sy_;
     a.vd = coldv_.p; a.sd = colds_.p;
-    launch_col_diff(a, st_);
+    a.row0 = yb_; a.jend = ye_; a.nranks = comm_.size; a.rank = comm_.rank;
+    run_col_diff(a);
     dev_sync(st_);
-    return;
   }
-  exchange(yx(P_), ldx_, X_[0].p, ldy_, ny_, rows_x, ex_, true, spec);
-  ProgramBuilder pb(1, sp_ortho_->axis(1).slot_len, xlines(rows_x, spec), ex_);
-  pb.set_fft(sp_ortho_->axis(1));
-  pb.set_line0(xb(spec));
-  const int a = pb.arr(X_[0].p, ldy_, ex_, ex_ == 2 ? 1 : 0), b = pb.arr(X_[1].p, ldy_, ex_, ex_ == 2 ? 1 : 0);
-  pb.load(0, a, ny_); pb.cdiff(0, 0, ny_, 1.0 / sy_); pb.store(0, b, ny_);
-  pb.run(st_);
-  exchange(X_[1].p, ldy_, yx(GY_), ldx_, rows_x, ny_, ex_, false, spec);
-  dev_sync(st_);
 }
 
 // ==========================================================================================
@@ -1359,9 +1422,7 @@ void Navier2DEngine::build_confined() {
   };
 
   // ---- halos of the state for the cross-line y stencils of S3
-  add_halo(yx(U_), (int)ldx, "H0 halo velx");
-  add_halo(yx(V_), (int)ldx, "H0 halo vely");
-  add_halo(yx(T_), (int)ldx, "H0 halo temp");
+  add_halo({yx(U_), yx(V_), yx(T_)}, 2, 0, "H0 halo velx, vely, temp");
   // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
   struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
@@ -1501,41 +1562,17 @@ void Navier2DEngine::build_confined() {
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  if (P == 1) {
-    // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays: no T3, no T4
+  {
+    // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays: no T3, no T4.  Sharded: the blocks of a
+    // rank read four rows of the next rank, and the ranks exchange one summary per column (run_col_hholtz)
+    add_halo({yx(Y_[3]), yx(Y_[4]), yx(Y_[5])}, 0, 4, "H3 halo hholtz-y rhs");
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, mx, "C4 y: hholtz-y (column scan)");
-    // d/dy vely for the divergence (rows ny, composite x)
+    // d/dy vely for the divergence (rows ny, composite x); the halo of velx serves the cross-line stencil of S5
+    add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, mx, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
-  } else {
-    // ---- T3
-    for (int k = 0; k < 3; ++k) T(yx(Y_[3 + k]), X_[k].p, my, mx, true, "T3");
-    // ---- S4: y part of the Helmholtz solves (+ d/dy vely for the divergence)
-    for (int which = 0; which < 3; ++which) {
-      HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-      ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(X_[which].p, ldy), my);                 // entries my, my+1 only meet zero table entries
-      pb.pinv_matvec(0, yD);
-      pb.fdma_solve(0, my, hh.fdma[1]);
-      pb.store(0, pb.arr(X_[3 + which].p, ldy), my);
-      pb.guard_last_store(flagp());
-      if (which == 1) {
-        pb.zero(0, my, sly);
-        pb.to_ortho(0, yD);
-        pb.cdiff(0, 0, ny, 1.0 / sy_);
-        pb.store(0, pb.arr(X_[6].p, ldy), ny);
-      }
-      add_line(pb, "S4 y: hholtz-y");
-    }
-    // ---- T4: new (uncorrected) state back to YX
-    T(X_[3].p, yx(U_), mx, my, false, "T4");
-    T(X_[4].p, yx(V_), mx, my, false, "T4");
-    T(X_[5].p, yx(T_), mx, my, false, "T4");
-    T(X_[6].p, yx(Y_[0]), mx, ny, false, "T4");
   }
-  add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
   PoissonOp& po = *pois_;
   {
@@ -1587,44 +1624,19 @@ void Navier2DEngine::build_confined() {
     GemmProblem g1{po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy, yx(Y_[4]) + po.half, ldx};
     g0.ct = g1.ct = true;
     add_gemm_pair(true, g0, g1, "G2 even + odd");
-    { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
-    // ---- C7: y part of the velocity correction as column scans: from_ortho_y(to_ortho_y ps) and
-    // from_ortho_y(-d/dy to_ortho_y ps), columns interleaved on the way out (no S7, no T5)
-    add_col_corr(yx(Y_[4]), po.half, yx(Y_[2]), yx(Y_[3]), mx, "C7 y: correction-y (column scan)");
-    pseu_half_ = po.half;
   } else {
     T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");
-    // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land de-interleaved in x
-    add_gemm_pair(false, GemmProblem{myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[3]), ldx},
-                  GemmProblem{myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld, yx(Y_[3]) + po.half, ldx},
+    // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land side by side in x, like on one GPU
+    add_gemm_pair(false, GemmProblem{myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[4]), ldx},
+                  GemmProblem{myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld, yx(Y_[4]) + po.half, ldx},
                   "G2 even + odd");
-    {
-      ProgramBuilder pb = ypb(1, my);
-      pb.set_fft(xN);
-      pb.load(0, pb.arr(yx(Y_[3]), ldx), mx, 1.0, false, po.half);
-      pb.store(0, pb.arr(yx(Y_[4]), ldx), mx);
-      add_line(pb, "G2 x: interleave parities");
-    }
-    if (yb_ == 0) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
-    T(yx(Y_[4]), PS_.p, my, mx, true, "T4d");
-    // ---- S7: y part of the velocity correction
-    {
-      ProgramBuilder pb = xpb(2, mx);
-      pb.set_fft(yN);
-      pb.load(0, pb.arr(PS_.p, ldy), my);
-      pb.to_ortho(0, yN);
-      pb.cdiff(1, 0, ny, -1.0 / sy_);
-      pb.from_ortho(0, yD);
-      pb.store(0, pb.arr(X_[2].p, ldy), my);
-      pb.from_ortho(1, yD);
-      pb.store(1, pb.arr(X_[3].p, ldy), my);
-      add_line(pb, "S7 y: correction-y");
-    }
-    // ---- T5
-    T(X_[2].p, yx(Y_[2]), mx, my, false, "T5");
-    T(X_[3].p, yx(Y_[3]), mx, my, false, "T5");
-    add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
   }
+  if (yb_ == 0) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
+  // ---- C7: y part of the velocity correction as column scans: from_ortho_y(to_ortho_y ps) and
+  // from_ortho_y(-d/dy to_ortho_y ps), columns interleaved on the way out (no S7, no T5)
+  add_halo({yx(Y_[4])}, 2, 4, "H2 halo pseu");
+  add_col_corr(yx(Y_[4]), po.half, yx(Y_[2]), yx(Y_[3]), mx, "C7 y: correction-y (column scan)");
+  pseu_half_ = po.half;
   // ---- S8: x part of the velocity correction
   {
     ProgramBuilder pb = ypb(2, my);   // the two velocity components side by side: their loads travel in pairs
@@ -1650,7 +1662,7 @@ void Navier2DEngine::build_confined() {
   {
     ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xN);
-    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt, false, P == 1 ? po.half : 0);   // one GPU: parity blocks side by side
+    pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt, false, po.half);   // parity blocks side by side
     pb.to_ortho(0, xN);
     pb.load(0, pb.arr(yx(DIV_), ldx), nx, -nu_, true);
     pb.load(0, pb.arr(yx(P_), ldx), nx, 1.0, true);
@@ -1662,20 +1674,8 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step
-  if (P == 1) {
-    add_col_diff(yx(P_), yx(GY_), ny, nullptr, nx, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
-  } else {
-    T(yx(P_), X_[0].p, ny, nx, true, "T6");
-    {
-      ProgramBuilder pb = xpb(1, nx);
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(X_[0].p, ldy), ny);
-      pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.store(0, pb.arr(X_[1].p, ldy), ny);
-      add_line(pb, "S10 y: d/dy pres");
-    }
-    T(X_[1].p, yx(GY_), nx, ny, false, "T7");
-  }
+  add_halo({yx(P_)}, 2, 4, "H4 halo pres");
+  add_col_diff(yx(P_), yx(GY_), ny, nullptr, nx, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
 }
 
 // ==========================================================================================
@@ -1714,9 +1714,7 @@ void Navier2DEngine::build_periodic() {
     add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 2, to_xy, true, tag);
   };
 
-  add_halo(yx(U_), (int)ldx, "H0 halo velx");
-  add_halo(yx(V_), (int)ldx, "H0 halo vely");
-  add_halo(yx(T_), (int)ldx, "H0 halo temp");
+  add_halo({yx(U_), yx(V_), yx(T_)}, 2, 0, "H0 halo velx, vely, temp");
   // ---- S1: spectral x-lines -> physical x (value and x-derivative)
   struct { DBuf* st; DBuf* w0; DBuf* w1; } s1[3] = {
       {&U_, &Y_[0], &Y_[1]}, {&V_, &Y_[2], &Y_[3]}, {&T_, &Y_[4], &Y_[5]}};
@@ -1809,39 +1807,16 @@ void Navier2DEngine::build_periodic() {
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");
-  const int P = comm_.size;
-  if (P == 1) {
+  {
     // ---- C4: y part of the Helmholtz solves as column scans on the YX arrays (real-linear: the
     // interleaved re / im columns are independent columns)
+    add_halo({yx(Y_[3]), yx(Y_[4]), yx(Y_[5])}, 0, 4, "H3 halo hholtz-y rhs");
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, nc, "C4 y: hholtz-y (column scan)");
+    add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
-  } else {
-    for (int k = 0; k < 3; ++k) Tc(yx(Y_[3 + k]), X_[k].p, my, kx, true, "T3");
-    // ---- S4: y part of the Helmholtz solves on complex lines (one component per grid.y)
-    for (int which = 0; which < 3; ++which) {
-      HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
-      ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(X_[which].p, ldy, 2, 1), my);
-      pb.pinv_matvec(0, yD);
-      pb.fdma_solve(0, my, hh.fdma[1]);
-      pb.store(0, pb.arr(X_[3 + which].p, ldy, 2, 1), my);
-      if (which == 1) {
-        pb.zero(0, my, sly);
-        pb.to_ortho(0, yD);
-        pb.cdiff(0, 0, ny, 1.0 / sy_);
-        pb.store(0, pb.arr(X_[6].p, ldy, 2, 1), ny);
-      }
-      add_line(pb, "S4 y: hholtz-y");
-    }
-    Tc(X_[3].p, yx(U_), kx, my, false, "T4");
-    Tc(X_[4].p, yx(V_), kx, my, false, "T4");
-    Tc(X_[5].p, yx(T_), kx, my, false, "T4");
-    Tc(X_[6].p, yx(Y_[0]), kx, ny, false, "T4");
   }
-  add_halo(yx(U_), (int)ldx, "H1 halo velx");
   // ---- S5: divergence
   {
     ProgramBuilder pb = ypb(1, ny);
@@ -1884,7 +1859,7 @@ void Navier2DEngine::build_periodic() {
   Tc(X_[2].p, yx(Y_[2]), kx, my, false, "T5");
   Tc(X_[3].p, yx(Y_[3]), kx, my, false, "T5");
   Tc(PS_.p, yx(Y_[4]), kx, my, false, "T5");
-  add_halo(yx(Y_[4]), (int)ldx, "H2 halo pseu");
+  add_halo({yx(Y_[4])}, 2, 0, "H2 halo pseu");
   // ---- S8: x part of the velocity correction
   {
     ProgramBuilder pb = ypb(1, my);
@@ -1914,20 +1889,8 @@ void Navier2DEngine::build_periodic() {
     add_line(pb, "S9 x: pressure update");
   }
   // ---- d/dy pres for the next step
-  if (P == 1) {
-    add_col_diff(yx(P_), yx(GY_), ny, nullptr, nc, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
-  } else {
-    Tc(yx(P_), X_[0].p, ny, kx, true, "T6");
-    {
-      ProgramBuilder pb = xpb(1, kx, true);
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
-      pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.store(0, pb.arr(X_[1].p, ldy, 2, 1), ny);
-      add_line(pb, "S10 y: d/dy pres");
-    }
-    Tc(X_[1].p, yx(GY_), kx, ny, false, "T7");
-  }
+  add_halo({yx(P_)}, 2, 4, "H4 halo pres");
+  add_col_diff(yx(P_), yx(GY_), ny, nullptr, nc, 1.0 / sy_, "C10 y: d/dy pres (column scan)");
 }
 
 }  // namespace rpde

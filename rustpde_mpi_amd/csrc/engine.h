@@ -5,6 +5,7 @@
 // per step (the eigen-decomposition Poisson solve, src/solver/poisson.rs:195-236).
 #pragma once
 #include <functional>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -157,7 +158,13 @@ class Navier2DEngine {
   // all-to-all); returns the index of the next launch
   size_t run_from(size_t i);
   static constexpr int kMaxBatch = 6;
-  void halo(double* base, long ld, int ncols);   // rows [-2,0) <- last two local rows of rank-1
+  // halo rows of up to three YX arrays in one exchange: `front` rows in front of the local rows (from rank - 1), `tail`
+  // rows behind them (from rank + 1)
+  void halo_rows(double* const* arr, int n, int front, int tail);
+  void run_col_hholtz(ColHhArgs a);   // column scans, one rank or rows split over the ranks (colscan.h)
+  void run_col_diff(ColDiffArgs a);
+  ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
+  DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;
   void scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols);
   void scatter_rows_xy(const double* full, long ldf, DBuf& dst, int rows, int ncols, bool spec);
   void gather_rows(const double* local, long ld, int rows_global, const std::vector<int>& part,
@@ -205,6 +212,8 @@ class Navier2DEngine {
     ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;
     Program pg;                  // kLine
+    double* hal[3] = {nullptr, nullptr, nullptr};   // kHalo: arrays, rows in front / behind
+    int nhal = 0, front = 0, tail = 0;
     const double* in = nullptr;  // transposes
     double* out = nullptr;
     long ldi = 0, ldo = 0;
@@ -227,7 +236,7 @@ class Navier2DEngine {
   void add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag);
   void add_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                      bool to_xy, bool spec, const char* tag);
-  void add_halo(double* base, int ncols, const char* tag);
+  void add_halo(std::initializer_list<double*> arrays, int front, int tail, const char* tag);
   // Helmholtz solve along y of the three fields on YX arrays / Chebyshev y-derivative of a YX array
   // (single GPU: column scans instead of transpose -> line program -> transpose)
   void add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag);

@@ -202,48 +202,66 @@ FdmaTables fdma_tables(const Bands& s) {
   return t;
 }
 
-ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR) {
+// transfer of the rows [j0, j1) of one parity taken as one block: forward factor, backward 2 x 2 matrix, and the backward
+// end state per unit of forward inflow (zero backward inflow).  An empty chain keeps its inflow.
+static void colhh_block_transfer(const ColHhHost& h, int j0, int j1, int par, std::vector<long double>& ya, double* m1,
+                                 double* m2, double* g) {
+  // forward chain (ascending): response to a unit inflow y_{j0+par-2} = 1
+  long double y = 1.0L;
+  for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; ya[j] = y; }
+  *m1 = (double)y;
+  // backward chain (descending): runs from the inflow states (1,0) and (0,1); third column: zero inflow state,
+  // driven by the forward response above (what a unit of forward inflow leaves at the block's lower end)
+  long double x1[3] = {1.0L, 0.0L, 0.0L}, x2[3] = {0.0L, 1.0L, 0.0L};
+  int jt = j1 - 1;
+  if ((jt & 1) != par) --jt;                // highest row of this parity in the block
+  for (int j = jt; j >= j0; j -= 2) {
+    for (int c = 0; c < 3; ++c) {
+      long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
+      if (c == 2) nw += (long double)h.p2[j] * ya[j];
+      x2[c] = x1[c]; x1[c] = nw;
+    }
+  }
+  m2[0] = (double)x1[0]; m2[1] = (double)x1[1]; m2[2] = (double)x2[0]; m2[3] = (double)x2[1];
+  g[0] = (double)x1[2]; g[1] = (double)x2[2];
+}
+
+ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR, int row0, int jend, const std::vector<int>* ranks) {
   RPDE_REQUIRE(BR >= 2 && BR % 2 == 0, "column-scan block must hold an even number of rows");
+  RPDE_REQUIRE(row0 >= 0 && row0 % 2 == 0, "column-scan blocks start at an even row");
   ColHhHost h;
   const int n = (int)f.p2.size();
-  h.n = n; h.BR = BR; h.NB = (n + BR - 1) / BR;
-  const size_t np = (size_t)h.NB * BR + 4;   // zero padding: rows past the system come out as zeros without a branch
+  if (jend < 0 || jend > n) jend = n;
+  h.n = n; h.BR = BR; h.NB = (jend > row0) ? (jend - row0 + BR - 1) / BR : 0;
+  const size_t np = (size_t)n + 2 * BR + 8;   // zero padding: rows past the system come out as zeros
   auto padded = [&](const Vec& v) { Vec o(np, 0.0); std::copy(v.begin(), v.begin() + std::min<size_t>(v.size(), n), o.begin()); return o; };
   h.t0 = padded(pv.t0); h.t1 = padded(pv.t1); h.t2 = padded(pv.t2);
   h.q1 = padded(f.q1); h.p2 = padded(f.p2); h.q2 = padded(f.q2); h.r2 = padded(f.r2);
-  h.m1.assign((size_t)h.NB * 2, 0.0);
-  h.m2.assign((size_t)h.NB * 8, 0.0);
-  h.g.assign((size_t)h.NB * 4, 0.0);
+  h.m1.assign((size_t)std::max(h.NB, 1) * 2, 1.0);
+  h.m2.assign((size_t)std::max(h.NB, 1) * 8, 0.0);
+  h.g.assign((size_t)std::max(h.NB, 1) * 4, 0.0);
   std::vector<long double> ya(np, 0.0L);
   for (int b = 0; b < h.NB; ++b) {
-    const int j0 = b * BR, j1 = std::min(j0 + BR, n);
-    for (int par = 0; par < 2; ++par) {
-      // forward chain (ascending): response to a unit inflow y_{j0+par-2} = 1
-      long double y = 1.0L;
-      for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; ya[j] = y; }
-      h.m1[(size_t)b * 2 + par] = (double)y;   // an empty chain keeps the inflow (m = 1)
-      // backward chain (descending): runs from the inflow states (1,0) and (0,1); third column: zero inflow state,
-      // driven by the forward response above (what a unit of forward inflow leaves at the block's lower end)
-      long double x1[3] = {1.0L, 0.0L, 0.0L}, x2[3] = {0.0L, 1.0L, 0.0L};
-      int jt = j1 - 1;
-      if ((jt & 1) != par) --jt;                // highest row of this parity in the block
-      for (int j = jt; j >= j0; j -= 2) {
-        for (int c = 0; c < 3; ++c) {
-          long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
-          if (c == 2) nw += (long double)h.p2[j] * ya[j];
-          x2[c] = x1[c]; x1[c] = nw;
-        }
-      }
-      double* m = &h.m2[((size_t)b * 2 + par) * 4];
-      m[0] = (double)x1[0]; m[1] = (double)x1[1]; m[2] = (double)x2[0]; m[3] = (double)x2[1];
-      h.g[((size_t)b * 2 + par) * 2 + 0] = (double)x1[2];
-      h.g[((size_t)b * 2 + par) * 2 + 1] = (double)x2[2];
+    const int j0 = row0 + b * BR, j1 = std::min(j0 + BR, jend);
+    for (int par = 0; par < 2; ++par)
+      colhh_block_transfer(h, j0, j1, par, ya, &h.m1[(size_t)b * 2 + par], &h.m2[((size_t)b * 2 + par) * 4],
+                           &h.g[((size_t)b * 2 + par) * 2]);
+  }
+  if (ranks) {   // every rank's rows as one block: [nranks][14] = m1[2], m2[2][4], g[2][2]
+    const int P = (int)ranks->size() - 1;
+    h.rk.assign((size_t)P * 14, 0.0);
+    for (int r = 0; r < P; ++r) {
+      const int j0 = std::min((*ranks)[r], n), j1 = std::min((*ranks)[r + 1], n);
+      RPDE_REQUIRE(j0 % 2 == 0 || j0 == n, "column scans: a rank's first row must be even");
+      for (int par = 0; par < 2; ++par)
+        colhh_block_transfer(h, j0, j1, par, ya, &h.rk[(size_t)r * 14 + par], &h.rk[(size_t)r * 14 + 2 + par * 4],
+                             &h.rk[(size_t)r * 14 + 10 + par * 2]);
     }
   }
   return h;
 }
 
-ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR) {
+ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR, int row0, int jend, const std::vector<int>* ranks) {
   RPDE_REQUIRE(bd.is_composite() && bn.is_composite() && bd.m == bn.m && bd.n == bn.n, "colcorr: two composite bases of one size");
   const int m = bd.m, n = bd.n;
   const Vec lowd = stencil_low(bd), lown = stencil_low(bn);
@@ -259,7 +277,7 @@ ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, 
       t.t1[k] = fo.p_up[k] * (1.0 + lowd[k] * ln(k));
       t.t2[k] = fo.p_up[k] * lowd[k];
     }
-    out.a = build_colhh_tables(t, f, BR);
+    out.a = build_colhh_tables(t, f, BR, row0, jend, ranks);
   }
   {   // b: rhs_k = dscale 2 (k + 1) c_{k+1} (k >= 1), rhs_0 = dscale (c_1 - d_2 / 2)
     Mv3Tables t{Vec(m), Vec(m), Vec(m, 0.0)};
@@ -268,7 +286,7 @@ ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, 
       t.t0[k] = fo.p_up[k] * sk * ln(k - 1);
       t.t1[k] = fo.p_up[k] * sk;
     }
-    out.b = build_colhh_tables(t, f, BR);
+    out.b = build_colhh_tables(t, f, BR, row0, jend, ranks);
     const size_t np = out.b.t0.size();
     // kappa = -dscale / 2 * d_2,  d_2 = sum_{odd j >= 3} 2 j c_j,  c_j = ps_j + lown_{j-2} ps_{j-2}
     out.b.w.assign(np, 0.0);

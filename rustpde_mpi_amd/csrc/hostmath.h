@@ -71,8 +71,12 @@ struct ColHhHost {
   int n = 0, BR = 0, NB = 0;
   Vec t0, t1, t2, q1, m1, p2, q2, r2, m2, g;
   Vec w, h;   // optional rank-one term (colscan.h): weights of the column sum, response; empty: none
+  Vec rk;     // pencil-sharded runs: [nranks][14] transfer of every rank's rows taken as one block; empty: one rank
 };
-ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR);
+// blocks cover the rows [row0, jend) of the system (this rank's rows; jend < 0: to the end); `ranks`: the row
+// partition (nranks + 1 boundaries, all even) when the rows are split over several ranks
+ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR, int row0 = 0, int jend = -1,
+                             const std::vector<int>* ranks = nullptr);
 // y part of the velocity correction (navier_eq.rs:117-125) as two banded column problems on the pseudo-pressure
 // (Neumann-composite rows, base `bn`), results in the Dirichlet-composite base `bd` of the velocities:
 //   a = from_ortho_D( to_ortho_N(ps) )                          taps ps_{k-2}, ps_k, ps_{k+2}          (shift 2)
@@ -81,7 +85,8 @@ ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR);
 // LOCAL term 2 (k + 1) c_{k+1} of the derivative's recurrence d_k = d_{k+2} + 2 (k + 1) c_{k+1}; only row 0 (d_0 is
 // halved) keeps a sum over the column: rhs_0 = dscale (c_1 - d_2 / 2) -- the rank-one term.
 struct ColCorrHost { ColHhHost a, b; };
-ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR);
+ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR, int row0 = 0, int jend = -1,
+                                 const std::vector<int>* ranks = nullptr);
 
 // dense helpers (row-major) + LAPACK (loaded at run time from the OpenBLAS that ships with SciPy,
 // the same library family the reference links: Cargo.toml:39,45-46)

@@ -638,34 +638,48 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
 // ------------------------------------------------------------------------------- column scans (colscan.h)
 template <int PASS>
 __global__ __launch_bounds__(256) void col_hholtz_kernel(const ColHhArgs a) {
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x), f = (int)blockIdx.z;
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), f = (int)blockIdx.z;
   if (i >= a.ncols) return;
   if constexpr (PASS == 0) colhh_block<false>(a, f, (int)blockIdx.y, i);
-  if constexpr (PASS == 1) colhh_carry(a, f, i, (int)blockIdx.y);
-  if constexpr (PASS == 2) colhh_block<true>(a, f, (int)blockIdx.y, i);
+  if constexpr (PASS == 1) colhh_carry<0>(a, f, i, (int)blockIdx.y);
+  if constexpr (PASS == 2) colhh_carry<1>(a, f, i, (int)blockIdx.y);
+  if constexpr (PASS == 3) colhh_carry<2>(a, f, i, (int)blockIdx.y);
+  if constexpr (PASS == 4) colhh_block<true>(a, f, (int)blockIdx.y, i);
 }
-void launch_col_hholtz(const ColHhArgs& a, Stream& st) {
+void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0) return;
-  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB, a.nf), gc((a.ncols + 255) / 256, 2, a.nf);
-  hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_hholtz_kernel<2>, gb, blk, 0, st.s, a);
+  // the carry kernels are serial chains over the blocks, one thread per (column, parity): small workgroups spread
+  // the few thousand threads over all CUs
+  static const int ct = [] { const char* e = std::getenv("RPDE_COL_CARRY_T"); const int v = e ? std::atoi(e) : 64; return (v == 64 || v == 128 || v == 256) ? v : 64; }();
+  const dim3 blk(256), gb((a.ncols + 255) / 256, std::max(a.NB, 1), a.nf), cblk(ct), gc((a.ncols + ct - 1) / ct, 2, a.nf);
+  if (phase == 0) { if (a.NB > 0) hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a); }
+  else if (phase == 1) {
+    if (a.nranks <= 1) hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, cblk, 0, st.s, a);
+    else hipLaunchKernelGGL(col_hholtz_kernel<2>, gc, cblk, 0, st.s, a);
+  } else if (phase == 2) hipLaunchKernelGGL(col_hholtz_kernel<3>, gc, cblk, 0, st.s, a);
+  else if (a.NB > 0) hipLaunchKernelGGL(col_hholtz_kernel<4>, gb, blk, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
 }
 template <int PASS>
 __global__ __launch_bounds__(256) void col_diff_kernel(const ColDiffArgs a) {
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i >= a.ncols) return;
   if constexpr (PASS == 0) coldiff_pass<false>(a, (int)blockIdx.y, i);
-  if constexpr (PASS == 1) coldiff_carry(a, i, (int)blockIdx.y);
-  if constexpr (PASS == 2) coldiff_pass<true>(a, (int)blockIdx.y, i);
+  if constexpr (PASS == 1) coldiff_carry<0>(a, i, (int)blockIdx.y);
+  if constexpr (PASS == 2) coldiff_carry<1>(a, i, (int)blockIdx.y);
+  if constexpr (PASS == 3) coldiff_carry<2>(a, i, (int)blockIdx.y);
+  if constexpr (PASS == 4) coldiff_pass<true>(a, (int)blockIdx.y, i);
 }
-void launch_col_diff(const ColDiffArgs& a, Stream& st) {
+void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st) {
   if (a.ncols <= 0 || a.nout <= 0) return;
-  const dim3 blk(256), gb((a.ncols + 255) / 256, a.NB), gc((a.ncols + 255) / 256, 2);
-  hipLaunchKernelGGL(col_diff_kernel<0>, gb, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_diff_kernel<1>, gc, blk, 0, st.s, a);
-  hipLaunchKernelGGL(col_diff_kernel<2>, gb, blk, 0, st.s, a);
+  static const int ct = [] { const char* e = std::getenv("RPDE_COL_CARRY_T"); const int v = e ? std::atoi(e) : 64; return (v == 64 || v == 128 || v == 256) ? v : 64; }();
+  const dim3 blk(256), gb((a.ncols + 255) / 256, std::max(a.NB, 1)), cblk(ct), gc((a.ncols + ct - 1) / ct, 2);
+  if (phase == 0) { if (a.NB > 0) hipLaunchKernelGGL(col_diff_kernel<0>, gb, blk, 0, st.s, a); }
+  else if (phase == 1) {
+    if (a.nranks <= 1) hipLaunchKernelGGL(col_diff_kernel<1>, gc, cblk, 0, st.s, a);
+    else hipLaunchKernelGGL(col_diff_kernel<2>, gc, cblk, 0, st.s, a);
+  } else if (phase == 2) hipLaunchKernelGGL(col_diff_kernel<3>, gc, cblk, 0, st.s, a);
+  else if (a.NB > 0) hipLaunchKernelGGL(col_diff_kernel<4>, gb, blk, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
 }
 
@@ -1083,17 +1097,19 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
   }
   for (int c = 0; c < 4; ++c) out4[c] = a[c];
 }
-void launch_col_hholtz(const ColHhArgs& a, Stream&) {
+void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream&) {
   for (int f = 0; f < a.nf; ++f) {
-    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<false>(a, f, b, i);
-    for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry(a, f, i, par);
-    for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<true>(a, f, b, i);
+    if (phase == 0) for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<false>(a, f, b, i);
+    if (phase == 1) for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) { if (a.nranks <= 1) colhh_carry<0>(a, f, i, par); else colhh_carry<1>(a, f, i, par); }
+    if (phase == 2) for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) colhh_carry<2>(a, f, i, par);
+    if (phase == 3) for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) colhh_block<true>(a, f, b, i);
   }
 }
-void launch_col_diff(const ColDiffArgs& a, Stream&) {
-  for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
-  for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry(a, i, par);
-  for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
+void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream&) {
+  if (phase == 0) for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<false>(a, b, i);
+  if (phase == 1) for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) { if (a.nranks <= 1) coldiff_carry<0>(a, i, par); else coldiff_carry<1>(a, i, par); }
+  if (phase == 2) for (int par = 0; par < 2; ++par) for (int i = 0; i < a.ncols; ++i) coldiff_carry<2>(a, i, par);
+  if (phase == 3) for (int b = 0; b < a.NB; ++b) for (int i = 0; i < a.ncols; ++i) coldiff_pass<true>(a, b, i);
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   if (!conv_line_ok(c)) return false;

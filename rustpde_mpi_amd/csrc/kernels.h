@@ -65,8 +65,12 @@ void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 
 // column scans (colscan.h): the Helmholtz solve along y of up to three YX fields (five launches: pass A,
 // carry, pass B, carry, pass C) and the Chebyshev y-derivative of one YX array (three launches)
-void launch_col_hholtz(const ColHhArgs& a, Stream& st);
-void launch_col_diff(const ColDiffArgs& a, Stream& st);
+// phase 0: block summaries; 1: carry (one rank: final; sharded: this rank's summary); 2: carry from the gathered
+// summaries (sharded only, after the exchange); 3: final pass
+void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st);
+void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st);
+inline void launch_col_hholtz(const ColHhArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_hholtz_phase(a, ph, st); }   // one rank
+inline void launch_col_diff(const ColDiffArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_diff_phase(a, ph, st); }
 
 // backward Chebyshev transform of whole lines with four workgroups per CU (dct_line.h); false: shape / alignment
 // not covered (the caller runs the line program instead)

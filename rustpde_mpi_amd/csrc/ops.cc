@@ -407,6 +407,7 @@ void ColHhDev::upload(const ColHhHost& h) {
   t0.upload(h.t0); t1.upload(h.t1); t2.upload(h.t2); q1.upload(h.q1); m1.upload(h.m1);
   p2.upload(h.p2); q2.upload(h.q2); r2.upload(h.r2); m2.upload(h.m2); g.upload(h.g);
   if (!h.w.empty()) { w.upload(h.w); hr.upload(h.h); }
+  if (!h.rk.empty()) rk.upload(h.rk);
 }
 
 HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
@@ -419,7 +420,6 @@ HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
       fdma_sweep(mtx);
       host[axis] = fdma_tables(mtx);
       fdma[axis] = upload_fdma(host[axis], sp.axis(axis).slot_len);
-      if (axis == 1) col_y.upload(build_colhh_tables(pinv_tables(b), fdma_tables(mtx), kColBlockRows));
     } else {
       Vec d(b.m);
       for (int k = 0; k < b.m; ++k) d[k] = 1.0 - (-(double)k * (double)k) * c[axis];

@@ -161,10 +161,10 @@ class Space2Ops {
 
 // device tables of the column-scan form of one Helmholtz-y solve (colscan.h)
 struct ColHhDev {
-  DBuf t0, t1, t2, q1, m1, p2, q2, r2, m2, g, w, hr;
+  DBuf t0, t1, t2, q1, m1, p2, q2, r2, m2, g, w, hr, rk;
   int n = 0, BR = 0, NB = 0;
   void upload(const ColHhHost& h);
-  ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, m1.p, p2.p, q2.p, r2.p, m2.p, g.p, w.p, hr.p}; }
+  ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, m1.p, p2.p, q2.p, r2.p, m2.p, g.p, w.p, hr.p, rk.p}; }
 };
 constexpr int kColBlockRows = kColBR; // rows per block of the column scans (colscan.h)
 
@@ -175,7 +175,6 @@ class HholtzAdiOp {
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
   FdmaDev fdma[2];      // Chebyshev axes
   FdmaTables host[2];   // the same tables on the host, natural order (other kernels re-order them for their own chunking)
-  ColHhDev col_y;       // axis 1 as a column scan over YX arrays (the fused step on one GPU)
   DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
   Space2Ops& sp;
 };

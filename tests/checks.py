@@ -255,3 +255,36 @@ def check_conv_line(lib, n, nlines=5, lift=True):
     e = rel(out, want)
     assert e < 2e-12, (n, lift, e)
     return e
+
+
+def compare_with_independent_golden(nav, path, max_steps=None):
+    """Engine (its OWN eigen-decomposition: one dgeev per parity block in C++) against a golden file written by
+    tests/golden/make_headline_golden.py: the oracle in the REFERENCE's setup (eig_mode="full": one dgeev of the whole
+    x operator, src/solver/utils.rs:67-99, fdma_tensor.rs:106-154), sub-sampled in physical space.  Returns
+    {step: {field: (relative L2 over the sample points, the oracle's own full-vs-parity difference at that step)}}.
+    `nav` must be freshly constructed with the golden's parameters; the deterministic IC is applied here."""
+    g = np.load(path)
+    stride = int(g["stride"])
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    out, done = {}, 0
+    for s in [int(v) for v in g["snaps"]]:
+        if f"velx_{s}" not in g.files or (max_steps is not None and s > max_steps):
+            continue
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        out[s] = {}
+        for k in ("velx", "vely", "temp", "pres"):
+            want = g[f"{k}_{s}"]
+            got = f[k][::stride, ::stride]
+            out[s][k] = (float(np.linalg.norm(got - want) / np.linalg.norm(want)), float(g[f"{k}_{s}_full_vs_parity"]))
+    return out
+
+
+def independent_golden_bound(full_vs_parity, tol=1e-10):
+    """The bar of a comparison with an INDEPENDENT eigen-decomposition: `tol` once two valid LAPACK
+    eigenbases inside the oracle agree to tol / 10 themselves; during the start-up transient before that, ten times
+    the oracle's own full-vs-parity difference (the reference's Poisson solve amplifies dgeev's round-off by the 1e10 of
+    poisson.rs:84-87; the difference decays as the flow becomes divergence-free)."""
+    return tol if full_vs_parity < tol / 10 else max(tol, 10.0 * full_vs_parity)

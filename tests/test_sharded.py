@@ -31,6 +31,9 @@ def _spawn(world, lib_path, device_build, cases, tmp_path):
 
 CASES = [(False, 17, 17, 1e4, 0.01, 3, 1.0), (False, 33, 17, 1e5, 0.01, 6, 2.0),
          (True, 16, 17, 1e5, 0.01, 4, 1.0), (True, 32, 33, 1e5, 0.01, 6, 1.0)]
+# several column-scan blocks per rank with a ragged last one (129 rows), and the line length the whole-line kernels
+# of the emulation build cover (257): the kernels of the single-GPU step run on the local lines of every rank
+CASES_BLOCKS = [(False, 129, 129, 1e5, 0.01, 3, 1.0), (True, 128, 129, 1e5, 0.01, 3, 1.0), (False, 257, 257, 1e6, 0.005, 3, 1.0)]
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -42,6 +45,19 @@ def test_sharded_matches_oracle_emulation(world, tmp_path, emu_lib):
             assert e < 1e-10, (r["case"], k, e)
         assert abs(r["div"][0] - r["div"][1]) < 1e-9 * max(1.0, r["div"][1])
         assert r["comm"][1] > 0 and r["comm"][0] > 0   # exchanges per step, bytes per step
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_column_scans_and_whole_line_kernels_emulation(world, tmp_path, emu_lib):
+    """The y-direction stages of a sharded step are the column scans of the single-GPU step: a rank reduces its blocks
+    to one summary per column, the summaries travel in one small exchange, every rank derives its inflow (colscan.h).
+    13 exchanges per confined step: T1, T2, T4b, T4c, five halo exchanges, four column-scan summaries."""
+    res = _spawn(world, emu_lib.path, False, CASES_BLOCKS, tmp_path)
+    assert len(res) == len(CASES_BLOCKS)
+    for r in res:
+        for k, e in r["err"].items():
+            assert e < (1e-10 if k == "pseu" else 1e-12), (r["case"], k, e)
+        assert r["comm"][1] == (12 if r["case"][0] else 13)
 
 
 def test_sharded_long_fourier_lines_emulation(tmp_path, emu_lib):
@@ -63,16 +79,17 @@ def test_sharded_matches_oracle_hip(world, tmp_path, hip_lib):
 
 
 @pytest.mark.gpu
-def test_config4_geometry_sharded_equals_single_device(tmp_path, hip_lib):
-    """BASELINE.json configs[3] (confined, pencil-sharded, here 2049 x 2049 over 4 ranks sharing the
-    GPU): the sharded fields equal the single-device fields after 3 steps."""
-    res = _spawn(4, hip_lib.path, True, [(False, 2049, 2049, 1e8, 5e-4, 3, 1.0)], tmp_path)
+@pytest.mark.parametrize("n,world,dt", [(2049, 4, 5e-4), (4097, 2, 2e-4)])
+def test_config4_geometry_sharded_equals_single_device(tmp_path, hip_lib, n, world, dt):
+    """BASELINE.json configs[3] (confined 4097 x 4097, pencil-sharded; also 2049 x 2049 over 4 ranks; the ranks share
+    the one GPU of the test box): the sharded fields equal the single-device fields after 3 steps."""
+    res = _spawn(world, hip_lib.path, True, [(False, n, n, 1e8, dt, 3, 1.0)], tmp_path)
     for k, e in res[0]["err"].items():
-        # u, v, T, p: 1e-11.  The single-device engine solves the Helmholtz-y systems as column scans, the
-        # sharded one as line scans (same recurrences, another association of the block carries); pseu is
-        # the raw output of the Poisson solve, which amplifies such round-off (measured 1.4e-11)
+        # u, v, T, p: 1e-11.  Same kernels on both sides; the association of the column-scan carries (per rank, then
+        # across the ranks) and the GEMM tile shapes differ; pseu is the raw output of the Poisson solve, which
+        # amplifies such round-off (measured 1.4e-11)
         assert e < (1e-9 if k == "pseu" else 1e-11), (k, e)
-    assert res[0]["comm"][1] == 16   # 11 batched all-to-alls + 5 halos per step
+    assert res[0]["comm"][1] == 13   # 4 batched all-to-alls (T1, T2, T4b, T4c) + 5 halo exchanges + 4 column-scan summaries per step
 
 
 def _nccl_single(rank, port, out):
