@@ -182,8 +182,22 @@ def pmc_traffic(workload, tag):
         except (OSError, ValueError):
             continue
         if d.get("workload") == workload and tag in d.get("per_launch", {}):
-            return d["per_launch"][tag]["traffic_bytes"], os.path.relpath(path, ROOT)
+            src = {"file": os.path.relpath(path, ROOT), "commit": d.get("commit"),
+                   # the counters were collected on these kernel sources?  (sha256 over rustpde_mpi_amd/csrc/*.{h,cc})
+                   "stale": d.get("csrc_sha256") != csrc_sha256()}
+            return d["per_launch"][tag]["traffic_bytes"], src
     return None, None
+
+
+def csrc_sha256():
+    import hashlib
+    root = os.path.join(ROOT, "rustpde_mpi_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".h", ".cc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -337,7 +351,7 @@ def main():
     ms_t = line_ms + stage_ms(("T1", "T2"))
     ref_bytes = 416.0 * args.nx * args.ny
     pure = [r for r in prof if r["tag"] in ("S1 x: state -> phys-x + d/dx", "S1 x: state -> phys-x", "S2 y: velx, vely -> phys",
-                                            "S2 y: velx -> phys")]
+                                            "S2 y: velx -> phys", "S2 y: vely -> phys")]
     transform_pass = {
         # the headline figure: bytes the transform stages REALLY move (their loads and stores) over their time
         "bytes_moved_S1_S2_S3": moved,

@@ -81,6 +81,9 @@ RPDE_HD inline long col_sm(const ColHhArgs& a, int r, int f, int k) { return (((
 // loads of the carry passes and of the derivative are issued in batches of kColBatch (they do not depend on
 // the recurrence); one load in flight per thread would leave the kernels latency bound
 constexpr int kColBatch = 8;
+// the carry passes are ONE serial chain per thread over all blocks: their loads go out sixteen blocks at a time (the
+// chain waits once per batch for memory: 128 blocks = 8 round trips per direction)
+constexpr int kCarryBatch = 16;
 
 // one block of one column: FINAL = false keeps the block-end states of a run from zero inflow, FINAL = true
 // runs from the exact inflow states and stores the rows.  All BR + 4 row loads are in flight at once.
@@ -197,28 +200,28 @@ RPDE_HD inline void colhh_carry(const ColHhArgs& a, int f, int i, int par) {
     if (PHASE == 0) { if (t.w) a.kap[(long)f * a.ld + i] = k; }
     else a.summ[col_sm(a, 0, f, 6) + i] = k;
   }
-  for (int bb = 0; bb < a.NB; bb += kColBatch) {
-    double v[kColBatch];
+  for (int bb = 0; bb < a.NB; bb += kCarryBatch) {
+    double v[kCarryBatch];
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) v[u] = (bb + u < a.NB) ? a.v1[col_c1(a, f, bb + u, par) + i] : 0.0;
+    for (int u = 0; u < kCarryBatch; ++u) v[u] = (bb + u < a.NB) ? a.v1[col_c1(a, f, bb + u, par) + i] : 0.0;
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u)
+    for (int u = 0; u < kCarryBatch; ++u)
       if (bb + u < a.NB) {
         a.s1[col_c1(a, f, bb + u, par) + i] = s;
         s = t.m1[(bb + u) * 2 + par] * s + v[u];
       }
   }
   if (PHASE == 1) a.summ[col_sm(a, 0, f, par) + i] = s;
-  for (int bt = a.NB - 1; bt >= 0; bt -= kColBatch) {
-    double v0[kColBatch], v1[kColBatch], fi[kColBatch];
+  for (int bt = a.NB - 1; bt >= 0; bt -= kCarryBatch) {
+    double v0[kCarryBatch], v1[kCarryBatch], fi[kCarryBatch];
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) {
+    for (int u = 0; u < kCarryBatch; ++u) {
       v0[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 0) + i] : 0.0;
       v1[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 1) + i] : 0.0;
       fi[u] = (bt - u >= 0) ? a.s1[col_c1(a, f, bt - u, par) + i] : 0.0;   // written above by this thread
     }
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) {
+    for (int u = 0; u < kCarryBatch; ++u) {
       const int b = bt - u;
       if (b >= 0) {
         a.s2[col_c2(a, f, b, par, 0) + i] = s0;
@@ -295,12 +298,12 @@ RPDE_HD inline void coldiff_carry(const ColDiffArgs& a, int i, int par) {
   double s = 0.0;
   if (PHASE == 2)
     for (int r = a.rank + 1; r < a.nranks; ++r) s += a.gath[((long)r * 2 + par) * a.ldo + i];
-  for (int bt = a.NB - 1; bt >= 0; bt -= kColBatch) {
-    double v[kColBatch];
+  for (int bt = a.NB - 1; bt >= 0; bt -= kCarryBatch) {
+    double v[kCarryBatch];
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u) v[u] = (bt - u >= 0) ? a.vd[((long)(bt - u) * 2 + par) * a.ldo + i] : 0.0;
+    for (int u = 0; u < kCarryBatch; ++u) v[u] = (bt - u >= 0) ? a.vd[((long)(bt - u) * 2 + par) * a.ldo + i] : 0.0;
 #pragma unroll
-    for (int u = 0; u < kColBatch; ++u)
+    for (int u = 0; u < kCarryBatch; ++u)
       if (bt - u >= 0) { if (PHASE != 1) a.sd[((long)(bt - u) * 2 + par) * a.ldo + i] = s; s += v[u]; }
   }
   if (PHASE == 1) a.summ[(long)par * a.ldo + i] = s;

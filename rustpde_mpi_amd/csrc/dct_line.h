@@ -37,8 +37,9 @@ struct DctLineArgs {
 
 RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16; }
 // the 16-byte staging loads need an aligned line start and, for an odd count, one readable element behind the line
+// (N = 1024 runs on the half-length core, hdct_line.h, only)
 RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
-  return (a.N == 256 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
+  return (a.N == 256 || a.N == 1024 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
          ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2 || (a.sten == 1 && a.low != nullptr));
 }
 
@@ -366,7 +367,7 @@ RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
   DctLineArgs b = a;
   b.in = c.f0;
-  return dct_line_ok(a) && dct_line_ok(b);
+  return c.N != 1024 && dct_line_ok(a) && dct_line_ok(b);   // three transforms on the full-length core: N = 16^k
 }
 
 template <int N>

@@ -370,7 +370,16 @@ void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int c
                                     bool to_xy, bool spec) {
   const int P = comm_.size, me = comm_.rank;
   if (P == 1) {
-    for (const Xfer& x : xs) launch_transpose(x.in, x.ldi, x.out, x.ldo, rows, cols, elem, st_);
+    static const bool batch = [] { const char* e = std::getenv("RPDE_TP_BATCH"); return !e || std::atoi(e) != 0; }();
+    bool same = batch && xs.size() > 1 && xs.size() <= (size_t)kMaxTransposeBatch;
+    for (const Xfer& x : xs) same = same && x.ldi == xs[0].ldi && x.ldo == xs[0].ldo;
+    if (same) {   // one launch for all arrays of the batch
+      TransposeBatch b{};
+      for (size_t a = 0; a < xs.size(); ++a) { b.in[a] = xs[a].in; b.out[a] = xs[a].out; }
+      launch_transpose_batch(b, (int)xs.size(), xs[0].ldi, xs[0].ldo, rows, cols, elem, st_);
+    } else {
+      for (const Xfer& x : xs) launch_transpose(x.in, x.ldi, x.out, x.ldo, rows, cols, elem, st_);
+    }
     return;
   }
   RPDE_REQUIRE((int)xs.size() <= kMaxBatch, "exchange batch too large");
@@ -608,9 +617,9 @@ static bool whole_line_on(const char* stage_env) {
   return true;
 }
 #ifdef RPDE_EMU
-static bool whole_line_len(int N) { return N == 256 || N == 4096; }
+static bool whole_line_len(int N) { return N == 256 || N == 1024 || N == 4096; }
 #else
-static bool whole_line_len(int N) { return N == 4096; }
+static bool whole_line_len(int N) { return N == 1024 || N == 4096; }   // 1024: the kernels on the half-length core (no convection term)
 #endif
 
 bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
@@ -729,18 +738,25 @@ void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const
   l.bytes = 8.0 * ncols * (2.0 * ylines(m_in) + nyl_);   // the input twice (block sums, final pass), the output once
   step_.push_back(l);
 }
-size_t Navier2DEngine::run_from(size_t i) {
+size_t Navier2DEngine::group_end(size_t i) const {
+  // compatible consecutive transposes go out together: one launch on one GPU, one all-to-all when sharded
   const Launch& l = step_[i];
-  if (l.type != Launch::kTranspose || comm_.size == 1) { run_launch(l); return i + 1; }
-  std::vector<Xfer> xs;
+  if (l.type != Launch::kTranspose) return i + 1;
   size_t j = i;
-  while (j < step_.size() && (int)xs.size() < kMaxBatch) {
+  while (j < step_.size() && (int)(j - i) < kMaxBatch) {
     const Launch& m = step_[j];
     if (m.type != Launch::kTranspose || m.rows != l.rows || m.cols != l.cols || m.elem != l.elem ||
-        m.to_xy != l.to_xy || m.spec != l.spec) break;
-    xs.push_back(Xfer{m.in, m.ldi, m.out, m.ldo});
+        m.to_xy != l.to_xy || m.spec != l.spec || m.ldi != l.ldi || m.ldo != l.ldo) break;
     ++j;
   }
+  return j;
+}
+size_t Navier2DEngine::run_from(size_t i) {
+  const Launch& l = step_[i];
+  if (l.type != Launch::kTranspose) { run_launch(l); return i + 1; }
+  const size_t j = group_end(i);
+  std::vector<Xfer> xs;
+  for (size_t k = i; k < j; ++k) xs.push_back(Xfer{step_[k].in, step_[k].ldi, step_[k].out, step_[k].ldo});
   exchange_batch(xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
   return j;
 }
@@ -778,14 +794,14 @@ void Navier2DEngine::update(int nsteps) {
   if (comm_.size == 1 && use_graph_ && timed_tag_.empty() && nsteps > 0) {
     if (!graph_tried_) {
       graph_tried_ = true;
-      for (const Launch& l : step_) run_launch(l);   // warm the lazily configured kernels outside capture
+      for (size_t i = 0; i < step_.size();) i = run_from(i);   // warm the lazily configured kernels outside capture
       time_ += dt_;
       --nsteps;
       hipGraph_t g = nullptr;
       if (hipStreamBeginCapture(st_.s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         bool ok = true;
         try {   // a throw between Begin and EndCapture must not leave the stream in capture mode
-          for (const Launch& l : step_) run_launch(l);
+          for (size_t i = 0; i < step_.size();) i = run_from(i);
         } catch (...) {
           ok = false;
         }
@@ -848,33 +864,43 @@ std::string Navier2DEngine::profile(int nsteps) {
   std::vector<std::string> order;
   std::map<std::string, Acc> acc;
   for (int s = 0; s < nsteps; ++s) {
+    // the launches as update() issues them (run_from: compatible consecutive transposes go out as one launch /
+    // one exchange); the time of such a group is shared equally among its members
+    std::vector<std::pair<size_t, size_t>> groups;
+    std::vector<float> gms;
 #ifndef RPDE_EMU
     std::vector<hipEvent_t> ev(step_.size() + 1);
     for (auto& e : ev) RPDE_HIP(hipEventCreate(&e));
     RPDE_HIP(hipEventRecord(ev[0], st_.s));
-    for (size_t i = 0; i < step_.size(); ++i) {
-      run_launch(step_[i]);
-      RPDE_HIP(hipEventRecord(ev[i + 1], st_.s));
+    for (size_t i = 0; i < step_.size();) {
+      const size_t j = run_from(i);
+      groups.emplace_back(i, j);
+      RPDE_HIP(hipEventRecord(ev[groups.size()], st_.s));
+      i = j;
     }
-    RPDE_HIP(hipEventSynchronize(ev.back()));
-#endif
-    for (size_t i = 0; i < step_.size(); ++i) {
+    RPDE_HIP(hipEventSynchronize(ev[groups.size()]));
+    for (size_t g = 0; g < groups.size(); ++g) {
       float t = 0.f;
-#ifndef RPDE_EMU
-      RPDE_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      RPDE_HIP(hipEventElapsedTime(&t, ev[g], ev[g + 1]));
+      gms.push_back(t);
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
 #else
+    for (size_t i = 0; i < step_.size();) {
       auto t0 = std::chrono::steady_clock::now();
-      run_launch(step_[i]);
-      t = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      const size_t j = run_from(i);
+      gms.push_back((float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      groups.emplace_back(i, j);
+      i = j;
+    }
 #endif
-      const std::string tag = step_[i].tag;
+    for (size_t g = 0; g < groups.size(); ++g) {   // a group of transposes counts as ONE launch with the bytes of all its arrays
+      const std::string tag = step_[groups[g].first].tag;
       if (!acc.count(tag)) order.push_back(tag);
       Acc& a = acc[tag];
-      a.n += 1; a.ms += t; a.bytes = step_[i].bytes; a.flops = step_[i].flops;
+      a.n += 1; a.ms += gms[g]; a.bytes = 0; a.flops = step_[groups[g].first].flops;
+      for (size_t i = groups[g].first; i < groups[g].second; ++i) a.bytes += step_[i].bytes;
     }
-#ifndef RPDE_EMU
-    for (auto& e : ev) (void)hipEventDestroy(e);
-#endif
     time_ += dt_;
   }
   std::string out;
@@ -888,15 +914,23 @@ std::string Navier2DEngine::profile(int nsteps) {
 }
 
 std::string Navier2DEngine::describe_step() const {
+  // one row per launch as update() issues it: compatible consecutive transposes are one launch (one exchange when sharded)
   std::string out;
-  for (const Launch& l : step_) {
+  for (size_t i = 0; i < step_.size();) {
+    const Launch& l = step_[i];
+    const size_t j = group_end(i);
     char buf[512];
     const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x"};
-    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", l.tag, l.bytes, l.flops, ndisp, kKind[(int)l.type]);
+    double bytes = 0.0;
+    for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
+    std::string kind = kKind[(int)l.type];
+    if (j - i > 1) kind += " (" + std::to_string(j - i) + " arrays)";
+    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", l.tag, bytes, l.flops, ndisp, kind.c_str());
     out += buf;
+    i = j;
   }
   return out;
 }

@@ -157,6 +157,7 @@ class Navier2DEngine {
   // runs step_[i] (and, when sharded, the compatible exchanges that directly follow it in one
   // all-to-all); returns the index of the next launch
   size_t run_from(size_t i);
+  size_t group_end(size_t i) const;   // one past the last launch that goes out together with step_[i]
   static constexpr int kMaxBatch = 6;
   // halo rows of up to three YX arrays in one exchange: `front` rows in front of the local rows (from rank - 1), `tail`
   // rows behind them (from rank + 1)

@@ -16,7 +16,7 @@
 // 7e-15 relative L2 at N = 4096 (first form: 3e-16); the step-level bar is 1e-10, the operator tests use 2e-12.
 //
 // N = 16 T points, T threads (256 for N = 4096: one wave per SIMD), M = N/2 = 8 T complex points, passes 8 x 8 x 8 x 4
-// (N = 256 in the emulation build: 8 x 8 x 2).  The running sum needs no second data layout: thread t owns k = t + u T,
+// (N = 1024, one wave per line: 8 x 8 x 8; N = 256 in the emulation build: 8 x 8 x 2).  The running sum needs no second data layout: thread t owns k = t + u T,
 // so row u is scanned across the threads (DPP inside a wave, wave totals through LDS) and the rows are chained.
 #pragma once
 #include "dct_line.h"
@@ -51,7 +51,7 @@ template <int N, class Fetch, class Emit>
 RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch& fetch, const Emit& emit) {
   using G = HdctGeom<N>;
   constexpr int T = G::T, M = G::M, PL = G::PL, NW = G::NW;
-  static_assert(N == 4096 || N == 256, "N = 16^2 or 16^3");
+  static_assert(N == 4096 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 4, 8 x 8 x 8 or 8 x 8 x 2");
   static_assert(T % 16 == 0, "padded indices assume T a multiple of 16");
   lds_t buf = (lds_t)blk.lds;
   lds2_t buf2 = (lds2_t)blk.lds;
@@ -296,6 +296,8 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     exchange(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     pass(integral_constant<int, 9>{}, integral_constant<int, 4>{});
+  } else if constexpr (N == 1024) {
+    pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
   } else {
     pass(integral_constant<int, 6>{}, integral_constant<int, 2>{});
   }

@@ -132,6 +132,28 @@ __global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ in
   transpose_tile<E, TS>(blk, tile, in, ldi, out, ldo, rows, cols, (int)blockIdx.y * TS, (int)blockIdx.x * TS);
 }
 
+// several arrays of one shape in ONE launch (blockIdx.z picks the array): the six transposes of T1 and the three of T2
+template <class E, int TS>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TransposeBatch b, long ldi, long ldo, int rows, int cols) {
+  __shared__ E tile[TS * (TS + 1)];
+  Blk blk{0, 0, 256, nullptr};
+  transpose_tile<E, TS>(blk, tile, reinterpret_cast<const E*>(b.in[blockIdx.z]), ldi, reinterpret_cast<E*>(b.out[blockIdx.z]), ldo,
+                        rows, cols, (int)blockIdx.y * TS, (int)blockIdx.x * TS);
+}
+void launch_transpose_batch(const TransposeBatch& b, int n, long ldi, long ldo, int rows, int cols, int elem, Stream& st) {
+  if (rows <= 0 || cols <= 0 || n <= 0) return;
+  RPDE_REQUIRE(n <= kMaxTransposeBatch, "transpose batch too large");
+  if (elem == 1) {
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64, n);
+    hipLaunchKernelGGL((transpose_batch_kernel<double, 64>), grid, dim3(256), 0, st.s, b, ldi, ldo, rows, cols);
+  } else {
+    RPDE_REQUIRE(elem == 2 && ldi % 2 == 0 && ldo % 2 == 0, "complex transpose needs even pitches");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, n);
+    hipLaunchKernelGGL((transpose_batch_kernel<Cplx, 32>), grid, dim3(256), 0, st.s, b, ldi / 2, ldo / 2, rows, cols);
+  }
+  RPDE_HIP(hipGetLastError());
+}
+
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
                       int elem, Stream& st) {
   if (rows <= 0 || cols <= 0) return;
@@ -769,10 +791,14 @@ __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs
   RPDE_TRACE_END();
 }
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
-  if (a.N != 4096 || !rhs_line_ok(a)) return false;
+  if ((a.N != 4096 && a.N != 1024) || !rhs_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
-  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(256);
-  if (trace) {
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
+  if (a.N == 1024) {   // one wave per line
+    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<1024, 0, false, 3>), grid, block, 0, st.s, a, nullptr);
+    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<1024, 1, false, 3>), grid, block, 0, st.s, a, nullptr);
+    else hipLaunchKernelGGL((rhs_line_kernel<1024, 2, false, 3>), grid, block, 0, st.s, a, nullptr);
+  } else if (trace) {
     if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, true>), grid, block, 0, st.s, a, trace);
     else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, true>), grid, block, 0, st.s, a, trace);
     else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, true>), grid, block, 0, st.s, a, trace);
@@ -787,8 +813,13 @@ bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   return true;
 }
 bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
-  if (a.N != 4096 || !dct_line_ok(a)) return false;
+  if ((a.N != 4096 && a.N != 1024) || !dct_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
+  if (a.N == 1024) {   // one wave per line, the half-length core only
+    hipLaunchKernelGGL((hdct_line_kernel<1024>), dim3(8 * ((a.nlines + 7) / 8)), dim3(64), 0, st.s, a, nullptr);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   if ((g_hdct & 1) || trace) {
     if (trace) hipLaunchKernelGGL((hdct_line_kernel<4096, true>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
     else hipLaunchKernelGGL((hdct_line_kernel<4096>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
@@ -842,8 +873,13 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   return true;
 }
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
-  if (a0.N != 4096 || a1.N != 4096 || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
+  if ((a0.N != 4096 && a0.N != 1024) || a1.N != a0.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   if (a0.nlines <= 0) return true;
+  if (a0.N == 1024) {
+    hipLaunchKernelGGL((hdct_line2_kernel<1024>), dim3(8 * ((a0.nlines + 7) / 8)), dim3(64), 0, st.s, a0, a1);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   if (g_hdct & 2) {
     static const int wpc = [] { const char* e = std::getenv("RPDE_S1_WPC"); return e ? std::atoi(e) : 4; }();   // A/B switch
     if (wpc == 3) hipLaunchKernelGGL((hdct_line2_kernel<4096, 3>), dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
@@ -1014,6 +1050,9 @@ void launch_transpose(const double* in, long ldi, double* out, long ldo, int row
     emu_transpose<Cplx, 32>(reinterpret_cast<const Cplx*>(in), ldi / 2, reinterpret_cast<Cplx*>(out), ldo / 2, rows, cols);
   }
 }
+void launch_transpose_batch(const TransposeBatch& b, int n, long ldi, long ldo, int rows, int cols, int elem, Stream& st) {
+  for (int a = 0; a < n; ++a) launch_transpose(b.in[a], ldi, b.out[a], ldo, rows, cols, elem, st);
+}
 void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream&) {
   for (int m = 0; m < M; ++m)
@@ -1135,6 +1174,7 @@ bool launch_rhs_line(const RhsLineArgs& a, Stream&, long long*) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
     if (a.N == 4096) { if (a.which == 0) rhs_line<4096, 0>(blk, a); else if (a.which == 1) rhs_line<4096, 1>(blk, a); else rhs_line<4096, 2>(blk, a); }
+    else if (a.N == 1024) { if (a.which == 0) rhs_line<1024, 0>(blk, a); else if (a.which == 1) rhs_line<1024, 1>(blk, a); else rhs_line<1024, 2>(blk, a); }
     else { if (a.which == 0) rhs_line<256, 0>(blk, a); else if (a.which == 1) rhs_line<256, 1>(blk, a); else rhs_line<256, 2>(blk, a); }
   }
   return true;
@@ -1146,7 +1186,8 @@ bool launch_dct_line(const DctLineArgs& a, Stream&, long long*) {
   for (int line = 0; line < a.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
-    if (g_hdct & 1) { if (a.N == 4096) hdct_bwd_line<4096>(blk, a); else hdct_bwd_line<256>(blk, a); }
+    if (a.N == 1024) hdct_bwd_line<1024>(blk, a);
+    else if (g_hdct & 1) { if (a.N == 4096) hdct_bwd_line<4096>(blk, a); else hdct_bwd_line<256>(blk, a); }
     else if (a.N == 4096) dct_bwd_line<4096>(blk, a); else dct_bwd_line<256>(blk, a);
   }
   return true;

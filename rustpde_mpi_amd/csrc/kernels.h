@@ -32,6 +32,11 @@ void launch_line_program(const Program& pg, Stream& st);
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
                       int elem, Stream& st);
 
+// up to six arrays of one shape in one launch
+constexpr int kMaxTransposeBatch = 6;
+struct TransposeBatch { const double* in[kMaxTransposeBatch]; double* out[kMaxTransposeBatch]; };
+void launch_transpose_batch(const TransposeBatch& b, int n, long ldi, long ldo, int rows, int cols, int elem, Stream& st);
+
 // C[m, n] = sum_k A[m, k] * B[n, k]   (A: M x K lda, B: N x K ldb, C: M x N ldc), f64
 void launch_gemm_nt(int M, int N, int K, const double* A, long lda, const double* B, long ldb,
                     double* C, long ldc, Stream& st);

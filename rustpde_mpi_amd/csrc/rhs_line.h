@@ -45,7 +45,7 @@ struct RhsLineArgs {
   const double *p2 = nullptr, *q2 = nullptr, *r2 = nullptr;   // back substitution, chunk-major DESCENDING [i * T + t] = tab[16 (T-1-t) + i]
 };
 RPDE_HD inline bool rhs_line_ok(const RhsLineArgs& a) {
-  return (a.N == 256 || a.N == 4096) && (((size_t)a.conv) & 15) == 0 && (((size_t)a.st) & 15) == 0 && (a.ld & 1) == 0 &&
+  return (a.N == 256 || a.N == 1024 || a.N == 4096) && (((size_t)a.conv) & 15) == 0 && (((size_t)a.st) & 15) == 0 && (a.ld & 1) == 0 &&
          a.ld > a.N + 1 && a.which >= 0 && a.which <= 2 && a.stx == (a.which == 2 ? 1 : 2) && (a.which == 0 || a.lowx != nullptr);
 }
 

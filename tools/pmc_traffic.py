@@ -13,8 +13,21 @@ microbench whose traffic is known exactly: 4096 lines x 4097 f64 read and writte
 import argparse
 import csv
 import glob
+import hashlib
 import json
 import os
+
+
+def csrc_sha256():
+    """sha256 over the kernel / engine sources the counters were collected on (bench.py marks a traffic file stale when
+    the sources it runs on hash differently)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rustpde_mpi_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".h", ".cc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
 
 
 def per_position(dirname, counter, steps, L):
@@ -67,7 +80,8 @@ def main():
         t["traffic_bytes"] = t["read_bytes"] + t["write_bytes"]
         t["traffic_over_algorithmic"] = t["traffic_bytes"] / t["algorithmic_bytes"] if t["algorithmic_bytes"] else None
         t["event_ms_per_launch"] = sch["event_ms"].get(tag)
-    out = {"workload": sch["workload"], "steps_averaged": steps,
+    out = {"workload": sch["workload"], "steps_averaged": steps, "csrc_sha256": csrc_sha256(),
+           "commit": os.environ.get("EVIDENCE_COMMIT", "").strip() or None,
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-B requests tallied as 64 B); WRITE_SIZE x1",
            "per_launch": tags,
            "step_total_traffic_bytes": sum(t["traffic_bytes"] * t["launches_per_step"] for t in tags.values()),

@@ -17,7 +17,7 @@ def kind_of_tag(tag):
     if tag.startswith("G"): return "gemm"
     if tag.startswith("pseu"): return "set_element"
     if tag.startswith("H"): return "copy2d"
-    if tag.startswith("C4 y: hholtz"): return "col_hholtz"
+    if tag.startswith("C4 y: hholtz") or tag.startswith("C7"): return "col_hholtz"
     if tag.startswith("C"): return "col_diff"
     return "line_kernel"
 
@@ -25,6 +25,7 @@ def kind_of_tag(tag):
 def kind_of_kernel(name):
     for k in ("transpose", "gemm", "set_element", "line_kernel", "copy2d", "col_hholtz", "col_diff"):
         if k in name: return k
+    if "_line" in name: return "line_kernel"   # whole-line kernels: hdct_line2_kernel, conv_line_kernel, rhs_line_kernel ...
     return "other"
 
 
