@@ -31,7 +31,8 @@ typedef struct rpde_hholtz_adi rpde_hholtz_adi; /* HholtzAdi<f64,2>             
 typedef struct rpde_poisson rpde_poisson;     /* Poisson<f64,2>                      src/solver/poisson.rs:33-40 */
 
 /* base kinds (funspace BaseKind, used at src/field.rs:172-179) */
-enum { RPDE_CHEBYSHEV = 0, RPDE_CHEB_DIRICHLET = 1, RPDE_CHEB_NEUMANN = 2, RPDE_FOURIER_R2C = 3 };
+enum { RPDE_CHEBYSHEV = 0, RPDE_CHEB_DIRICHLET = 1, RPDE_CHEB_NEUMANN = 2, RPDE_FOURIER_R2C = 3,
+       RPDE_CHEB_DIRICHLET_NEUMANN = 4 };   /* axis 1 only: the temperature of bc = "hc", src/navier_stokes/navier.rs:245-248 */
 enum { RPDE_PHYSICAL = 0, RPDE_SPECTRAL = 1 };
 
 const char* rpde_last_error(void);

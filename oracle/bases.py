@@ -19,6 +19,7 @@ from .timing import timed  # noqa: E402  (per-phase CPU baseline of bench.py)
 CHEBYSHEV = "chebyshev"
 CHEB_DIRICHLET = "cheb_dirichlet"
 CHEB_NEUMANN = "cheb_neumann"
+CHEB_DIRICHLET_NEUMANN = "cheb_dirichlet_neumann"
 FOURIER_R2C = "fourier_r2c"
 
 
@@ -32,7 +33,7 @@ def _axis0(fn, x, axis, *a, **k):
 class Base:
     """One 1-D basis (funspace ``BaseR2r`` / ``BaseR2c``).
 
-    kind: chebyshev | cheb_dirichlet | cheb_neumann | fourier_r2c
+    kind: chebyshev | cheb_dirichlet | cheb_neumann | cheb_dirichlet_neumann | fourier_r2c
     n   : number of grid points (physical size)
     m   : number of spectral coefficients (n, n-2, or n//2+1 complex)
     """
@@ -42,7 +43,7 @@ class Base:
         self.n = n
         if kind == CHEBYSHEV:
             self.m = n
-        elif kind in (CHEB_DIRICHLET, CHEB_NEUMANN):
+        elif kind in (CHEB_DIRICHLET, CHEB_NEUMANN, CHEB_DIRICHLET_NEUMANN):
             self.m = n - 2
         elif kind == FOURIER_R2C:
             self.m = n // 2 + 1
@@ -52,18 +53,31 @@ class Base:
             k = np.arange(self.m, dtype=np.float64)
             # stencil S (n x m): S[k,k] = dia[k], S[k+2,k] = low[k]   (App. A.3)
             self.dia = np.ones(self.m)
+            self.low1 = None     # S[k+1,k]: only the three-term stencil of cheb_dirichlet_neumann has it
             if kind == CHEB_DIRICHLET:
                 self.low = -np.ones(self.m)
-            else:
+            elif kind == CHEB_NEUMANN:
                 self.low = -((k / (k + 2.0)) ** 2)
-            # normal equations (S^T S) a = S^T c : offsets -2, 0, +2
+            else:
+                # phi_k = T_k + a_k T_{k+1} + b_k T_{k+2} with phi_k(-1) = 0 and phi_k'(+1) = 0 (Shen's mixed basis;
+                # T_k(-1) = (-1)^k, T_k'(1) = k^2):  b_k = a_k - 1,  k^2 + a_k (k+1)^2 + b_k (k+2)^2 = 0.
+                # The wall assignment follows the lift of the reference: bc_hc (boundary_conditions.rs:96-134)
+                # carries the bottom temperature at y[0] = -1 and has T = T' = 0 at y[n-1] = +1, so the
+                # homogeneous part is Dirichlet at -1 and Neumann at +1 (navier.rs:245-248).
+                den = (k + 1.0) ** 2 + (k + 2.0) ** 2
+                self.low1 = 4.0 * (k + 1.0) / den
+                self.low = -(k ** 2 + (k + 1.0) ** 2) / den
+            # normal equations (S^T S) a = S^T c : offsets -2, 0, +2 (and -1, +1 for the three-term stencil)
             self.ls_main = self.dia ** 2 + self.low ** 2
             self.ls_off = self.dia[2:] * self.low[:-2]
+            if self.low1 is not None:
+                self.ls_main = self.ls_main + self.low1 ** 2
+                self.ls_off1 = self.low1[:-1] * self.dia[1:] + self.low[:-1] * self.low1[1:]
 
     # ------------------------------------------------------------------ kinds
     @property
     def is_composite(self):
-        return self.kind in (CHEB_DIRICHLET, CHEB_NEUMANN)
+        return self.kind in (CHEB_DIRICHLET, CHEB_NEUMANN, CHEB_DIRICHLET_NEUMANN)
 
     @property
     def is_cheb(self):
@@ -128,6 +142,8 @@ class Base:
         c = np.zeros((self.n,) + a.shape[1:], dtype=a.dtype)
         c[: self.m] = self.dia[:, None] * a
         c[2:] += self.low[:, None] * a
+        if self.low1 is not None:
+            c[1: self.m + 1] += self.low1[:, None] * a
         return c
 
     @timed("stencil_gradient")
@@ -140,6 +156,16 @@ class Base:
     def _from_ortho0(self, c):
         m = self.m
         d = self.dia[:, None] * c[:m] + self.low[:, None] * c[2:]
+        if self.low1 is not None:
+            # three-term stencil: S^T S is pentadiagonal and symmetric positive definite; any exact solver gives
+            # the least-squares projection (the algorithm funspace uses for it is not visible from the reference)
+            import scipy.linalg as _la
+            d = d + self.low1[:, None] * c[1: m + 1]
+            ab = np.zeros((3, m))
+            ab[0] = self.ls_main
+            ab[1, : m - 1] = self.ls_off1
+            ab[2, : m - 2] = self.ls_off
+            return _la.solveh_banded(ab, d, lower=True)
         off, main = self.ls_off, self.ls_main
         # forward sweep (data independent part)
         w = np.zeros(m)
@@ -222,6 +248,27 @@ class Base:
         d4 = np.where(r + 2 <= n - 5, 1.0 / (4.0 * i * (i + 1.0)), 0.0)
         return d0, d2, d4
 
+    def hholtz_bands7(self):
+        """(mat_a, mat_b) = (pinv.S, peye.S) of ``field.rs:208-212`` for any composite stencil as dictionaries
+        offset -> array of length m (entry r = mat[r, r + offset], zero where the column is out of range):
+        mat_a has offsets -2 .. +4, mat_b offsets 0 .. +2.  With a two-term stencil the odd offsets vanish and the
+        rest equals ``hholtz_bands``; the three-term stencil of cheb_dirichlet_neumann fills all seven -- the
+        matrix ``PdmaPlus2`` solves (``hholtz_adi.rs:62-64``, ``pdma_plus2.rs:45-53``)."""
+        assert self.is_composite
+        m = self.m
+        p = dict(zip((0, 2, 4), self.pinv_bands()))
+        low1 = self.low1 if self.low1 is not None else np.zeros(m)
+        sten = {0: self.dia, 1: low1, 2: self.low}          # sten[t][j] = S[j + t, j]
+        r = np.arange(m)
+
+        def s(t, j):          # S[j + t, j] for an index array j, zero outside 0 <= j < m
+            ok = (j >= 0) & (j < m)
+            return np.where(ok, sten[t][np.clip(j, 0, m - 1)], 0.0)
+
+        mat_a = {o: sum(p[q] * s(q - o, r + o) for q in (0, 2, 4) if 0 <= q - o <= 2) for o in range(-2, 5)}
+        mat_b = {o: s(2 - o, r + o) for o in (0, 1, 2)}     # peye[r, r+2] = 1
+        return mat_a, mat_b
+
     def hholtz_bands(self):
         """Band forms of (mat_a, mat_b) = (pinv.S, peye.S) of ``field.rs:208-212``.
 
@@ -251,6 +298,8 @@ class Base:
         for k in range(self.m):
             s[k, k] = self.dia[k]
             s[k + 2, k] = self.low[k]
+            if self.low1 is not None:
+                s[k + 1, k] = self.low1[k]
         return s
 
     def laplace_inv_dense(self):
@@ -287,6 +336,10 @@ def cheb_dirichlet(n):
 
 def cheb_neumann(n):
     return Base(CHEB_NEUMANN, n)
+
+
+def cheb_dirichlet_neumann(n):
+    return Base(CHEB_DIRICHLET_NEUMANN, n)
 
 
 def fourier_r2c(n):

@@ -2,7 +2,7 @@
 
 Follows, in this order:
   constructors      ``src/navier_stokes/navier.rs:215-308`` (confined), ``336-428`` (periodic)
-  BC lift           ``src/navier_stokes/boundary_conditions.rs:18-36, 143-161``
+  BC lift           ``src/navier_stokes/boundary_conditions.rs:18-36, 143-161`` ("rbc"), ``96-134, 163-202`` ("hc")
   nu / ka           ``src/navier_stokes/functions.rs:12-21``
   IC helpers        ``src/navier_stokes/functions.rs:85-126``
   conv_term/dealias ``src/navier_stokes/functions.rs:56-82``
@@ -88,6 +88,21 @@ def _bc_rbc(space):
     return f
 
 
+def _bc_hc(space):
+    """Horizontal convection, ``boundary_conditions.rs:96-134`` (confined) / ``163-202`` (periodic): per x a parabola
+    in y with its vertex (value 0, slope 0) at the top wall y[n-1] and the value -0.5 cos(2 pi (x - x0) / L) at the
+    bottom wall y[0]."""
+    f = Field2(space)
+    x, y = f.x
+    x0, length = x[0], x[-1] - x[0]
+    f_x = -0.5 * np.cos(2.0 * np.pi * (x - x0) / length)
+    a = f_x / (y[0] - y[-1]) ** 2
+    f.v[:, :] = a[:, None] * ((y - y[-1]) ** 2)[None, :]
+    f.forward()
+    f.backward()
+    return f
+
+
 def _apply_sin_cos(field, amp, m, n):
     x, y = field.x
     x = (x - x[0]) / (x[-1] - x[0])
@@ -108,8 +123,13 @@ class Navier2D:
     """Oracle mirror of ``Navier2D<T, S>`` (confined: T = f64, periodic: T = Complex<f64>)."""
 
     def __init__(self, nx, ny, ra, pr, dt, aspect, bc, periodic, eig_mode="full", eig_override=None):
-        if bc != "rbc":
+        if bc not in ("rbc", "hc"):
             raise ValueError(f"Boundary condition type {bc!r} not recognized!")
+        self.bc = bc
+        # temperature: Dirichlet at both walls ("rbc") or Dirichlet at the bottom, Neumann at the top ("hc",
+        # navier.rs:245-249 / 366-370); the lift carries the inhomogeneous part
+        temp_y = B.cheb_dirichlet if bc == "rbc" else B.cheb_dirichlet_neumann
+        lift = _bc_rbc if bc == "rbc" else _bc_hc
         self.periodic = periodic
         self.nx, self.ny = nx, ny
         self.scale = [aspect, 1.0]
@@ -122,16 +142,16 @@ class Navier2D:
             bx = B.fourier_r2c
             self.velx = Field2(S(bx(nx), B.cheb_dirichlet(ny)))
             self.vely = Field2(S(bx(nx), B.cheb_dirichlet(ny)))
-            self.temp = Field2(S(bx(nx), B.cheb_dirichlet(ny)))
-            self.tempbc = _bc_rbc(S(bx(nx), B.chebyshev(ny)))
+            self.temp = Field2(S(bx(nx), temp_y(ny)))
+            self.tempbc = lift(S(bx(nx), B.chebyshev(ny)))
             self.pres = Field2(S(bx(nx), B.chebyshev(ny)))
             self.pseu = Field2(S(bx(nx), B.cheb_neumann(ny)))
             self.field = Field2(S(bx(nx), B.chebyshev(ny)))
         else:
             self.velx = Field2(S(B.cheb_dirichlet(nx), B.cheb_dirichlet(ny)))
             self.vely = Field2(S(B.cheb_dirichlet(nx), B.cheb_dirichlet(ny)))
-            self.temp = Field2(S(B.cheb_neumann(nx), B.cheb_dirichlet(ny)))
-            self.tempbc = _bc_rbc(S(B.chebyshev(nx), B.chebyshev(ny)))
+            self.temp = Field2(S(B.cheb_neumann(nx), temp_y(ny)))
+            self.tempbc = lift(S(B.chebyshev(nx), B.chebyshev(ny)))
             self.pres = Field2(S(B.chebyshev(nx), B.chebyshev(ny)))
             self.pseu = Field2(S(B.cheb_neumann(nx), B.cheb_neumann(ny)))
             self.field = Field2(S(B.chebyshev(nx), B.chebyshev(ny)))

@@ -4,6 +4,7 @@ Restates, lane-vectorised in NumPy:
   Fdma          ``src/solver/fdma.rs:33-118``      (4-diagonal solve, offsets -2,0,+2,+4)
   MatVecFdma    ``src/solver/matvec.rs:177-228``   (banded mat-vec, the B2 preconditioner)
   Sdma          ``src/solver/sdma.rs:21-46``       (diagonal solve)
+  PdmaPlus2     ``src/solver/pdma_plus2.rs:45-157`` (7-diagonal solve, offsets -2 .. +4: the "hc" temperature)
   HholtzAdi     ``src/solver/hholtz_adi.rs:48-76,149-169``
   FdmaTensor    ``src/solver/fdma_tensor.rs:106-154``
   Poisson       ``src/solver/poisson.rs:54-94,195-236``
@@ -15,7 +16,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.linalg as _la
 
-from .bases import Base, Space2, FOURIER_R2C, _axis0
+from .bases import Base, Space2, FOURIER_R2C, CHEB_DIRICHLET_NEUMANN, _axis0
 from .timing import phase, timed
 
 
@@ -106,6 +107,67 @@ class Sdma:
         return x / self.dia.reshape(shape)
 
 
+# --------------------------------------------------------------------------- PdmaPlus2
+class PdmaPlus2:
+    """Banded system with offsets -2 .. +4 (``pdma_plus2.rs``): LU without pivoting, the factorisation is
+    precomputed (``from_matrix``, ``:45-117``), a solve is a two-term forward and a four-term backward recurrence
+    (``solve_lane``, ``:119-157``).  ``bands``: offset -> array of length n, entry r = a[r, r + offset] (row
+    indexed, zero where the column is out of range) -- the reference extracts the same numbers with ``diag(a, k)``
+    (column-indexed for the lower diagonals: ``l2[i] = a[i+2, i]``, ``l1[i] = a[i+1, i]``).  Written with
+    zero-padded arrays, so the reference's special cases for the first two and last four rows are the general
+    row with vanishing out-of-range terms, in the reference's order of operations."""
+
+    def __init__(self, bands):
+        n = len(bands[0])
+        self.n = n
+        z = lambda: np.zeros(n + 4)
+        l2, l1, d0, u1, u2, u3, u4 = z(), z(), z(), z(), z(), z(), z()
+        l2[: n - 2] = np.asarray(bands[-2], float)[2:]        # l2[i] = a[i+2, i]
+        l1[: n - 1] = np.asarray(bands[-1], float)[1:]        # l1[i] = a[i+1, i]
+        d0[:n] = bands[0]
+        for arr, o in ((u1, 1), (u2, 2), (u3, 3), (u4, 4)):
+            arr[: n - o] = np.asarray(bands[o], float)[: n - o]
+        al, be, ga, de, ka, mu = z(), z(), z(), z(), z(), z()
+        for i in range(n):
+            a2 = al[i - 2] if i >= 2 else 0.0
+            b2 = be[i - 2] if i >= 2 else 0.0
+            g2 = ga[i - 2] if i >= 2 else 0.0
+            e2 = de[i - 2] if i >= 2 else 0.0
+            w2 = l2[i - 2] if i >= 2 else 0.0
+            a1 = al[i - 1] if i >= 1 else 0.0
+            b1 = be[i - 1] if i >= 1 else 0.0
+            g1 = ga[i - 1] if i >= 1 else 0.0
+            e1 = de[i - 1] if i >= 1 else 0.0
+            ka[i] = (l1[i - 1] if i >= 1 else 0.0) - a2 * w2
+            mu[i] = d0[i] - b2 * w2 - a1 * ka[i]
+            al[i] = (u1[i] - g2 * w2 - b1 * ka[i]) / mu[i]
+            be[i] = (u2[i] - e2 * w2 - g1 * ka[i]) / mu[i]
+            ga[i] = (u3[i] - e1 * ka[i]) / mu[i]
+            de[i] = u4[i] / mu[i]
+        self.al, self.be, self.ga, self.de, self.l2, self.ka, self.mu = al, be, ga, de, l2, ka, mu
+
+    def _solve0(self, rhs):
+        n = self.n
+        l2, ka, mu = self.l2, self.ka, self.mu
+        ze = np.zeros((n + 4,) + rhs.shape[1:], dtype=rhs.dtype)
+        for i in range(n):
+            acc = rhs[i]
+            if i >= 2:
+                acc = acc - ze[i - 2] * l2[i - 2]
+            if i >= 1:
+                acc = acc - ze[i - 1] * ka[i]
+            ze[i] = acc / mu[i]
+        x = ze                      # entries n .. n+3 stay zero: the four-term recurrence needs no end cases
+        al, be, ga, de = self.al, self.be, self.ga, self.de
+        for i in range(n - 2, -1, -1):
+            x[i] = ze[i] - x[i + 1] * al[i] - x[i + 2] * be[i] - x[i + 3] * ga[i] - x[i + 4] * de[i]
+        return x[:n].copy()
+
+    def solve(self, x, axis):
+        assert x.shape[axis] == self.n, "PdmaPlus2: dimension mismatch"
+        return _axis0(self._solve0, x, axis)
+
+
 # --------------------------------------------------------------------------- ingredients
 def ingredients_for_hholtz(base: Base):
     """``field.rs:195-216``: band forms of (mat_a, mat_b, precond)."""
@@ -115,6 +177,9 @@ def ingredients_for_hholtz(base: Base):
     if not base.is_composite:
         raise NotImplementedError("solver ingredients for the orthonormal Chebyshev base "
                                   "are not on the Navier2D path")
+    if base.kind == CHEB_DIRICHLET_NEUMANN:
+        mat_a, mat_b = base.hholtz_bands7()
+        return ("band7", mat_a), ("band7", mat_b), base.pinv_bands()
     mat_a, mat_b = base.hholtz_bands()
     return ("band", mat_a), ("band", mat_b), base.pinv_bands()
 
@@ -132,6 +197,9 @@ class HholtzAdi:
             if ka == "diag":
                 self.solver.append(Sdma(a - b * ci))
                 self.matvec.append(None)
+            elif ka == "band7":       # BaseKind::ChebDirichletNeumann => PdmaPlus2 (hholtz_adi.rs:62-64)
+                self.solver.append(PdmaPlus2({o: a[o] - b.get(o, 0.0) * ci for o in a}))
+                self.matvec.append(MatVecFdma(*precond, n_in=base.n))
             else:
                 a_low, a_dia, a_up1, a_up2 = a
                 b_dia, b_up1 = b
@@ -154,9 +222,12 @@ class HholtzAdi1:
     def __init__(self, base: Base, c):
         self._h = HholtzAdi.__new__(HholtzAdi)
         (ka, a), (_, b), precond = ingredients_for_hholtz(base)
-        a_low, a_dia, a_up1, a_up2 = a
-        b_dia, b_up1 = b
-        self.solver = Fdma(a_low, a_dia - b_dia * c, a_up1 - b_up1 * c, a_up2)
+        if ka == "band7":
+            self.solver = PdmaPlus2({o: a[o] - b.get(o, 0.0) * c for o in a})
+        else:
+            a_low, a_dia, a_up1, a_up2 = a
+            b_dia, b_up1 = b
+            self.solver = Fdma(a_low, a_dia - b_dia * c, a_up1 - b_up1 * c, a_up2)
         self.matvec = MatVecFdma(*precond, n_in=base.n)
 
     def solve(self, b):

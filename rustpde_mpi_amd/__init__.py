@@ -27,7 +27,7 @@ import numpy as np
 from ._capi import Lib, RpdeError, as_f64, ptr
 
 __all__ = ["Navier2D", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
-           "chebyshev", "cheb_dirichlet", "cheb_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
+           "chebyshev", "cheb_dirichlet", "cheb_neumann", "cheb_dirichlet_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
 _lib = None
@@ -44,13 +44,14 @@ def lib() -> Lib:
 
 
 PHYSICAL, SPECTRAL = 0, 1
-CHEBYSHEV, CHEB_DIRICHLET, CHEB_NEUMANN, FOURIER_R2C = 0, 1, 2, 3
+CHEBYSHEV, CHEB_DIRICHLET, CHEB_NEUMANN, FOURIER_R2C, CHEB_DIRICHLET_NEUMANN = 0, 1, 2, 3, 4
 
 
 def chebyshev(n): return (CHEBYSHEV, n)
 def cheb_dirichlet(n): return (CHEB_DIRICHLET, n)
 def cheb_neumann(n): return (CHEB_NEUMANN, n)
 def fourier_r2c(n): return (FOURIER_R2C, n)
+def cheb_dirichlet_neumann(n): return (CHEB_DIRICHLET_NEUMANN, n)   # axis 1 only (the "hc" temperature, navier.rs:245-248)
 
 
 class _FieldView:

@@ -412,7 +412,7 @@ int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_ev
 int rpde_space2_create(int kind0, int n0, int kind1, int n1, int device, rpde_space2** out) {
   RPDE_TRY({
     RPDE_REQUIRE(out, "null pointer");
-    RPDE_REQUIRE(kind0 >= 0 && kind0 <= 3 && kind1 >= 0 && kind1 <= 2, "unknown base kind");
+    RPDE_REQUIRE(kind0 >= 0 && kind0 <= 3 && ((kind1 >= 0 && kind1 <= 2) || kind1 == kChebDirichletNeumann), "unknown base kind");
     select_device(device);
     auto* s = new rpde_space2{nullptr, Stream{}, device};
     try {

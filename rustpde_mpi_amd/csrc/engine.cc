@@ -53,7 +53,9 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   RPDE_REQUIRE(comm_.size <= 8, "at most 8 ranks (one xGMI-connected MI355X node; the exchange descriptors hold 8 peers)");
   RPDE_REQUIRE(comm_.size == 1 || comm_.fn != nullptr || comm_.rccl != nullptr,
                "sharded engine needs an all-to-all transport");
-  RPDE_REQUIRE(bc == "rbc", "Boundary condition type \"" + bc + "\" not recognized! (supported: \"rbc\")");
+  RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");   // navier.rs:251 / 372
+  hc_ = bc == "hc";
+  RPDE_REQUIRE(!hc_ || comm_.size == 1, "bc = \"hc\" runs on one GPU (the three-term stencil of its temperature has no pencil-sharded kernels)");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   // everything that can throw comes after this block; the members below are released by
@@ -102,7 +104,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   const BaseKind bx_tmp = periodic ? kFourierR2c : kChebNeumann;
   const BaseKind bx_ort = periodic ? kFourierR2c : kChebyshev;
   sp_vel_ = std::make_unique<Space2Ops>(make_base(bx_vel, nx), make_base(kChebDirichlet, ny));
-  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebDirichlet, ny));
+  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(hc_ ? kChebDirichletNeumann : kChebDirichlet, ny));
   sp_ortho_ = std::make_unique<Space2Ops>(make_base(bx_ort, nx), make_base(kChebyshev, ny));
   sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
   hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, dt * nu_ / (sx_ * sx_), dt * nu_ / (sy_ * sy_));
@@ -128,6 +130,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   const size_t nxy = (size_t)nxl_ * ldy_;
   for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &GX_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
+  if (hc_) TO_.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   red_.alloc(2);
@@ -142,7 +145,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     const int jend = std::min(ye_, my_);
     const Base& by = sp_vel_->base(1);
     colhh_vel_.upload(build_colhh_tables(pinv_tables(by), hh_vel_->host[1], kColBlockRows, yb_, jend, rk));
-    colhh_temp_.upload(build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
+    if (!hc_) colhh_temp_.upload(build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
     if (!periodic) {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables)
       const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows, yb_, jend, rk);
       colcorr_a_.upload(cc.a); colcorr_b_.upload(cc.b);
@@ -189,6 +192,18 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     Vec prof((size_t)nx * ny);
     for (int i = 0; i < nx; ++i)
       for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = m * y[j] + n;
+    if (hc_) {
+      // horizontal convection (boundary_conditions.rs:96-134 / 163-202): per x a parabola in y with its vertex (value 0,
+      // slope 0) at the top wall y[ny-1] and the value -0.5 cos(2 pi (x - x0) / L) at the bottom wall y[0].  The grid of
+      // the lift is unscaled in the reference as well (only velx, vely, temp, pres are scaled, navier.rs:258-261)
+      const Vec x = base_coords(so.base(0));
+      const double x0 = x.front(), len = x.back() - x.front();
+      for (int i = 0; i < nx; ++i) {
+        const double f_x = -0.5 * std::cos(2.0 * M_PI * (x[i] - x0) / len);
+        const double a = f_x / ((y.front() - y.back()) * (y.front() - y.back()));
+        for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = a * (y[j] - y.back()) * (y[j] - y.back());
+      }
+    }
     Arr2 v(nx, ny, 1), vh(so.ortho_rows(), ny, ex_), g(so.ortho_rows(), ny, ex_), g2(so.ortho_rows(), ny, ex_);
     dev_upload2d(v.p(), v.ld, prof.data(), nx, ny);
     so.forward(v, vh, st_);
@@ -696,16 +711,39 @@ void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const out
   l.type = Launch::kColHholtz;
   l.tag = tag;
   ColHhArgs& a = l.ch;
-  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = colhh_vel_.NB; a.ld = ldx_; a.nf = 3;
+  const int nf = hc_ ? 2 : 3;   // "hc": the temperature goes through add_hc_hholtz (seven diagonals)
+  a.n = my_; a.nin = my_; a.ncols = ncols; a.NB = colhh_vel_.NB; a.ld = ldx_; a.nf = nf;
   a.row0 = yb_; a.jend = std::min(ye_, my_); a.nranks = comm_.size; a.rank = comm_.rank;
-  for (int f = 0; f < 3; ++f) {
+  for (int f = 0; f < nf; ++f) {
     a.in[f] = in[f]; a.out[f] = out[f]; a.shift[f] = 0;
     a.tab[f] = (f == 2 ? colhh_temp_ : colhh_vel_).tabs();
   }
   a.in_half = 0;
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = flagp();
-  l.bytes = 3.0 * 2.0 * 8.0 * (double)ylines(my_) * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
+  l.bytes = nf * 2.0 * 8.0 * (double)ylines(my_) * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
+  step_.push_back(l);
+}
+void Navier2DEngine::add_hc_to_ortho(int ncols) {
+  // temp.to_ortho() along y once per step (three-term stencil, pdma.h): S1, the buoyancy and the right-hand side of the
+  // temperature equation read orthonormal-y rows from TO_ where the "rbc" step applies the Dirichlet stencil on the fly
+  const AxisTables& yT = sp_temp_->axis(1);
+  Launch l;
+  l.type = Launch::kSten3Rows;
+  l.tag = "H0 y: temp -> ortho-y (three-term stencil)";
+  l.s3 = Sten3RowsArgs{yx(T_), ldx_, yx(TO_), ldx_, my_, ncols, yT.low1.p, yT.low.p, 0, ny_};
+  l.bytes = 8.0 * ncols * ((double)my_ + ny_);
+  step_.push_back(l);
+}
+void Navier2DEngine::add_hc_hholtz(const double* in, double* out, int ncols) {
+  // y part of the temperature's Helmholtz solve: B2 rows (matvec.rs:207-228) + PdmaPlus2 (pdma_plus2.rs:119-157) along
+  // the columns of the YX array
+  const AxisTables& yT = sp_temp_->axis(1);
+  Launch l;
+  l.type = Launch::kPdmaCols;
+  l.tag = "C4 y: hholtz-y temp (PdmaPlus2 columns)";
+  l.pc = PdmaColsArgs{in, ldx_, out, ldx_, my_, ncols, yT.pv0.p, yT.pv1.p, yT.pv2.p, hh_temp_->pdma[1].tabs(), flagp()};
+  l.bytes = 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: one read, one write (the intermediate ze rows are written and read back)
   step_.push_back(l);
 }
 void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag) {
@@ -775,6 +813,8 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: run_col_diff(l.cd); break;
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
+    case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
+    case Launch::kPdmaCols: launch_pdma_cols(l.pc, st_); break;
   }
 }
 
@@ -923,7 +963,7 @@ std::string Navier2DEngine::describe_step() const {
     const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
-                                        "whole-line rhs + hholtz-x"};
+                                        "whole-line rhs + hholtz-x", "row stencil", "column solve"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -1455,16 +1495,23 @@ void Navier2DEngine::build_confined() {
     add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 1, to_xy, false, tag);
   };
 
+  // "hc": the temperature is cheb_dirichlet_neumann along y.  Its three-term stencil is applied once per step on the YX
+  // state (TO_: orthonormal y, ny rows); every stage below then treats the temperature as orthonormal in y (`yO`, no
+  // stencil, ny rows instead of my) and the Helmholtz solve along y is a seven-diagonal column solve.
+  const bool hc = hc_;
+  AxisTables& yO = sp_ortho_->axis(1);
+  const int tr = hc ? ny : my;   // rows of the temperature arrays in front of the y transforms
   // ---- halos of the state for the cross-line y stencils of S3
   add_halo({yx(U_), yx(V_), yx(T_)}, 2, 0, "H0 halo velx, vely, temp");
+  if (hc) add_hc_to_ortho(mx);
   // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
-  struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; } s1[3] = {
-      {&U_, &xD, &Y_[0], &Y_[1]}, {&V_, &xD, &Y_[2], &Y_[3]}, {&T_, &xN, &Y_[4], &Y_[5]}};
+  struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; int rows; } s1[3] = {
+      {&U_, &xD, &Y_[0], &Y_[1], my}, {&V_, &xD, &Y_[2], &Y_[3], my}, {hc ? &TO_ : &T_, &xN, &Y_[4], &Y_[5], tr}};
   static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
   for (auto& f : s1) {
     {   // whole-line kernel, two transforms per line: Dirichlet stencil in x for the velocities, the Neumann table for T
       const bool dir = f.ax == &xD;
-      DctLineArgs v{yx(*f.st), ldx, mx, yx(*f.w0), ldx, ylines(my), nx - 1, dir ? 2 : 1, f.ax->tw.p, f.ax->tw2.p, 1.0};
+      DctLineArgs v{yx(*f.st), ldx, mx, yx(*f.w0), ldx, ylines(f.rows), nx - 1, dir ? 2 : 1, f.ax->tw.p, f.ax->tw2.p, 1.0};
       v.low = dir ? nullptr : f.ax->low.p;
       DctLineArgs d = v;
       d.out = yx(*f.w1); d.deriv = 1; d.dscale = 1.0 / sx_;
@@ -1473,7 +1520,7 @@ void Navier2DEngine::build_confined() {
     if (s1_merge) {
       // one program per field: the orthonormal coefficients wait in the register stash while the value is
       // transformed, then come back for the derivative -- the state line is read once instead of twice
-      ProgramBuilder pb = ypb(2, my);
+      ProgramBuilder pb = ypb(2, f.rows);
       pb.set_fft(*f.ax);
       pb.load(0, pb.arr(yx(*f.st), ldx), mx);
       pb.to_ortho(0, *f.ax);
@@ -1488,7 +1535,7 @@ void Navier2DEngine::build_confined() {
     // two programs of two LDS slots each (the DCT works in place across slots 0 and 1), so
     // that two workgroups fit on a CU; the price is reading the state line twice
     for (int deriv = 0; deriv < 2; ++deriv) {
-      ProgramBuilder pb = ypb(2, my);
+      ProgramBuilder pb = ypb(2, f.rows);
       pb.set_fft(*f.ax);
       pb.load(0, pb.arr(yx(*f.st), ldx), mx);
       const int out = pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx);
@@ -1503,7 +1550,7 @@ void Navier2DEngine::build_confined() {
     }
   }
   // ---- T1: to XY
-  for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
+  for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, k >= 4 ? tr : my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
   // physical velocities once per step (shared by the three convection programs)
   for (int w = 0; w < 2; ++w) {
@@ -1517,38 +1564,40 @@ void Navier2DEngine::build_confined() {
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, pb.arr((w ? VP_ : UP_).p, ldy), ny);
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
-  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag, AxisTables& ys, int nin) {
+    // ys / nin: the y base of the input coefficients and their count -- the Dirichlet stencil of my coefficients, or
+    // ("hc" temperature) ny orthonormal coefficients, no stencil
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash, so two workgroups share a CU
     const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                           xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
-      pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
+      pb.set_fft(ys);
+      pb.load(0, pb.arr(c.fx, ldy), nin);        // d/dx f (x-derivative taken in S1)
+      pb.dct_fused(0, ys, true, ys.bwd_pre.p, nullptr);
       if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.up, ldy), ny);
-      pb.load(1, pb.arr(c.f0, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+      pb.load(1, pb.arr(c.f0, ldy), nin);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
       pb.pair_last_loads();
       pb.stash(0);
-      pb.to_ortho_from(0, 1, yD);
+      pb.to_ortho_from(0, 1, ys);
       pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+      pb.dct(0, ny, ys.bwd_pre.p, nullptr);
       if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.vp, ldy), ny);
       if (c.by) pb.pair_last_loads();
       pb.unstash_axpy(0, 1.0, 1.0, ny);
-      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+      pb.dct_fused(0, ys, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     };
-    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
+    if (&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
     ProgramBuilder pb = xpb(2, nx);
     program(pb, cl);
     add_line(pb, tag);
   };
-  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
-  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
-  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
+  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx", yD, my);
+  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely", yD, my);
+  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp", hc ? yO : yD, tr);
   // ---- T2: conv terms to YX
   for (int k = 0; k < 3; ++k) T(X_[6 + k].p, yx(Y_[k]), nx, ny, false, "T2");
   // ---- S3: x-lines: forward x transform, RHS assembly, x part of the ADI Helmholtz solve
@@ -1558,7 +1607,7 @@ void Navier2DEngine::build_confined() {
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
     // only the first my = ny - 2 orthonormal y-rows are needed: the B2-y preconditioner of S4 never
     // reads the last two (matvec.rs:215-226) -- and 4095 lines fill the CUs without a ragged tail
-    if (ax.fft_n == nx - 1) {   // one kernel per field (rhs_line.h)
+    if (ax.fft_n == nx - 1 && !(hc && which != 0)) {   // one kernel per field (rhs_line.h); it applies the Dirichlet stencil to the temperature rows
       RhsLineArgs r;
       r.which = which; r.conv = yx(Y_[which]); r.st = yx(state); r.out = yx(Y_[3 + which]); r.ld = ldx;
       r.nlines = ylines(my); r.line0 = yb_; r.N = nx - 1; r.cut = cut_x; r.dt = dt; r.ka = ka_;
@@ -1573,7 +1622,8 @@ void Navier2DEngine::build_confined() {
     pb.set_fft(ax);
     pb.load(0, pb.arr(yx(Y_[which]), ldx), nx);               // conv term first: the DCT needs both slots
     pb.dct(0, nx, nullptr, postcut_x_.p, cut_x);                 // forward transform + 2/3 rule in x
-    pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
+    if (hc && which == 2) pb.load(1, pb.arr(yx(TO_), ldx), mx);   // "hc": the orthonormal-y rows of the step's first launch
+    else pb.loadx(1, pb.arr(yx(state), ldx), mx, my, yD.low.p);    // S_y (cross-line), Dirichlet in y
     if (which == 2) {   // dt ka lap(tempbc) rides with the convection term: slot 0 = conv - ka lap(tempbc), scaled by -dt below
       pb.load(0, pb.arr(yx(TBC2_), ldx), nx, -ka_, true);
       pb.pair_last_loads();
@@ -1582,7 +1632,8 @@ void Navier2DEngine::build_confined() {
     if (which == 0) {
       pb.load(0, pb.arr(yx(GX_), ldx), nx, -dt, true);           // d/dx p, kept from the pressure update
     } else if (which == 1) {
-      pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
+      if (hc) pb.load(1, pb.arr(yx(TO_), ldx), mx);
+      else pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
       pb.pair_last_loads();
       pb.to_ortho_axpby(0, 1.0, 1, dt, xN);
@@ -1603,6 +1654,7 @@ void Navier2DEngine::build_confined() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, mx, "C4 y: hholtz-y (column scan)");
+    if (hc) add_hc_hholtz(yx(Y_[5]), yx(T_), mx);
     // d/dy vely for the divergence (rows ny, composite x); the halo of velx serves the cross-line stencil of S5
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, mx, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
@@ -1748,13 +1800,19 @@ void Navier2DEngine::build_periodic() {
     add_transpose(in, to_xy ? ldx : ldy, out, to_xy ? ldy : ldx, rows, cols, 2, to_xy, true, tag);
   };
 
+  // "hc": see build_confined -- the three-term stencil of the temperature once per step on the YX state (TO_), then the
+  // temperature is orthonormal in y for every stage, and its Helmholtz solve along y is a seven-diagonal column solve
+  const bool hc = hc_;
+  AxisTables& yO = sp_ortho_->axis(1);
+  const int tr = hc ? ny : my;
   add_halo({yx(U_), yx(V_), yx(T_)}, 2, 0, "H0 halo velx, vely, temp");
+  if (hc) add_hc_to_ortho(nc);
   // ---- S1: spectral x-lines -> physical x (value and x-derivative)
-  struct { DBuf* st; DBuf* w0; DBuf* w1; } s1[3] = {
-      {&U_, &Y_[0], &Y_[1]}, {&V_, &Y_[2], &Y_[3]}, {&T_, &Y_[4], &Y_[5]}};
+  struct { DBuf* st; DBuf* w0; DBuf* w1; int rows; } s1[3] = {
+      {&U_, &Y_[0], &Y_[1], my}, {&V_, &Y_[2], &Y_[3], my}, {hc ? &TO_ : &T_, &Y_[4], &Y_[5], tr}};
   for (auto& f : s1)
     for (int deriv = 0; deriv < 2; ++deriv) {
-      ProgramBuilder pb = ypb(1, my);
+      ProgramBuilder pb = ypb(1, f.rows);
       pb.set_fft(xF);
       pb.load(0, pb.arr(yx(*f.st), ldx), nc);
       if (deriv) pb.cik(0, 0, kx, 1.0 / sx_, 1);
@@ -1762,7 +1820,7 @@ void Navier2DEngine::build_periodic() {
       pb.store(0, pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx), nx);
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
-  for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, my, nx, true, "T1");
+  for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, k >= 4 ? tr : my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
   for (int w = 0; w < 2; ++w) {
@@ -1776,38 +1834,38 @@ void Navier2DEngine::build_periodic() {
     pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr, pb.arr((w ? VP_ : UP_).p, ldy), ny);
     add_line(pb, w ? "S2 y: vely -> phys" : "S2 y: velx -> phys");
   }
-  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag) {
+  auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag, AxisTables& ys, int nin) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash
     const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                           xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
-      pb.set_fft(yD);
-      pb.load(0, pb.arr(c.fx, ldy), my);        // d/dx f (x-derivative taken in S1)
-      pb.dct_fused(0, yD, true, yD.bwd_pre.p, nullptr);
+      pb.set_fft(ys);
+      pb.load(0, pb.arr(c.fx, ldy), nin);        // d/dx f (x-derivative taken in S1)
+      pb.dct_fused(0, ys, true, ys.bwd_pre.p, nullptr);
       if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.up, ldy), ny);
-      pb.load(1, pb.arr(c.f0, ldy), my);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
+      pb.load(1, pb.arr(c.f0, ldy), nin);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
       pb.pair_last_loads();
       pb.stash(0);
-      pb.to_ortho_from(0, 1, yD);
+      pb.to_ortho_from(0, 1, ys);
       pb.cdiff(0, 0, ny, 1.0 / sy_);
-      pb.dct(0, ny, yD.bwd_pre.p, nullptr);
+      pb.dct(0, ny, ys.bwd_pre.p, nullptr);
       if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.vp, ldy), ny);
       if (c.by) pb.pair_last_loads();
       pb.unstash_axpy(0, 1.0, 1.0, ny);
-      pb.dct_fused(0, yD, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
+      pb.dct_fused(0, ys, false, nullptr, postcut_y_.p, pb.arr(c.out, ldy), ny, 1.0, cut_y);   // forward + 2/3 rule + store
     };
-    if (yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
+    if (&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag)) return;
     ProgramBuilder pb = xpb(2, nx, false);
     program(pb, cl);
     add_line(pb, tag);
   };
-  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx");
-  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely");
-  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp");
+  conv(X_[1], X_[0], nullptr, nullptr, X_[6], "S2 y: conv_velx", yD, my);
+  conv(X_[3], X_[2], nullptr, nullptr, X_[7], "S2 y: conv_vely", yD, my);
+  conv(X_[5], X_[4], &BX_, &BY_, X_[8], "S2 y: conv_temp", hc ? yO : yD, tr);
   for (int k = 0; k < 3; ++k) Tr(X_[6 + k].p, yx(Y_[k]), nx, ny, false, "T2");
   // ---- S3: forward real FFT in x, RHS assembly, diagonal Helmholtz factor in x
   auto rhs = [&](int which, const char* tag) {
@@ -1821,13 +1879,15 @@ void Navier2DEngine::build_periodic() {
     pb.rfft_f(0, nx);
     pb.zero(0, 2 * cut_x, nc);
     pb.axpby(0, 0, -dt, 0, 0.0, nc);                                   // -dt * conv
-    pb.loadx(0, pb.arr(yx(state), ldx), nc, my, yD.low.p, 1.0, true);   // + S_y state
+    if (hc && which == 2) pb.load(0, pb.arr(yx(TO_), ldx), nc, 1.0, true);   // "hc": orthonormal-y rows of the step's first launch
+    else pb.loadx(0, pb.arr(yx(state), ldx), nc, my, yD.low.p, 1.0, true);   // + S_y state
     if (which == 0) {
       pb.load_cik(0, pb.arr(yx(P_), ldx), nc, -dt / sx_, true);         // - dt d/dx pres
     } else if (which == 1) {
       pb.load(0, pb.arr(yx(GY_), ldx), nc, -dt, true);
       pb.pair_last_loads();                                             // with the state rows
-      pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
+      if (hc) pb.load(0, pb.arr(yx(TO_), ldx), nc, dt, true);
+      else pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(TBC_), ldx), nc, dt, true);
       pb.pair_last_loads();
     } else {
@@ -1848,6 +1908,7 @@ void Navier2DEngine::build_periodic() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, nc, "C4 y: hholtz-y (column scan)");
+    if (hc) add_hc_hholtz(yx(Y_[5]), yx(T_), nc);
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
   }

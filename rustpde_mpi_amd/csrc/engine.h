@@ -173,6 +173,7 @@ class Navier2DEngine {
 
   int nx_, ny_, mx_, my_, kx_;   // kx_: x-modes of a spectral line (nx, or nx/2+1 complex)
   bool periodic_;
+  bool hc_ = false;              // bc = "hc": the temperature is cheb_dirichlet_neumann along y (navier.rs:245-248 / 366-369)
   double ra_, pr_, nu_, ka_, dt_, time_ = 0.0, sx_, sy_;
   double last_ms_ = 0.0;
   long ldx_, ldy_;               // pitches (doubles) of YX and XY work arrays
@@ -185,6 +186,7 @@ class Navier2DEngine {
   // state + constants (YX layout: row = y index, contiguous x)
   DBuf U_, V_, T_, P_, GY_, GX_, TBC_, TBC2_, DIV_;   // GX_, GY_: d/dx p, d/dy p kept from the pressure update
   DBuf Y_[6];
+  DBuf TO_;                      // "hc": the temperature in orthonormal-y, composite-x coefficients (ny rows), rebuilt every step
   // XY layout work arrays (row = x index, contiguous y)
   DBuf X_[9], BX_, BY_, PS_;
   DBuf red_;                     // reduction scratch (2 doubles)
@@ -204,7 +206,10 @@ class Navier2DEngine {
 
   // the step as a list of launches
   struct Launch {
-    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine } type;
+    enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine,
+                kSten3Rows, kPdmaCols } type;
+    Sten3RowsArgs s3{};          // kSten3Rows ("hc": temperature composite -> orthonormal along y, pdma.h)
+    PdmaColsArgs pc{};           // kPdmaCols  ("hc": Helmholtz-y of the temperature, PdmaPlus2)
     RhsLineArgs rl{};            // kRhsLine
     ConvLineArgs cl{};           // kConvLine
     DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
@@ -240,7 +245,9 @@ class Navier2DEngine {
   void add_halo(std::initializer_list<double*> arrays, int front, int tail, const char* tag);
   // Helmholtz solve along y of the three fields on YX arrays / Chebyshev y-derivative of a YX array
   // (single GPU: column scans instead of transpose -> line program -> transpose)
-  void add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag);
+  void add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag);   // "hc": the velocities only
+  void add_hc_to_ortho(int ncols);                                  // "hc": T_ -> TO_ (three-term stencil along y)
+  void add_hc_hholtz(const double* in, double* out, int ncols);     // "hc": Helmholtz-y of the temperature (PdmaPlus2 along y)
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   void add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag);
   ColHhDev colcorr_a_, colcorr_b_;   // column problems of the velocity correction (confined, one GPU)

@@ -16,7 +16,7 @@ static const long double kPiL = 3.141592653589793238462643383279502884L;
 
 Base make_base(BaseKind kind, int n) {
   Base b{kind, n, n};
-  if (kind == kChebDirichlet || kind == kChebNeumann) b.m = n - 2;
+  if (kind == kChebDirichlet || kind == kChebNeumann || kind == kChebDirichletNeumann) b.m = n - 2;
   if (kind == kFourierR2c) {
     RPDE_REQUIRE(n % 2 == 0, "fourier_r2c needs an even number of points");
     b.m = n / 2 + 1;
@@ -53,9 +53,28 @@ Vec stencil_low(const Base& b) {
   Vec low(b.m);
   for (int k = 0; k < b.m; ++k) {
     if (b.kind == kChebDirichlet) low[k] = -1.0;
-    else { const double r = (double)k / ((double)k + 2.0); low[k] = -(r * r); }
+    else if (b.kind == kChebNeumann) { const double r = (double)k / ((double)k + 2.0); low[k] = -(r * r); }
+    else {   // phi_k = T_k + a_k T_{k+1} + b_k T_{k+2}, phi_k(-1) = 0, phi_k'(+1) = 0:  b_k = a_k - 1 (see stencil_low1)
+      const double kk = (double)k;
+      low[k] = -(kk * kk + (kk + 1.0) * (kk + 1.0)) / ((kk + 1.0) * (kk + 1.0) + (kk + 2.0) * (kk + 2.0));
+    }
   }
   return low;
+}
+
+Vec stencil_low1(const Base& b) {
+  RPDE_REQUIRE(b.is_composite(), "stencil of a non-composite base");
+  Vec low1(b.m, 0.0);
+  if (b.kind == kChebDirichletNeumann)
+    // Dirichlet at x = -1 (T_k(-1) = (-1)^k), Neumann at x = +1 (T_k'(1) = k^2):
+    // 1 - a_k + b_k = 0 and k^2 + a_k (k+1)^2 + b_k (k+2)^2 = 0  =>  a_k = 4 (k+1) / ((k+1)^2 + (k+2)^2).
+    // The wall assignment is the one the lift bc_hc needs (boundary_conditions.rs:96-134: the bottom temperature
+    // at y[0] = -1, T = T' = 0 at y[n-1] = +1).
+    for (int k = 0; k < b.m; ++k) {
+      const double kk = (double)k;
+      low1[k] = 4.0 * (kk + 1.0) / ((kk + 1.0) * (kk + 1.0) + (kk + 2.0) * (kk + 2.0));
+    }
+  return low1;
 }
 
 Vec cheb_fwd_post(int n) {
@@ -105,8 +124,83 @@ Vec dct_direct_costab(int N) {
   return t;
 }
 
+// ---------------------------------------------------------------------------------------------
+// three-term stencil: seven-diagonal matrices and their PdmaPlus2 factorisation
+static double sten_at(const Vec& low1, const Vec& low2, int m, int t, int j) {   // S[j + t, j]
+  if (j < 0 || j >= m) return 0.0;
+  return t == 0 ? 1.0 : t == 1 ? low1[j] : t == 2 ? low2[j] : 0.0;
+}
+Bands7 hholtz7_mat_a(const Base& b) {
+  const int m = b.m;
+  const Mv3Tables p = pinv_tables(b);
+  const Vec l1 = stencil_low1(b), l2 = stencil_low(b);
+  Bands7 a;
+  for (auto& v : a.d) v.assign(m, 0.0);
+  for (int r = 0; r < m; ++r)
+    for (int o = -2; o <= 4; ++o) {
+      double s = 0.0;   // sum_q pinv[r, r+q] S[r+q, r+o], q = 0, 2, 4; S[i, j] != 0 for 0 <= i - j <= 2
+      if (o <= 0) s += p.t0[r] * sten_at(l1, l2, m, 0 - o, r + o);
+      if (o <= 2 && o >= 0) s += p.t1[r] * sten_at(l1, l2, m, 2 - o, r + o);
+      if (o >= 2) s += p.t2[r] * sten_at(l1, l2, m, 4 - o, r + o);
+      a.d[o + 2][r] = s;
+    }
+  return a;
+}
+Bands7 hholtz7_mat_b(const Base& b) {
+  const int m = b.m;
+  const Vec l1 = stencil_low1(b), l2 = stencil_low(b);
+  Bands7 x;
+  for (auto& v : x.d) v.assign(m, 0.0);
+  for (int r = 0; r < m; ++r)
+    for (int o = 0; o <= 2; ++o) x.d[o + 2][r] = sten_at(l1, l2, m, 2 - o, r + o);   // peye[r, r+2] = 1
+  return x;
+}
+Bands7 bands7_axpy(const Bands7& a, double c, const Bands7& b) {
+  Bands7 r;
+  for (int o = 0; o < 7; ++o) {
+    r.d[o].resize(a.d[o].size());
+    for (size_t i = 0; i < a.d[o].size(); ++i) r.d[o][i] = a.d[o][i] + c * b.d[o][i];
+  }
+  return r;
+}
+Bands7 from_ortho7(const Base& b) {
+  const int m = b.m;
+  const Vec l1 = stencil_low1(b), l2 = stencil_low(b);
+  Bands7 x;
+  for (auto& v : x.d) v.assign(m, 0.0);
+  for (int r = 0; r < m; ++r)
+    for (int o = -2; o <= 2; ++o) {
+      if (r + o < 0 || r + o >= m) continue;
+      double s = 0.0;   // sum_i S[i, r] S[i, r + o]
+      for (int t = 0; t <= 2; ++t) s += sten_at(l1, l2, m, t, r) * sten_at(l1, l2, m, t - o, r + o);
+      x.d[o + 2][r] = s;
+    }
+  return x;
+}
+PdmaTables pdma_factor(const Bands7& mt) {
+  const int n = (int)mt.d[2].size();
+  PdmaTables t;
+  t.n = n;
+  for (Vec* v : {&t.l2, &t.ka, &t.imu, &t.al, &t.be, &t.ga, &t.de}) v->assign((size_t)n + 4, 0.0);
+  auto at = [&](int o, int r) { return (r >= 0 && r < n && r + o >= 0 && r + o < n) ? mt.d[o + 2][r] : 0.0; };
+  Vec mu((size_t)n + 4, 1.0);
+  auto prev = [](const Vec& v, int i) { return i >= 0 ? v[i] : 0.0; };
+  for (int i = 0; i < n; ++i) {   // pdma_plus2.rs:66-103 with vanishing out-of-range terms (its rows 0, 1, n-4 .. n-1)
+    const double w2 = at(-2, i);                       // the reference's l2[i-2] = a[i, i-2]
+    t.l2[i] = w2;
+    t.ka[i] = at(-1, i) - prev(t.al, i - 2) * w2;
+    mu[i] = at(0, i) - prev(t.be, i - 2) * w2 - prev(t.al, i - 1) * t.ka[i];
+    t.al[i] = (at(1, i) - prev(t.ga, i - 2) * w2 - prev(t.be, i - 1) * t.ka[i]) / mu[i];
+    t.be[i] = (at(2, i) - prev(t.de, i - 2) * w2 - prev(t.ga, i - 1) * t.ka[i]) / mu[i];
+    t.ga[i] = (at(3, i) - prev(t.de, i - 1) * t.ka[i]) / mu[i];
+    t.de[i] = at(4, i) / mu[i];
+    t.imu[i] = 1.0 / mu[i];
+  }
+  return t;
+}
+
 FromOrthoTables from_ortho_tables(const Base& b) {
-  RPDE_REQUIRE(b.is_composite(), "from_ortho of a non-composite base");
+  RPDE_REQUIRE(b.is_two_term(), "from_ortho tables of the stride-2 form need a two-term stencil");
   const int m = b.m;
   const Vec low = stencil_low(b);
   Vec main(m), off(std::max(0, m - 2));
@@ -145,6 +239,7 @@ Mv3Tables pinv_tables(const Base& b) {
 }
 
 Bands hholtz_mat_a(const Base& b) {
+  RPDE_REQUIRE(b.is_two_term(), "four-diagonal Helmholtz matrices need a two-term stencil (see hholtz7_mat_a)");
   const int m = b.m;
   const Mv3Tables p = pinv_tables(b);
   const Vec low = stencil_low(b);
@@ -161,6 +256,7 @@ Bands hholtz_mat_a(const Base& b) {
 }
 
 Bands hholtz_mat_b(const Base& b) {
+  RPDE_REQUIRE(b.is_two_term(), "four-diagonal Helmholtz matrices need a two-term stencil (see hholtz7_mat_b)");
   const int m = b.m;
   const Vec low = stencil_low(b);
   Bands x{Vec(m, 0.0), low, Vec(m, 0.0), Vec(m, 0.0)};

@@ -12,7 +12,8 @@
 
 namespace rpde {
 
-enum BaseKind : int { kChebyshev = 0, kChebDirichlet = 1, kChebNeumann = 2, kFourierR2c = 3 };
+enum BaseKind : int { kChebyshev = 0, kChebDirichlet = 1, kChebNeumann = 2, kFourierR2c = 3,
+                      kChebDirichletNeumann = 4 };   // the "hc" temperature along y (navier.rs:245-248): three-term stencil
 
 using Vec = std::vector<double>;
 
@@ -21,7 +22,10 @@ struct Base {
   int n;  // physical points
   int m;  // spectral coefficients (complex count for Fourier)
   bool is_cheb() const { return kind != kFourierR2c; }
-  bool is_composite() const { return kind == kChebDirichlet || kind == kChebNeumann; }
+  bool is_composite() const { return kind == kChebDirichlet || kind == kChebNeumann || kind == kChebDirichletNeumann; }
+  // two-term stencil (T_k + low_k T_{k+2}): even and odd coefficients decouple -- what the stride-2 scans, the
+  // parity-block GEMMs and the column scans rely on; cheb_dirichlet_neumann has S[k+1,k] != 0 and goes through pdma.h
+  bool is_two_term() const { return kind == kChebDirichlet || kind == kChebNeumann; }
   int n_ortho() const { return kind == kFourierR2c ? m : n; }
 };
 Base make_base(BaseKind kind, int n);
@@ -29,6 +33,7 @@ Base make_base(BaseKind kind, int n);
 Vec base_coords(const Base& b);                 // grid points (unscaled)
 Vec base_dx(const Base& b, const Vec& x);       // src/field.rs:135-163
 Vec stencil_low(const Base& b);                 // S[k+2,k]  (S[k,k] = 1), length m
+Vec stencil_low1(const Base& b);                // S[k+1,k]: zero for the two-term stencils, length m
 
 // DCT-I scaling tables for a Chebyshev line of n points (N = n-1)
 Vec cheb_fwd_post(int n);   // (-1)^k / N, halved at both ends
@@ -62,6 +67,19 @@ void fdma_sweep(Bands& m);            // in place, reference op order
 // solve tables for a swept Fdma: ascending REC1 (q1) then descending REC2 (p2, q2, r2)
 struct FdmaTables { Vec q1, p2, q2, r2; };
 FdmaTables fdma_tables(const Bands& swept);
+
+// Seven-diagonal systems (offsets -2 .. +4) of the three-term stencil: `PdmaPlus2` (src/solver/pdma_plus2.rs:45-157).
+// Row-indexed bands: d[o + 2][r] = a[r, r + o], zero where the column is out of range.
+struct Bands7 { Vec d[7]; };
+Bands7 hholtz7_mat_a(const Base& b);                      // pinv . S
+Bands7 hholtz7_mat_b(const Base& b);                      // peye . S (offsets 0, +1, +2)
+Bands7 bands7_axpy(const Bands7& a, double c, const Bands7& b);
+Bands7 from_ortho7(const Base& b);                        // S^T S (offsets -2 .. +2): the normal equations of from_ortho
+// the factorisation PdmaPlus2::from_matrix precomputes (same order of operations; 1 / mu instead of mu, and every
+// table padded with four zeros so that the four-term backward recurrence needs no end cases): a solve is
+//   ze_i = (rhs_i - l2_{i-2} ze_{i-2} - ka_i ze_{i-1}) imu_i ,   x_i = ze_i - al_i x_{i+1} - be_i x_{i+2} - ga_i x_{i+3} - de_i x_{i+4}
+struct PdmaTables { int n = 0; Vec l2, ka, imu, al, be, ga, de; };   // l2 is shifted: l2[i] = a[i, i-2]
+PdmaTables pdma_factor(const Bands7& m);
 
 // Tables of the column-scan Helmholtz solve (colscan.h) for one swept Fdma and its B2 preconditioner,
 // rows cut into blocks of BR: per-row coefficients (zero-padded to NB * BR + 4), the block transfer

@@ -985,6 +985,47 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
   RPDE_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------- three-term stencil (pdma.h)
+__global__ __launch_bounds__(256) void sten3_rows_kernel(const Sten3RowsArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ncols) return;
+  for (int j = a.row0 + blockIdx.y; j < a.row0 + a.nrows; j += gridDim.y) sten3_rows_point(a, j, c);
+}
+void launch_sten3_rows(const Sten3RowsArgs& a, Stream& st) {
+  if (a.nrows <= 0 || a.ncols <= 0) return;
+  dim3 grid((a.ncols + 255) / 256, std::min(a.nrows, 1024));
+  hipLaunchKernelGGL(sten3_rows_kernel, grid, dim3(256), 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void pdma_cols_kernel(const PdmaColsArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.ncols) return;
+  if (pdma_column(a, c) && a.nanflag) *a.nanflag = 1;
+}
+void launch_pdma_cols(const PdmaColsArgs& a, Stream& st) {
+  if (a.n <= 0 || a.ncols <= 0) return;
+  hipLaunchKernelGGL(pdma_cols_kernel, dim3((a.ncols + 63) / 64), dim3(64), 0, st.s, a);   // one wave per workgroup: the columns spread over as many CUs as there are waves
+  RPDE_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void sten3_lines_kernel(const Sten3LinesArgs a) {
+  const int line = blockIdx.x * 64 + threadIdx.x;
+  if (line < a.nlines) sten3_line(a, line, blockIdx.y);
+}
+void launch_sten3_lines(const Sten3LinesArgs& a, Stream& st) {
+  if (a.nlines <= 0) return;
+  hipLaunchKernelGGL(sten3_lines_kernel, dim3((a.nlines + 63) / 64, a.ncomp), dim3(64), 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void pdma_lines_kernel(const PdmaLinesArgs a) {
+  const int line = blockIdx.x * 64 + threadIdx.x;
+  if (line < a.nlines) pdma_line(a, line, blockIdx.y);
+}
+void launch_pdma_lines(const PdmaLinesArgs& a, Stream& st) {
+  if (a.nlines <= 0) return;
+  hipLaunchKernelGGL(pdma_lines_kernel, dim3((a.nlines + 63) / 64, a.ncomp), dim3(64), 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+}
+
 __global__ void set_element_kernel(double* p, long idx, double v) { p[idx] = v; }
 void launch_set_element(double* p, long idx, double value, Stream& st) {
   hipLaunchKernelGGL(set_element_kernel, dim3(1), dim3(1), 0, st.s, p, idx, value);
@@ -1116,6 +1157,22 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
     for (int cc = 0; cc < cols; ++cc) out[(long)r * ldo + cc] = in[(long)r * ldi + cc];
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
+void launch_sten3_rows(const Sten3RowsArgs& a, Stream&) {
+  for (int j = a.row0; j < a.row0 + a.nrows; ++j)
+    for (int c = 0; c < a.ncols; ++c) sten3_rows_point(a, j, c);
+}
+void launch_pdma_cols(const PdmaColsArgs& a, Stream&) {
+  for (int c = 0; c < a.ncols; ++c)
+    if (pdma_column(a, c) && a.nanflag) *a.nanflag = 1;
+}
+void launch_sten3_lines(const Sten3LinesArgs& a, Stream&) {
+  for (int comp = 0; comp < a.ncomp; ++comp)
+    for (int l = 0; l < a.nlines; ++l) sten3_line(a, l, comp);
+}
+void launch_pdma_lines(const PdmaLinesArgs& a, Stream&) {
+  for (int comp = 0; comp < a.ncomp; ++comp)
+    for (int l = 0; l < a.nlines; ++l) pdma_line(a, l, comp);
+}
 void launch_mfma_peak(double*, int, int, Stream&) {}
 void launch_diag_reduce(const double* T, const double* dT, const double* ux, const double* uy, long ld, int nx, int ny,
                         const double* wx, const double* wy, double c_nu, double c_v1, double c_v2, double c_re,

@@ -2,6 +2,7 @@
 #pragma once
 #include "colscan.h"
 #include "line_vm.h"
+#include "pdma.h"
 #include "rhs_line.h"
 
 namespace rpde {
@@ -104,6 +105,12 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
 
 // measurement only: `blocks` workgroups x 4 waves x `iters` x 8 independent v_mfma_f64_16x16x4_f64 chains
 void launch_mfma_peak(double* out, int blocks, int iters, Stream& st, int kind = 0);
+
+// the three-term stencil (cheb_dirichlet_neumann: the "hc" temperature along y) and its seven-diagonal solves, pdma.h
+void launch_sten3_rows(const Sten3RowsArgs& a, Stream& st);     // YX array, composite -> orthonormal rows
+void launch_pdma_cols(const PdmaColsArgs& a, Stream& st);       // YX array, B2 rows + PdmaPlus2 along y (one thread per column)
+void launch_sten3_lines(const Sten3LinesArgs& a, Stream& st);   // contiguous lines (generic operators)
+void launch_pdma_lines(const PdmaLinesArgs& a, Stream& st);
 
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);

@@ -25,7 +25,12 @@ AxisTables::AxisTables(const Base& b) : base(b) {
     bwd_pre.upload(cheb_bwd_pre(b.n));
     Mv3Tables pv = pinv_tables(b);
     pv0.upload(pv.t0); pv1.upload(pv.t1); pv2.upload(pv.t2);
-    if (b.is_composite()) {
+    if (b.kind == kChebDirichletNeumann) {
+      low.upload(stencil_low(b));
+      low1.upload(stencil_low1(b));
+      fo_pdma.upload(pdma_factor(from_ortho7(b)));
+      ortho = std::make_unique<AxisTables>(make_base(kChebyshev, b.n));
+    } else if (b.is_composite()) {
       low.upload(stencil_low(b));
       FromOrthoTables f = from_ortho_tables(b);
       fo_t0.upload(f.t0); fo_t1.upload(f.t1); fo_t2.upload(f.t2);
@@ -41,6 +46,11 @@ AxisTables::AxisTables(const Base& b) : base(b) {
     tw2.upload(rfft_split_twiddles(b.n));
     slot_len = slot_len_for(b.n + 2);
   }
+}
+
+void PdmaDev::upload(const PdmaTables& t) {
+  n = t.n;
+  l2.upload(t.l2); ka.upload(t.ka); imu.upload(t.imu); al.upload(t.al); be.upload(t.be); ga.upload(t.ga); de.upload(t.de);
 }
 
 FdmaDev upload_fdma(const FdmaTables& t, int slot_len) {
@@ -128,6 +138,9 @@ void ProgramBuilder::guard_last_store(int* flag) {
   pg.ops[pg.nops - 1].acc = 1;
   pg.nanflag = flag;
 }
+static void two_term_only(const AxisTables& ax) {
+  RPDE_REQUIRE(!ax.base.is_composite() || ax.base.is_two_term(), "line programs hold two-term stencils only (pdma.h)");
+}
 void ProgramBuilder::sten(int d, int a, int n_ortho, const double* low) {
   Op& o = push(OP_STEN); o.d = d; o.a = a; o.n = n_ortho; o.tab = tab(low);
 }
@@ -181,6 +194,7 @@ void ProgramBuilder::dct_fused(int d, const AxisTables& ax, bool sten_, const do
     return;
   }
   RPDE_REQUIRE(d + 1 < pg.nslots, "OP_DCT needs slot d+1 as scratch");
+  RPDE_REQUIRE(!sten_ || !ax.base.is_composite() || ax.base.is_two_term(), "line programs hold two-term stencils only (pdma.h)");
   // the Dirichlet stencil is the constant -1: no table
   const int ilow = !(sten_ && ax.base.is_composite()) ? -1 : (ax.base.kind == kChebDirichlet ? -2 : tab(ax.low.p));
   Op& o = push(OP_DCT); o.d = d; o.n = n; o.i1 = ilow;
@@ -209,10 +223,12 @@ void ProgramBuilder::cik(int d, int a, int nc, double s0, int power) {
   Op& o = push(OP_CIK); o.d = d; o.a = a; o.n = nc; o.s0 = s0; o.i0 = power;
 }
 void ProgramBuilder::to_ortho(int d, const AxisTables& ax) {
+  two_term_only(ax);
   if (ax.base.is_composite()) sten(d, d, ax.base.n, ax.low.p);
 }
 void ProgramBuilder::to_ortho_axpby(int d, double sd, int a, double sa, const AxisTables& ax) {
   RPDE_REQUIRE(d != a, "to_ortho_axpby: out of place only");
+  two_term_only(ax);
   if (ax.base.is_composite()) {
     sten(d, a, ax.base.n, ax.low.p);
     Op& o = pg.ops[pg.nops - 1];
@@ -222,11 +238,13 @@ void ProgramBuilder::to_ortho_axpby(int d, double sd, int a, double sa, const Ax
   }
 }
 void ProgramBuilder::to_ortho_from(int d, int a, const AxisTables& ax) {
+  two_term_only(ax);
   if (ax.base.is_composite()) sten(d, a, ax.base.n, ax.low.p);
   else axpby(d, a, 1.0, a, 0.0, ax.base.n);
 }
 void ProgramBuilder::from_ortho(int d, const AxisTables& ax) {
   if (!ax.base.is_composite()) return;
+  two_term_only(ax);
   const int m = ax.base.m;
   mv3(d, d, m, ax.fo_t0.p, ax.fo_t1.p, ax.fo_t2.p);
   rec1(d, d, m, ax.fo_pup.p, ax.fo_qup.p, +1);
@@ -251,7 +269,11 @@ Space2Ops::Space2Ops(const Base& b0, const Base& b1) {
 
 void Space2Ops::run_lines(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
                           double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st,
-                          int order, double scale, const FdmaDev* fd, const double* diag) {
+                          int order, double scale, const FdmaDev* fd, const double* diag, const PdmaDev* pd) {
+  if (ax.base.kind == kChebDirichletNeumann) {
+    run_lines3(kind, ax, in, ldi, len_in, out, ldo, len_out, nlines, ncomp, st, order, scale, pd);
+    return;
+  }
   // ncomp = 2: the lines are interleaved complex but the op is real (acts on re and im alike)
   // Chebyshev kinds need the second slot (DCT work area, scratch of the banded solve); a Fourier
   // axis never does, and its longest configuration has room for one slot only
@@ -299,8 +321,59 @@ void Space2Ops::run_lines(Kind kind, const AxisTables& ax, const double* in, lon
   pb.run(st);
 }
 
+// A three-term axis (cheb_dirichlet_neumann): the stencil and the banded solves are the pdma.h kernels, everything else
+// is a line program of the orthonormal parent.  Setup / diagnostics / operator API only -- the time step has its own
+// YX-layout kernels (engine.cc).
+void Space2Ops::run_lines3(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in, double* out, long ldo,
+                           int len_out, int nlines, int ncomp, Stream& st, int order, double scale, const PdmaDev* pd) {
+  const AxisTables& ox = *ax.ortho;
+  const int n = ax.base.n, m = ax.base.m;
+  const long ldt = pitch((long)n * ncomp);
+  auto sten3 = [&](const double* src, long lds_, double* dst, long ldd) {
+    launch_sten3_lines(Sten3LinesArgs{src, lds_, dst, ldd, nlines, m, ncomp, ncomp, ax.low1.p, ax.low.p}, st);
+  };
+  auto solve = [&](const double* src, long lds_, double* dst, long ldd, bool normal_eq, const PdmaDev& f) {
+    launch_pdma_lines(PdmaLinesArgs{src, lds_, dst, ldd, nlines, m, ncomp, ncomp, normal_eq ? ax.low1.p : nullptr,
+                                    normal_eq ? ax.low.p : nullptr, f.tabs()}, st);
+  };
+  switch (kind) {
+    case kToOrtho: sten3(in, ldi, out, ldo); return;
+    case kFromOrtho: solve(in, ldi, out, ldo, true, ax.fo_pdma); return;
+    case kForward: {
+      DBuf t((size_t)nlines * ldt);
+      run_lines(kForwardOrtho, ox, in, ldi, n, t.p, ldt, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
+      solve(t.p, ldt, out, ldo, true, ax.fo_pdma);
+      dev_sync(st);
+      return;
+    }
+    case kBackward: {
+      DBuf t((size_t)nlines * ldt);
+      sten3(in, ldi, t.p, ldt);
+      run_lines(kBackwardOrtho, ox, t.p, ldt, n, out, ldo, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
+      dev_sync(st);
+      return;
+    }
+    case kDiff: {
+      DBuf t((size_t)nlines * ldt);
+      sten3(in, ldi, t.p, ldt);
+      run_lines(kDiff, ox, t.p, ldt, n, out, ldo, n, nlines, ncomp, st, order, scale, nullptr, nullptr);
+      dev_sync(st);
+      return;
+    }
+    case kForwardOrtho: case kBackwardOrtho: case kPinvMatvec:
+      run_lines(kind, ox, in, ldi, len_in, out, ldo, len_out, nlines, ncomp, st, order, scale, nullptr, nullptr);
+      return;
+    case kFdmaSolve:
+      RPDE_REQUIRE(pd != nullptr && pd->n == m, "banded solve along a three-term axis needs its PdmaPlus2 tables");
+      solve(in, ldi, out, ldo, false, *pd);
+      return;
+    case kDiagSolve: break;
+  }
+  fail("operator not defined for a cheb_dirichlet_neumann axis");
+}
+
 void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Stream& st, int order,
-                           double scale, const FdmaDev* fd, const double* diag) {
+                           double scale, const FdmaDev* fd, const double* diag, const PdmaDev* pd) {
   const AxisTables& ax = *ax_[axis];
   const Base& b = ax.base;
   // element counts along the axis, in and out, and element types
@@ -324,7 +397,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
     RPDE_REQUIRE(in.cols == li && out.cols == lo && in.rows == out.rows && in.elem == out.elem,
                  "shape mismatch in axis-1 operator");
     run_lines(kind, ax, in.p(), in.ld, li, out.p(), out.ld, lo, in.rows, in.elem, st, order, scale,
-              fd, diag);
+              fd, diag, pd);
     return;
   }
   // axis 0: transpose, run along the now contiguous axis, transpose back
@@ -352,7 +425,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
   } else {
     RPDE_REQUIRE(in.elem == out.elem, "element type mismatch");
     run_lines(kind, ax, tin.p(), tin.ld, li, tout.p(), tout.ld, lo, ncols, in.elem, st, order, scale,
-              fd, diag);
+              fd, diag, pd);
   }
   launch_transpose(tout.p(), tout.ld, out.p(), out.ld, tout.rows, tout.cols, out.elem, st);
   dev_sync(st);  // temporaries are released on return
@@ -416,6 +489,10 @@ HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
     const Base& b = sp.base(axis);
     if (b.is_cheb()) {
       RPDE_REQUIRE(b.is_composite(), "HholtzAdi: orthonormal Chebyshev base is not supported");
+      if (b.kind == kChebDirichletNeumann) {   // BaseKind::ChebDirichletNeumann => PdmaPlus2 (hholtz_adi.rs:62-64)
+        pdma[axis].upload(pdma_factor(bands7_axpy(hholtz7_mat_a(b), -c[axis], hholtz7_mat_b(b))));
+        continue;
+      }
       Bands mtx = bands_axpy(hholtz_mat_a(b), -c[axis], hholtz_mat_b(b));
       fdma_sweep(mtx);
       host[axis] = fdma_tables(mtx);
@@ -440,9 +517,9 @@ void HholtzAdiOp::solve(const Arr2& in, Arr2& out, Stream& st) {
   const Arr2* cur = &in;
   if (cheb0) { sp.apply_axis(Space2Ops::kPinvMatvec, 0, in, t0, st); cur = &t0; }
   sp.apply_axis(Space2Ops::kPinvMatvec, 1, *cur, t1, st);
-  if (cheb0) sp.apply_axis(Space2Ops::kFdmaSolve, 0, t1, t2, st, 0, 1.0, &fdma[0]);
+  if (cheb0) sp.apply_axis(Space2Ops::kFdmaSolve, 0, t1, t2, st, 0, 1.0, &fdma[0], nullptr, &pdma[0]);
   else sp.apply_axis(Space2Ops::kDiagSolve, 0, t1, t2, st, 0, 1.0, nullptr, diag0.p);
-  sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, out, st, 0, 1.0, &fdma[1]);
+  sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, out, st, 0, 1.0, &fdma[1], nullptr, &pdma[1]);
   dev_sync(st);
 }
 
@@ -456,10 +533,10 @@ static Arr2 upload_dense(const double* src, int rows, int cols) {
 PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_end) : sp(s) {
   const Base& b0 = sp.base(0);
   const Base& b1 = sp.base(1);
-  RPDE_REQUIRE(b1.is_composite(), "Poisson: axis 1 must be a composite Chebyshev base");
+  RPDE_REQUIRE(b1.is_two_term(), "Poisson: axis 1 must be a composite Chebyshev base with a two-term stencil");
   const int m0 = b0.m, m1 = b1.m;
   if (b0.is_cheb()) {
-    RPDE_REQUIRE(b0.is_composite(), "Poisson: axis 0 must be composite Chebyshev or Fourier");
+    RPDE_REQUIRE(b0.is_two_term(), "Poisson: axis 0 must be composite Chebyshev (two-term stencil) or Fourier");
     Bands ax = bands_axpy(Bands{Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0)}, c0,
                           hholtz_mat_b(b0));
     Bands cx = hholtz_mat_a(b0);

@@ -15,13 +15,25 @@ namespace rpde {
 
 inline long pitch(long n) { return (n + 15) & ~15L; }
 
+// factorised seven-diagonal system on the device (hostmath.h PdmaTables, pdma.h)
+struct PdmaDev {
+  DBuf l2, ka, imu, al, be, ga, de;
+  int n = 0;
+  void upload(const PdmaTables& t);
+  PdmaTabs tabs() const { return PdmaTabs{l2.p, ka.p, imu.p, al.p, be.p, ga.p, de.p, n}; }
+};
+
 // device-resident tables of one 1-D basis
 struct AxisTables {
   Base base{};
   int fft_n = 0;       // complex FFT length (0: direct O(n^2) DCT)
   int slot_len = 0;    // slot length for lines of this axis (doubles)
   DBuf tw, tw2, fwd_post, bwd_pre;             // transforms
-  DBuf low;                                     // stencil (composite)
+  DBuf low;                                     // stencil (composite): S[k+2,k]
+  DBuf low1;                                    // S[k+1,k]: the three-term stencil of cheb_dirichlet_neumann only
+  PdmaDev fo_pdma;                              // its from_ortho: the factorised normal equations S^T S
+  std::unique_ptr<AxisTables> ortho;            // its orthonormal parent (same n): transforms, derivatives and B2 rows of a
+                                                // three-term axis run as line programs of the parent around the pdma.h kernels
   DBuf fo_t0, fo_t1, fo_t2, fo_pup, fo_qup, fo_qdn;  // from_ortho
   DBuf pv0, pv1, pv2;                           // B2 pseudo-inverse rows (Chebyshev family)
   explicit AxisTables(const Base& b);
@@ -149,14 +161,19 @@ class Space2Ops {
   // single-axis building blocks on canonical arrays (axis 0 goes through a transposed copy)
   enum Kind { kToOrtho, kFromOrtho, kForwardOrtho, kBackwardOrtho, kForward, kBackward, kDiff,
               kPinvMatvec, kFdmaSolve, kDiagSolve };
+  // kFdmaSolve along a three-term axis takes `pd` (PdmaPlus2) instead of `fd`
   void apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Stream& st, int order = 0,
-                  double scale = 1.0, const FdmaDev* fd = nullptr, const double* diag = nullptr);
+                  double scale = 1.0, const FdmaDev* fd = nullptr, const double* diag = nullptr,
+                  const PdmaDev* pd = nullptr);
 
  private:
   std::unique_ptr<AxisTables> ax_[2];
   void run_lines(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
                  double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st, int order,
-                 double scale, const FdmaDev* fd, const double* diag);
+                 double scale, const FdmaDev* fd, const double* diag, const PdmaDev* pd = nullptr);
+  void run_lines3(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
+                  double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st, int order,
+                  double scale, const PdmaDev* pd);
 };
 
 // device tables of the column-scan form of one Helmholtz-y solve (colscan.h)
@@ -173,8 +190,9 @@ class HholtzAdiOp {
  public:
   HholtzAdiOp(Space2Ops& sp, double c0, double c1);
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
-  FdmaDev fdma[2];      // Chebyshev axes
+  FdmaDev fdma[2];      // Chebyshev axes with a two-term stencil
   FdmaTables host[2];   // the same tables on the host, natural order (other kernels re-order them for their own chunking)
+  PdmaDev pdma[2];      // Chebyshev axes with the three-term stencil: PdmaPlus2 (hholtz_adi.rs:62-64)
   DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
   Space2Ops& sp;
 };

@@ -13,7 +13,7 @@ import rustpde_mpi_amd as R
 from oracle import bases as B, navier as N, solver as S
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = {0: "chebyshev", 1: "cheb_dirichlet", 2: "cheb_neumann", 3: "fourier_r2c"}
+NAMES = {0: "chebyshev", 1: "cheb_dirichlet", 2: "cheb_neumann", 3: "fourier_r2c", 4: "cheb_dirichlet_neumann"}
 KINDS = {v: k for k, v in NAMES.items()}
 
 
@@ -131,7 +131,7 @@ def check_reference_known_answers(lib):
         assert np.abs(out - fac_p * v).max() < 1e-3
 
 
-def make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode="parity"):
+def make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode="parity", bc="rbc"):
     """Engine + oracle with the same deterministic initial condition.
 
     eig_mode "shared": the oracle runs the reference's algorithm on the ENGINE's x
@@ -144,11 +144,11 @@ def make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode="parity"):
     oracle alone).  Step parity at the large sizes is therefore checked on a shared
     decomposition; the decomposition itself is checked by check_eigenbasis_is_valid."""
     ctor = "new_periodic" if periodic else "new_confined"
-    nav = getattr(R.Navier2D, ctor)(nx, ny, ra, pr, dt, aspect, "rbc", library=lib)
+    nav = getattr(R.Navier2D, ctor)(nx, ny, ra, pr, dt, aspect, bc, library=lib)
     kw = {"eig_mode": eig_mode}
     if eig_mode == "shared":
         kw = {"eig_mode": "parity"} if periodic else {"eig_override": nav.poisson_eigenbasis()}
-    ora = getattr(N.Navier2D, ctor)(nx, ny, ra, pr, dt, aspect, "rbc", **kw)
+    ora = getattr(N.Navier2D, ctor)(nx, ny, ra, pr, dt, aspect, bc, **kw)
     for z in (nav, ora):
         z.set_velocity(0.2, 1.0, 1.0)
         z.set_temperature(0.2, 1.0, 1.0)
@@ -156,9 +156,9 @@ def make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode="parity"):
 
 
 def check_step_parity(lib, periodic, nx, ny, ra, dt, steps, aspect=1.0, tol=1e-10, check_at=None, pr=1.0,
-                      eig_mode="parity"):
+                      eig_mode="parity", bc="rbc"):
     """u, v, T, p (physical) after `steps` x update() vs the oracle; BASELINE.json bar 1e-10."""
-    nav, ora = make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode=eig_mode)
+    nav, ora = make_pair(lib, periodic, nx, ny, ra, pr, dt, aspect, eig_mode=eig_mode, bc=bc)
     for k in ("velx", "vely", "temp"):
         assert rel(getattr(nav, k).vhat, getattr(ora, k).vhat) < 1e-12, k
     check_at = set(check_at or [steps])
