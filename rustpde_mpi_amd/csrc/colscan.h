@@ -59,6 +59,8 @@ struct ColHhArgs {
   int shift[kColMaxFields];          // tap 0 of row j is input row j - shift (rows < 0 read as zero)
   int in_half;                       // > 0: the input columns are parity de-interleaved (column i of the output =
                                      // input column (i & 1) * in_half + (i >> 1)); 0: same columns
+  int pair = 0;                      // 1: nf = 2 fields read the SAME input (the velocity correction): the block passes put the
+                                     // two workgroups that read the same rows next to each other on one XCD (second read = L2 hit)
   ColHhTabs tab[kColMaxFields];
   double *v1, *s1;       // [nf][NB][2][ld]     block-end values / block inflow of the forward chain
   double *v2, *s2;       // [nf][NB][2][2][ld]  block-end states / block inflow states of the backward chain

@@ -695,6 +695,36 @@ bool Navier2DEngine::add_rhs_line(RhsLineArgs a, int which, const char* tag) {
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::add_corr_line(CorrLineArgs a, const char* tag) {
+  // S8 (x part of the velocity correction) as one kernel: the folded form of build_colcorr_tables along x (corr_line.h)
+  if (!whole_line_on("RPDE_S8_LINE") || !whole_line_len(a.N) || periodic_) return false;
+  if (!corr_tabs_[0].t0.p) {
+    const int T = a.N / 16;
+    const ColCorrHost c = build_colcorr_tables(sp_vel_->base(0), sp_pseu_->base(0), -1.0 / sx_, kColBlockRows);
+    const ColHhHost* hs[2] = {&c.b, &c.a};   // branch 0: with the derivative (shift 1, rank-one term), branch 1: without (shift 2)
+    for (int b = 0; b < 2; ++b) {
+      RhsTabs& t = corr_tabs_[b];
+      const ColHhHost& h = *hs[b];
+      t.t0.upload(chunk_major16(h.t0, T, +1)); t.t1.upload(chunk_major16(h.t1, T, +1)); t.t2.upload(chunk_major16(h.t2, T, +1));
+      t.q1.upload(chunk_major16(h.q1, T, +1));
+      t.p2.upload(chunk_major16(h.p2, T, -1, 1.0)); t.q2.upload(chunk_major16(h.q2, T, -1)); t.r2.upload(chunk_major16(h.r2, T, -1));
+    }
+    corr_w_.upload(c.b.w); corr_h_.upload(c.b.h);
+  }
+  for (int b = 0; b < 2; ++b) {
+    const RhsTabs& t = corr_tabs_[b];
+    a.tab[b] = CorrLineTabs{t.t0.p, t.t1.p, t.t2.p, t.q1.p, t.p2.p, t.q2.p, t.r2.p};
+  }
+  a.w = corr_w_.p; a.h = corr_h_.p;
+  if (!corr_line_ok(a)) return false;
+  Launch l;
+  l.type = Launch::kCorrLine;
+  l.crl = a;
+  l.tag = tag;
+  l.bytes = 8.0 * a.nlines * 6.0 * (a.N - 1);   // two inputs, two velocities read and written
+  step_.push_back(l);
+  return true;
+}
 void Navier2DEngine::add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag) {
   Launch l;
   l.type = nn ? Launch::kGemmPairNN : Launch::kGemmPairNT;
@@ -758,6 +788,8 @@ void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, doub
   a.in[0] = ps; a.in[1] = ps; a.out[0] = outa; a.out[1] = outb; a.shift[0] = 2; a.shift[1] = 1;
   a.tab[0] = colcorr_a_.tabs(); a.tab[1] = colcorr_b_.tabs();
   a.in_half = half;
+  static const bool pair = [] { const char* e = std::getenv("RPDE_COL_PAIR"); return !e || std::atoi(e) != 0; }();   // A/B only
+  a.pair = pair ? 1 : 0;
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = nullptr;
   l.bytes = 3.0 * 8.0 * (double)ylines(my_) * ncols;  // algorithmic: the pseudo-pressure once, two arrays out
@@ -813,6 +845,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
     case Launch::kColDiff: run_col_diff(l.cd); break;
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
+    case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
     case Launch::kPdmaCols: launch_pdma_cols(l.pc, st_); break;
   }
@@ -963,7 +996,7 @@ std::string Navier2DEngine::describe_step() const {
     const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
-                                        "whole-line rhs + hholtz-x", "row stencil", "column solve"};
+                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -1724,7 +1757,10 @@ void Navier2DEngine::build_confined() {
   add_col_corr(yx(Y_[4]), po.half, yx(Y_[2]), yx(Y_[3]), mx, "C7 y: correction-y (column scan)");
   pseu_half_ = po.half;
   // ---- S8: x part of the velocity correction
-  {
+  CorrLineArgs crl;
+  crl.in[0] = yx(Y_[2]); crl.in[1] = yx(Y_[3]); crl.out[0] = yx(U_); crl.out[1] = yx(V_);
+  crl.ld = ldx; crl.nlines = ylines(my); crl.N = nx - 1; crl.nanflag = flagp();
+  if (!(xD.fft_n == nx - 1 && add_corr_line(crl, "S8 x: correction-x"))) {
     ProgramBuilder pb = ypb(2, my);   // the two velocity components side by side: their loads travel in pairs
     pb.set_fft(xD);
     pb.load(0, pb.arr(yx(Y_[2]), ldx), mx);

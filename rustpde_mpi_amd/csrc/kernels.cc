@@ -660,7 +660,14 @@ void launch_diag_reduce(const double* T, const double* dT, const double* ux, con
 // ------------------------------------------------------------------------------- column scans (colscan.h)
 template <int PASS>
 __global__ __launch_bounds__(256) void col_hholtz_kernel(const ColHhArgs a) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), f = (int)blockIdx.z;
+  int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), f = (int)blockIdx.z;
+  if ((PASS == 0 || PASS == 4) && a.pair) {
+    // two fields, one input: workgroups go to the XCDs round robin (grid.x is a multiple of 8), so x and x + 8 share an L2 and
+    // run back to back -- they take the same column tile, one field each
+    const int q = (int)blockIdx.x >> 3;
+    f = q & 1;
+    i = (((q >> 1) << 3) + ((int)blockIdx.x & 7)) * (int)blockDim.x + (int)threadIdx.x;
+  }
   if (i >= a.ncols) return;
   if constexpr (PASS == 0) colhh_block<false>(a, f, (int)blockIdx.y, i);
   if constexpr (PASS == 1) colhh_carry<0>(a, f, i, (int)blockIdx.y);
@@ -673,7 +680,8 @@ void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st) {
   // the carry kernels are serial chains over the blocks, one thread per (column, parity): small workgroups spread
   // the few thousand threads over all CUs
   static const int ct = [] { const char* e = std::getenv("RPDE_COL_CARRY_T"); const int v = e ? std::atoi(e) : 64; return (v == 64 || v == 128 || v == 256) ? v : 64; }();
-  const dim3 blk(256), gb((a.ncols + 255) / 256, std::max(a.NB, 1), a.nf), cblk(ct), gc((a.ncols + ct - 1) / ct, 2, a.nf);
+  const int tiles = (a.ncols + 255) / 256;
+  const dim3 blk(256), gb(a.pair ? 16 * ((tiles + 7) / 8) : tiles, std::max(a.NB, 1), a.pair ? 1 : a.nf), cblk(ct), gc((a.ncols + ct - 1) / ct, 2, a.nf);
   if (phase == 0) { if (a.NB > 0) hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a); }
   else if (phase == 1) {
     if (a.nranks <= 1) hipLaunchKernelGGL(col_hholtz_kernel<1>, gc, cblk, 0, st.s, a);
@@ -789,6 +797,24 @@ __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs
   RPDE_TRACE_BEGIN(trace);
   rhs_line<N, WHICH>(blk, a);
   RPDE_TRACE_END();
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void corr_line_kernel(const CorrLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  corr_line<N>(blk, a);
+}
+bool launch_corr_line(const CorrLineArgs& a, Stream& st) {
+  if ((a.N != 4096 && a.N != 1024) || !corr_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
+  if (a.N == 1024) hipLaunchKernelGGL(corr_line_kernel<1024>, grid, block, 0, st.s, a);
+  else hipLaunchKernelGGL(corr_line_kernel<4096>, grid, block, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+  return true;
 }
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   if ((a.N != 4096 && a.N != 1024) || !rhs_line_ok(a)) return false;
@@ -1222,6 +1248,17 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   return launch_dct_line(a0, st) && launch_dct_line(a1, st);
+}
+bool launch_corr_line(const CorrLineArgs& a, Stream&) {
+  if (!corr_line_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) corr_line<4096>(blk, a); else if (a.N == 1024) corr_line<1024>(blk, a); else corr_line<256>(blk, a);
+  }
+  return true;
 }
 bool launch_rhs_line(const RhsLineArgs& a, Stream&, long long*) {
   if (!rhs_line_ok(a)) return false;

@@ -4,6 +4,7 @@
 #include "line_vm.h"
 #include "pdma.h"
 #include "rhs_line.h"
+#include "corr_line.h"
 
 namespace rpde {
 
@@ -87,6 +88,7 @@ extern int g_dct_line_pf;   // 0: one line per workgroup; 3 / 4: persistent work
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
+bool launch_corr_line(const CorrLineArgs& a, Stream& st);   // corr_line.h: S8 of the confined step per x-line
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace = nullptr);   // rhs_line.h: S3 of the confined step per x-line
 // one y-line of a convection term: two backward transforms, the physical products, the forward transform with the
 // 2/3 rule, all in registers + one exchange buffer (dct_line.h conv_line; three workgroups per CU)
