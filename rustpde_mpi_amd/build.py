@@ -35,9 +35,12 @@ def _newest_header():
     return t
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", flags=()) -> str:
+    """`variant` / `flags`: an A/B build with extra compiler flags into librustpde_hip_<variant>.so (experiments only;
+    the package loads librustpde_hip.so)."""
     hipcc = _hipcc()
-    bdir = os.path.join(CSRC, "build")
+    out = OUT if not variant else OUT.replace(".so", f"_{variant}.so")
+    bdir = os.path.join(CSRC, "build" if not variant else f"build_{variant}")
     os.makedirs(bdir, exist_ok=True)
     hdr_t = _newest_header()
     objs = []
@@ -49,19 +52,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t)):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-Wno-unused-result", "-c", sp, "-o", obj]
+               "-Wno-unused-result", *flags, "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    if (force or not os.path.exists(OUT)
-            or os.path.getmtime(OUT) < max(os.path.getmtime(o) for o in objs)):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+    if (force or not os.path.exists(out)
+            or os.path.getmtime(out) < max(os.path.getmtime(o) for o in objs)):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    # python -m rustpde_mpi_amd.build [--force] [variant -DFLAG ...]
+    print(build(force="--force" in sys.argv, variant=args[0] if args else "", flags=tuple(args[1:])))

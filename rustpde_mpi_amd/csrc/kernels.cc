@@ -491,23 +491,30 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   if (BK < K) gload(BK);
   __syncthreads();
   int st = 0;
-  for (int k0 = 0; k0 < K; k0 += BK, st ^= 1) {
-    const bool more = k0 + BK < K;
+  // the barrier of a stage sits in front of its LAST group of MFMAs, and the first fragments of the next stage are read
+  // behind it: the barrier and the LDS latency of a stage change hide under 16 MFMAs instead of idling the pipe
+  {
     double a0[MT], b0[MT], a1[MT], b1[MT];
-    frag(st, 0, a0, b0);
-    frag(st, 1, a1, b1);
-    mma(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) lstore(st ^ 1);                 // stage t + 1 (its global loads were issued a full stage ago)
-    frag(st, 2, a0, b0);
-    mma(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (k0 + 2 * BK < K) gload(k0 + 2 * BK);  // stage t + 2
-    frag(st, 3, a1, b1);
-    mma(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1);
-    __syncthreads();
+    frag(0, 0, a0, b0);
+    for (int k0 = 0; k0 < K; k0 += BK, st ^= 1) {
+      const bool more = k0 + BK < K;
+      frag(st, 1, a1, b1);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore(st ^ 1);
+      frag(st, 2, a0, b0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k0 + 2 * BK < K) gload(k0 + 2 * BK);
+      frag(st, 3, a1, b1);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                          // stage t + 1 is complete; every read of stage t has been issued
+      if (more) frag(st ^ 1, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   mfma_drain();
 #pragma unroll
