@@ -55,7 +55,6 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
                "sharded engine needs an all-to-all transport");
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");   // navier.rs:251 / 372
   hc_ = bc == "hc";
-  RPDE_REQUIRE(!hc_ || comm_.size == 1, "bc = \"hc\" runs on one GPU (the three-term stencil of its temperature has no pencil-sharded kernels)");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   // everything that can throw comes after this block; the members below are released by
@@ -761,8 +760,11 @@ void Navier2DEngine::add_hc_to_ortho(int ncols) {
   Launch l;
   l.type = Launch::kSten3Rows;
   l.tag = "H0 y: temp -> ortho-y (three-term stencil)";
-  l.s3 = Sten3RowsArgs{yx(T_), ldx_, yx(TO_), ldx_, my_, ncols, yT.low1.p, yT.low.p, 0, ny_};
-  l.bytes = 8.0 * ncols * ((double)my_ + ny_);
+  // pencil-sharded: a rank produces its own rows; rows j - 1, j - 2 of the previous rank are the front halo of T_ (H0).
+  // The arrays are indexed with the global row.
+  const long sh = (long)yb_ * ldx_;
+  l.s3 = Sten3RowsArgs{yx(T_) - sh, ldx_, yx(TO_) - sh, ldx_, my_, ncols, yT.low1.p, yT.low.p, yb_, ylines(ny_)};
+  l.bytes = 8.0 * ncols * ((double)ylines(my_) + ylines(ny_));
   step_.push_back(l);
 }
 void Navier2DEngine::add_hc_hholtz(const double* in, double* out, int ncols) {
@@ -775,6 +777,21 @@ void Navier2DEngine::add_hc_hholtz(const double* in, double* out, int ncols) {
   l.pc = PdmaColsArgs{in, ldx_, out, ldx_, my_, ncols, yT.pv0.p, yT.pv1.p, yT.pv2.p, hh_temp_->pdma[1].tabs(), flagp()};
   l.bytes = 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: one read, one write (the intermediate ze rows are written and read back)
   step_.push_back(l);
+}
+void Navier2DEngine::add_hc_hholtz_sharded(const double* in, double* out, int rows_x, int elem, bool spec) {
+  // pencil-sharded: the seven-diagonal solve is one sequential sweep per column over ALL rows, so the right-hand side goes
+  // to x-pencils (y complete on every rank: the reference's own route, src/solver_mpi/hholtz_adi.rs), is solved along its
+  // contiguous y-lines and comes back.  X_[0], X_[1] are free between T2 and the first Poisson product.
+  const AxisTables& yT = sp_temp_->axis(1);
+  add_transpose(in, ldx_, X_[0].p, ldy_, my_, rows_x, elem, true, spec, "T3 hc: hholtz-y rhs temp");
+  Launch l;
+  l.type = Launch::kPdmaLines;
+  l.tag = "S4 y: hholtz-y temp (PdmaPlus2 lines)";
+  l.pl = PdmaLinesArgs{X_[0].p, ldy_, X_[1].p, ldy_, xlines(rows_x, spec), my_, elem, elem, nullptr, nullptr, hh_temp_->pdma[1].tabs()};
+  l.pl.t0 = yT.pv0.p; l.pl.t1 = yT.pv1.p; l.pl.t2 = yT.pv2.p; l.pl.nanflag = flagp();
+  l.bytes = 2.0 * 8.0 * (double)my_ * elem * xlines(rows_x, spec);
+  step_.push_back(l);
+  add_transpose(X_[1].p, ldy_, out, ldx_, rows_x, my_, elem, false, spec, "T4 hc: temp");
 }
 void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag) {
   // y part of correct_velocity (navier_eq.rs:117-125) on the YX pseudo-pressure: two banded column problems with
@@ -848,6 +865,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
     case Launch::kPdmaCols: launch_pdma_cols(l.pc, st_); break;
+    case Launch::kPdmaLines: launch_pdma_lines(l.pl, st_); break;
   }
 }
 
@@ -996,7 +1014,7 @@ std::string Navier2DEngine::describe_step() const {
     const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
-                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x"};
+                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -1687,7 +1705,7 @@ void Navier2DEngine::build_confined() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, mx, "C4 y: hholtz-y (column scan)");
-    if (hc) add_hc_hholtz(yx(Y_[5]), yx(T_), mx);
+    if (hc) { if (P == 1) add_hc_hholtz(yx(Y_[5]), yx(T_), mx); else add_hc_hholtz_sharded(yx(Y_[5]), yx(T_), mx, 1, false); }
     // d/dy vely for the divergence (rows ny, composite x); the halo of velx serves the cross-line stencil of S5
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, mx, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
@@ -1944,7 +1962,7 @@ void Navier2DEngine::build_periodic() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, nc, "C4 y: hholtz-y (column scan)");
-    if (hc) add_hc_hholtz(yx(Y_[5]), yx(T_), nc);
+    if (hc) { if (comm_.size == 1) add_hc_hholtz(yx(Y_[5]), yx(T_), nc); else add_hc_hholtz_sharded(yx(Y_[5]), yx(T_), kx, 2, true); }
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
   }

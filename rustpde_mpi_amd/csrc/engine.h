@@ -207,7 +207,8 @@ class Navier2DEngine {
   // the step as a list of launches
   struct Launch {
     enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine,
-                kSten3Rows, kPdmaCols, kCorrLine } type;
+                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines } type;
+    PdmaLinesArgs pl{};          // kPdmaLines ("hc", pencil-sharded: Helmholtz-y of the temperature on the y-lines of an x-pencil)
     CorrLineArgs crl{};          // kCorrLine
     Sten3RowsArgs s3{};          // kSten3Rows ("hc": temperature composite -> orthonormal along y, pdma.h)
     PdmaColsArgs pc{};           // kPdmaCols  ("hc": Helmholtz-y of the temperature, PdmaPlus2)
@@ -249,6 +250,7 @@ class Navier2DEngine {
   void add_col_hholtz(const double* const in[3], double* const out[3], int ncols, const char* tag);   // "hc": the velocities only
   void add_hc_to_ortho(int ncols);                                  // "hc": T_ -> TO_ (three-term stencil along y)
   void add_hc_hholtz(const double* in, double* out, int ncols);     // "hc": Helmholtz-y of the temperature (PdmaPlus2 along y)
+  void add_hc_hholtz_sharded(const double* in, double* out, int rows_x, int elem, bool spec);   // the same through x-pencils
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   void add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag);
   ColHhDev colcorr_a_, colcorr_b_;   // column problems of the velocity correction (confined, one GPU)

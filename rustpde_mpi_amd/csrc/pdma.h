@@ -49,6 +49,10 @@ struct PdmaLinesArgs {
   int nlines, n, es, ncomp;
   const double *low1, *low2;     // non-null: rhs_k = c_k + low1_k c_{k+1} + low2_k c_{k+2} (S^T of from_ortho); null: rhs = in
   PdmaTabs f;
+  // pencil-sharded "hc" step (lines = the y-lines of an x-pencil): B2 rows in front of the solve (taps j, j + 2, j + 4 of
+  // the n input values; matvec.rs:207-228) and the NaN flag of Integrate::exit.  All null by default.
+  const double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;
+  int* nanflag = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -145,16 +149,24 @@ RPDE_HD inline void pdma_line(const PdmaLinesArgs& a, int line, int comp) {
   for (int j = 0; j < n; ++j) {
     double r = in[(long)j * es];
     if (a.low1) r += a.low1[j] * in[(long)(j + 1) * es] + a.low2[j] * in[(long)(j + 2) * es];   // S^T c: the input has n + 2 entries
+    if (a.t0) {                                                                              // B2 row: the input has n entries
+      r *= a.t0[j];
+      if (j + 2 < n) r += a.t1[j] * in[(long)(j + 2) * es];
+      if (j + 4 < n) r += a.t2[j] * in[(long)(j + 4) * es];
+    }
     const double z = (r - a.f.l2[j] * z2 - a.f.ka[j] * z1) * a.f.imu[j];
     out[(long)j * es] = z;
     z2 = z1; z1 = z;
   }
   double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0;
+  bool bad = false;
   for (int i = n - 1; i >= 0; --i) {
     const double x = out[(long)i * es] - a.f.al[i] * x1 - a.f.be[i] * x2 - a.f.ga[i] * x3 - a.f.de[i] * x4;
     out[(long)i * es] = x;
+    bad |= (x != x);
     x4 = x3; x3 = x2; x2 = x1; x1 = x;
   }
+  if (bad && a.nanflag) *a.nanflag = 1;
 }
 
 }  // namespace rpde

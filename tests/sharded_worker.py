@@ -26,9 +26,11 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
     lib = Lib(lib_path)
     comm = TorchComm(device_buffers=device_build)
     results = []
-    for (periodic, nx, ny, ra, dt, steps, aspect) in cases:
+    for case in cases:
+        periodic, nx, ny, ra, dt, steps, aspect = case[:7]
+        bc = case[7] if len(case) > 7 else "rbc"       # "hc": horizontal convection (three-term temperature base along y)
         ctor = "new_periodic" if periodic else "new_confined"
-        nav = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", library=lib, comm=comm)
+        nav = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, library=lib, comm=comm)
         nav.set_velocity(0.2, 1.0, 1.0)
         nav.set_temperature(0.2, 1.0, 1.0)
         nav.update(steps)
@@ -41,7 +43,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         got["stat_temp"], got["stat_nusselt"] = st.t_avg.vhat, st.nusselt.vhat
         if rank == 0 and nx * ny > 1500 * 1500:
             # big grids: compare with the single-device engine instead of the (slow) oracle
-            one = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", library=lib)
+            one = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
             one.set_velocity(0.2, 1.0, 1.0)
             one.set_temperature(0.2, 1.0, 1.0)
             one.update(steps)
@@ -53,7 +55,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
                             "comm": stats, "calls": comm.calls})
             del one
         elif rank == 0:
-            ora = getattr(N.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, "rbc", eig_mode="parity")
+            ora = getattr(N.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, eig_mode="parity")
             ora.set_velocity(0.2, 1.0, 1.0)
             ora.set_temperature(0.2, 1.0, 1.0)
             for _ in range(steps):

@@ -60,6 +60,24 @@ def test_sharded_column_scans_and_whole_line_kernels_emulation(world, tmp_path, 
         assert r["comm"][1] == (12 if r["case"][0] else 13)
 
 
+# "hc": the three-term stencil of the temperature reads two halo rows, its seven-diagonal Helmholtz solve along y goes
+# through x-pencils (two more array exchanges per step)
+CASES_HC = [(False, 33, 33, 1e5, 0.01, 5, 1.0, "hc"), (True, 32, 33, 1e5, 0.01, 5, 1.0, "hc"), (False, 17, 65, 1e5, 0.01, 3, 2.0, "hc"),
+            (False, 257, 33, 1e5, 0.01, 3, 1.0, "hc")]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hc_matches_oracle_emulation(world, tmp_path, emu_lib):
+    res = _spawn(world, emu_lib.path, False, CASES_HC, tmp_path)
+    assert len(res) == len(CASES_HC)
+    for r in res:
+        for k, e in r["err"].items():
+            assert e < 1e-10, (r["case"], k, e)
+        # the "rbc" count + T3 / T4 of the temperature + one more for T1 (the temperature arrays have ny rows instead of my:
+        # two batches)
+        assert r["comm"][1] == (15 if r["case"][0] else 16)
+
+
 def test_sharded_long_fourier_lines_emulation(tmp_path, emu_lib):
     """BASELINE configs[4] geometry in miniature: periodic, x-lines of 8192 reals (the one-slot
     1024-thread line configuration), aspect 8, two ranks."""
@@ -71,7 +89,7 @@ def test_sharded_long_fourier_lines_emulation(tmp_path, emu_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_matches_oracle_hip(world, tmp_path, hip_lib):
-    cases = CASES + [(False, 129, 65, 1e5, 0.01, 10, 1.0), (True, 128, 65, 1e5, 0.01, 10, 1.0)]
+    cases = CASES + [(False, 129, 65, 1e5, 0.01, 10, 1.0), (True, 128, 65, 1e5, 0.01, 10, 1.0)] + CASES_HC[:3]
     res = _spawn(world, hip_lib.path, True, cases, tmp_path)
     for r in res:
         for k, e in r["err"].items():
