@@ -367,7 +367,7 @@ RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
   DctLineArgs b = a;
   b.in = c.f0;
-  return c.N != 1024 && dct_line_ok(a) && dct_line_ok(b);   // three transforms on the full-length core: N = 16^k
+  return dct_line_ok(a) && dct_line_ok(b);   // N = 16^k: three transforms on the full-length core; N = 1024: hconv_line (hdct_line.h), one wave per line
 }
 
 template <int N>

@@ -825,9 +825,27 @@ void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const
   l.bytes = 8.0 * ncols * (2.0 * ylines(m_in) + nyl_);   // the input twice (block sums, final pass), the output once
   step_.push_back(l);
 }
+#ifndef RPDE_EMU
+static bool hipStreamIsCapturingNow(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+#endif
+int Navier2DEngine::line_batch_kind(const Launch& l) {   // kernels.h LineBatch::kind of a launch, -1: not a batched kind
+  return l.type == Launch::kDctLine ? 0 : l.type == Launch::kDctLine2 ? 1 : l.type == Launch::kConvLine ? 2 : l.type == Launch::kRhsLine ? 3 : -1;
+}
 size_t Navier2DEngine::group_end(size_t i) const {
   // compatible consecutive transposes go out together: one launch on one GPU, one all-to-all when sharded
   const Launch& l = step_[i];
+  if (line_batch_kind(l) >= 0) {
+    // whole-line kernels of short lines (1025 points: one wave per line): the fields of a stage in one launch
+    static const int mask = [] { const char* e = std::getenv("RPDE_LINE_BATCH"); return e ? std::atoi(e) : 15; }();   // A/B only: bit k = LineBatch kind k
+    auto len = [](const Launch& m) { return m.type == Launch::kConvLine ? m.cl.N : m.type == Launch::kRhsLine ? m.rl.N : m.dl.N; };
+    if (!((mask >> line_batch_kind(l)) & 1) || !line_batch_ok(len(l))) return i + 1;
+    size_t j = i + 1;
+    while (j < step_.size() && (int)(j - i) < kLineBatch && step_[j].type == l.type && len(step_[j]) == len(l)) ++j;
+    return j;
+  }
   if (l.type != Launch::kTranspose) return i + 1;
   size_t j = i;
   while (j < step_.size() && (int)(j - i) < kMaxBatch) {
@@ -838,10 +856,48 @@ size_t Navier2DEngine::group_end(size_t i) const {
   }
   return j;
 }
+std::string Navier2DEngine::group_tag(size_t i, size_t j) const {
+  // the tag of a group of launches: the common tag, or "<common words> a + b + c" when the members' tags differ in their tails
+  std::string t = step_[i].tag;
+  bool same = true;
+  for (size_t k = i + 1; k < j; ++k) same = same && t == step_[k].tag;
+  if (same) return t;
+  size_t c = t.size();
+  for (size_t k = i + 1; k < j; ++k) {
+    const std::string u = step_[k].tag;
+    size_t x = 0;
+    while (x < c && x < u.size() && t[x] == u[x]) ++x;
+    c = x;
+  }
+  while (c > 0 && t[c - 1] != ' ') --c;            // cut at a word boundary
+  std::string out = t.substr(0, c);
+  for (size_t k = i; k < j; ++k) out += (k > i ? " + " : "") + std::string(step_[k].tag).substr(c);
+  return out;
+}
 size_t Navier2DEngine::run_from(size_t i) {
   const Launch& l = step_[i];
-  if (l.type != Launch::kTranspose) { run_launch(l); return i + 1; }
   const size_t j = group_end(i);
+#ifndef RPDE_EMU
+  // diagnostics: RPDE_SYNC_LAUNCHES=1 names every launch on stderr and waits for it (a device fault then points at its launch)
+  static const bool sync_each = [] { const char* e = std::getenv("RPDE_SYNC_LAUNCHES"); return e && std::atoi(e) != 0; }();
+  struct SyncAfter {
+    Navier2DEngine* e; bool on;
+    ~SyncAfter() { if (on) { (void)hipStreamSynchronize(e->st_.s); fprintf(stderr, " done\n"); fflush(stderr); } }
+  } sync_after{this, sync_each && hipStreamIsCapturingNow(st_.s) == false};
+  if (sync_after.on) { fprintf(stderr, "[launch] %s ...", group_tag(i, j).c_str()); fflush(stderr); }
+#endif
+  if (line_batch_kind(l) >= 0 && j - i > 1) {
+    LineBatch b;
+    b.kind = line_batch_kind(l);
+    for (size_t k = i; k < j; ++k) {
+      const Launch& m = step_[k];
+      b.d0[b.n] = m.dl; b.d1[b.n] = m.dl2; b.c[b.n] = m.cl; b.r[b.n] = m.rl;
+      ++b.n;
+    }
+    launch_line_batch(b, st_);
+    return j;
+  }
+  if (l.type != Launch::kTranspose) { run_launch(l); return i + 1; }
   std::vector<Xfer> xs;
   for (size_t k = i; k < j; ++k) xs.push_back(Xfer{step_[k].in, step_[k].ldi, step_[k].out, step_[k].ldo});
   exchange_batch(xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
@@ -916,7 +972,7 @@ void Navier2DEngine::update(int nsteps) {
     for (size_t i = 0; i < step_.size();) {
       const Launch& l = step_[i];
 #ifndef RPDE_EMU
-      const bool timed = !timed_tag_.empty() && std::string(l.tag).find(timed_tag_) != std::string::npos;
+      const bool timed = !timed_tag_.empty() && group_tag(i, group_end(i)).find(timed_tag_) != std::string::npos;
       if (timed) {
         hipEvent_t a, b;
         RPDE_HIP(hipEventCreate(&a)); RPDE_HIP(hipEventCreate(&b));
@@ -986,7 +1042,7 @@ std::string Navier2DEngine::profile(int nsteps) {
     }
 #endif
     for (size_t g = 0; g < groups.size(); ++g) {   // a group of transposes counts as ONE launch with the bytes of all its arrays
-      const std::string tag = step_[groups[g].first].tag;
+      const std::string tag = group_tag(groups[g].first, groups[g].second);
       if (!acc.count(tag)) order.push_back(tag);
       Acc& a = acc[tag];
       a.n += 1; a.ms += gms[g]; a.bytes = 0; a.flops = step_[groups[g].first].flops;
@@ -1019,7 +1075,7 @@ std::string Navier2DEngine::describe_step() const {
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
     if (j - i > 1) kind += " (" + std::to_string(j - i) + " arrays)";
-    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", l.tag, bytes, l.flops, ndisp, kind.c_str());
+    snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", group_tag(i, j).c_str(), bytes, l.flops, ndisp, kind.c_str());
     out += buf;
     i = j;
   }

@@ -230,6 +230,8 @@ class Navier2DEngine {
     double bytes = 0.0;          // algorithmic HBM bytes of one launch (reads + writes)
     double flops = 0.0;          // floating point operations of one launch (GEMMs)
   };
+  static int line_batch_kind(const Launch& l);
+  std::string group_tag(size_t i, size_t j) const;
   std::string timed_tag_;
   double timed_ms_ = 0.0;
   long timed_count_ = 0;

@@ -696,6 +696,8 @@ void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st) {
   } else if (phase == 2) hipLaunchKernelGGL(col_hholtz_kernel<3>, gc, cblk, 0, st.s, a);
   else if (a.NB > 0) hipLaunchKernelGGL(col_hholtz_kernel<4>, gb, blk, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
+  static const bool sync_each = [] { const char* e = std::getenv("RPDE_SYNC_LAUNCHES"); return e && std::atoi(e) > 1; }();   // diagnostics
+  if (sync_each) { (void)hipStreamSynchronize(st.s); fprintf(stderr, " [phase %d ok]", phase); fflush(stderr); }
 }
 template <int PASS>
 __global__ __launch_bounds__(256) void col_diff_kernel(const ColDiffArgs a) {
@@ -805,6 +807,74 @@ __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs
   rhs_line<N, WHICH>(blk, a);
   RPDE_TRACE_END();
 }
+// ---- batched forms for 1025-point lines (kernels.h LineBatch): blockIdx.y picks the field
+struct Dct1Batch { DctLineArgs a[kLineBatch]; };
+struct Dct2Batch { DctLineArgs a0[kLineBatch], a1[kLineBatch]; };
+struct ConvBatch { ConvLineArgs c[kLineBatch]; };
+struct RhsBatch { RhsLineArgs r[kLineBatch]; };
+#define RPDE_BATCH_LINE(nl) \
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64]; \
+  const int chunk = (int)gridDim.x >> 3; \
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3); \
+  if (line >= (nl)) return; \
+  Blk blk{line, 0, N / 16, buf, nullptr, 0}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void hdct_line_batch_kernel(const Dct1Batch b) {
+  const DctLineArgs& a = b.a[blockIdx.y];
+  RPDE_BATCH_LINE(a.nlines);
+  hdct_bwd_line<N>(blk, a);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void hdct_line2_batch_kernel(const Dct2Batch b) {
+  const DctLineArgs& a0 = b.a0[blockIdx.y];
+  const DctLineArgs& a1 = b.a1[blockIdx.y];
+  RPDE_BATCH_LINE(a0.nlines);
+  hdct_bwd_line<N>(blk, a0);
+  __syncthreads();
+  hdct_bwd_line<N>(blk, a1);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 1) void hconv_line_batch_kernel(const ConvBatch b) {
+  const ConvLineArgs& c = b.c[blockIdx.y];
+  RPDE_BATCH_LINE(c.nlines);
+  hconv_line<N>(blk, c);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 3) void rhs_line_batch_kernel(const RhsBatch b) {
+  const RhsLineArgs& a = b.r[blockIdx.y];
+  RPDE_BATCH_LINE(a.nlines);
+  if (a.which == 0) rhs_line<N, 0>(blk, a);
+  else if (a.which == 1) rhs_line<N, 1>(blk, a);
+  else rhs_line<N, 2>(blk, a);
+}
+bool line_batch_ok(int N) { return N == 1024; }
+void launch_line_batch(const LineBatch& b, Stream& st) {
+  constexpr int N = 1024;
+  RPDE_REQUIRE(b.n >= 1 && b.n <= kLineBatch, "line batch: 1 .. 3 fields");
+  int nl = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int li = b.kind == 0 ? b.d0[i].nlines : b.kind == 1 ? b.d0[i].nlines : b.kind == 2 ? b.c[i].nlines : b.r[i].nlines;
+    const int Ni = b.kind <= 1 ? b.d0[i].N : b.kind == 2 ? b.c[i].N : b.r[i].N;
+    RPDE_REQUIRE(Ni == N, "line batch: lines of 1025 points");
+    nl = std::max(nl, li);
+  }
+  if (nl <= 0) return;
+  const dim3 grid(8 * ((nl + 7) / 8), b.n), block(N / 16);
+  if (b.kind == 0) {
+    Dct1Batch k; for (int i = 0; i < b.n; ++i) k.a[i] = b.d0[i];
+    hipLaunchKernelGGL(hdct_line_batch_kernel<N>, grid, block, 0, st.s, k);
+  } else if (b.kind == 1) {
+    Dct2Batch k; for (int i = 0; i < b.n; ++i) { k.a0[i] = b.d0[i]; k.a1[i] = b.d1[i]; }
+    hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
+  } else if (b.kind == 2) {
+    ConvBatch k; for (int i = 0; i < b.n; ++i) k.c[i] = b.c[i];
+    hipLaunchKernelGGL(hconv_line_batch_kernel<N>, grid, block, 0, st.s, k);
+  } else {
+    RhsBatch k; for (int i = 0; i < b.n; ++i) k.r[i] = b.r[i];
+    hipLaunchKernelGGL(rhs_line_batch_kernel<N>, grid, block, 0, st.s, k);
+  }
+  RPDE_HIP(hipGetLastError());
+}
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void corr_line_kernel(const CorrLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
@@ -892,8 +962,13 @@ __global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs
   conv_line<N>(blk, c);
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
-  if (c.N != 4096 || !conv_line_ok(c)) return false;
+  if ((c.N != 4096 && c.N != 1024) || !conv_line_ok(c)) return false;
   if (c.nlines <= 0) return true;
+  if (c.N == 1024) {   // one wave per line on the half-length core; a 1025^2 grid is four lines per CU: the whole register file per wave
+    hipLaunchKernelGGL((hconv_line_kernel<1024, 1>), dim3(8 * ((c.nlines + 7) / 8)), dim3(64), 0, st.s, c);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   if (g_hdct & 4) {
     static const int wpc = [] { const char* e = std::getenv("RPDE_CONV_WPC"); return e ? std::atoi(e) : 3; }();   // A/B switch
     if (wpc == 2) hipLaunchKernelGGL((hconv_line_kernel<4096, 2>), dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
@@ -1247,7 +1322,8 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   for (int line = 0; line < c.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
-    if (g_hdct & 4) { if (c.N == 4096) hconv_line<4096>(blk, c); else hconv_line<256>(blk, c); }
+    if (c.N == 1024) hconv_line<1024>(blk, c);
+    else if (g_hdct & 4) { if (c.N == 4096) hconv_line<4096>(blk, c); else hconv_line<256>(blk, c); }
     else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);
   }
   return true;
@@ -1255,6 +1331,17 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
   return launch_dct_line(a0, st) && launch_dct_line(a1, st);
+}
+bool line_batch_ok(int N) { return N == 1024 || N == 256; }
+void launch_line_batch(const LineBatch& b, Stream& st) {   // the same lines, one field after the other
+  for (int i = 0; i < b.n; ++i) {
+    bool ok = false;
+    if (b.kind == 0) ok = launch_dct_line(b.d0[i], st);
+    else if (b.kind == 1) ok = launch_dct_line2(b.d0[i], b.d1[i], st);
+    else if (b.kind == 2) ok = launch_conv_line(b.c[i], st);
+    else ok = launch_rhs_line(b.r[i], st);
+    RPDE_REQUIRE(ok, "line batch: shape");
+  }
 }
 bool launch_corr_line(const CorrLineArgs& a, Stream&) {
   if (!corr_line_ok(a)) return false;

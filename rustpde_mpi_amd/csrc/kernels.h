@@ -88,6 +88,17 @@ extern int g_dct_line_pf;   // 0: one line per workgroup; 3 / 4: persistent work
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
+// Small grids (lines of 1025 points, one wave per line): a launch of one field's lines leaves most of the chip idle and
+// costs a kernel's latency; the launches of the three fields of a stage go out as ONE launch (blockIdx.y = field).
+constexpr int kLineBatch = 3;
+struct LineBatch {
+  int n = 0, kind = 0;                       // kind: 0 transform, 1 transform pair, 2 convection term, 3 rhs + hholtz-x
+  DctLineArgs d0[kLineBatch], d1[kLineBatch];
+  ConvLineArgs c[kLineBatch];
+  RhsLineArgs r[kLineBatch];
+};
+bool line_batch_ok(int N);                   // the line lengths launch_line_batch covers
+void launch_line_batch(const LineBatch& b, Stream& st);
 bool launch_corr_line(const CorrLineArgs& a, Stream& st);   // corr_line.h: S8 of the confined step per x-line
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace = nullptr);   // rhs_line.h: S3 of the confined step per x-line
 // one y-line of a convection term: two backward transforms, the physical products, the forward transform with the

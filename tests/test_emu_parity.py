@@ -119,7 +119,7 @@ def test_step_with_every_whole_line_path(emu_lib):
 
 def test_step_with_lines_of_1025_points(emu_lib):
     """N = 1024: one wave per line on the half-length core (hdct_line.h): S1, S3 (nx = 1025) and the pure transforms of
-    S2 (ny = 1025); the convection terms keep their line programs at this length (their kernel needs N = 16^k)."""
+    S2 and the convection terms (ny = 1025: hconv_line, the three transforms of a term on the half-length core)."""
     # nx = 1025: both sides on the engine's eigen-decomposition, like at 4097 (DESIGN.md section 4: two LAPACK runs
     # differ by 1e-9 in u after one step at this size -- the reference's own sensitivity)
     K.check_step_parity(emu_lib, False, 1025, 17, 1e6, 2e-3, 3, check_at=[1, 3], eig_mode="shared")
@@ -127,7 +127,7 @@ def test_step_with_lines_of_1025_points(emu_lib):
     assert not _has_line_program(nav, "S1 x") and not _has_line_program(nav, "S3 x")
     K.check_step_parity(emu_lib, False, 17, 1025, 1e6, 2e-3, 2, check_at=[2])
     nav, _ = K.make_pair(emu_lib, False, 17, 1025, 1e6, 1.0, 2e-3, 1.0)
-    assert not _has_line_program(nav, "S2 y: velx") and _has_line_program(nav, "conv_velx")
+    assert not _has_line_program(nav, "S2 y: velx") and not _has_line_program(nav, "conv_velx") and not _has_line_program(nav, "conv_temp")
 
 
 def test_confined_step_aspect(emu_lib):
