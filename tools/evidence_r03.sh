@@ -8,7 +8,7 @@ O=$R/gpurun_out/r03
 rm -rf $O; mkdir -p $O
 cat $R/.evidence_commit > $O/commit.txt 2>/dev/null   # written by the caller (git rev-parse HEAD): the GPU box has no .git
 export EVIDENCE_COMMIT=$(cat $O/commit.txt 2>/dev/null)
-(timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --durations=12 ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -30) > $O/pytest_gpu.txt
+(timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -s --durations=12 ${PYTEST_K:+-k "$PYTEST_K"} 2>&1 | tail -30) > $O/pytest_gpu.txt
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_write.log 2>&1
