@@ -6,6 +6,8 @@ each check; the step-level bar of BASELINE.json is 1e-10.
 """
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 
@@ -288,3 +290,54 @@ def independent_golden_bound(full_vs_parity, tol=1e-10):
     the oracle's own full-vs-parity difference (the reference's Poisson solve amplifies dgeev's round-off by the 1e10 of
     poisson.rs:84-87; the difference decays as the flow becomes divergence-free)."""
     return tol if full_vs_parity < tol / 10 else max(tol, 10.0 * full_vs_parity)
+
+
+def check_config2_golden(lib):
+    """BASELINE.json configs[1] against the committed oracle samples (tests/golden/make_config2_golden.py); see
+    tests/test_gpu_parity.py::test_config2_golden_1025_200_steps for the bounds."""
+    g = np.load(os.path.join(GOLDEN, "config2_1025_200steps.npz"))
+    nx, ny, stride = int(g["nx"]), int(g["ny"]), int(g["stride"])
+    nav = R.Navier2D.new_confined(nx, ny, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=lib)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    done = 0
+    for s in (10, 100, 200):
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        for k in ("velx", "vely", "temp", "pres"):
+            want = g[f"{k}_{s}"]
+            got = f[k][::stride, ::stride]
+            tol = 1e-7 if s == 10 else 1e-10
+            err = np.linalg.norm(got - want) / np.linalg.norm(want)
+            assert err < tol, (k, s, err)
+            # the full-field norm pins the points between the samples as well
+            assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < tol * float(g[f"{k}_{s}_norm"]), (k, s)
+    assert abs(nav.div_norm() - float(g["div_norm"])) < 1e-8 * max(1.0, float(g["div_norm"]))
+
+
+def check_independent_golden(lib, n):
+    """Engine (own setup) against the golden of the oracle in the reference's setup, n x n; bounds: independent_golden_bound."""
+    path = os.path.join(GOLDEN, f"headline_{n}_full.npz")
+    g = np.load(path)
+    nav = R.Navier2D.new_confined(n, n, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=lib)
+    res = compare_with_independent_golden(nav, path)
+    assert res, "no snapshot compared"
+    print({s: {k: f"{e:.1e} (oracle full vs parity {b:.1e})" for k, (e, b) in r.items()} for s, r in res.items()})
+    for s, r in res.items():
+        for k, (err, fvp) in r.items():
+            assert err < independent_golden_bound(fvp), (n, s, k, err, fvp)
+
+
+def run_isolated(call, timeout=900):
+    """Run `checks.<call>` (an expression like "check_config2_golden(lib)", with lib = the product library) in a child
+    process.  A device fault ends the process that owns the GPU context (the HIP runtime aborts); in a child it fails THIS
+    test, with the child's output, instead of ending the pytest session.  No retry: a fault is a failure.  Used for the
+    1025 x 1025 engines (an open first-step fault at that size)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import rustpde_mpi_amd as R\nfrom tests import checks as K\nlib = R.lib()\nassert lib.is_device_build\n"
+            f"K.{call}\nprint('ISOLATED-OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
+    sys.stdout.write(r.stdout[-4000:])
+    assert r.returncode == 0 and "ISOLATED-OK" in r.stdout, (f"child process ended with code {r.returncode}\n"
+                                                             f"{r.stdout[-3000:]}\n{r.stderr[-3000:]}")

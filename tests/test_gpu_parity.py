@@ -107,26 +107,7 @@ def test_config2_golden_1025_200_steps(hip_lib):
     the bound is 1e-7: the first steps of this initial condition amplify eigenvector round-off of
     the near-singular Poisson mode (measured 2e-9 in p, 1e-11 in u, v, and
     the same size between two LAPACK eigenbases inside the oracle itself)."""
-    import os
-    g = np.load(os.path.join(K.GOLDEN, "config2_1025_200steps.npz"))
-    nx, ny, stride = int(g["nx"]), int(g["ny"]), int(g["stride"])
-    nav = R.Navier2D.new_confined(nx, ny, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=hip_lib)
-    nav.set_velocity(0.2, 1.0, 1.0)
-    nav.set_temperature(0.2, 1.0, 1.0)
-    done = 0
-    for s in (10, 100, 200):
-        nav.update(s - done)
-        done = s
-        f = nav.physical_fields()
-        for k in ("velx", "vely", "temp", "pres"):
-            want = g[f"{k}_{s}"]
-            got = f[k][::stride, ::stride]
-            tol = 1e-7 if s == 10 else 1e-10
-            err = np.linalg.norm(got - want) / np.linalg.norm(want)
-            assert err < tol, (k, s, err)
-            # the full-field norm pins the points between the samples as well
-            assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < tol * float(g[f"{k}_{s}_norm"]), (k, s)
-    assert abs(nav.div_norm() - float(g["div_norm"])) < 1e-8 * max(1.0, float(g["div_norm"]))
+    K.run_isolated("check_config2_golden(lib)")   # 1025 x 1025: in a child process (checks.run_isolated)
 
 
 @pytest.mark.parametrize("n", [1025, 2049, 4097])
@@ -139,14 +120,10 @@ def test_headline_independent_reference_setup(hip_lib, n):
     path = os.path.join(K.GOLDEN, f"headline_{n}_full.npz")
     if not os.path.exists(path):
         pytest.skip(f"{os.path.basename(path)} not generated (tests/golden/make_headline_golden.py)")
-    g = np.load(path)
-    nav = R.Navier2D.new_confined(n, n, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=hip_lib)
-    res = K.compare_with_independent_golden(nav, path)
-    assert res, "no snapshot compared"
-    print({s: {k: f"{e:.1e} (oracle full vs parity {b:.1e})" for k, (e, b) in r.items()} for s, r in res.items()})
-    for s, r in res.items():
-        for k, (err, fvp) in r.items():
-            assert err < K.independent_golden_bound(fvp), (n, s, k, err, fvp)
+    if n == 1025:
+        K.run_isolated("check_independent_golden(lib, 1025)")   # in a child process (checks.run_isolated)
+    else:
+        K.check_independent_golden(hip_lib, n)
 
 
 # ------------------------------------------------------------------------------------------------

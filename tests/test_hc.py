@@ -223,7 +223,7 @@ def test_hc_step_gpu(hip_lib, periodic, nx, ny, steps, aspect):
 def test_hc_step_1025_gpu(hip_lib):
     """1025 x 1025 (one-wave whole-line kernels for the velocities, batched column solve over 65 blocks of rows for the
     temperature), Ra = 1e7, dt = 1e-3; shared eigen-decomposition like every large confined comparison."""
-    K.check_step_parity(hip_lib, False, 1025, 1025, 1e7, 1e-3, 3, check_at=[1, 3], bc="hc", eig_mode="shared")
+    K.run_isolated('check_step_parity(lib, False, 1025, 1025, 1e7, 1e-3, 3, check_at=[1, 3], bc="hc", eig_mode="shared")')
 
 
 @pytest.mark.gpu
