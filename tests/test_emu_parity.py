@@ -130,6 +130,23 @@ def test_step_with_lines_of_1025_points(emu_lib):
     assert not _has_line_program(nav, "S2 y: velx") and not _has_line_program(nav, "conv_velx") and not _has_line_program(nav, "conv_temp")
 
 
+def test_whole_line_launches_of_short_lines_go_out_batched(emu_lib):
+    """Lines the batched form covers (1025 points on the GPU, also 257 in the emulation build): the whole-line launches of
+    the three fields of a stage are ONE launch (LineBatch, blockIdx.y = field) and the schedule says so: 17 launches
+    instead of 24.  RPDE_LINE_BATCH (a bit mask per kind, read once per process) is the A/B switch; the results of the
+    batched step are checked against the oracle by test_step_with_every_whole_line_path and the 257 / 1025 cases above."""
+    nav, _ = K.make_pair(emu_lib, False, 257, 257, 1e6, 1.0, 2e-3, 1.0)
+    sched = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert sched["S1 x: state -> phys-x + d/dx"] == "whole-line transform pair (3 arrays)"
+    assert sched["S2 y: velx -> phys + vely -> phys"] == "whole-line transform (2 arrays)"
+    assert sched["S2 y: conv_velx + conv_vely + conv_temp"] == "whole-line convection term (3 arrays)"
+    assert sched["S3 x: rhs + hholtz-x velx + vely + temp"] == "whole-line rhs + hholtz-x (3 arrays)"
+    assert len(sched) == 17
+    # the per-launch profile uses the same grouping and tags
+    tags = [r["tag"] for r in nav.profile(1)]
+    assert "S2 y: conv_velx + conv_vely + conv_temp" in tags and len(tags) == 17
+
+
 def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 
