@@ -392,8 +392,8 @@ def main():
         "roofline": roof,
         "phases": phases,
         "transform_pass": transform_pass,
-        # which form of each stage this engine chose at construction (whole-line kernels are taken after an on-device
-        # comparison with the line program: RPDE_DCT_LINE / RPDE_S1_LINE / RPDE_CONV_LINE)
+        # which stages of this engine run whole-line kernels (the default wherever they cover the line length; the
+        # RPDE_*_LINE switches are A/B overrides)
         "step_kernels": {k: sorted({t for t, _, _, _, kind in sched if kind == k})
                          for k in sorted({kind for _, _, _, _, kind in sched}) if k.startswith("whole-line")},
     }

@@ -120,8 +120,8 @@ def test_headline_independent_reference_setup(hip_lib, n):
     path = os.path.join(K.GOLDEN, f"headline_{n}_full.npz")
     if not os.path.exists(path):
         pytest.skip(f"{os.path.basename(path)} not generated (tests/golden/make_headline_golden.py)")
-    if n == 1025:
-        K.run_isolated("check_independent_golden(lib, 1025)")   # in a child process (checks.run_isolated)
+    if n < 4097:   # in a child process (checks.run_isolated): 1025 is the size of the open first-step fault, 2049 has not run often
+        K.run_isolated(f"check_independent_golden(lib, {n})")
     else:
         K.check_independent_golden(hip_lib, n)
 
