@@ -130,6 +130,14 @@ def test_step_with_lines_of_1025_points(emu_lib):
     assert not _has_line_program(nav, "S2 y: velx") and not _has_line_program(nav, "conv_velx") and not _has_line_program(nav, "conv_temp")
 
 
+def test_periodic_step_with_lines_of_1025_points(emu_lib):
+    """BASELINE configs[2] geometry in the y direction (periodic, ny = 1025): the pure transforms and the convection terms of
+    S2 on the half-length core, batched over the fields."""
+    K.check_step_parity(emu_lib, True, 16, 1025, 1e6, 2e-3, 3, check_at=[1, 3])
+    nav, _ = K.make_pair(emu_lib, True, 16, 1025, 1e6, 1.0, 2e-3, 1.0)
+    assert not _has_line_program(nav, "S2 y: velx") and not _has_line_program(nav, "conv_temp")
+
+
 def test_whole_line_launches_of_short_lines_go_out_batched(emu_lib):
     """Lines the batched form covers (1025 points on the GPU, also 257 in the emulation build): the whole-line launches of
     the three fields of a stage are ONE launch (LineBatch, blockIdx.y = field) and the schedule says so: 17 launches
