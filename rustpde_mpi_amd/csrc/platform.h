@@ -126,6 +126,9 @@ inline void* dev_alloc(size_t bytes) {
   void* p = nullptr;
   RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
   RPDE_HIP(hipMemset(p, 0, bytes ? bytes : 8));
+  // diagnostics: RPDE_LOG_ALLOC=1 prints every allocation, so that a fault address can be placed
+  static const bool log = [] { const char* e = std::getenv("RPDE_LOG_ALLOC"); return e && std::atoi(e) != 0; }();
+  if (log) fprintf(stderr, "[alloc] %p %zu\n", p, bytes);
   return p;
 #endif
 }
@@ -133,7 +136,8 @@ inline void dev_free(void* p) {
 #ifdef RPDE_EMU
   if (p) std::free(static_cast<char*>(p) - kEmuGuardBytes);
 #else
-  if (p) (void)hipFree(p);
+  static const bool keep = [] { const char* e = std::getenv("RPDE_NO_FREE"); return e && std::atoi(e) != 0; }();   // diagnostics: leak instead of freeing
+  if (p && !keep) (void)hipFree(p);
 #endif
 }
 inline void dev_upload(void* dst, const void* src, size_t bytes) {
