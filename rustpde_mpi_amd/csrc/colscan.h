@@ -86,6 +86,7 @@ constexpr int kColBatch = 8;
 // the carry passes are ONE serial chain per thread over all blocks: their loads go out sixteen blocks at a time (the
 // chain waits once per batch for memory: 128 blocks = 8 round trips per direction)
 constexpr int kCarryBatch = 16;
+constexpr int kCarryBatchBack = 8;     // backward chain: nine values per block (two end states, the forward inflow, M, g)
 
 // one block of one column: FINAL = false keeps the block-end states of a run from zero inflow, FINAL = true
 // runs from the exact inflow states and stores the rows.  All BR + 4 row loads are in flight at once.
@@ -202,36 +203,46 @@ RPDE_HD inline void colhh_carry(const ColHhArgs& a, int f, int i, int par) {
     if (PHASE == 0) { if (t.w) a.kap[(long)f * a.ld + i] = k; }
     else a.summ[col_sm(a, 0, f, 6) + i] = k;
   }
+  // The block transfer factors of a batch are loaded TOGETHER with its block-end values, in front of the batch's stores: read
+  // one by one inside the chain, every table entry is a memory round trip of its own (the compiler may not move a load
+  // from `t.m1` across the store to `a.s1` in front of it: both are plain global pointers).
   for (int bb = 0; bb < a.NB; bb += kCarryBatch) {
-    double v[kCarryBatch];
+    double v[kCarryBatch], mm[kCarryBatch];
 #pragma unroll
-    for (int u = 0; u < kCarryBatch; ++u) v[u] = (bb + u < a.NB) ? a.v1[col_c1(a, f, bb + u, par) + i] : 0.0;
+    for (int u = 0; u < kCarryBatch; ++u) {
+      v[u] = (bb + u < a.NB) ? a.v1[col_c1(a, f, bb + u, par) + i] : 0.0;
+      mm[u] = (bb + u < a.NB) ? t.m1[(bb + u) * 2 + par] : 0.0;
+    }
 #pragma unroll
     for (int u = 0; u < kCarryBatch; ++u)
       if (bb + u < a.NB) {
         a.s1[col_c1(a, f, bb + u, par) + i] = s;
-        s = t.m1[(bb + u) * 2 + par] * s + v[u];
+        s = mm[u] * s + v[u];
       }
   }
   if (PHASE == 1) a.summ[col_sm(a, 0, f, par) + i] = s;
-  for (int bt = a.NB - 1; bt >= 0; bt -= kCarryBatch) {
-    double v0[kCarryBatch], v1[kCarryBatch], fi[kCarryBatch];
+  for (int bt = a.NB - 1; bt >= 0; bt -= kCarryBatchBack) {
+    double v0[kCarryBatchBack], v1[kCarryBatchBack], fi[kCarryBatchBack], m[kCarryBatchBack][4], g[kCarryBatchBack][2];
 #pragma unroll
-    for (int u = 0; u < kCarryBatch; ++u) {
-      v0[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 0) + i] : 0.0;
-      v1[u] = (bt - u >= 0) ? a.v2[col_c2(a, f, bt - u, par, 1) + i] : 0.0;
-      fi[u] = (bt - u >= 0) ? a.s1[col_c1(a, f, bt - u, par) + i] : 0.0;   // written above by this thread
+    for (int u = 0; u < kCarryBatchBack; ++u) {
+      const bool ok = bt - u >= 0;
+      const int b = ok ? bt - u : 0;
+      v0[u] = ok ? a.v2[col_c2(a, f, b, par, 0) + i] : 0.0;
+      v1[u] = ok ? a.v2[col_c2(a, f, b, par, 1) + i] : 0.0;
+      fi[u] = ok ? a.s1[col_c1(a, f, b, par) + i] : 0.0;   // written above by this thread
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m[u][c] = ok ? t.m2[(b * 2 + par) * 4 + c] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) g[u][c] = ok ? t.g[(b * 2 + par) * 2 + c] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < kCarryBatch; ++u) {
+    for (int u = 0; u < kCarryBatchBack; ++u) {
       const int b = bt - u;
       if (b >= 0) {
         a.s2[col_c2(a, f, b, par, 0) + i] = s0;
         a.s2[col_c2(a, f, b, par, 1) + i] = s1;
-        const double* m = t.m2 + (b * 2 + par) * 4;
-        const double* g = t.g + (b * 2 + par) * 2;
-        const double n0 = m[0] * s0 + m[1] * s1 + (v0[u] + g[0] * fi[u]);
-        const double n1 = m[2] * s0 + m[3] * s1 + (v1[u] + g[1] * fi[u]);
+        const double n0 = m[u][0] * s0 + m[u][1] * s1 + (v0[u] + g[u][0] * fi[u]);
+        const double n1 = m[u][2] * s0 + m[u][3] * s1 + (v1[u] + g[u][1] * fi[u]);
         s0 = n0; s1 = n1;
       }
     }
