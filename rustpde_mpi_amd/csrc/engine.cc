@@ -694,6 +694,18 @@ bool Navier2DEngine::add_rhs_line(RhsLineArgs a, int which, const char* tag) {
   step_.push_back(l);
   return true;
 }
+bool Navier2DEngine::add_div_line(const DivLineArgs& a, const char* tag) {
+  // S5 (divergence + x preconditioner of the Poisson solve) as one kernel (div_line.h)
+  if (!whole_line_on("RPDE_S5_LINE") || !whole_line_len(a.N) || periodic_ || !div_line_ok(a)) return false;
+  Launch l;
+  l.type = Launch::kDivLine;
+  l.dvl = a;
+  l.tag = tag;
+  const double n = a.N + 1, m = a.N - 1;
+  l.bytes = 8.0 * a.nlines * (2.0 * m + n + m);   // velx row, d/dy vely in; div, g out (row j - 2 is a re-read of a neighbour's row j)
+  step_.push_back(l);
+  return true;
+}
 bool Navier2DEngine::add_corr_line(CorrLineArgs a, const char* tag) {
   // S8 (x part of the velocity correction) as one kernel: the folded form of build_colcorr_tables along x (corr_line.h)
   if (!whole_line_on("RPDE_S8_LINE") || !whole_line_len(a.N) || periodic_) return false;
@@ -919,6 +931,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kColDiff: run_col_diff(l.cd); break;
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
     case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
+    case Launch::kDivLine: RPDE_REQUIRE(launch_div_line(l.dvl, st_), "internal: div line shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
     case Launch::kPdmaCols: launch_pdma_cols(l.pc, st_); break;
     case Launch::kPdmaLines: launch_pdma_lines(l.pl, st_); break;
@@ -1070,7 +1083,7 @@ std::string Navier2DEngine::describe_step() const {
     const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
-                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve"};
+                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -1768,7 +1781,11 @@ void Navier2DEngine::build_confined() {
   }
   // ---- S5: divergence + x preconditioner of the Poisson solve, parity de-interleaved for the GEMM
   PoissonOp& po = *pois_;
-  {
+  DivLineArgs dvl;
+  dvl.u = yx(U_); dvl.dyv = yx(Y_[0]); dvl.div = yx(DIV_); dvl.g = yx(Y_[1]); dvl.ld = ldx; dvl.nlines = ylines(ny); dvl.line0 = yb_;
+  dvl.N = nx - 1; dvl.my = my; dvl.half = po.half; dvl.dscale = 1.0 / sx_; dvl.lowy = yD.low.p;
+  dvl.p0 = xN.pv0.p; dvl.p1 = xN.pv1.p; dvl.p2 = xN.pv2.p;
+  if (!(xD.fft_n == nx - 1 && add_div_line(dvl, "S5 x: div + poisson precond-x"))) {
     ProgramBuilder pb = ypb(2, ny);
     pb.set_fft(xD);
     pb.loadx(0, pb.arr(yx(U_), ldx), mx, my, yD.low.p);

@@ -876,6 +876,24 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
   RPDE_HIP(hipGetLastError());
 }
 template <int N>
+__global__ __launch_bounds__(N / 16, 4) void div_line_kernel(const DivLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  div_line<N>(blk, a);
+}
+bool launch_div_line(const DivLineArgs& a, Stream& st) {
+  if ((a.N != 4096 && a.N != 1024) || !div_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
+  if (a.N == 1024) hipLaunchKernelGGL(div_line_kernel<1024>, grid, block, 0, st.s, a);
+  else hipLaunchKernelGGL(div_line_kernel<4096>, grid, block, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+template <int N>
 __global__ __launch_bounds__(N / 16, 4) void corr_line_kernel(const CorrLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
@@ -1342,6 +1360,17 @@ void launch_line_batch(const LineBatch& b, Stream& st) {   // the same lines, on
     else ok = launch_rhs_line(b.r[i], st);
     RPDE_REQUIRE(ok, "line batch: shape");
   }
+}
+bool launch_div_line(const DivLineArgs& a, Stream&) {
+  if (!div_line_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) div_line<4096>(blk, a); else if (a.N == 1024) div_line<1024>(blk, a); else div_line<256>(blk, a);
+  }
+  return true;
 }
 bool launch_corr_line(const CorrLineArgs& a, Stream&) {
   if (!corr_line_ok(a)) return false;

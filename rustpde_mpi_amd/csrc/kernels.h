@@ -5,6 +5,7 @@
 #include "pdma.h"
 #include "rhs_line.h"
 #include "corr_line.h"
+#include "div_line.h"
 
 namespace rpde {
 
@@ -99,6 +100,7 @@ struct LineBatch {
 };
 bool line_batch_ok(int N);                   // the line lengths launch_line_batch covers
 void launch_line_batch(const LineBatch& b, Stream& st);
+bool launch_div_line(const DivLineArgs& a, Stream& st);     // div_line.h: S5 of the confined step per x-line
 bool launch_corr_line(const CorrLineArgs& a, Stream& st);   // corr_line.h: S8 of the confined step per x-line
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace = nullptr);   // rhs_line.h: S3 of the confined step per x-line
 // one y-line of a convection term: two backward transforms, the physical products, the forward transform with the

@@ -88,6 +88,23 @@ def test_confined_step_s8_through_the_whole_line_kernel(emu_lib, monkeypatch, nx
         assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-11), k   # two orders of summation
 
 
+@pytest.mark.parametrize("nx,ny,eig", [(257, 17, "parity"), (257, 33, "parity"), (1025, 17, "shared")])
+def test_confined_step_s5_through_the_whole_line_kernel(emu_lib, monkeypatch, nx, ny, eig):
+    """Divergence + x preconditioner of the Poisson solve (csrc/div_line.h) against the oracle, and against the line program
+    of the stage (RPDE_S5_LINE=0: the A/B switch); the divergence norm is what Integrate::exit looks at."""
+    K.check_step_parity(emu_lib, False, nx, ny, 1e5, 0.01, 3, check_at=[1, 3], eig_mode=eig)
+    nav, _ = K.make_pair(emu_lib, False, nx, ny, 1e5, 1.0, 0.01, 1.0)
+    assert not _has_line_program(nav, "S5 x")
+    nav.update(2)
+    monkeypatch.setenv("RPDE_S5_LINE", "0")
+    ref, _ = K.make_pair(emu_lib, False, nx, ny, 1e5, 1.0, 0.01, 1.0)
+    assert _has_line_program(ref, "S5 x")
+    ref.update(2)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-11), k
+    assert abs(nav.div_norm() - ref.div_norm()) < 1e-9 * max(1.0, ref.div_norm())
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, monkeypatch, periodic):
     """conv_velx / conv_vely / conv_temp as three transforms per y-line in registers (csrc/dct_line.h conv_line);
