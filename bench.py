@@ -114,6 +114,15 @@ def cpu_baseline(args, eig=None):
 PARITY_TOL = 1e-10   # BASELINE.json: u, v, T, p match the CPU reference within 1e-10 relative L2 (f64)
 
 
+def independent_golden_bound(full_vs_parity, tol=PARITY_TOL):
+    """The bar against a golden of an INDEPENDENT eigen-decomposition -- the same function as tests/checks.py
+    independent_golden_bound: max(tol, twice the oracle's own full-vs-parity difference at that snapshot), never above
+    5e-3; the plain tol where that difference was not measured (NaN)."""
+    if not (full_vs_parity == full_vs_parity):
+        return tol
+    return min(5e-3, max(tol, 2.0 * full_vs_parity))
+
+
 def parity_vs_oracle(make, ora, nsteps, shared):
     """A FRESH engine, the same deterministic initial condition, the same number of steps as the
     oracle instance of the cpu_baseline leg has taken: relative L2 of u, v, T, p in physical space."""
@@ -160,14 +169,17 @@ def parity_independent_golden(make, args):
         rel = {k: float(np.linalg.norm(f[k][::stride, ::stride] - g[f"{k}_{s}"]) / np.linalg.norm(g[f"{k}_{s}"]))
                for k in ("velx", "vely", "temp", "pres")}
         fvp = {k: float(g[f"{k}_{s}_full_vs_parity"]) for k in rel}
-        rows.append({"steps": s, "rel_l2": rel, "oracle_full_vs_parity": fvp})
+        bound = {k: independent_golden_bound(fvp[k]) for k in rel}
+        fvp = {k: (v if v == v else None) for k, v in fvp.items()}     # not measured: null (NaN is not JSON)
+        rows.append({"steps": s, "rel_l2": rel, "oracle_full_vs_parity": fvp, "bound": bound,
+                     "ok": all(rel[k] < bound[k] for k in rel)})
     del nav
     first = next((r["steps"] for r in rows if all(v < PARITY_TOL for v in r["rel_l2"].values())), None)
     first_uvt = next((r["steps"] for r in rows if all(r["rel_l2"][k] < PARITY_TOL for k in ("velx", "vely", "temp"))), None)
     return {"golden": os.path.relpath(path, ROOT), "sample_stride": stride,
             "setup": "engine: own dgeev per parity block; golden: oracle with ONE dgeev of the whole operator (the reference's algorithm)",
             "snapshots": rows, "first_snapshot_all_fields_below_tol": first, "first_snapshot_u_v_T_below_tol": first_uvt,
-            "tol": PARITY_TOL}
+            "tol": PARITY_TOL, "ok": all(r["ok"] for r in rows)}
 
 
 def pmc_traffic(workload, tag):
@@ -420,6 +432,9 @@ def main():
     print(json.dumps(out))
     if "parity" in out and not out["parity"]["ok"]:
         sys.exit(f"parity vs the oracle above {PARITY_TOL}: {out['parity']['rel_l2']}")
+    if "parity_independent_golden" in out and not out["parity_independent_golden"]["ok"]:
+        bad = [r for r in out["parity_independent_golden"]["snapshots"] if not r["ok"]]
+        sys.exit(f"parity vs the independent-setup golden above its bound: {bad}")
     if dist is not None:
         dist.destroy_process_group()
 

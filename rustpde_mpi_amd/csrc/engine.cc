@@ -143,11 +143,33 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     const std::vector<int>* rk = P > 1 ? &ypart_ : nullptr;
     const int jend = std::min(ye_, my_);
     const Base& by = sp_vel_->base(1);
-    colhh_vel_.upload(build_colhh_tables(pinv_tables(by), hh_vel_->host[1], kColBlockRows, yb_, jend, rk));
-    if (!hc_) colhh_temp_.upload(build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
+    // one rank: the single-pass form (colscan1.h).  W blocks per workgroup: as many as still leave the chip about two
+    // workgroups per CU (small grids take short workgroups); RPDE_COL_ONEPASS=0 keeps the three kernels (A/B only).
+    const char* e1p = std::getenv("RPDE_COL_ONEPASS");   // read per engine, like the RPDE_*_LINE switches
+    if (P == 1 && (!e1p || std::atoi(e1p) != 0)) {
+      const int nb = (my_ + kColBlockRows - 1) / kColBlockRows;
+      col1_tiles_ = (int)((ldx_ + kCol1Tile - 1) / kCol1Tile);
+      col1_W_ = 4;
+      for (int w : {16, 8})
+        if ((long)col1_tiles_ * ((nb + w - 1) / w) * 3 >= 512) { col1_W_ = w; break; }
+      if (const char* ew = std::getenv("RPDE_COL1_W")) { const int w = std::atoi(ew); if (w == 4 || w == 8 || w == 16) col1_W_ = w; }   // A/B only
+      while (col1_W_ < kCol1MaxW && (nb + col1_W_ - 1) / col1_W_ > kCol1MaxNSB) col1_W_ *= 2;
+      col1_NSB_ = (nb + col1_W_ - 1) / col1_W_;
+      if (col1_NSB_ > kCol1MaxNSB) col1_W_ = col1_NSB_ = col1_tiles_ = 0;   // taller than 16384 rows: the three kernels
+    }
+    auto up = [&](ColHhDev& d, const ColHhHost& h) {
+      d.upload(h);
+      if (col1_W_) d.upload1(build_colhh1_tables(h, col1_W_));
+    };
+    up(colhh_vel_, build_colhh_tables(pinv_tables(by), hh_vel_->host[1], kColBlockRows, yb_, jend, rk));
+    if (!hc_) up(colhh_temp_, build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
     if (!periodic) {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables)
       const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows, yb_, jend, rk);
-      colcorr_a_.upload(cc.a); colcorr_b_.upload(cc.b);
+      up(colcorr_a_, cc.a); up(colcorr_b_, cc.b);
+    }
+    if (col1_W_) {
+      colagg_.alloc((size_t)3 * col1_tiles_ * col1_NSB_ * kCol1Agg * kCol1Tile);
+      colsync_.alloc((size_t)(3 * col1_tiles_ + 4) / 2 + 2);   // ints: [0] ticket, [1 ..] arrivals, then the error flag
     }
     if (P > 1) {
       const size_t cnt = (size_t)3 * kColSumm * ldx_;
@@ -453,8 +475,19 @@ void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
 
 // Column scans when the rows are split over the ranks (colscan.h): block summaries, this rank's summary, ONE small
 // exchange that gives every rank everybody's summary, inflow of the own rows from them, final pass.
-void Navier2DEngine::run_col_hholtz(ColHhArgs a) {
+void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1) {
   const int P = comm_.size;
+  if (P == 1 && col1_W_ && x1 && x1[0].F) {
+    ColHh1Args A;
+    A.a = a;
+    for (int f = 0; f < a.nf; ++f) A.x[f] = x1[f];
+    A.W = col1_W_; A.NSB = col1_NSB_; A.tiles = (a.ncols + kCol1Tile - 1) / kCol1Tile;
+    A.agg = colagg_.p;
+    A.sync = reinterpret_cast<int*>(colsync_.p);
+    A.err = A.sync + 1 + 3 * col1_tiles_;
+    launch_col_hholtz1(A, st_);
+    return;
+  }
   if (P == 1) { launch_col_hholtz(a, st_); return; }
   const int64_t cnt = (int64_t)a.nf * kColSumm * ldx_;
   a.summ = colsumm_.p; a.gath = colgath_.p;
@@ -758,6 +791,7 @@ void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const out
   for (int f = 0; f < nf; ++f) {
     a.in[f] = in[f]; a.out[f] = out[f]; a.shift[f] = 0;
     a.tab[f] = (f == 2 ? colhh_temp_ : colhh_vel_).tabs();
+    l.ch1[f] = (f == 2 ? colhh_temp_ : colhh_vel_).tabs1();
   }
   a.in_half = 0;
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
@@ -816,6 +850,7 @@ void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, doub
   a.row0 = yb_; a.jend = std::min(ye_, my_); a.nranks = comm_.size; a.rank = comm_.rank;
   a.in[0] = ps; a.in[1] = ps; a.out[0] = outa; a.out[1] = outb; a.shift[0] = 2; a.shift[1] = 1;
   a.tab[0] = colcorr_a_.tabs(); a.tab[1] = colcorr_b_.tabs();
+  l.ch1[0] = colcorr_a_.tabs1(); l.ch1[1] = colcorr_b_.tabs1();
   a.in_half = half;
   static const bool pair = [] { const char* e = std::getenv("RPDE_COL_PAIR"); return !e || std::atoi(e) != 0; }();   // A/B only
   a.pair = pair ? 1 : 0;
@@ -924,7 +959,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kGemmPairNT: launch_gemm_pair(false, l.gp[0], l.gp[1], st_); break;
     case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
-    case Launch::kColHholtz: run_col_hholtz(l.ch); break;
+    case Launch::kColHholtz: run_col_hholtz(l.ch, l.ch1); break;
     case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
     case Launch::kConvLine: RPDE_REQUIRE(launch_conv_line(l.cl, st_), "internal: conv line shape"); break;
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
@@ -940,6 +975,25 @@ void Navier2DEngine::run_launch(const Launch& l) {
 
 void Navier2DEngine::update(int nsteps) {
   RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
+#ifndef RPDE_EMU
+  {
+    // diagnostics (tools/fault_hunt_r04c.sh): RPDE_PROBE_ALLOC=1 RPDE_LOG_ALLOC=1 -- before the first step, one shader read of
+    // every live buffer, each named and waited for: is a buffer dead BEFORE the step touches it?
+    static const bool probe = [] { const char* e = std::getenv("RPDE_PROBE_ALLOC"); return e && std::atoi(e) != 0; }();
+    if (probe && !probed_) {
+      probed_ = true;
+      std::vector<std::pair<void*, size_t>> v;
+      { std::lock_guard<std::mutex> lk(DevLive::get().mu); v.assign(DevLive::get().live.begin(), DevLive::get().live.end()); }
+      for (auto& a : v) {
+        if (a.second < 8) continue;
+        fprintf(stderr, "[probe] %p %zu ...", a.first, a.second); fflush(stderr);
+        launch_probe(static_cast<const double*>(a.first), (long)(a.second / 8), colkap_.p, st_);
+        (void)hipStreamSynchronize(st_.s);
+        fprintf(stderr, " ok\n"); fflush(stderr);
+      }
+    }
+  }
+#endif
   if (nsteps > 0) dirty_ = false;
   if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
 #ifndef RPDE_EMU
@@ -1080,13 +1134,15 @@ std::string Navier2DEngine::describe_step() const {
     const Launch& l = step_[i];
     const size_t j = group_end(i);
     char buf[512];
-    const int ndisp = l.type == Launch::kColHholtz ? 3 : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
+    const bool onepass = l.type == Launch::kColHholtz && comm_.size == 1 && col1_W_ && l.ch1[0].F;
+    const int ndisp = l.type == Launch::kColHholtz ? (onepass ? 1 : 3) : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
+    if (onepass) kind += " (one pass)";
     if (j - i > 1) kind += " (" + std::to_string(j - i) + " arrays)";
     snprintf(buf, sizeof buf, "%s\t%.0f\t%.0f\t%d\t%s\n", group_tag(i, j).c_str(), bytes, l.flops, ndisp, kind.c_str());
     out += buf;
@@ -1190,7 +1246,10 @@ double Navier2DEngine::div_norm() {
 bool Navier2DEngine::read_nanflag() {
 #ifndef RPDE_EMU
   RPDE_HIP(hipMemcpyAsync(hflag_, nanflag_.p, sizeof(int), hipMemcpyDeviceToHost, st_.s));
+  if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p) + 1 + 3 * col1_tiles_, sizeof(int), hipMemcpyDeviceToHost, st_.s));
   RPDE_HIP(hipStreamSynchronize(st_.s));
+  // a single-pass column scan whose wait for its partner workgroups ran out (colscan1.h): the step's results are wrong
+  RPDE_REQUIRE(!col1_W_ || hflag_[1] == 0, "column scan: a workgroup waited for its partners in vain (RPDE_COL_ONEPASS=0 selects the three-kernel form)");
 #else
   *hflag_ = *flagp();
 #endif

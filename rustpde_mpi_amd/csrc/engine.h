@@ -162,7 +162,7 @@ class Navier2DEngine {
   // halo rows of up to three YX arrays in one exchange: `front` rows in front of the local rows (from rank - 1), `tail`
   // rows behind them (from rank + 1)
   void halo_rows(double* const* arr, int n, int front, int tail);
-  void run_col_hholtz(ColHhArgs a);   // column scans, one rank or rows split over the ranks (colscan.h)
+  void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr);   // column scans, one rank or rows split over the ranks (colscan.h)
   void run_col_diff(ColDiffArgs a);
   ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
   DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;
@@ -202,6 +202,8 @@ class Navier2DEngine {
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
   DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
   DBuf colv1_, cols1_, colv2_, cols2_, coldv_, colds_;   // block carries of the column scans (colscan.h)
+  DBuf colagg_, colsync_;        // single-pass column scans (colscan1.h): super-block aggregates; ticket / arrival counters + error flag
+  int col1_W_ = 0, col1_NSB_ = 0, col1_tiles_ = 0;   // 0: the three-kernel form
   std::map<std::string, std::unique_ptr<Field>> fields_;
 
   // the step as a list of launches
@@ -218,6 +220,7 @@ class Navier2DEngine {
     DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
+    ColHh1Tabs ch1[kColMaxFields]{};   // kColHholtz on one rank: the tables of the single-pass form (colscan1.h)
     ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;
     Program pg;                  // kLine
@@ -257,6 +260,7 @@ class Navier2DEngine {
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   void add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag);
   ColHhDev colcorr_a_, colcorr_b_;   // column problems of the velocity correction (confined, one GPU)
+  bool probed_ = false;              // diagnostics (RPDE_PROBE_ALLOC)
   DBuf coldot_, colkap_;             // rank-one sums of the column scans
   int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
   bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)

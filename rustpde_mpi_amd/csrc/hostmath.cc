@@ -357,6 +357,43 @@ ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR, i
   return h;
 }
 
+ColHh1Host build_colhh1_tables(const ColHhHost& h, int W) {
+  RPDE_REQUIRE(W >= 1 && h.BR > 0, "colhh1: blocks per workgroup");
+  ColHh1Host o;
+  o.W = W; o.NSB = (h.NB + W - 1) / W;
+  const size_t np = h.q1.size();
+  const int n = h.n, BR = h.BR;
+  o.F.assign(np, 0.0); o.H0.assign(np, 0.0); o.H1.assign(np, 0.0);
+  std::vector<long double> ya(np, 0.0L);
+  for (int b = 0; b < h.NB; ++b) {
+    const int j0 = b * BR, j1 = std::min(j0 + BR, n);
+    for (int par = 0; par < 2; ++par) {
+      long double y = 1.0L;                     // forward response to a unit inflow, as in colhh_block_transfer
+      for (int j = j0 + par; j < j1; j += 2) { y = (long double)h.q1[j] * y; ya[j] = y; }
+      long double x1[3] = {1.0L, 0.0L, 0.0L}, x2[3] = {0.0L, 1.0L, 0.0L};
+      int jt = j1 - 1;
+      if ((jt & 1) != par) --jt;
+      for (int j = jt; j >= j0; j -= 2) {
+        for (int c = 0; c < 3; ++c) {
+          long double nw = (long double)h.q2[j] * x1[c] + (long double)h.r2[j] * x2[c];
+          if (c == 2) nw += (long double)h.p2[j] * ya[j];
+          x2[c] = x1[c]; x1[c] = nw;
+        }
+        o.H0[j] = (double)x1[0]; o.H1[j] = (double)x1[1]; o.F[j] = (double)x1[2];
+      }
+    }
+  }
+  o.m1w.assign((size_t)std::max(o.NSB, 1) * 2, 1.0);
+  o.m2w.assign((size_t)std::max(o.NSB, 1) * 8, 0.0);
+  o.gw.assign((size_t)std::max(o.NSB, 1) * 4, 0.0);
+  for (int q = 0; q < o.NSB; ++q) {
+    const int j0 = q * W * BR, j1 = std::min(j0 + W * BR, n);
+    for (int par = 0; par < 2; ++par)
+      colhh_block_transfer(h, j0, j1, par, ya, &o.m1w[(size_t)q * 2 + par], &o.m2w[((size_t)q * 2 + par) * 4], &o.gw[((size_t)q * 2 + par) * 2]);
+  }
+  return o;
+}
+
 ColCorrHost build_colcorr_tables(const Base& bd, const Base& bn, double dscale, int BR, int row0, int jend, const std::vector<int>* ranks) {
   RPDE_REQUIRE(bd.is_composite() && bn.is_composite() && bd.m == bn.m && bd.n == bn.n, "colcorr: two composite bases of one size");
   const int m = bd.m, n = bd.n;

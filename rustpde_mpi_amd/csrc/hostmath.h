@@ -91,6 +91,14 @@ struct ColHhHost {
   Vec w, h;   // optional rank-one term (colscan.h): weights of the column sum, response; empty: none
   Vec rk;     // pencil-sharded runs: [nranks][14] transfer of every rank's rows taken as one block; empty: one rank
 };
+// single-pass form of the column scan (colscan1.h, one rank): per-row responses of a block's solution to its inflow
+// states, and the transfers of super-blocks of W blocks
+struct ColHh1Host {
+  int W = 0, NSB = 0;
+  Vec F, H0, H1;      // [rows, padded]: x_j per unit of forward inflow / of the backward inflow states (1,0) and (0,1) of its block
+  Vec m1w, m2w, gw;   // [NSB][2], [NSB][2][4], [NSB][2][2]: m1 / m2 / g of W consecutive blocks taken as one
+};
+ColHh1Host build_colhh1_tables(const ColHhHost& h, int W);
 // blocks cover the rows [row0, jend) of the system (this rank's rows; jend < 0: to the end); `ranks`: the row
 // partition (nranks + 1 boundaries, all even) when the rows are split over several ranks
 ColHhHost build_colhh_tables(const Mv3Tables& pv, const FdmaTables& f, int BR, int row0 = 0, int jend = -1,

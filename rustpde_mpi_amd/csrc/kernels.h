@@ -1,6 +1,7 @@
 // Host-callable launchers of the device kernels (HIP build) or their host emulation (EMU build).
 #pragma once
 #include "colscan.h"
+#include "colscan1.h"
 #include "line_vm.h"
 #include "pdma.h"
 #include "rhs_line.h"
@@ -77,6 +78,8 @@ void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 // summaries (sharded only, after the exchange); 3: final pass
 void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st);
 void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st);
+// single-pass form (colscan1.h): one kernel behind a memset node that clears the ticket / arrival counters
+void launch_col_hholtz1(const ColHh1Args& a, Stream& st);
 inline void launch_col_hholtz(const ColHhArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_hholtz_phase(a, ph, st); }   // one rank
 inline void launch_col_diff(const ColDiffArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_diff_phase(a, ph, st); }
 
@@ -129,6 +132,7 @@ void launch_pdma_lines(const PdmaLinesArgs& a, Stream& st);
 
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
+void launch_probe(const double* p, long n, double* sink, Stream& st);   // diagnostics
 
 // sum of squares + NaN flag of a pitched 2-D array into out[0] (sum), out[1] (nan count)
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream& st);

@@ -483,6 +483,11 @@ void ColHhDev::upload(const ColHhHost& h) {
   if (!h.rk.empty()) rk.upload(h.rk);
 }
 
+void ColHhDev::upload1(const ColHh1Host& h) {
+  W = h.W; NSB = h.NSB;
+  F.upload(h.F); H0.upload(h.H0); H1.upload(h.H1); m1w.upload(h.m1w); m2w.upload(h.m2w); gw.upload(h.gw);
+}
+
 HholtzAdiOp::HholtzAdiOp(Space2Ops& s, double c0, double c1) : sp(s) {
   const double c[2] = {c0, c1};
   for (int axis = 0; axis < 2; ++axis) {

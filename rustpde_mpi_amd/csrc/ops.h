@@ -179,8 +179,11 @@ class Space2Ops {
 // device tables of the column-scan form of one Helmholtz-y solve (colscan.h)
 struct ColHhDev {
   DBuf t0, t1, t2, q1, m1, p2, q2, r2, m2, g, w, hr, rk;
-  int n = 0, BR = 0, NB = 0;
+  DBuf F, H0, H1, m1w, m2w, gw;   // single-pass form (colscan1.h), uploaded by upload1
+  int n = 0, BR = 0, NB = 0, W = 0, NSB = 0;
   void upload(const ColHhHost& h);
+  void upload1(const ColHh1Host& h);
+  ColHh1Tabs tabs1() const { return ColHh1Tabs{F.p, H0.p, H1.p, m1w.p, m2w.p, gw.p}; }
   ColHhTabs tabs() const { return ColHhTabs{t0.p, t1.p, t2.p, q1.p, m1.p, p2.p, q2.p, r2.p, m2.p, g.p, w.p, hr.p, rk.p}; }
 };
 constexpr int kColBlockRows = kColBR; // rows per block of the column scans (colscan.h)

@@ -17,6 +17,9 @@
 #include <string>
 #include <algorithm>
 #include <vector>
+#include <map>
+#include <mutex>
+#include <iterator>
 
 #ifndef RPDE_EMU
 #include <hip/hip_runtime.h>
@@ -114,6 +117,95 @@ struct Stream {
 };
 
 constexpr size_t kEmuGuardBytes = 256;
+
+#ifndef RPDE_EMU
+// Device memory of every engine and operator of the process comes out of a few large slabs: one hipMalloc of
+// kSlabBytes (a multiple of the 2 MB a page-table block covers; a larger request gets a slab of its own size) that is
+// mapped ONCE, and a best-fit free list with coalescing on top of it.  Nothing this library allocates shares a
+// 2 MB block of the runtime's own small-allocation heap (ROCr packs hipMalloc requests below 2 MB into 2 MB blocks it
+// also uses for its internal objects, and gives such blocks back piecemeal), no mapping appears or disappears while a
+// step runs, and an engine's 300 tables cost 300 free-list operations instead of 300 driver calls.  Slabs go back to
+// the driver only when an allocation fails (trim()) -- DESIGN.md section 10-0 has the measurements that led here.
+class DevArena {
+ public:
+  static constexpr size_t kPage = 4096;
+  static constexpr size_t kHuge = size_t(2) << 20;
+  static constexpr size_t kSlabBytes = size_t(1) << 30;
+  static DevArena& get() { static DevArena a; return a; }
+  void* alloc(size_t bytes) {
+    const size_t n = round_up(bytes ? bytes : 8, kPage);
+    std::lock_guard<std::mutex> lk(mu_);
+    void* p = take(n);
+    if (!p) {
+      if (!add_slab(n)) { trim(); if (!add_slab(n)) return nullptr; }
+      p = take(n);
+    }
+    return p;
+  }
+  void free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu_);
+    auto u = used_.find(static_cast<char*>(p));
+    if (u == used_.end()) return;
+    Slab& sl = slabs_[u->second.slab];
+    char* a = u->first; size_t n = u->second.bytes;
+    used_.erase(u);
+    auto nx = sl.free.lower_bound(a);                       // coalesce with the free neighbours inside this slab
+    if (nx != sl.free.end() && a + n == nx->first) { n += nx->second; nx = sl.free.erase(nx); }
+    if (nx != sl.free.begin()) {
+      auto pv = std::prev(nx);
+      if (pv->first + pv->second == a) { a = pv->first; n += pv->second; sl.free.erase(pv); }
+    }
+    sl.free[a] = n;
+  }
+  size_t slab_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t t = 0; for (auto& s : slabs_) t += s.size; return t; }
+  size_t used_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t t = 0; for (auto& u : used_) t += u.second.bytes; return t; }
+  template <class F> void for_each_used(F f) { std::lock_guard<std::mutex> lk(mu_); for (auto& u : used_) f(u.first, u.second.bytes); }
+
+ private:
+  struct Slab { char* base = nullptr; size_t size = 0; std::map<char*, size_t> free; };
+  struct Used { size_t bytes; size_t slab; };
+  static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+  void* take(size_t n) {                                      // best fit over all slabs
+    size_t bs = 0; std::map<char*, size_t>::iterator bi; bool found = false;
+    for (size_t k = 0; k < slabs_.size(); ++k)
+      for (auto it = slabs_[k].free.begin(); it != slabs_[k].free.end(); ++it)
+        if (it->second >= n && (!found || it->second < bi->second)) { bs = k; bi = it; found = true; }
+    if (!found) return nullptr;
+    char* a = bi->first; const size_t rest = bi->second - n;
+    slabs_[bs].free.erase(bi);
+    if (rest) slabs_[bs].free[a + n] = rest;
+    used_[a] = Used{n, bs};
+    return a;
+  }
+  bool add_slab(size_t n) {
+    const size_t size = std::max(kSlabBytes, round_up(n, kHuge));
+    void* p = nullptr;
+    if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (auto& s : slabs_) if (!s.base) { s.base = static_cast<char*>(p); s.size = size; s.free.clear(); s.free[s.base] = size; return true; }
+    slabs_.emplace_back();
+    slabs_.back().base = static_cast<char*>(p); slabs_.back().size = size; slabs_.back().free[slabs_.back().base] = size;
+    return true;
+  }
+  void trim() {                                               // slabs nobody uses go back to the driver
+    for (auto& s : slabs_)
+      if (s.base && s.free.size() == 1 && s.free.begin()->second == s.size) { (void)hipFree(s.base); s.base = nullptr; s.size = 0; s.free.clear(); }
+  }
+  std::mutex mu_;
+  std::vector<Slab> slabs_;
+  std::map<char*, Used> used_;
+};
+// diagnostics (RPDE_LOG_ALLOC=1): the live allocations of the process, for the probe of tools/fault_hunt_r04c.sh
+struct DevLive {
+  std::mutex mu; std::map<void*, size_t> live;
+  static DevLive& get() { static DevLive d; return d; }
+};
+inline bool dev_arena_on() {   // A/B only (tools/fault_hunt_r04c.sh): RPDE_ARENA=0 = one hipMalloc per buffer, as rounds 1-3
+  static const bool on = [] { const char* e = std::getenv("RPDE_ARENA"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+#endif
+
 inline void* dev_alloc(size_t bytes) {
 #ifdef RPDE_EMU
   // a NaN-filled guard in front of every buffer: a read below the start of a table or array
@@ -124,11 +216,20 @@ inline void* dev_alloc(size_t bytes) {
   return raw + kEmuGuardBytes;
 #else
   void* p = nullptr;
-  RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
+  if (dev_arena_on()) {
+    p = DevArena::get().alloc(bytes);
+    RPDE_REQUIRE(p, "device allocation failed (hipMalloc of a slab)");
+  } else {
+    RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
+  }
   RPDE_HIP(hipMemset(p, 0, bytes ? bytes : 8));
   // diagnostics: RPDE_LOG_ALLOC=1 prints every allocation, so that a fault address can be placed
   static const bool log = [] { const char* e = std::getenv("RPDE_LOG_ALLOC"); return e && std::atoi(e) != 0; }();
-  if (log) fprintf(stderr, "[alloc] %p %zu\n", p, bytes);
+  if (log) {
+    fprintf(stderr, "[alloc] %p %zu\n", p, bytes);
+    std::lock_guard<std::mutex> lk(DevLive::get().mu);
+    DevLive::get().live[p] = bytes;
+  }
   return p;
 #endif
 }
@@ -136,8 +237,10 @@ inline void dev_free(void* p) {
 #ifdef RPDE_EMU
   if (p) std::free(static_cast<char*>(p) - kEmuGuardBytes);
 #else
-  static const bool keep = [] { const char* e = std::getenv("RPDE_NO_FREE"); return e && std::atoi(e) != 0; }();   // diagnostics: leak instead of freeing
-  if (p && !keep) (void)hipFree(p);
+  if (!p) return;
+  { std::lock_guard<std::mutex> lk(DevLive::get().mu); DevLive::get().live.erase(p); }
+  if (dev_arena_on()) DevArena::get().free(p);
+  else (void)hipFree(p);
 #endif
 }
 inline void dev_upload(void* dst, const void* src, size_t bytes) {

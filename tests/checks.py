@@ -285,22 +285,33 @@ def compare_with_independent_golden(nav, path, max_steps=None):
 
 
 def independent_golden_bound(full_vs_parity, tol=1e-10):
-    """The bar of a comparison with an INDEPENDENT eigen-decomposition: `tol` once two valid LAPACK
-    eigenbases inside the oracle agree to tol / 10 themselves; during the start-up transient before that, ten times
-    the oracle's own full-vs-parity difference (the reference's Poisson solve amplifies dgeev's round-off by the 1e10 of
-    poisson.rs:84-87; the difference decays as the flow becomes divergence-free)."""
-    return tol if full_vs_parity < tol / 10 else max(tol, 10.0 * full_vs_parity)
+    """The bar of a comparison with an INDEPENDENT eigen-decomposition.  The reference's Poisson
+    solve amplifies dgeev's round-off by the 1e10 of poisson.rs:84-87, so two valid LAPACK eigenbases of the same
+    operator give pressures that differ by `full_vs_parity` (measured inside the oracle, stored per snapshot and field
+    in the golden file) during the start-up transient; the difference decays as the flow becomes divergence-free.
+    The engine has measured 1.06 ... 1.10 times that difference at every snapshot of every size (round 3), so the bar is
+        max(tol, 2 * full_vs_parity)   and never above 5e-3,
+    i.e. the plain 1e-10 wherever the oracle's own two bases agree to 5e-11, and a factor-2 envelope of the oracle's own
+    ambiguity before.  A snapshot without a full-vs-parity figure (NaN: the extended part of the 4097 golden) gets the
+    plain 1e-10.  The EFFECTIVE bar per size (pressure, the worst field): 1025^2 -- 1e-10 from step 100; 2049^2 -- 1e-10
+    from step 150 (1.9e-10 at 100); 4097^2 -- 2.7e-9 at step 200, 1e-10 for the snapshots from step 700 on (their
+    full-vs-parity is not measured)."""
+    if not (full_vs_parity == full_vs_parity):   # NaN
+        return tol
+    return min(5e-3, max(tol, 2.0 * full_vs_parity))
 
 
 def check_config2_golden(lib):
-    """BASELINE.json configs[1] against the committed oracle samples (tests/golden/make_config2_golden.py); see
-    tests/test_gpu_parity.py::test_config2_golden_1025_200_steps for the bounds."""
+    """BASELINE.json configs[1] against the committed oracle samples (tests/golden/make_config2_golden.py: the oracle in
+    the REFERENCE's setup, one dgeev of the whole operator -- independent of the engine's); bounds:
+    independent_golden_bound, i.e. 1e-10 for u, v, T, p after 100 and 200 steps."""
     g = np.load(os.path.join(GOLDEN, "config2_1025_200steps.npz"))
+    assert str(g["eig_mode"]) == "full", "config-2 golden must come from the reference's one-dgeev setup"
     nx, ny, stride = int(g["nx"]), int(g["ny"]), int(g["stride"])
     nav = R.Navier2D.new_confined(nx, ny, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=lib)
     nav.set_velocity(0.2, 1.0, 1.0)
     nav.set_temperature(0.2, 1.0, 1.0)
-    done = 0
+    done, report = 0, {}
     for s in (10, 100, 200):
         nav.update(s - done)
         done = s
@@ -308,11 +319,15 @@ def check_config2_golden(lib):
         for k in ("velx", "vely", "temp", "pres"):
             want = g[f"{k}_{s}"]
             got = f[k][::stride, ::stride]
-            tol = 1e-7 if s == 10 else 1e-10
+            tol = independent_golden_bound(float(g[f"{k}_{s}_full_vs_parity"]))
+            if s >= 100:
+                assert tol == 1e-10, (k, s, tol)     # the golden itself must have left the transient: the 1e-10 bar is exercised
             err = np.linalg.norm(got - want) / np.linalg.norm(want)
-            assert err < tol, (k, s, err)
+            report[(k, s)] = float(err)
+            assert err < tol, (k, s, err, tol)
             # the full-field norm pins the points between the samples as well
             assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < tol * float(g[f"{k}_{s}_norm"]), (k, s)
+    print({f"{k}@{s}": f"{e:.1e}" for (k, s), e in report.items()})
     assert abs(nav.div_norm() - float(g["div_norm"])) < 1e-8 * max(1.0, float(g["div_norm"]))
 
 
@@ -322,7 +337,7 @@ def check_independent_golden(lib, n):
     g = np.load(path)
     nav = R.Navier2D.new_confined(n, n, float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=lib)
     res = compare_with_independent_golden(nav, path)
-    assert res, "no snapshot compared"
+    assert len(res) >= 9, f"golden {path} holds {len(res)} snapshots, expected at least 9"
     print({s: {k: f"{e:.1e} (oracle full vs parity {b:.1e})" for k, (e, b) in r.items()} for s, r in res.items()})
     for s, r in res.items():
         for k, (err, fvp) in r.items():
@@ -331,21 +346,13 @@ def check_independent_golden(lib, n):
 
 def run_isolated(call, timeout=900):
     """Run `checks.<call>` (an expression like "check_config2_golden(lib)", with lib = the product library) in a child
-    process.  A device fault ends the process that owns the GPU context (the HIP runtime aborts); in a child it does not end
-    the pytest session.  Used for the 1025 x 1025 engines: DESIGN.md section 10-0 describes an OPEN first-step fault at that
-    size (about one fresh process in twelve).  A child that died of exactly that -- "Memory access fault" on its stderr, no
-    Python error -- is run ONCE more and the event is reported as a warning in the test summary; a second fault, or any
-    assertion / exception of the check itself, fails the test with the child's output."""
-    import warnings
+    process: a large engine gets a fresh HIP context and its HBM back at exit, and a device fault -- which ends the process
+    that owns the GPU context (the HIP runtime aborts) -- fails THIS test instead of ending the pytest session.  There is no
+    second run: any failure of the child, device fault included, fails the test with the child's output."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import rustpde_mpi_amd as R\nfrom tests import checks as K\nlib = R.lib()\nassert lib.is_device_build\n"
             f"K.{call}\nprint('ISOLATED-OK')\n")
-    for attempt in (1, 2):
-        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
-        ok = r.returncode == 0 and "ISOLATED-OK" in r.stdout
-        device_fault = (not ok) and "Memory access fault" in r.stderr and "Traceback" not in r.stderr
-        if ok or not device_fault or attempt == 2:
-            break
-        warnings.warn(f"GPU memory fault in the child process of {call} (DESIGN.md section 10-0, open defect); running it once more")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
+    ok = r.returncode == 0 and "ISOLATED-OK" in r.stdout
     sys.stdout.write(r.stdout[-4000:])
     assert ok, f"child process ended with code {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"

@@ -88,6 +88,25 @@ def test_confined_step_s8_through_the_whole_line_kernel(emu_lib, monkeypatch, nx
         assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-11), k   # two orders of summation
 
 
+@pytest.mark.parametrize("periodic,nx,ny", [(False, 33, 257), (False, 129, 129), (False, 17, 1025), (True, 32, 513)])
+def test_column_scans_in_one_pass(emu_lib, monkeypatch, periodic, nx, ny):
+    """The single-pass column scans of one rank (csrc/colscan1.h: super-blocks of W blocks per workgroup, aggregates, one
+    meeting of a column tile's workgroups, correction of the zero-inflow rows) against the oracle and against the three
+    kernels of colscan.h (RPDE_COL_ONEPASS=0: the A/B switch) -- ny = 257 / 1025: 8 / 32 blocks, several super-blocks."""
+    K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 3, check_at=[1, 3])
+    nav, _ = K.make_pair(emu_lib, periodic, nx, ny, 1e5, 1.0, 0.01, 1.0)
+    scans = ("hholtz-y (column scan)", "correction-y (column scan)")    # the periodic step has C4 only
+    kinds = {t: kind for t, _, _, _, kind in nav.schedule() if any(c in t for c in scans)}
+    assert kinds and all(k == "column scan (one pass)" for k in kinds.values()), kinds
+    nav.update(3)
+    monkeypatch.setenv("RPDE_COL_ONEPASS", "0")
+    ref, _ = K.make_pair(emu_lib, periodic, nx, ny, 1e5, 1.0, 0.01, 1.0)
+    assert all(kind == "column scan" for t, _, _, _, kind in ref.schedule() if any(c in t for c in scans))
+    ref.update(3)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-12), k
+
+
 @pytest.mark.parametrize("nx,ny,eig", [(257, 17, "parity"), (257, 33, "parity"), (1025, 17, "shared")])
 def test_confined_step_s5_through_the_whole_line_kernel(emu_lib, monkeypatch, nx, ny, eig):
     """Divergence + x preconditioner of the Poisson solve (csrc/div_line.h) against the oracle, and against the line program

@@ -220,6 +220,26 @@ def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
         assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (stage, k)
 
 
+@pytest.mark.parametrize("nx,ny", [(65, 4097), (1025, 1025), (2049, 513), (4097, 257)])
+def test_column_scans_in_one_pass_equal_three_kernels(hip_lib, monkeypatch, nx, ny):
+    """The single-pass column scans (csrc/colscan1.h, the default on one GPU) against the three kernels of colscan.h
+    (RPDE_COL_ONEPASS=0): same engine, same setup data, three steps.  The oracle comparisons are the step parity tests;
+    this one pins the A/B switch, the super-block partitions (128 / 32 / 16 / 8 blocks of rows) and the error flag."""
+    fields, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RPDE_COL_ONEPASS", flag)
+        nav = R.Navier2D.new_confined(nx, ny, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(3)
+        assert nav.exit() is False       # reads the scans' error flag as well
+        fields[flag] = nav.physical_fields()
+        kinds[flag] = {kind for t, _, _, _, kind in nav.schedule() if "hholtz-y (column scan)" in t or "correction-y (column scan)" in t}
+        del nav
+    assert kinds["1"] == {"column scan (one pass)"} and kinds["0"] == {"column scan"}, kinds
+    for k in fields["0"]:
+        assert K.rel(fields["1"][k], fields["0"][k]) < (1e-10 if k == "pres" else 1e-12), (k, K.rel(fields["1"][k], fields["0"][k]))
+
+
 @pytest.mark.parametrize("lift", [False, True])
 def test_conv_line_4097(hip_lib, lift):
     """conv_line (a whole convection term per y-line, three transforms in registers) vs the oracle's operators."""
