@@ -689,7 +689,7 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
       return 0;
     }
 #endif
-    if (w.rfind("dct_line", 0) == 0) {   // whole-line backward transform (dct_line.h): "dct_line", "dct_line_pf3", "dct_line_pf4"
+    if (w == "dct_line") {   // whole-line backward transform (hdct_line.h)
       AxisTables ax(make_base(kChebDirichlet, n));
       const long ld = pitch(n + 2);
       DBuf in((size_t)nlines * ld), out((size_t)nlines * ld);
@@ -699,8 +699,6 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
         in.upload(hbuf);
       }
       DctLineArgs d{in.p, ld, n - 2, out.p, ld, nlines, n - 1, 2, ax.tw.p, ax.tw2.p, 1.0};
-      const int saved = g_dct_line_pf;
-      g_dct_line_pf = w == "dct_line_pf3" ? 3 : (w == "dct_line_pf4" ? 4 : 0);
       RPDE_REQUIRE(launch_dct_line(d, st), "dct_line: shape not covered");
       dev_sync(st);
 #ifndef RPDE_EMU
@@ -717,7 +715,6 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
 #else
       *ms = 0.0;
 #endif
-      g_dct_line_pf = saved;
       return 0;
     }
     const bool fourier = w == "rfft";

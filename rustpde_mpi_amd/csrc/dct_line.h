@@ -322,34 +322,6 @@ RPDE_DEV void dct_bwd_line(Blk& blk, const DctLineArgs& a) {
   dct_line_core<N>(blk, a, false, DctStoreEmit{(gmem_t)(a.out + (long)blk.line * a.ldo), a.scale});
 }
 
-// The staging step of dct_line_core in two halves, for workgroups that walk over several lines: the loads of the NEXT
-// line are issued before the transform of the current one starts and wait in registers (QP pairs per thread) until
-// the exchange buffer is free again -- the HBM round trip of a line is hidden behind the transform of its predecessor.
-template <int N>
-struct DctLineStage {
-  static constexpr int T = N / 16;
-  static constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);
-  template <class V>
-  static RPDE_DEV void load(const DctLineArgs& a, int line, int tid, V* v) {
-    cgmem2_t src2 = (cgmem2_t)(a.in + (long)line * a.ldi);
-#pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      const int p = tid + q * T, k = 2 * p - 2;
-      v[q] = (k >= 0 && k < a.n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
-    }
-  }
-  template <class V>
-  static RPDE_DEV void put(const DctLineArgs& a, lds2_t buf2, int tid, const V* v) {
-#pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      const int p = tid + q * T, k = 2 * p - 2;
-      dbl2 w = v[q];
-      if (k + 1 >= a.n_in) w.y = 0.0;
-      if (2 * p + 1 < N + 4) buf2[p] = w;
-    }
-  }
-};
-
 // One y-line of a convection term (src/navier_stokes/functions.rs:56-72, navier_eq.rs conv_velx / conv_vely / conv_temp):
 //   out = forward_y[ u (A + bx) + v (B + by) ] with the 2/3 rule,  A = backward_y(fx),  B = backward_y(dscale d/dy f0),
 // fx = d/dx f and f0 = f in (physical x, Dirichlet-composite y), u / v / bx / by physical along the line.  Three transforms

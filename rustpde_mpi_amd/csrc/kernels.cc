@@ -57,9 +57,6 @@ RPDE_DEV void transpose_tile(Blk& blk, E* tile, const E* __restrict__ in, long l
   }
 }
 
-int g_hdct = [] { const char* e = std::getenv("RPDE_HDCT"); return e ? std::atoi(e) : 3; }();   // which whole-line kernels run on the half-length core (hdct_line.h) instead of dct_line.h: bit 0 the pure transform, bit 1 the S1 pair, bit 2 the convection term (A/B switch)
-static const int g_rhs_wpc = [] { const char* e = std::getenv("RPDE_RHS_WPC"); return e ? std::atoi(e) : 3; }();   // workgroups per CU the register budget of rhs_line is cut for (measured: 3 without spills 0.215 / 0.267 / 0.214 ms, 4 with 70 - 90 spilled registers 0.258 / 0.315 / 0.275)
-int g_dct_line_pf = [] { const char* e = std::getenv("RPDE_DCT_PF"); return e ? std::atoi(e) : 0; }();   // A/B switch (tools, microbench)
 #ifndef RPDE_EMU
 // =================================================================================== HIP build
 // Three kernels per configuration (line_vm.h kVar*): light, with the second-order back-substitution
@@ -193,157 +190,7 @@ __device__ __forceinline__ void mfma_f64_vgpr(dbl4& acc, double a, double b) {
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 constexpr long kGemmSmallTileBelow = 512;   // fewer 128 x 128 tiles than this (two per CU): use 64 x 64 tiles
-constexpr int kGemmDefaultVariant = 4;   // 0 = one LDS stage of BK 16, 1 = + s_setprio, 2 = BK 32, 3 = BK 32 + s_setprio, 4 = two stages, pipeline written out (gemm_f64_db_tile)
 
-// BK: k-depth of one LDS stage (16: 32 KB of LDS, 32: 64 KB and half as many barriers per flop);
-// PRIO: raise the wave priority around the MFMA bursts (s_setprio) so that the partner wave's memory
-// phase does not delay them.  The variant is chosen by the launcher (RPDE_GEMM_VARIANT, default below).
-template <bool NN, int BK, bool PRIO>
-__device__ __forceinline__ void gemm_f64_tile(int M, int N, int K, const double* __restrict__ A, long lda,
-                                              const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
-                                              int tile_m, int tile_n) {
-  constexpr int KS = BK / 4;      // k sub-steps (one MFMA k-depth each) per stage
-  constexpr int KT = BK / 2;      // doubles per thread and operand per stage
-  __shared__ __attribute__((aligned(16))) double As[KS][128][4];
-  __shared__ __attribute__((aligned(16))) double Bs[KS][128][4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tile_m * 128, n0 = tile_n * 128;
-  const int l15 = lane & 15, l4 = lane >> 4;
-
-  dbl4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
-
-  double ra[KT], rb[KT];
-  const int arow = tid >> 1, akk = (tid & 1) * KT;       // A (and B when !NN): row, first k
-  const int bn = tid & 127, bkp = tid >> 7;               // B when NN: column n, k pair (k = 4e + 2 bkp + {0,1})
-  // interior tiles (every row / column of the 128 x 128 block and all BK k exist) load without
-  // bounds checks and with 16-byte accesses; `vec16` = the operands allow aligned 16-byte loads
-  // edge tiles read the last valid row / column again instead of predicating every load (their results are
-  // never stored), so only the last, partial k-stage takes the guarded path
-  const int arow_a = min(m0 + arow, M - 1), arow_b = min(n0 + arow, N - 1), bcol = min(n0 + bn, N - 1);
-  const bool vec16 = ((lda | ldb) & 1) == 0 && (((size_t)A | (size_t)B) & 15) == 0;
-
-  auto gload = [&](int k0) {
-    if (k0 + BK <= K) {
-      if (vec16) {
-        const dbl2v* p = reinterpret_cast<const dbl2v*>(A + (long)arow_a * lda + k0 + akk);
-#pragma unroll
-        for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; ra[2 * e] = v.x; ra[2 * e + 1] = v.y; }
-      } else {
-        const double* p = A + (long)arow_a * lda + k0 + akk;
-#pragma unroll
-        for (int e = 0; e < KT; ++e) ra[e] = p[e];
-      }
-      if constexpr (!NN) {
-        if (vec16) {
-          const dbl2v* p = reinterpret_cast<const dbl2v*>(B + (long)arow_b * ldb + k0 + akk);
-#pragma unroll
-          for (int e = 0; e < KT / 2; ++e) { const dbl2v v = p[e]; rb[2 * e] = v.x; rb[2 * e + 1] = v.y; }
-        } else {
-          const double* p = B + (long)arow_b * ldb + k0 + akk;
-#pragma unroll
-          for (int e = 0; e < KT; ++e) rb[e] = p[e];
-        }
-      } else {
-        const double* p = B + (long)(k0 + 2 * bkp) * ldb + bcol;
-#pragma unroll
-        for (int e = 0; e < KS; ++e) { rb[2 * e] = p[(long)(4 * e) * ldb]; rb[2 * e + 1] = p[(long)(4 * e + 1) * ldb]; }
-      }
-      return;
-    }
-    {
-      const int r = m0 + arow;
-      const double* p = A + (long)r * lda + k0 + akk;
-#pragma unroll
-      for (int e = 0; e < KT; ++e) ra[e] = (r < M && k0 + akk + e < K) ? p[e] : 0.0;
-    }
-    if constexpr (!NN) {
-      const int r = n0 + arow;
-      const double* p = B + (long)r * ldb + k0 + akk;
-#pragma unroll
-      for (int e = 0; e < KT; ++e) rb[e] = (r < N && k0 + akk + e < K) ? p[e] : 0.0;
-    } else {
-      // lanes run along n (coalesced 512-byte rows); each thread fetches the k-values it will
-      // write to LDS as 16-byte (k, k+1) pairs
-      const int n = n0 + bn;
-#pragma unroll
-      for (int e = 0; e < KS; ++e) {
-        const int k = k0 + 4 * e + 2 * bkp;
-        rb[2 * e] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0;
-        rb[2 * e + 1] = (k + 1 < K && n < N) ? B[(long)(k + 1) * ldb + n] : 0.0;
-      }
-    }
-  };
-  auto lstore = [&]() {
-    // 16-byte LDS stores: the KT k-values of a thread are KT / 4 runs of four (k % 4 = 0..3) of one row
-#pragma unroll
-    for (int h = 0; h < KT / 4; ++h) {
-      dbl2v* d = reinterpret_cast<dbl2v*>(&As[(akk >> 2) + h][arow][0]);
-      d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
-      d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
-    }
-    if constexpr (!NN) {
-#pragma unroll
-      for (int h = 0; h < KT / 4; ++h) {
-        dbl2v* d = reinterpret_cast<dbl2v*>(&Bs[(akk >> 2) + h][arow][0]);
-        d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
-        d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < KS; ++e)
-        *reinterpret_cast<dbl2v*>(&Bs[e][bn][2 * bkp]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
-    }
-  };
-
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    lstore();
-    __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[s][wm * 64 + i * 16 + l15][l4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[s][wn * 64 + j * 16 + l15][l4];
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          mfma_f64_vgpr(acc[i][j], a[i], b[j]);
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-    __syncthreads();
-  }
-  mfma_drain();
-  // D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + l4 + 4 * r;
-        if (m < M && n < N) C[(long)m * ldc + n] = acc[i][j][r];
-      }
-    }
-}
-
-template <bool NN, int BK, bool PRIO>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K,
-                                                       const double* __restrict__ A, long lda,
-                                                       const double* __restrict__ B, long ldb,
-                                                       double* __restrict__ C, long ldc) {
-  gemm_f64_tile<NN, BK, PRIO>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
-}
 // two independent products in one launch (blockIdx.z picks): the even and the odd block of the Poisson
 // eigen-transforms.  512 tiles are exactly one round on 256 CUs with two workgroups each -- prologue, epilogue
 // and the store burst of a round are not hidden; 1024 tiles give every CU a second round to overlap them with
@@ -538,7 +385,7 @@ __global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
                                                           double* __restrict__ C, long ldc) {
   gemm_f64_db_tile<NN, TM>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
 }
-// DB: 0 = one-stage 128-tile, 1 = two-stage 128-tile, 2 = two-stage 64-tile
+// DB: 1 = 128-tile, 2 = 64-tile (both two-stage)
 template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
@@ -547,29 +394,21 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
   gemm_tile_of_block(z, tx, ty);
   if (ty * TM >= g.M || tx * TM >= g.N) return;
   if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else if constexpr (DB == 1) gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else gemm_f64_tile<NN, 16, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx);
+  else gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
 }
 
 template <bool NN>
 static void launch_gemm(int M, int N, int K, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                         Stream& st) {
   if (M <= 0 || N <= 0) return;
-  static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
   dim3 grid((N + 127) / 128, (M + 127) / 128);
-  if (variant == 4 && (long)grid.x * grid.y < kGemmSmallTileBelow) {   // too few 128-tiles for the chip
+  if ((long)grid.x * grid.y < kGemmSmallTileBelow) {   // too few 128-tiles for the chip
     dim3 g64((N + 63) / 64, (M + 63) / 64);
     hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 64>), g64, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
     RPDE_HIP(hipGetLastError());
     return;
   }
-  switch (variant) {
-    case 1: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-    case 2: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-    case 3: hipLaunchKernelGGL((gemm_f64_kernel<NN, 32, true>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-    case 4: hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-    default: hipLaunchKernelGGL((gemm_f64_kernel<NN, 16, false>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc); break;
-  }
+  hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
   RPDE_HIP(hipGetLastError());
 }
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
@@ -581,26 +420,18 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     }
     return;
   }
-  static const int variant = [] { const char* e = std::getenv("RPDE_GEMM_VARIANT"); return e ? std::atoi(e) : kGemmDefaultVariant; }();
   const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc, p0.ct}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.ct};
-  RPDE_REQUIRE(!(p0.ct || p1.ct) || variant == 4, "transposed store: two-stage GEMM variant only");
   const int Mx = std::max(p0.M, p1.M), Nx = std::max(p0.N, p1.N);
   dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, 2);
-  const bool db = variant == 4;
-  if (db && (long)grid.x * grid.y * 2 < kGemmSmallTileBelow) {
+  if ((long)grid.x * grid.y * 2 < kGemmSmallTileBelow) {
     dim3 g64((Nx + 63) / 64, (Mx + 63) / 64, 2);
     const GemmSwizzle z = gemm_swizzle((int)g64.x, (int)g64.y);
     if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
     else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
   } else {
     const GemmSwizzle z = gemm_swizzle((int)grid.x, (int)grid.y);
-    if (nn) {
-      if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
-      else hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 0>), grid, dim3(256), 0, st.s, g0, g1, z);
-    } else {
-      if (db) hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
-      else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 0>), grid, dim3(256), 0, st.s, g0, g1, z);
-    }
+    if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
+    else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 1>), grid, dim3(256), 0, st.s, g0, g1, z);
   }
   RPDE_HIP(hipGetLastError());
 }
@@ -832,43 +663,6 @@ void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st) {
   RPDE_HIP(hipGetLastError());
 }
 
-// dct_line.h: one line per workgroup of N / 16 threads, 34.8 KB of LDS, 128 VGPRs: four workgroups per CU
-template <int N>
-__global__ __launch_bounds__(N / 16, 4) void dct_line_kernel(const DctLineArgs a) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
-  const int chunk = (int)gridDim.x >> 3;                     // XCD-aware line map, as in line_kernel
-  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
-  if (line >= a.nlines) return;
-  Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  dct_bwd_line<N>(blk, a);
-}
-// the same transform by workgroups that stay: each walks over its share of the lines and fetches the next line while
-// it transforms the current one (DctLineStage); WPS = workgroups per CU the register budget is cut for
-template <int N, int WPS>
-__global__ __launch_bounds__(N / 16, WPS) void dct_line_pf_kernel(const DctLineArgs a) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
-  using St = DctLineStage<N>;
-  const int per = (int)gridDim.x >> 3;                       // workgroups per XCD
-  const int chunk = (a.nlines + 7) >> 3;                     // lines per XCD: a contiguous band, as in line_kernel
-  const int x = (int)blockIdx.x & 7, w = (int)blockIdx.x >> 3;
-  const int tid = (int)threadIdx.x;
-  dbl2 v[St::QP];
-  int idx = w;
-  int line = x * chunk + idx;
-  bool have = idx < chunk && line < a.nlines;
-  if (have) St::load(a, line, tid, v);
-  while (have) {
-    St::put(a, (lds2_t)buf, tid, v);
-    __syncthreads();
-    const int nidx = idx + per, nline = x * chunk + nidx;
-    const bool nhave = nidx < chunk && nline < a.nlines;
-    if (nhave) St::load(a, nline, tid, v);
-    Blk blk{line, 0, N / 16, buf, nullptr, 0};
-    dct_line_core<N>(blk, a, true, DctStoreEmit{(gmem_t)(a.out + (long)line * a.ldo), a.scale});
-    __syncthreads();                                         // the split phase has read the buffer
-    idx = nidx; line = nline; have = nhave;
-  }
-}
 // TRACE: instrumented twins (Navier2DEngine::trace_launch): thread 0 leaves a clock value behind every barrier
 #define RPDE_TRACE_BEGIN(trace) \
   Blk blk{line, 0, N / 16, buf, TRACE ? (trace) + (long)blockIdx.x * kTraceStride : nullptr, 0}; \
@@ -898,7 +692,7 @@ __global__ __launch_bounds__(N / 16, WPC) void hdct_line2_kernel(const DctLineAr
   __syncthreads();
   hdct_bwd_line<N>(blk, a1);
 }
-template <int N, int WPC = 3>
+template <int N, int WPC>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
@@ -907,7 +701,7 @@ __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineA
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
   hconv_line<N>(blk, c);
 }
-template <int N, int WHICH, bool TRACE = false, int WPC = 4>
+template <int N, int WHICH, bool TRACE = false, int WPC = 3>
 __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
   const int chunk = (int)gridDim.x >> 3;
@@ -1026,20 +820,18 @@ bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   if (a.nlines <= 0) return true;
   const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
   if (a.N == 1024) {   // one wave per line
-    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<1024, 0, false, 3>), grid, block, 0, st.s, a, nullptr);
-    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<1024, 1, false, 3>), grid, block, 0, st.s, a, nullptr);
-    else hipLaunchKernelGGL((rhs_line_kernel<1024, 2, false, 3>), grid, block, 0, st.s, a, nullptr);
+    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<1024, 0>), grid, block, 0, st.s, a, nullptr);
+    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<1024, 1>), grid, block, 0, st.s, a, nullptr);
+    else hipLaunchKernelGGL((rhs_line_kernel<1024, 2>), grid, block, 0, st.s, a, nullptr);
   } else if (trace) {
     if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, true>), grid, block, 0, st.s, a, trace);
     else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, true>), grid, block, 0, st.s, a, trace);
     else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, true>), grid, block, 0, st.s, a, trace);
-  } else if (g_rhs_wpc == 3) {   // default: register budget of three workgroups per CU (no spills) instead of four
-    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0, false, 3>), grid, block, 0, st.s, a, trace);
-    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1, false, 3>), grid, block, 0, st.s, a, trace);
-    else hipLaunchKernelGGL((rhs_line_kernel<4096, 2, false, 3>), grid, block, 0, st.s, a, trace);
-  } else if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0>), grid, block, 0, st.s, a, trace);
-  else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1>), grid, block, 0, st.s, a, trace);
-  else hipLaunchKernelGGL((rhs_line_kernel<4096, 2>), grid, block, 0, st.s, a, trace);
+  } else {   // register budget of three workgroups per CU (no spills; four per CU spilled 70 - 90 registers and was slower)
+    if (a.which == 0) hipLaunchKernelGGL((rhs_line_kernel<4096, 0>), grid, block, 0, st.s, a, trace);
+    else if (a.which == 1) hipLaunchKernelGGL((rhs_line_kernel<4096, 1>), grid, block, 0, st.s, a, trace);
+    else hipLaunchKernelGGL((rhs_line_kernel<4096, 2>), grid, block, 0, st.s, a, trace);
+  }
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1051,34 +843,10 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
     RPDE_HIP(hipGetLastError());
     return true;
   }
-  if ((g_hdct & 1) || trace) {
-    if (trace) hipLaunchKernelGGL((hdct_line_kernel<4096, true>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
-    else hipLaunchKernelGGL((hdct_line_kernel<4096>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
-    RPDE_HIP(hipGetLastError());
-    return true;
-  }
-  const int pf = g_dct_line_pf;
-  if (pf == 3 || pf == 4) {
-    const int grid = std::min(256 * pf, 8 * ((a.nlines + 7) / 8));
-    if (pf == 3) hipLaunchKernelGGL((dct_line_pf_kernel<4096, 3>), dim3(grid), dim3(256), 0, st.s, a);
-    else hipLaunchKernelGGL((dct_line_pf_kernel<4096, 4>), dim3(grid), dim3(256), 0, st.s, a);
-    RPDE_HIP(hipGetLastError());
-    return true;
-  }
-  hipLaunchKernelGGL(dct_line_kernel<4096>, dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a);
+  if (trace) hipLaunchKernelGGL((hdct_line_kernel<4096, true>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
+  else hipLaunchKernelGGL((hdct_line_kernel<4096>), dim3(8 * ((a.nlines + 7) / 8)), dim3(256), 0, st.s, a, trace);
   RPDE_HIP(hipGetLastError());
   return true;
-}
-template <int N>
-__global__ __launch_bounds__(N / 16, 4) void dct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
-  const int chunk = (int)gridDim.x >> 3;
-  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
-  if (line >= a0.nlines) return;
-  Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  dct_bwd_line<N>(blk, a0);
-  __syncthreads();
-  dct_bwd_line<N>(blk, a1);
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs c) {
@@ -1097,13 +865,7 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
     RPDE_HIP(hipGetLastError());
     return true;
   }
-  if (g_hdct & 4) {
-    static const int wpc = [] { const char* e = std::getenv("RPDE_CONV_WPC"); return e ? std::atoi(e) : 3; }();   // A/B switch
-    if (wpc == 2) hipLaunchKernelGGL((hconv_line_kernel<4096, 2>), dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
-    else hipLaunchKernelGGL(hconv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
-    RPDE_HIP(hipGetLastError());
-    return true;
-  }
+  // 4097-point lines: the full-length core (168 VGPRs, three workgroups per CU); on the half-length core the term spills
   hipLaunchKernelGGL(conv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
   RPDE_HIP(hipGetLastError());
   return true;
@@ -1116,14 +878,7 @@ bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) 
     RPDE_HIP(hipGetLastError());
     return true;
   }
-  if (g_hdct & 2) {
-    static const int wpc = [] { const char* e = std::getenv("RPDE_S1_WPC"); return e ? std::atoi(e) : 4; }();   // A/B switch
-    if (wpc == 3) hipLaunchKernelGGL((hdct_line2_kernel<4096, 3>), dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
-    else hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
-    RPDE_HIP(hipGetLastError());
-    return true;
-  }
-  hipLaunchKernelGGL(dct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+  hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1519,8 +1274,7 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
     if (c.N == 1024) hconv_line<1024>(blk, c);
-    else if (g_hdct & 4) { if (c.N == 4096) hconv_line<4096>(blk, c); else hconv_line<256>(blk, c); }
-    else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);
+    else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);   // the device's choice of core per length
   }
   return true;
 }
@@ -1582,8 +1336,7 @@ bool launch_dct_line(const DctLineArgs& a, Stream&, long long*) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
     if (a.N == 1024) hdct_bwd_line<1024>(blk, a);
-    else if (g_hdct & 1) { if (a.N == 4096) hdct_bwd_line<4096>(blk, a); else hdct_bwd_line<256>(blk, a); }
-    else if (a.N == 4096) dct_bwd_line<4096>(blk, a); else dct_bwd_line<256>(blk, a);
+    else if (a.N == 4096) hdct_bwd_line<4096>(blk, a); else hdct_bwd_line<256>(blk, a);
   }
   return true;
 }

@@ -87,8 +87,6 @@ inline void launch_col_diff(const ColDiffArgs& a, Stream& st) { for (int ph : {0
 // not covered (the caller runs the line program instead)
 struct DctLineArgs;
 bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace = nullptr);   // trace: diagnostics record (kTraceStride words per workgroup)
-extern int g_hdct;          // bit mask: which whole-line kernels run on the half-length core (hdct_line.h) -- 1 pure transform, 2 S1 pair (default: both), 4 convection term; RPDE_HDCT, A/B switch
-extern int g_dct_line_pf;   // 0: one line per workgroup; 3 / 4: persistent workgroups with a prefetched next line (A/B switch, RPDE_DCT_PF)
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
