@@ -143,16 +143,15 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     const std::vector<int>* rk = P > 1 ? &ypart_ : nullptr;
     const int jend = std::min(ye_, my_);
     const Base& by = sp_vel_->base(1);
-    // one rank: the single-pass form (colscan1.h).  W blocks per workgroup: as many as still leave the chip about two
-    // workgroups per CU (small grids take short workgroups); RPDE_COL_ONEPASS=0 keeps the three kernels (A/B only).
+    // one rank: the single-pass form (colscan1.h).  W = 8 blocks per workgroup (two workgroups per CU: one loads or stores
+    // while the other waits for its partners), 16 for columns of more than 32 x 8 blocks; RPDE_COL_ONEPASS=0 keeps the
+    // three kernels (A/B only).
     const char* e1p = std::getenv("RPDE_COL_ONEPASS");   // read per engine, like the RPDE_*_LINE switches
     if (P == 1 && (!e1p || std::atoi(e1p) != 0)) {
       const int nb = (my_ + kColBlockRows - 1) / kColBlockRows;
       col1_tiles_ = (int)((ldx_ + kCol1Tile - 1) / kCol1Tile);
-      col1_W_ = 4;
-      for (int w : {16, 8})
-        if ((long)col1_tiles_ * ((nb + w - 1) / w) * 3 >= 512) { col1_W_ = w; break; }
-      if (const char* ew = std::getenv("RPDE_COL1_W")) { const int w = std::atoi(ew); if (w == 4 || w == 8 || w == 16) col1_W_ = w; }   // A/B only
+      col1_W_ = 8;
+      if (const char* ew = std::getenv("RPDE_COL1_W")) { const int w = std::atoi(ew); if (w == 8 || w == 16) col1_W_ = w; }   // A/B only
       while (col1_W_ < kCol1MaxW && (nb + col1_W_ - 1) / col1_W_ > kCol1MaxNSB) col1_W_ *= 2;
       col1_NSB_ = (nb + col1_W_ - 1) / col1_W_;
       if (col1_NSB_ > kCol1MaxNSB) col1_W_ = col1_NSB_ = col1_tiles_ = 0;   // taller than 16384 rows: the three kernels
@@ -169,7 +168,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     }
     if (col1_W_) {
       colagg_.alloc((size_t)3 * col1_tiles_ * col1_NSB_ * kCol1Agg * kCol1Tile);
-      colsync_.alloc((size_t)(3 * col1_tiles_ + 4) / 2 + 2);   // ints: [0] ticket, [1 ..] arrivals, then the error flag
+      colsync_.alloc((col1_sync_ints(col1_tiles_) + 1) / 2 + 1);   // ints: ticket, arrivals, ready flags, error flag (colscan1.h)
     }
     if (P > 1) {
       const size_t cnt = (size_t)3 * kColSumm * ldx_;
@@ -475,7 +474,7 @@ void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
 
 // Column scans when the rows are split over the ranks (colscan.h): block summaries, this rank's summary, ONE small
 // exchange that gives every rank everybody's summary, inflow of the own rows from them, final pass.
-void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1) {
+void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1, long long* trace) {
   const int P = comm_.size;
   if (P == 1 && col1_W_ && x1 && x1[0].F) {
     ColHh1Args A;
@@ -484,7 +483,9 @@ void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1) {
     A.W = col1_W_; A.NSB = col1_NSB_; A.tiles = (a.ncols + kCol1Tile - 1) / kCol1Tile;
     A.agg = colagg_.p;
     A.sync = reinterpret_cast<int*>(colsync_.p);
-    A.err = A.sync + 1 + 3 * col1_tiles_;
+    A.ready = A.sync + 1 + kColMaxFields * A.tiles;
+    A.err = A.sync + col1_err_index(col1_tiles_);
+    A.trace = trace;
     launch_col_hholtz1(A, st_);
     return;
   }
@@ -1155,7 +1156,10 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   static const char* const kOpNames[] = {"end", "load", "loadx", "store", "sten", "mv3", "cdiff", "rec1", "rec2", "dct",
                                          "mul", "axpby", "zero", "tabdiv", "rfft_f", "rfft_b", "cik", "push", "popaxpy"};
   size_t which = step_.size();
-  auto traceable = [](const Launch& l) { return l.type == Launch::kLine || l.type == Launch::kRhsLine || l.type == Launch::kDctLine; };
+  auto traceable = [&](const Launch& l) {
+    return l.type == Launch::kLine || l.type == Launch::kRhsLine || l.type == Launch::kDctLine ||
+           (l.type == Launch::kColHholtz && comm_.size == 1 && col1_W_ && l.ch1[0].F);   // the single-pass column scan: marks 0 .. 9 of col_hholtz1_kernel
+  };
   for (size_t i = 0; i < step_.size(); ++i)
     if (traceable(step_[i]) && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
   RPDE_REQUIRE(which < step_.size(), "trace_launch: no line program with tag containing \"" + tag + "\"");
@@ -1164,8 +1168,13 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
 #ifndef RPDE_EMU
   Launch l = step_[which];
   const bool prog = l.type == Launch::kLine;
+  const bool col1 = l.type == Launch::kColHholtz;
   const int tl = prog ? l.pg.nlines : (l.type == Launch::kRhsLine ? l.rl.nlines : l.dl.nlines);
-  const long nblk = 8L * ((tl + 7) / 8) * (prog ? l.pg.ncomp : 1);
+  long nblk = 8L * ((tl + 7) / 8) * (prog ? l.pg.ncomp : 1);
+  if (col1) {
+    const long per = (long)col1_NSB_ * ((l.ch.ncols + kCol1Tile - 1) / kCol1Tile);
+    nblk = (l.ch.pair && l.ch.nf == 2) ? 16 * ((per + 7) / 8) : per * l.ch.nf;
+  }
   DBuf buf;
   buf.alloc((size_t)nblk * kTraceStride);            // doubles and long longs are both 8 bytes
   RPDE_HIP(hipMemsetAsync(buf.p, 0, (size_t)nblk * kTraceStride * 8, st_.s));
@@ -1174,6 +1183,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   for (size_t i = 0; i < step_.size(); ++i) {
     if (i != which) { run_launch(step_[i]); continue; }
     if (prog) run_launch(l);
+    else if (col1) run_col_hholtz(l.ch, l.ch1, trec);
     else if (l.type == Launch::kRhsLine) RPDE_REQUIRE(launch_rhs_line(l.rl, st_, trec), "trace: rhs line");
     else RPDE_REQUIRE(launch_dct_line(l.dl, st_, trec), "trace: dct line");
   }
@@ -1246,7 +1256,7 @@ double Navier2DEngine::div_norm() {
 bool Navier2DEngine::read_nanflag() {
 #ifndef RPDE_EMU
   RPDE_HIP(hipMemcpyAsync(hflag_, nanflag_.p, sizeof(int), hipMemcpyDeviceToHost, st_.s));
-  if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p) + 1 + 3 * col1_tiles_, sizeof(int), hipMemcpyDeviceToHost, st_.s));
+  if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p) + col1_err_index(col1_tiles_), sizeof(int), hipMemcpyDeviceToHost, st_.s));
   RPDE_HIP(hipStreamSynchronize(st_.s));
   // a single-pass column scan whose wait for its partner workgroups ran out (colscan1.h): the step's results are wrong
   RPDE_REQUIRE(!col1_W_ || hflag_[1] == 0, "column scan: a workgroup waited for its partners in vain (RPDE_COL_ONEPASS=0 selects the three-kernel form)");

@@ -162,7 +162,7 @@ class Navier2DEngine {
   // halo rows of up to three YX arrays in one exchange: `front` rows in front of the local rows (from rank - 1), `tail`
   // rows behind them (from rank + 1)
   void halo_rows(double* const* arr, int n, int front, int tail);
-  void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr);   // column scans, one rank or rows split over the ranks (colscan.h)
+  void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr, long long* trace = nullptr);   // column scans, one rank or rows split over the ranks (colscan.h)
   void run_col_diff(ColDiffArgs a);
   ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
   DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;

@@ -47,7 +47,9 @@ struct HdctStoreEmit {
 // staged: the input line is already in the buffer (x[m] at buf[m + 2], zeros around it) and a barrier has been passed.
 // fetch(tid) is called once per thread ahead of the last barriers: the caller's chance to put the global loads its emit
 // needs in flight.
-template <int N, class Fetch, class Emit>
+// PAIR: the line runs in one half of a workgroup whose other half runs another transform of the same length
+// (hdct_pair_line): every barrier is met by both halves, so the barriers of the derivative are passed without it too.
+template <int N, class Fetch, class Emit, bool PAIR = false>
 RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch& fetch, const Emit& emit) {
   using G = HdctGeom<N>;
   constexpr int T = G::T, M = G::M, PL = G::PL, NW = G::NW;
@@ -118,26 +120,30 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     }
     RPDE_SYNC(blk);
   }
-  if (a.deriv) {
+  if (PAIR || a.deriv) {
     // d_k = dscale * sum_{j > k, j + k odd} 2 j c_j, d_0 halved (the suffix sums of scan_cheb_diff, line_vm.h): thread t
     // owns the chunk lo = 16 (T - 1 - t), so that the carry flows from thread t - 1 to thread t
+    const bool dv = a.deriv != 0;
     RPDE_TLS(blk, double, zz, 16);
     RPDE_TLS(blk, double, vd, 2);
     RPDE_PHASE(blk, tid) {
-      const int lo = (T - 1 - tid) * 16;
-      double bb[16];
+      RPDE_T(vd)[0] = 0.0; RPDE_T(vd)[1] = 0.0;
+      if (dv) {
+        const int lo = (T - 1 - tid) * 16;
+        double bb[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[lo + i + 3];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[lo + i + 3];   // 2 (k + 1) c_{k+1}, k + 1 <= N
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        double z = 0.0;
+        for (int par = 0; par < 2; ++par) {
+          double z = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int e = 14 + par - 2 * i;
-          z += bb[e];
-          RPDE_T(zz)[e] = z;
+          for (int i = 0; i < 8; ++i) {
+            const int e = 14 + par - 2 * i;
+            z += bb[e];
+            RPDE_T(zz)[e] = z;
+          }
+          RPDE_T(vd)[par] = z;
         }
-        RPDE_T(vd)[par] = z;
       }
     }
 #ifdef RPDE_EMU
@@ -147,7 +153,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     }
 #else
     {
-      const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      const int tid = (int)threadIdx.x - blk.t0, lane = tid & 63, wave = tid >> 6;
       double v[2] = {vd[0], vd[1]};
       v[0] = sum_wave_scan(v[0]);
       v[1] = sum_wave_scan(v[1]);
@@ -163,13 +169,15 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #endif
     RPDE_SYNC(blk);
     RPDE_PHASE(blk, tid) {
-      const int lo = (T - 1 - tid) * 16;
+      if (dv) {
+        const int lo = (T - 1 - tid) * 16;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = lo + i;
-        buf[k + 2] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+        for (int i = 0; i < 16; ++i) {
+          const int k = lo + i;
+          buf[k + 2] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+        }
+        if (tid == 0) buf[N + 2] = 0.0;          // d_N = 0
       }
-      if (tid == 0) buf[N + 2] = 0.0;          // d_N = 0
     }
     RPDE_SYNC(blk);
   }
@@ -208,7 +216,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   }
 #ifndef RPDE_EMU
   {  // wave totals of E_1's sum wait in the scratch area until the last phase
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int lane = ((int)threadIdx.x - blk.t0) & 63, wave = ((int)threadIdx.x - blk.t0) >> 6;
     const double tot = sum_wave_scan(e1p[0]);
     if (lane == ((T < 64) ? T - 1 : 63)) scr[wave] = tot;
   }
@@ -383,7 +391,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   }
 #else
   {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x - blk.t0, lane = tid & 63, wave = tid >> 6;
     const bool last = lane == ((T < 64) ? T - 1 : 63);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {                              // two row scans at a time (registers)
@@ -417,6 +425,62 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 template <int N>
 RPDE_DEV void hdct_bwd_line(Blk& blk, const DctLineArgs& a) {
   hdct_core<N>(blk, a, false, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)blk.line * a.ldo), a.scale});
+}
+
+// S1 of the step: the physical values AND the physical derivative of one state line (a0: the series, a1: deriv = 1 of the
+// same input) by ONE workgroup of 2 T threads.  The line is loaded once (the Dirichlet stencil on the way) into two
+// exchange buffers; then the two halves of the workgroup run the two transforms side by side, each in its buffer --
+// half the global reads of two transforms in a row, a latency chain of one transform instead of two.
+template <int N>
+RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const DctLineArgs& a1) {
+  constexpr int T = N / 16, T2 = 2 * T;
+  const long LB = (long)hdct_lds_doubles(N);
+  {
+    Blk all{line, 0, T2, lds};
+    lds2_t bufa = (lds2_t)lds, bufb = (lds2_t)(lds + LB);
+    cgmem2_t src2 = (cgmem2_t)(a0.in + (long)line * a0.ldi);
+    const bool dsten = a0.sten == 2;
+    const int n_in = a0.n_in;
+    RPDE_PHASE(all, tid) {
+      constexpr int QP = (N + 4 + 2 * T2 - 1) / (2 * T2);   // pairs per thread: 2 T2 QP >= N + 4
+      dbl2 v[QP], w[QP];
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int p = tid + q * T2, k = 2 * p - 2;
+        v[q] = (k >= 0 && k < n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
+        w[q] = (dsten && k >= 2 && k - 2 < n_in) ? src2[(k - 2) >> 1] : dbl2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        const int p = tid + q * T2, k = 2 * p - 2;
+        dbl2 c = v[q], o = w[q];
+        if (k + 1 >= n_in) c.y = 0.0;
+        if (k - 1 >= n_in) o.y = 0.0;
+        c.x -= o.x; c.y -= o.y;
+        if (2 * p + 1 < N + 4) { bufa[p] = c; bufb[p] = c; }
+      }
+    }
+    RPDE_SYNC(all);
+  }
+#ifdef RPDE_EMU
+  {
+    Blk b0{line, 0, T, lds};
+    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b0, a0, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a0.out + (long)line * a0.ldo), a0.scale});
+    Blk b1{line, 0, T, lds + LB};
+    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b1, a1, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a1.out + (long)line * a1.ldo), a1.scale});
+  }
+#else
+  {
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >= T ? 1 : 0);
+    Blk blk{line, 0, T, lds + half * LB, nullptr, 0, half * T};
+    const DctLineArgs& a = half ? a1 : a0;
+    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(blk, a, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)line * a.ldo), a.scale});
+  }
+#endif
+}
+RPDE_HD inline bool hdct_pair_ok(const DctLineArgs& a0, const DctLineArgs& a1) {
+  return a0.in == a1.in && a0.ldi == a1.ldi && a0.n_in == a1.n_in && a0.sten == a1.sten && a0.low == a1.low && a0.N == a1.N &&
+         a0.nlines == a1.nlines && !a0.fwd && !a1.fwd && !a0.deriv && a1.deriv;
 }
 
 // One y-line of a convection term on this core (see conv_line in dct_line.h for the mathematics): the physical factors

@@ -534,95 +534,149 @@ void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st) {
     if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(st.s); fprintf(stderr, " [phase %d ok]", phase); fflush(stderr); }
   }
 }
-// single-pass column scan (colscan1.h): W waves = W blocks of 64 columns per workgroup
-template <int W>
+// single-pass column scan (colscan1.h): W waves = W blocks of 64 columns per workgroup.  Everything a wave indexes tables
+// with (field, tile, super-block, its block) is made wave-uniform with readfirstlane: the row coefficients are scalar loads.
+// The aggregates travel between the workgroups as agent-scope relaxed atomics (write-through stores, loads that do not
+// hit stale lines of this XCD's L2): an acquire / release fence at agent scope is a write-back or an invalidation of the
+// WHOLE L2 on this chip -- in a polling loop that takes the L2 away from every other workgroup of the XCD.
+template <int W, bool TRACE = false>
 __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args A) {   // four waves per SIMD: 128 VGPRs
   extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
-  double* loc = rpde_lds;                                // [W][7][64] zero-inflow states of the W blocks
-  double* inf = loc + W * kCol1Agg * kCol1Tile;          // [W][6][64] their inflow states
-  double* tb = inf + W * kCol1Inf * kCol1Tile;           // [W][14] their transfers
-  double* kapl = tb + W * kCol1TabPerBlock;              // [64]
-  double* sc = kapl + kCol1Tile;                         // [2][NSB][64] compose scratch, one half per parity
+  double* loc = rpde_lds;                                // [W][7][64] block states (colhh1_chain works in place)
+  double* stg = loc + W * kCol1Agg * kCol1Tile;          // [NSB][6][64] aggregates of the tile's super-blocks
+  double* kapl = stg + A.NSB * kCol1Stg * kCol1Tile;     // [64]
   __shared__ int tk;
   const ColHhArgs& a = A.a;
-  const int tid = (int)threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long long* trc = TRACE ? A.trace + (long)blockIdx.x * kTraceStride : nullptr;
+  int nm = 0;
+#define RPDE_C1_MARK(id) do { if (TRACE && tid == 0 && nm < kTraceMarks) { trc[4 + 2 * nm] = (id); trc[5 + 2 * nm] = (long long)clock64(); ++nm; } } while (0)
+  if (TRACE && tid == 0) trc[0] = (long long)wall_clock64();
+  RPDE_C1_MARK(0);
   if (tid == 0) tk = atomicAdd(&A.sync[0], 1);
   __syncthreads();
+  RPDE_C1_MARK(1);
+  const int ticket = __builtin_amdgcn_readfirstlane(tk);
   // ticket -> (field, tile, super-block): the super-blocks of a tile are consecutive; with `pair` the two fields that read
   // the same rows sit eight tickets apart (workgroups go to the XCDs round robin: same L2)
-  int f, tile, q;
-  {
-    const int per = A.NSB * A.tiles;                    // (tile, super-block) combinations of one field
-    int c;
-    if (a.pair && a.nf == 2) { const int ch = tk >> 4, r = tk & 15; f = r >> 3; c = ch * 8 + (r & 7); }
-    else { f = tk / per; c = tk - f * per; }
-    if (c >= per || f >= a.nf) return;                  // padding tickets of the paired order
-    tile = c / A.NSB; q = c - tile * A.NSB;
-  }
+  // (integer division runs on the vector unit: every quotient goes back into a scalar register BEFORE anything branches
+  // on it, so that the branches stay scalar and field / tile / super-block stay wave-uniform for the compiler)
+  const int per = A.NSB * A.tiles;                      // (tile, super-block) combinations of one field
+  int f, c;
+  if (a.pair && a.nf == 2) { const int ch = ticket >> 4, r = ticket & 15; f = r >> 3; c = ch * 8 + (r & 7); }
+  else { f = __builtin_amdgcn_readfirstlane(ticket / per); c = ticket - f * per; }
+  if (c >= per || f >= a.nf) return;                    // padding tickets of the paired order
+  const int tile = __builtin_amdgcn_readfirstlane(c / A.NSB), q = __builtin_amdgcn_readfirstlane(c - tile * A.NSB);
   const ColHhTabs& t = a.tab[f];
   const ColHh1Tabs& x = A.x[f];
-  const int b = q * W + w, i = tile * kCol1Tile + lane;
+  const int b = __builtin_amdgcn_readfirstlane(q * W + w), i = tile * kCol1Tile + lane;
   const bool active = b < a.NB && i < a.ncols;
-  if (tid < W * kCol1TabPerBlock) colhh1_block_tab(t, q * W + tid / kCol1TabPerBlock, a.NB, tid % kCol1TabPerBlock, tb[tid]);
   double r[kColBR + 4];
   ColLoc L;
 #pragma unroll
   for (int k = 0; k < kCol1Agg; ++k) L.v[k] = 0.0;
   if (active) colhh1_local(a, f, b, i, r, L);
+  RPDE_C1_MARK(2);
 #pragma unroll
   for (int k = 0; k < kCol1Agg; ++k) loc[(w * kCol1Agg + k) * kCol1Tile + lane] = L.v[k];
   __syncthreads();
   double* ag = A.agg + col1_agg(A, f, tile, 0);
+  double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
   if (w < 2) {                                           // wave p: the chains of parity p from zero inflow = this super-block's aggregate
     double so, T0, T1;
-    colhh1_chain(loc, tb, inf, W, w, lane, 0.0, 0.0, 0.0, so, T0, T1);
-    double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
-    mine[w * kCol1Tile + lane] = so;
-    mine[(2 + 2 * w) * kCol1Tile + lane] = T0;
-    mine[(3 + 2 * w) * kCol1Tile + lane] = T1;
-    if (w == 0) {
-      double d = 0.0;
-      if (t.w) for (int u = 0; u < W; ++u) d += loc[(u * kCol1Agg + 6) * kCol1Tile + lane];
-      mine[6 * kCol1Tile + lane] = d;
-    }
-    __threadfence();
+    colhh1_chain<true>(loc, t, q * W, a.NB, W, w, lane, 0.0, 0.0, 0.0, so, T0, T1);
+    __hip_atomic_store(mine + w * kCol1Tile + lane, so, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + (2 + 2 * w) * kCol1Tile + lane, T0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + (3 + 2 * w) * kCol1Tile + lane, T1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (w == 2 && t.w) {
+    double d = 0.0;
+    for (int u = 0; u < W; ++u) d += loc[(u * kCol1Agg + 6) * kCol1Tile + lane];
+    __hip_atomic_store(mine + 6 * kCol1Tile + lane, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have arrived
+  RPDE_C1_MARK(4);
   __syncthreads();
   int* arrivals = A.sync + 1 + f * A.tiles + tile;
-  if (tid == 0) __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (w < 2) {
-    int it = 0;
-    while (__hip_atomic_load(arrivals, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < A.NSB) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++it > (1 << 24)) { if (lane == 0) *A.err = 1; break; }
-    }
-    __threadfence();
-    double s_in, S0, S1, so, T0, T1;
-    colhh1_compose(ag, x, sc + w * A.NSB * kCol1Tile, A.NSB, q, w, lane, s_in, S0, S1);
-    colhh1_chain(loc, tb, inf, W, w, lane, s_in, S0, S1, so, T0, T1);
-    if (w == 0) {
-      double k = 0.0;
-      if (t.w) for (int u = 0; u < A.NSB; ++u) k += ag[((long)u * kCol1Agg + 6) * kCol1Tile + lane];
-      kapl[lane] = k;
-    }
-  }
+  int* ready = A.ready + f * A.tiles + tile;
+  if (tid == 0) tk = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  const bool last = __builtin_amdgcn_readfirstlane(tk) == A.NSB - 1;
+  RPDE_C1_MARK(5);
+  if (TRACE && tid == 0) trc[3] = last ? 1 : 0;
+  double* mystg = stg + (long)q * kCol1Stg * kCol1Tile;  // this super-block's inflow states
+  if (last) {
+    // the last workgroup of the tile: all aggregates into LDS (eight rows of 64 doubles per wave in flight at a time) ...
+    const int rows = A.NSB * kCol1Stg;
+    for (int k0 = w; k0 < rows; k0 += 8 * W) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e * W;
+        if (k < rows) { const int qq = k / kCol1Stg; v[e] = __hip_atomic_load(ag + ((long)qq * kCol1Agg + (k - qq * kCol1Stg)) * kCol1Tile + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e * W;
+        if (k < rows) stg[(long)k * kCol1Tile + lane] = v[e];
+      }
+    }
+    if (w == W - 1) {                                    // the rank-one sum of the column (fields with tab.w)
+      double kp = 0.0;
+      if (t.w) for (int u = 0; u < A.NSB; ++u) kp += __hip_atomic_load(ag + ((long)u * kCol1Agg + 6) * kCol1Tile + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      kapl[lane] = kp;
+    }
+    __syncthreads();
+    if (w < 2) colhh1_sweep(stg, x, A.NSB, w, lane);      // ... the inflow states of every super-block ...
+    __syncthreads();
+    for (int k = w; k < rows; k += W) {                  // ... published in place of the aggregates
+      const int qq = k / kCol1Stg;
+      __hip_atomic_store(ag + ((long)qq * kCol1Agg + (k - qq * kCol1Stg)) * kCol1Tile + lane, stg[(long)k * kCol1Tile + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (w == W - 1) __hip_atomic_store(ag + 6 * kCol1Tile + lane, kapl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (w == 0) {
+      int it = 0;
+      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++it > (1 << 22)) { if (lane == 0) *A.err = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (w < kCol1Stg) mystg[w * kCol1Tile + lane] = __hip_atomic_load(ag + ((long)q * kCol1Agg + w) * kCol1Tile + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (w == kCol1Stg) kapl[lane] = __hip_atomic_load(ag + 6 * kCol1Tile + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  RPDE_C1_MARK(6);
+  if (w < 2) {
+    double so, T0, T1;
+    colhh1_chain<false>(loc, t, q * W, a.NB, W, w, lane, mystg[w * kCol1Tile + lane], mystg[(2 + 2 * w) * kCol1Tile + lane],
+                        mystg[(3 + 2 * w) * kCol1Tile + lane], so, T0, T1);
+  }
+  RPDE_C1_MARK(7);
+  __syncthreads();
+  RPDE_C1_MARK(8);
   if (active) {
     double in6[kCol1Inf];
 #pragma unroll
-    for (int k = 0; k < kCol1Inf; ++k) in6[k] = inf[(w * kCol1Inf + k) * kCol1Tile + lane];
+    for (int k = 0; k < kCol1Inf; ++k) in6[k] = loc[(w * kCol1Agg + k) * kCol1Tile + lane];
     colhh1_final(a, x, f, b, i, r, in6, kapl[lane]);
   }
+  RPDE_C1_MARK(9);
+  if (TRACE && tid == 0) { trc[1] = (long long)wall_clock64(); trc[2] = nm; }
+#undef RPDE_C1_MARK
 }
 void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
   const ColHhArgs& a = A.a;
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0 || a.NB <= 0) return;
   RPDE_REQUIRE(A.NSB <= kCol1MaxNSB && A.W * A.NSB >= a.NB, "colhh1: super-block partition");
-  RPDE_HIP(hipMemsetAsync(A.sync, 0, sizeof(int) * (size_t)(1 + a.nf * A.tiles), st.s));
+  RPDE_REQUIRE(A.W >= 8 && A.ready == A.sync + 1 + kColMaxFields * A.tiles, "colhh1: layout of the synchronisation area");
+  RPDE_HIP(hipMemsetAsync(A.sync, 0, sizeof(int) * (size_t)col1_err_index(A.tiles), st.s));
   const int per = A.NSB * A.tiles;
   const int wgs = (a.pair && a.nf == 2) ? 16 * ((per + 7) / 8) : per * a.nf;
-  const size_t bytes = sizeof(double) * ((size_t)A.W * (kCol1Agg + kCol1Inf) * kCol1Tile + (size_t)A.W * kCol1TabPerBlock + kCol1Tile +
-                                         2 * (size_t)A.NSB * kCol1Tile);
+  const size_t bytes = sizeof(double) * col1_lds_doubles(A.W, A.NSB);
   auto go = [&](auto kernel, int w) {
     static std::atomic<size_t> configured[32];           // dynamic-LDS permission, per device (as launch_kernel above)
     int dev = 0;
@@ -634,10 +688,10 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
     }
     hipLaunchKernelGGL(kernel, dim3(wgs), dim3(64 * w), bytes, st.s, A);
   };
-  if (A.W == 16) go(col_hholtz1_kernel<16>, 16);
+  if (A.trace) { if (A.W == 16) go(col_hholtz1_kernel<16, true>, 16); else go(col_hholtz1_kernel<8, true>, 8); }
+  else if (A.W == 16) go(col_hholtz1_kernel<16>, 16);
   else if (A.W == 8) go(col_hholtz1_kernel<8>, 8);
-  else if (A.W == 4) go(col_hholtz1_kernel<4>, 4);
-  else fail("colhh1: 4, 8 or 16 blocks per workgroup");
+  else fail("colhh1: 8 or 16 blocks per workgroup");
   RPDE_HIP(hipGetLastError());
 }
 template <int PASS>
@@ -692,6 +746,15 @@ __global__ __launch_bounds__(N / 16, WPC) void hdct_line2_kernel(const DctLineAr
   __syncthreads();
   hdct_bwd_line<N>(blk, a1);
 }
+// S1 with the line loaded once: two halves of a workgroup of N / 8 threads, one transform each (hdct_pair_line)
+template <int N>
+__global__ __launch_bounds__(N / 8, 4) void hdct_pair_kernel(const DctLineArgs a0, const DctLineArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  hdct_pair_line<N>(line, rpde_lds, a0, a1);
+}
 template <int N, int WPC>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
@@ -738,6 +801,16 @@ __global__ __launch_bounds__(N / 16, 4) void hdct_line2_batch_kernel(const Dct2B
   hdct_bwd_line<N>(blk, a1);
 }
 template <int N>
+__global__ __launch_bounds__(N / 8, 4) void hdct_pair_batch_kernel(const Dct2Batch b) {
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
+  const DctLineArgs& a0 = b.a0[blockIdx.y];
+  const DctLineArgs& a1 = b.a1[blockIdx.y];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  hdct_pair_line<N>(line, rpde_lds, a0, a1);
+}
+template <int N>
 __global__ __launch_bounds__(N / 16, 1) void hconv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
   RPDE_BATCH_LINE(c.nlines);
@@ -750,6 +823,11 @@ __global__ __launch_bounds__(N / 16, 3) void rhs_line_batch_kernel(const RhsBatc
   if (a.which == 0) rhs_line<N, 0>(blk, a);
   else if (a.which == 1) rhs_line<N, 1>(blk, a);
   else rhs_line<N, 2>(blk, a);
+}
+// A/B switch: RPDE_S1_PAIR=0 runs the two transforms of S1 one after the other in one workgroup of N / 16 threads
+static bool s1_pair_on() {
+  static const bool on = [] { const char* e = std::getenv("RPDE_S1_PAIR"); return !e || std::atoi(e) != 0; }();
+  return on;
 }
 bool line_batch_ok(int N) { return N == 1024; }
 void launch_line_batch(const LineBatch& b, Stream& st) {
@@ -769,7 +847,10 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
     hipLaunchKernelGGL(hdct_line_batch_kernel<N>, grid, block, 0, st.s, k);
   } else if (b.kind == 1) {
     Dct2Batch k; for (int i = 0; i < b.n; ++i) { k.a0[i] = b.d0[i]; k.a1[i] = b.d1[i]; }
-    hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
+    bool pair = s1_pair_on();
+    for (int i = 0; i < b.n; ++i) pair = pair && hdct_pair_ok(b.d0[i], b.d1[i]);
+    if (pair) hipLaunchKernelGGL(hdct_pair_batch_kernel<N>, grid, dim3(N / 8), 2 * sizeof(double) * hdct_lds_doubles(N), st.s, k);
+    else hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
   } else if (b.kind == 2) {
     ConvBatch k; for (int i = 0; i < b.n; ++i) k.c[i] = b.c[i];
     hipLaunchKernelGGL(hconv_line_batch_kernel<N>, grid, block, 0, st.s, k);
@@ -871,14 +952,24 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   return true;
 }
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
-  if ((a0.N != 4096 && a0.N != 1024) || a1.N != a0.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
+  if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1) || (a0.N != 4096 && a0.N != 1024)) return false;
   if (a0.nlines <= 0) return true;
-  if (a0.N == 1024) {
-    hipLaunchKernelGGL((hdct_line2_kernel<1024>), dim3(8 * ((a0.nlines + 7) / 8)), dim3(64), 0, st.s, a0, a1);
-    RPDE_HIP(hipGetLastError());
-    return true;
-  }
-  hipLaunchKernelGGL(hdct_line2_kernel<4096>, dim3(8 * ((a0.nlines + 7) / 8)), dim3(256), 0, st.s, a0, a1);
+  const dim3 grid(8 * ((a0.nlines + 7) / 8));
+  if (s1_pair_on() && hdct_pair_ok(a0, a1)) {
+    const size_t bytes = 2 * sizeof(double) * hdct_lds_doubles(a0.N);
+    if (a0.N == 1024) hipLaunchKernelGGL(hdct_pair_kernel<1024>, grid, dim3(128), bytes, st.s, a0, a1);
+    else {
+      static std::atomic<int> configured[32];             // dynamic-LDS permission above 64 KB, per device
+      int dev = 0;
+      RPDE_HIP(hipGetDevice(&dev));
+      if (!configured[dev & 31].load(std::memory_order_acquire)) {
+        RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hdct_pair_kernel<4096>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        configured[dev & 31].store(1, std::memory_order_release);
+      }
+      hipLaunchKernelGGL(hdct_pair_kernel<4096>, grid, dim3(512), bytes, st.s, a0, a1);
+    }
+  } else if (a0.N == 1024) hipLaunchKernelGGL((hdct_line2_kernel<1024>), grid, dim3(64), 0, st.s, a0, a1);
+  else hipLaunchKernelGGL(hdct_line2_kernel<4096>, grid, dim3(256), 0, st.s, a0, a1);
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1160,16 +1251,13 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0 || a.NB <= 0) return;
   RPDE_REQUIRE(A.NSB <= kCol1MaxNSB && A.W * A.NSB >= a.NB, "colhh1: super-block partition");
   const int W = A.W;
-  std::vector<double> loc((size_t)A.NSB * W * kCol1Agg * kCol1Tile), inf((size_t)W * kCol1Inf * kCol1Tile), tb((size_t)A.NSB * W * kCol1TabPerBlock),
-      sc((size_t)kCol1MaxNSB * kCol1Tile);
+  std::vector<double> loc((size_t)A.NSB * W * kCol1Agg * kCol1Tile), stg((size_t)A.NSB * kCol1Stg * kCol1Tile);
   double r[kColBR + 4];
   for (int f = 0; f < a.nf; ++f)
     for (int tile = 0; tile < A.tiles; ++tile) {
       double* ag = A.agg + col1_agg(A, f, tile, 0);
       for (int q = 0; q < A.NSB; ++q) {
         double* lq = loc.data() + (size_t)q * W * kCol1Agg * kCol1Tile;
-        double* tq = tb.data() + (size_t)q * W * kCol1TabPerBlock;
-        for (int k = 0; k < W * kCol1TabPerBlock; ++k) colhh1_block_tab(a.tab[f], q * W + k / kCol1TabPerBlock, a.NB, k % kCol1TabPerBlock, tq[k]);
         for (int w = 0; w < W; ++w)
           for (int lane = 0; lane < kCol1Tile; ++lane) {
             ColLoc L{};
@@ -1179,28 +1267,38 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
           }
         double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
         for (int lane = 0; lane < kCol1Tile; ++lane) {
-          for (int par = 0; par < 2; ++par) {
-            double so, T0, T1;
-            colhh1_chain(lq, tq, inf.data(), W, par, lane, 0.0, 0.0, 0.0, so, T0, T1);
-            mine[par * kCol1Tile + lane] = so; mine[(2 + 2 * par) * kCol1Tile + lane] = T0; mine[(3 + 2 * par) * kCol1Tile + lane] = T1;
-          }
           double d = 0.0;
           if (a.tab[f].w) for (int u = 0; u < W; ++u) d += lq[(u * kCol1Agg + 6) * kCol1Tile + lane];
           mine[6 * kCol1Tile + lane] = d;
+          for (int par = 0; par < 2; ++par) {
+            double so, T0, T1;
+            colhh1_chain<true>(lq, a.tab[f], q * W, a.NB, W, par, lane, 0.0, 0.0, 0.0, so, T0, T1);
+            mine[par * kCol1Tile + lane] = so; mine[(2 + 2 * par) * kCol1Tile + lane] = T0; mine[(3 + 2 * par) * kCol1Tile + lane] = T1;
+          }
         }
       }
+      // the last workgroup of the tile: aggregates -> inflow states of every super-block, published in place
+      std::vector<double> kap(kCol1Tile, 0.0);
+      for (int u = 0; u < A.NSB; ++u)
+        for (int k = 0; k < kCol1Stg; ++k)
+          for (int lane = 0; lane < kCol1Tile; ++lane) stg[((size_t)u * kCol1Stg + k) * kCol1Tile + lane] = ag[((long)u * kCol1Agg + k) * kCol1Tile + lane];
+      for (int lane = 0; lane < kCol1Tile; ++lane) {
+        for (int par = 0; par < 2; ++par) colhh1_sweep(stg.data(), A.x[f], A.NSB, par, lane);
+        if (a.tab[f].w) for (int u = 0; u < A.NSB; ++u) kap[lane] += ag[((long)u * kCol1Agg + 6) * kCol1Tile + lane];
+      }
+      for (int u = 0; u < A.NSB; ++u)
+        for (int k = 0; k < kCol1Stg; ++k)
+          for (int lane = 0; lane < kCol1Tile; ++lane) ag[((long)u * kCol1Agg + k) * kCol1Tile + lane] = stg[((size_t)u * kCol1Stg + k) * kCol1Tile + lane];
+      for (int lane = 0; lane < kCol1Tile; ++lane) ag[6 * kCol1Tile + lane] = kap[lane];
       for (int q = 0; q < A.NSB; ++q) {
         double* lq = loc.data() + (size_t)q * W * kCol1Agg * kCol1Tile;
-        double* tq = tb.data() + (size_t)q * W * kCol1TabPerBlock;
-        std::vector<double> kap(kCol1Tile, 0.0);
-        for (int lane = 0; lane < kCol1Tile; ++lane) {
+        const double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
+        for (int lane = 0; lane < kCol1Tile; ++lane)
           for (int par = 0; par < 2; ++par) {
-            double s_in, S0, S1, so, T0, T1;
-            colhh1_compose(ag, A.x[f], sc.data(), A.NSB, q, par, lane, s_in, S0, S1);
-            colhh1_chain(lq, tq, inf.data(), W, par, lane, s_in, S0, S1, so, T0, T1);
+            double so, T0, T1;
+            colhh1_chain<false>(lq, a.tab[f], q * W, a.NB, W, par, lane, mine[par * kCol1Tile + lane], mine[(2 + 2 * par) * kCol1Tile + lane],
+                                mine[(3 + 2 * par) * kCol1Tile + lane], so, T0, T1);
           }
-          if (a.tab[f].w) for (int u = 0; u < A.NSB; ++u) kap[lane] += ag[((long)u * kCol1Agg + 6) * kCol1Tile + lane];
-        }
         for (int w = 0; w < W; ++w)
           for (int lane = 0; lane < kCol1Tile; ++lane) {
             const int b = q * W + w, i = tile * kCol1Tile + lane;
@@ -1208,8 +1306,8 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
             ColLoc L{};
             colhh1_local(a, f, b, i, r, L);     // the rows again (registers on the device)
             double in6[kCol1Inf];
-            for (int k = 0; k < kCol1Inf; ++k) in6[k] = inf[(w * kCol1Inf + k) * kCol1Tile + lane];
-            colhh1_final(a, A.x[f], f, b, i, r, in6, kap[lane]);
+            for (int k = 0; k < kCol1Inf; ++k) in6[k] = lq[(w * kCol1Agg + k) * kCol1Tile + lane];
+            colhh1_final(a, A.x[f], f, b, i, r, in6, ag[6 * kCol1Tile + lane]);
           }
       }
     }
@@ -1280,7 +1378,17 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
 }
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) {
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1)) return false;
-  return launch_dct_line(a0, st) && launch_dct_line(a1, st);
+  static const bool pair_on = [] { const char* e = std::getenv("RPDE_S1_PAIR"); return !e || std::atoi(e) != 0; }();
+  if (!pair_on || !hdct_pair_ok(a0, a1)) return launch_dct_line(a0, st) && launch_dct_line(a1, st);
+  std::vector<double> lds(2 * hdct_lds_doubles(a0.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a0.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    if (a0.N == 4096) hdct_pair_line<4096>(line, base, a0, a1);
+    else if (a0.N == 1024) hdct_pair_line<1024>(line, base, a0, a1);
+    else hdct_pair_line<256>(line, base, a0, a1);
+  }
+  return true;
 }
 bool line_batch_ok(int N) { return N == 1024 || N == 256; }
 void launch_line_batch(const LineBatch& b, Stream& st) {   // the same lines, one field after the other

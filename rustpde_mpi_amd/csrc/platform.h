@@ -64,6 +64,7 @@ struct Blk {          // one workgroup
   int comp;           // blockIdx.y
   int T;              // blockDim.x
   double* lds;        // base of the workgroup's LDS
+  int t0 = 0;         // (device only: first thread of the part of a workgroup that runs this line)
 };
 #define RPDE_PHASE(blk, tid) for (int tid = 0; tid < (blk).T; ++tid)
 #define RPDE_PIN(x) ((void)0)
@@ -80,6 +81,8 @@ struct Blk {
   double* lds;
   long long* trc;   // diagnostics: this workgroup's record of Program::trace (null: no tracing)
   int nm;           // marks written so far
+  int t0 = 0;       // first thread of the part of the workgroup that runs this line: phases see tid = threadIdx.x - t0
+                    // (hdct_pair_line: two halves of a workgroup run two transforms side by side)
 };
 // one (id, shader clock) pair per mark: id >= 0 = thread 0 reaches op id of the program, -1 = thread 0 leaves a barrier
 constexpr int kTraceMarks = 126;
@@ -96,7 +99,7 @@ __device__ __forceinline__ int rpde_tid() {
   __builtin_assume(t >= 0 && t < 1024);
   return t;
 }
-#define RPDE_PHASE(blk, tid) for (int tid = rpde_tid(), _once = 1; _once; _once = 0)
+#define RPDE_PHASE(blk, tid) for (int tid = rpde_tid() - (blk).t0, _once = 1; _once; _once = 0)
 // A value loaded from global memory is pinned where all loads of the phase have been issued: the compiler
 // may not sink the load into the (per-lane predicated) block of its only user, where it would be followed by
 // an s_waitcnt vmcnt(0) -- one dependent memory round trip per element (tools/check_load_issue.py)
