@@ -52,10 +52,18 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", flags=()
                 and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t)):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-Wno-unused-result", *flags, "-c", sp, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+               "-Wno-unused-result", *flags, "-c", sp, "-o", obj + ".tmp"]
+        # hipcc reads the sources twice (device pass, host pass): an edit in between gives an object whose host and device
+        # halves disagree -- compile again until the sources stood still for the whole compile
+        while True:
+            seen = max(os.path.getmtime(sp), _newest_header())
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            if max(os.path.getmtime(sp), _newest_header()) == seen:
+                break
+        os.replace(obj + ".tmp", obj)
+        hdr_t = max(hdr_t, seen)
     if (force or not os.path.exists(out)
             or os.path.getmtime(out) < max(os.path.getmtime(o) for o in objs)):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]

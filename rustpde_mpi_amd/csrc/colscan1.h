@@ -64,12 +64,76 @@ RPDE_HD inline long col1_agg(const ColHh1Args& A, int f, int tile, int q) {
 
 struct ColLoc { double v[kCol1Agg]; };
 
+constexpr int kCol1TabPerBlock = 14;   // m1[2], m2[2][4], g[2][2] of a block / a super-block
+
+// Where a thread takes the coefficients of its block's rows from.  Col1TabDirect: the tables themselves (host emulation).
+// Col1TabLanes (device): every coefficient is wave-uniform, but a scalar load per row and table is a chain of cold misses
+// of the scalar cache (measured: 18 us of a workgroup's 52 us went into the zero-inflow solve, 13 us into the first chain)
+// -- and all waves of a workgroup wait at the same time.  Instead the lanes of a wave fetch the coefficients of the block's
+// 32 rows with ONE vector load per pair of tables, issued together with the row loads; row u's coefficient is read back
+// with v_readlane into a scalar register pair.
+struct Col1TabDirect {
+  const double *t0_, *t1_, *t2_, *q1_, *p2_, *q2_, *r2_, *w_, *F_, *H0_, *H1_, *h_;
+  int j0, jr;
+  Col1TabDirect(const ColHhTabs& t, const ColHh1Tabs& x, int j0_, int jr_)
+      : t0_(t.t0), t1_(t.t1), t2_(t.t2), q1_(t.q1), p2_(t.p2), q2_(t.q2), r2_(t.r2), w_(t.w), F_(x.F), H0_(x.H0), H1_(x.H1), h_(t.h), j0(j0_), jr(jr_) {}
+  double t0(int u) const { return t0_[j0 + u]; }
+  double t1(int u) const { return t1_[j0 + u]; }
+  double t2(int u) const { return t2_[j0 + u]; }
+  double q1(int u) const { return q1_[j0 + u]; }
+  double p2(int u) const { return p2_[j0 + u]; }
+  double q2(int u) const { return q2_[j0 + u]; }
+  double r2(int u) const { return r2_[j0 + u]; }
+  double w(int u) const { return w_[(jr + u > 0) ? jr + u : 0]; }
+  double F(int u) const { return F_[j0 + u]; }
+  double H0(int u) const { return H0_[j0 + u]; }
+  double H1(int u) const { return H1_[j0 + u]; }
+  double h(int u) const { return h_[j0 + u]; }
+};
+#ifndef RPDE_EMU
+__device__ __forceinline__ double col1_lane(double v, int l) {   // the value lane l holds, as a wave-uniform number
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+struct Col1TabLanes {
+  double a, b, c, d, e, g, k;          // lanes 0 .. 31 | 32 .. 63:  t0 | t1,  t2 | q1,  p2 | q2,  r2 | -,  w (36 lanes),  F | H0,  H1 | h
+  __device__ __forceinline__ Col1TabLanes(const ColHhTabs& t, const ColHh1Tabs& x, int j0, int jr, int lane) {
+    using gt = const __attribute__((address_space(1))) double*;
+    const int l = lane & 31, j = j0 + l;
+    const bool up = lane >= 32;
+    // the table pointers as VALUES in scalar registers first: a select between two fields of the argument block would
+    // otherwise become a per-lane load of the POINTER (one more memory round trip in front of every table load)
+    auto sp = [](const double* p) { asm volatile("" : "+s"(p)); return p; };
+    const double *pt0 = sp(t.t0), *pt1 = sp(t.t1), *pt2 = sp(t.t2), *pq1 = sp(t.q1), *pp2 = sp(t.p2), *pq2 = sp(t.q2), *pr2 = sp(t.r2),
+                 *pw = sp(t.w), *ph = sp(t.h), *pF = sp(x.F), *pH0 = sp(x.H0), *pH1 = sp(x.H1);
+    a = ((gt)(up ? pt1 : pt0))[j];
+    b = ((gt)(up ? pq1 : pt2))[j];
+    c = ((gt)(up ? pq2 : pp2))[j];
+    d = ((gt)pr2)[j];
+    g = ((gt)(up ? pH0 : pF))[j];
+    k = ((gt)((up && pw) ? ph : pH1))[j];
+    e = (pw && lane < kColBR + 4) ? ((gt)pw)[(jr + lane > 0) ? jr + lane : 0] : 0.0;
+  }
+  __device__ __forceinline__ double t0(int u) const { return col1_lane(a, u); }
+  __device__ __forceinline__ double t1(int u) const { return col1_lane(a, 32 + u); }
+  __device__ __forceinline__ double t2(int u) const { return col1_lane(b, u); }
+  __device__ __forceinline__ double q1(int u) const { return col1_lane(b, 32 + u); }
+  __device__ __forceinline__ double p2(int u) const { return col1_lane(c, u); }
+  __device__ __forceinline__ double q2(int u) const { return col1_lane(c, 32 + u); }
+  __device__ __forceinline__ double r2(int u) const { return col1_lane(d, u); }
+  __device__ __forceinline__ double w(int u) const { return col1_lane(e, u); }
+  __device__ __forceinline__ double F(int u) const { return col1_lane(g, u); }
+  __device__ __forceinline__ double H0(int u) const { return col1_lane(g, 32 + u); }
+  __device__ __forceinline__ double H1(int u) const { return col1_lane(k, u); }
+  __device__ __forceinline__ double h(int u) const { return col1_lane(k, 32 + u); }
+};
+#endif
+
 // zero-inflow solve of block b of column i (colhh_block<false> without the stores): on return r[0 .. BR) hold x0
-RPDE_HD inline void colhh1_local(const ColHhArgs& a, int f, int b, int i, double (&r)[kColBR + 4], ColLoc& L) {
+template <class Tab>
+RPDE_HD inline void colhh1_local(const ColHhArgs& a, int f, int b, int i, double (&r)[kColBR + 4], ColLoc& L, const Tab& tb) {
   constexpr int BR = kColBR;
   const ColHhTabs& t = a.tab[f];
-  ktab_t tw = (ktab_t)t.w, t0 = (ktab_t)t.t0, t1 = (ktab_t)t.t1, t2 = (ktab_t)t.t2, q1 = (ktab_t)t.q1, p2 = (ktab_t)t.p2, q2 = (ktab_t)t.q2,
-         r2 = (ktab_t)t.r2;
   const int ci = a.in_half ? (i & 1) * a.in_half + (i >> 1) : i;
   const double* __restrict__ w = a.in[f] + ci;
   const int j0 = b * BR, jr = j0 - a.shift[f];
@@ -82,15 +146,15 @@ RPDE_HD inline void colhh1_local(const ColHhArgs& a, int f, int b, int i, double
     const bool tail = b == a.NB - 1;
 #pragma unroll
     for (int u = 0; u < BR + 4; ++u)
-      if ((u < BR && (jr + u < a.n - a.shift[f] || tail)) || (u >= BR && tail)) dot += tw[(jr + u > 0) ? jr + u : 0] * r[u];
+      if ((u < BR && (jr + u < a.n - a.shift[f] || tail)) || (u >= BR && tail)) dot += tb.w(u) * r[u];
   }
   double ye = 0.0, yo = 0.0, e1 = 0.0, e2 = 0.0, o1 = 0.0, o2 = 0.0;
 #pragma unroll
   for (int u = 0; u < BR; ++u) {
     const int j = j0 + u;
-    const double bj = t0[j] * r[u] + t1[j] * r[u + 2] + t2[j] * r[u + 4];
+    const double bj = tb.t0(u) * r[u] + tb.t1(u) * r[u + 2] + tb.t2(u) * r[u + 4];
     double& yp = (u & 1) ? yo : ye;
-    const double yn = bj + q1[j] * yp;
+    const double yn = bj + tb.q1(u) * yp;
     yp = (j < j1) ? yn : yp;
     r[u] = yn;
   }
@@ -99,7 +163,7 @@ RPDE_HD inline void colhh1_local(const ColHhArgs& a, int f, int b, int i, double
     const int j = j0 + u;
     double& x1 = (u & 1) ? o1 : e1;
     double& x2 = (u & 1) ? o2 : e2;
-    const double xj = p2[j] * r[u] + q2[j] * x1 + r2[j] * x2;
+    const double xj = tb.p2(u) * r[u] + tb.q2(u) * x1 + tb.r2(u) * x2;
     x2 = (j < j1) ? x1 : x2;
     x1 = (j < j1) ? xj : x1;
     r[u] = xj;
@@ -107,35 +171,36 @@ RPDE_HD inline void colhh1_local(const ColHhArgs& a, int f, int b, int i, double
   L.v[0] = ye; L.v[1] = yo; L.v[2] = e1; L.v[3] = e2; L.v[4] = o1; L.v[5] = o2; L.v[6] = dot;
 }
 
-// rows of block b from x0 and the block's inflow states
-RPDE_HD inline void colhh1_final(const ColHhArgs& a, const ColHh1Tabs& x, int f, int b, int i, const double (&r)[kColBR + 4],
-                                 const double (&inf)[kCol1Inf], double kap) {
+// rows of block b from x0 and the block's inflow states (`store`: the column exists)
+template <class Tab>
+RPDE_HD inline void colhh1_final(const ColHhArgs& a, int f, int b, int i, const double (&r)[kColBR + 4], const double (&inf)[kCol1Inf],
+                                 double kap, const Tab& tb, bool store) {
   constexpr int BR = kColBR;
   const ColHhTabs& t = a.tab[f];
   const int j0 = b * BR, j1 = (j0 + BR < a.n) ? j0 + BR : a.n;
   double* __restrict__ out = a.out[f] + i;
-  ktab_t F = (ktab_t)x.F, H0 = (ktab_t)x.H0, H1 = (ktab_t)x.H1, h = (ktab_t)t.h;
   bool bad = false;
 #pragma unroll
   for (int u = 0; u < BR; ++u) {
     const int j = j0 + u, p = u & 1;
     if (j < j1) {
-      double v = r[u] + inf[p] * F[j] + inf[2 + 2 * p] * H0[j] + inf[3 + 2 * p] * H1[j];
-      if (t.w) v += kap * h[j];
-      out[(long)j * a.ld] = v;
-      bad |= (v != v);
+      double v = r[u] + inf[p] * tb.F(u) + inf[2 + 2 * p] * tb.H0(u) + inf[3 + 2 * p] * tb.H1(u);
+      if (t.w) v += kap * tb.h(u);
+      if (store) out[(long)j * a.ld] = v;
+      bad |= store && (v != v);
     }
   }
   if (bad && a.nanflag) *a.nanflag = 1;
 }
 
-// transfers of block b (identity behind the last block): m1, the 2 x 2 matrix m2, g of one parity
-RPDE_HD inline void colhh1_block_tab(const ColHhTabs& t, int b, int NB, int par, double& m1, double (&m2)[4], double (&g)[2]) {
-  if (b >= NB) { m1 = 1.0; m2[0] = 1.0; m2[1] = 0.0; m2[2] = 0.0; m2[3] = 1.0; g[0] = 0.0; g[1] = 0.0; return; }
-  m1 = ((ktab_t)t.m1)[b * 2 + par];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) m2[k] = ((ktab_t)t.m2)[b * 8 + par * 4 + k];
-  g[0] = ((ktab_t)t.g)[b * 4 + par * 2]; g[1] = ((ktab_t)t.g)[b * 4 + par * 2 + 1];
+// entry k of tb[14] = m1[2], m2[2][4], g[2][2] of block b (nullptr behind the last block: the identity, colhh1_ident_tab)
+RPDE_HD inline const double* colhh1_block_tab(const ColHhTabs& t, int b, int NB, int k) {
+  if (b >= NB) return nullptr;
+  return (k < 2) ? t.m1 + (b * 2 + k) : (k < 10) ? t.m2 + (b * 8 + (k - 2)) : t.g + (b * 4 + (k - 10));
+}
+RPDE_HD inline double colhh1_ident_tab(int k) { return (k < 2 || k == 2 || k == 5 || k == 6 || k == 9) ? 1.0 : 0.0; }   // m1 = 1, m2 = I, g = 0
+RPDE_HD inline const double* colhh1_super_tab(const ColHh1Tabs& x, int q, int k) {
+  return (k < 2) ? x.m1w + (q * 2 + k) : (k < 10) ? x.m2w + (q * 8 + (k - 2)) : x.gw + (q * 4 + (k - 10));
 }
 
 // The chains over the W blocks b0 .. b0 + W - 1 of a super-block, one parity, one column, IN PLACE in `loc` = [W][7][64]
@@ -145,14 +210,15 @@ RPDE_HD inline void colhh1_block_tab(const ColHhTabs& t, int b, int NB, int par,
 //   FIRST = false  with the super-block's exact inflow (s_in | S0, S1): slot par becomes the exact forward inflow
 //                  f1 + P s_in (P = product of the transfer factors in front of the block: the chain is linear), slots
 //                  2 + 2 par, 3 + 2 par the exact backward inflow states.
+// `tb` = [W][14] the blocks' transfers (colhh1_block_tab; LDS on the device).
 template <bool FIRST>
-RPDE_HD inline void colhh1_chain(double* loc, const ColHhTabs& t, int b0, int NB, int W, int par, int lane, double s_in, double S0,
-                                 double S1, double& s_out, double& T0, double& T1) {
+RPDE_HD inline void colhh1_chain(double* loc, const double* tb, int W, int par, int lane, double s_in, double S0, double S1, double& s_out,
+                                 double& T0, double& T1) {
   double s = FIRST ? 0.0 : 1.0;            // FIRST: running value, else: running product P
 #pragma unroll 4
   for (int w = 0; w < W; ++w) {
     double* L = loc + (long)w * kCol1Agg * kCol1Tile + lane;
-    const double m1 = (b0 + w < NB) ? ((ktab_t)t.m1)[(b0 + w) * 2 + par] : 1.0;
+    const double m1 = tb[w * kCol1TabPerBlock + par];
     if (FIRST) {
       const double a = L[par * kCol1Tile];
       L[par * kCol1Tile] = s;
@@ -167,8 +233,8 @@ RPDE_HD inline void colhh1_chain(double* loc, const ColHhTabs& t, int b0, int NB
 #pragma unroll 4
   for (int w = W - 1; w >= 0; --w) {
     double* L = loc + (long)w * kCol1Agg * kCol1Tile + lane;
-    double m1, m[4], g[2];
-    colhh1_block_tab(t, b0 + w, NB, par, m1, m, g);
+    const double* m = tb + w * kCol1TabPerBlock + 2 + par * 4;
+    const double* g = tb + w * kCol1TabPerBlock + 10 + par * 2;
     const double fi = L[par * kCol1Tile];
     const double v0 = L[(2 + 2 * par) * kCol1Tile], v1 = L[(3 + 2 * par) * kCol1Tile];
     if (!FIRST) { L[(2 + 2 * par) * kCol1Tile] = t0; L[(3 + 2 * par) * kCol1Tile] = t1; }
@@ -181,21 +247,22 @@ RPDE_HD inline void colhh1_chain(double* loc, const ColHhTabs& t, int b0, int NB
 
 // inflow states of ALL super-blocks of a column from their aggregates, one parity, IN PLACE in `stg` = [NSB][6][64]
 // (slot par: forward end value -> forward inflow; slots 2 + 2 par, 3 + 2 par: backward end state -> backward inflow states)
-RPDE_HD inline void colhh1_sweep(double* stg, const ColHh1Tabs& x, int NSB, int par, int lane) {
+// `tw` = [NSB][14] the super-blocks' transfers (colhh1_super_tab; LDS on the device).
+RPDE_HD inline void colhh1_sweep(double* stg, const double* tw, int NSB, int par, int lane) {
   double s = 0.0;
 #pragma unroll 4
   for (int q = 0; q < NSB; ++q) {
     double* G = stg + (long)q * kCol1Stg * kCol1Tile + lane;
     const double a = G[par * kCol1Tile];
     G[par * kCol1Tile] = s;
-    s = ((ktab_t)x.m1w)[q * 2 + par] * s + a;
+    s = tw[q * kCol1TabPerBlock + par] * s + a;
   }
   double t0 = 0.0, t1 = 0.0;
 #pragma unroll 4
   for (int q = NSB - 1; q >= 0; --q) {
     double* G = stg + (long)q * kCol1Stg * kCol1Tile + lane;
-    ktab_t m = (ktab_t)x.m2w + (q * 2 + par) * 4;
-    ktab_t g = (ktab_t)x.gw + (q * 2 + par) * 2;
+    const double* m = tw + q * kCol1TabPerBlock + 2 + par * 4;
+    const double* g = tw + q * kCol1TabPerBlock + 10 + par * 2;
     const double fi = G[par * kCol1Tile];
     const double v0 = G[(2 + 2 * par) * kCol1Tile], v1 = G[(3 + 2 * par) * kCol1Tile];
     G[(2 + 2 * par) * kCol1Tile] = t0; G[(3 + 2 * par) * kCol1Tile] = t1;
@@ -212,7 +279,53 @@ RPDE_HD inline size_t col1_sync_ints(int tiles) { return (size_t)col1_err_index(
 
 // dynamic LDS of the kernel (doubles): the blocks' states, the staged aggregates of the tile, the rank-one sums
 RPDE_HD inline size_t col1_lds_doubles(int W, int NSB) {
-  return (size_t)W * kCol1Agg * kCol1Tile + (size_t)NSB * kCol1Stg * kCol1Tile + kCol1Tile;
+  return (size_t)W * kCol1Agg * kCol1Tile + (size_t)NSB * kCol1Stg * kCol1Tile + kCol1Tile + (size_t)(W + NSB) * kCol1TabPerBlock;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chebyshev y-derivative of a YX array (coldiff_pass / coldiff_carry of colscan.h) in ONE pass, one rank: a workgroup of
+// kDiff1W waves owns 64 columns x kDiff1W blocks of kDiff1BR rows; a thread keeps the suffix sums of its rows in registers,
+// the block sums go through LDS, the super-block sums through global memory.  Suffix sums only need the super-blocks ABOVE:
+// tickets hand the super-blocks of a tile out from the top, so whatever a workgroup waits for was started before it.
+constexpr int kDiff1BR = 16;           // rows per thread
+constexpr int kDiff1W = 16;            // waves (= blocks) per workgroup: 256 rows
+constexpr int kDiff1Rows = kDiff1BR * kDiff1W;
+struct ColDiff1Args {
+  ColDiffArgs a;                       // one rank: row0 = 0, jend = nout
+  int NSB, tiles;                      // super-blocks per column, column tiles of 64
+  double* tot;                         // [tiles][NSB][2][64] sums of the super-blocks, per parity
+  int* sync;                           // [0] ticket counter, [1 + tile * NSB + q] "the sums of super-block q are published"; zero before the launch
+  int* err;                            // raised when a wait ran out
+};
+RPDE_HD inline long coldiff1_tot(const ColDiff1Args& A, int tile, int q) { return ((long)tile * A.NSB + q) * (2 * kCol1Tile); }
+
+// rows [j0, j0 + BR) of column i (j0 even): d[u] = the sum over the block's rows j' >= j0 + u of the parity of u of
+// 2 (j' + 1) c_{j'+1}, tot = the block's sums.  `lowc(u)` = the stencil coefficient low[j0 + u - 1] (k - 2 for k = j0 + u + 1).
+template <class LowC>
+RPDE_HD inline void coldiff1_local(const ColDiffArgs& a, int j0, int i, double (&d)[kDiff1BR], double (&tot)[2], const LowC& lowc) {
+  constexpr int BR = kDiff1BR;
+  const double* __restrict__ v = a.in + i;
+  double x[BR + 2];                    // x[u] = v_{j0 - 1 + u}
+#pragma unroll
+  for (int u = 0; u < BR + 2; ++u) { const int k = j0 - 1 + u; x[u] = (k >= 0 && k < a.m) ? v[(long)k * a.ldi] : 0.0; }
+  double acc[2] = {0.0, 0.0};
+#pragma unroll
+  for (int u = BR - 1; u >= 0; --u) {
+    const int j = j0 + u, k = j + 1;
+    double c = 0.0;
+    if (k < a.nout) c = a.low ? x[u + 2] + ((k >= 2) ? lowc(u) * x[u] : 0.0) : x[u + 2];
+    if (j < a.nout) acc[u & 1] += 2.0 * (double)(j + 1) * c;
+    d[u] = acc[u & 1];
+  }
+  tot[0] = acc[0]; tot[1] = acc[1];
+}
+RPDE_HD inline void coldiff1_store(const ColDiffArgs& a, int j0, int i, const double (&d)[kDiff1BR], const double (&in)[2]) {
+  double* __restrict__ out = a.out + i;
+#pragma unroll
+  for (int u = 0; u < kDiff1BR; ++u) {
+    const int j = j0 + u;
+    if (j < a.nout) out[(long)j * a.ldo] = (d[u] + in[u & 1]) * ((j == 0) ? 0.5 * a.scale : a.scale);
+  }
 }
 
 }  // namespace rpde

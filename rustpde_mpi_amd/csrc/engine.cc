@@ -143,14 +143,15 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     const std::vector<int>* rk = P > 1 ? &ypart_ : nullptr;
     const int jend = std::min(ye_, my_);
     const Base& by = sp_vel_->base(1);
-    // one rank: the single-pass form (colscan1.h).  W = 8 blocks per workgroup (two workgroups per CU: one loads or stores
-    // while the other waits for its partners), 16 for columns of more than 32 x 8 blocks; RPDE_COL_ONEPASS=0 keeps the
-    // three kernels (A/B only).
+    // one rank: the single-pass form (colscan1.h).  W blocks per workgroup: 16 (one workgroup of 1024 threads per CU, 8
+    // super-blocks per column at 4097 rows) for columns of 96 blocks and more, 8 below (measured at 4097^2: C4 0.310 / C7 0.187 ms
+    // with 16, 0.358 / 0.229 with 8 -- the wait for a tile's last workgroup grows with the number of partners; at 2049^2
+    // 0.109 / 0.060 against 0.104 / 0.055, at 1025^2 equal); RPDE_COL_ONEPASS=0 keeps the three kernels (A/B only).
     const char* e1p = std::getenv("RPDE_COL_ONEPASS");   // read per engine, like the RPDE_*_LINE switches
     if (P == 1 && (!e1p || std::atoi(e1p) != 0)) {
       const int nb = (my_ + kColBlockRows - 1) / kColBlockRows;
       col1_tiles_ = (int)((ldx_ + kCol1Tile - 1) / kCol1Tile);
-      col1_W_ = 8;
+      col1_W_ = nb >= 96 ? 16 : 8;
       if (const char* ew = std::getenv("RPDE_COL1_W")) { const int w = std::atoi(ew); if (w == 8 || w == 16) col1_W_ = w; }   // A/B only
       while (col1_W_ < kCol1MaxW && (nb + col1_W_ - 1) / col1_W_ > kCol1MaxNSB) col1_W_ *= 2;
       col1_NSB_ = (nb + col1_W_ - 1) / col1_W_;
@@ -167,6 +168,9 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
       up(colcorr_a_, cc.a); up(colcorr_b_, cc.b);
     }
     if (col1_W_) {
+      const int dnsb = (ny_ + kDiff1Rows - 1) / kDiff1Rows;
+      coldtot_.alloc((size_t)col1_tiles_ * dnsb * 2 * kCol1Tile);
+      coldsync_.alloc(((size_t)col1_tiles_ * dnsb + 2) / 2 + 1);
       colagg_.alloc((size_t)3 * col1_tiles_ * col1_NSB_ * kCol1Agg * kCol1Tile);
       colsync_.alloc((col1_sync_ints(col1_tiles_) + 1) / 2 + 1);   // ints: ticket, arrivals, ready flags, error flag (colscan1.h)
     }
@@ -502,6 +506,16 @@ void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1, long long
 }
 void Navier2DEngine::run_col_diff(ColDiffArgs a) {
   const int P = comm_.size;
+  if (P == 1 && col1_W_ && (a.nout + kDiff1Rows - 1) / kDiff1Rows <= 64) {
+    ColDiff1Args A;
+    A.a = a;
+    A.NSB = (a.nout + kDiff1Rows - 1) / kDiff1Rows; A.tiles = (a.ncols + kCol1Tile - 1) / kCol1Tile;
+    RPDE_REQUIRE((size_t)A.tiles * A.NSB * 2 * kCol1Tile <= coldtot_.n, "coldiff1: buffer");
+    A.tot = coldtot_.p; A.sync = reinterpret_cast<int*>(coldsync_.p);
+    A.err = reinterpret_cast<int*>(colsync_.p) + col1_err_index(col1_tiles_);
+    launch_col_diff1(A, st_);
+    return;
+  }
   if (P == 1) { launch_col_diff(a, st_); return; }
   const int64_t cnt = 2 * ldx_;
   a.summ = colsumm_.p; a.gath = colgath_.p;
@@ -1135,8 +1149,9 @@ std::string Navier2DEngine::describe_step() const {
     const Launch& l = step_[i];
     const size_t j = group_end(i);
     char buf[512];
-    const bool onepass = l.type == Launch::kColHholtz && comm_.size == 1 && col1_W_ && l.ch1[0].F;
-    const int ndisp = l.type == Launch::kColHholtz ? (onepass ? 1 : 3) : (l.type == Launch::kColDiff ? 3 : 1);   // kernels behind the launch
+    const bool onepass = comm_.size == 1 && col1_W_ && ((l.type == Launch::kColHholtz && l.ch1[0].F) ||
+                                                         (l.type == Launch::kColDiff && (l.cd.nout + kDiff1Rows - 1) / kDiff1Rows <= 64));
+    const int ndisp = (l.type == Launch::kColHholtz || l.type == Launch::kColDiff) ? (onepass ? 1 : 3) : 1;   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x"};

@@ -202,6 +202,7 @@ class Navier2DEngine {
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
   DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
   DBuf colv1_, cols1_, colv2_, cols2_, coldv_, colds_;   // block carries of the column scans (colscan.h)
+  DBuf coldtot_, coldsync_;      // single-pass y-derivative (colscan1.h): super-block sums; ticket + flags
   DBuf colagg_, colsync_;        // single-pass column scans (colscan1.h): super-block aggregates; ticket / arrival counters + error flag
   int col1_W_ = 0, col1_NSB_ = 0, col1_tiles_ = 0;   // 0: the three-kernel form
   std::map<std::string, std::unique_ptr<Field>> fields_;

@@ -545,6 +545,8 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   double* loc = rpde_lds;                                // [W][7][64] block states (colhh1_chain works in place)
   double* stg = loc + W * kCol1Agg * kCol1Tile;          // [NSB][6][64] aggregates of the tile's super-blocks
   double* kapl = stg + A.NSB * kCol1Stg * kCol1Tile;     // [64]
+  double* tbl = kapl + kCol1Tile;                        // [W][14] transfers of this super-block's blocks
+  double* twl = tbl + W * kCol1TabPerBlock;              // [NSB][14] transfers of the tile's super-blocks
   __shared__ int tk;
   const ColHhArgs& a = A.a;
   const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -570,21 +572,38 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   const ColHhTabs& t = a.tab[f];
   const ColHh1Tabs& x = A.x[f];
   const int b = __builtin_amdgcn_readfirstlane(q * W + w), i = tile * kCol1Tile + lane;
-  const bool active = b < a.NB && i < a.ncols;
+  // the transfers the chains and the sweep multiply with: one vector load per thread, issued in front of the row loads and
+  // put into LDS behind the zero-inflow solve (a scalar load inside a chain step is a cold miss of the scalar cache in front
+  // of every step)
+  double tv = 0.0;
+  const bool tfetch = tid < (W + A.NSB) * kCol1TabPerBlock;
+  if (tfetch) {
+    const int e = tid - W * kCol1TabPerBlock;
+    const double* p = (e < 0) ? colhh1_block_tab(t, q * W + tid / kCol1TabPerBlock, a.NB, tid % kCol1TabPerBlock)
+                              : colhh1_super_tab(x, e / kCol1TabPerBlock, e % kCol1TabPerBlock);
+    tv = p ? *(const __attribute__((address_space(1))) double*)p : colhh1_ident_tab(tid % kCol1TabPerBlock);
+  }
+  // a wave whose block exists runs all 64 lanes (lanes behind the last column take the last column's data and store
+  // nothing): the lanes carry the row coefficients for each other (Col1TabLanes)
+  const bool rowsok = b < a.NB, store = rowsok && i < a.ncols;
+  const int ic = (i < a.ncols) ? i : a.ncols - 1;
   double r[kColBR + 4];
   ColLoc L;
 #pragma unroll
   for (int k = 0; k < kCol1Agg; ++k) L.v[k] = 0.0;
-  if (active) colhh1_local(a, f, b, i, r, L);
+  const Col1TabLanes tabs(t, x, b * kColBR, b * kColBR - a.shift[f], lane);   // (tables are padded: reads behind the last block are harmless)
+  if (rowsok) colhh1_local(a, f, b, ic, r, L, tabs);
+  if (tfetch) tbl[tid] = tv;                             // (twl follows tbl)
   RPDE_C1_MARK(2);
 #pragma unroll
   for (int k = 0; k < kCol1Agg; ++k) loc[(w * kCol1Agg + k) * kCol1Tile + lane] = L.v[k];
   __syncthreads();
+  RPDE_C1_MARK(3);
   double* ag = A.agg + col1_agg(A, f, tile, 0);
   double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
   if (w < 2) {                                           // wave p: the chains of parity p from zero inflow = this super-block's aggregate
     double so, T0, T1;
-    colhh1_chain<true>(loc, t, q * W, a.NB, W, w, lane, 0.0, 0.0, 0.0, so, T0, T1);
+    colhh1_chain<true>(loc, tbl, W, w, lane, 0.0, 0.0, 0.0, so, T0, T1);
     __hip_atomic_store(mine + w * kCol1Tile + lane, so, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + (2 + 2 * w) * kCol1Tile + lane, T0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + (3 + 2 * w) * kCol1Tile + lane, T1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
       kapl[lane] = kp;
     }
     __syncthreads();
-    if (w < 2) colhh1_sweep(stg, x, A.NSB, w, lane);      // ... the inflow states of every super-block ...
+    if (w < 2) colhh1_sweep(stg, twl, A.NSB, w, lane);    // ... the inflow states of every super-block ...
     __syncthreads();
     for (int k = w; k < rows; k += W) {                  // ... published in place of the aggregates
       const int qq = k / kCol1Stg;
@@ -652,17 +671,17 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   RPDE_C1_MARK(6);
   if (w < 2) {
     double so, T0, T1;
-    colhh1_chain<false>(loc, t, q * W, a.NB, W, w, lane, mystg[w * kCol1Tile + lane], mystg[(2 + 2 * w) * kCol1Tile + lane],
+    colhh1_chain<false>(loc, tbl, W, w, lane, mystg[w * kCol1Tile + lane], mystg[(2 + 2 * w) * kCol1Tile + lane],
                         mystg[(3 + 2 * w) * kCol1Tile + lane], so, T0, T1);
   }
   RPDE_C1_MARK(7);
   __syncthreads();
   RPDE_C1_MARK(8);
-  if (active) {
+  if (rowsok) {
     double in6[kCol1Inf];
 #pragma unroll
     for (int k = 0; k < kCol1Inf; ++k) in6[k] = loc[(w * kCol1Agg + k) * kCol1Tile + lane];
-    colhh1_final(a, x, f, b, i, r, in6, kapl[lane]);
+    colhh1_final(a, f, b, i, r, in6, kapl[lane], tabs, store);
   }
   RPDE_C1_MARK(9);
   if (TRACE && tid == 0) { trc[1] = (long long)wall_clock64(); trc[2] = nm; }
@@ -692,6 +711,65 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
   else if (A.W == 16) go(col_hholtz1_kernel<16>, 16);
   else if (A.W == 8) go(col_hholtz1_kernel<8>, 8);
   else fail("colhh1: 8 or 16 blocks per workgroup");
+  RPDE_HIP(hipGetLastError());
+}
+// single-pass y-derivative (colscan1.h)
+__global__ __launch_bounds__(kDiff1W * 64, 8) void col_diff1_kernel(const ColDiff1Args A) {   // eight waves per SIMD: 64 VGPRs
+  __shared__ double lt[kDiff1W][2][kCol1Tile];          // the blocks' sums
+  __shared__ double sup[2][kCol1Tile];                  // the sums of the super-blocks above
+  __shared__ int tk;
+  const ColDiffArgs& a = A.a;
+  const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) tk = atomicAdd(&A.sync[0], 1);
+  __syncthreads();
+  const int ticket = __builtin_amdgcn_readfirstlane(tk);
+  const int tile = __builtin_amdgcn_readfirstlane(ticket / A.NSB);
+  const int q = __builtin_amdgcn_readfirstlane(A.NSB - 1 - (ticket - tile * A.NSB));   // from the top
+  if (tile >= A.tiles) return;
+  const int b = q * kDiff1W + w, j0 = b * kDiff1BR, i = tile * kCol1Tile + lane;
+  const bool rowsok = j0 < a.nout, store = rowsok && i < a.ncols;
+  const int ic = (i < a.ncols) ? i : a.ncols - 1;
+  // the stencil coefficients of the block's rows, one per lane (row u: lane u), read back with v_readlane
+  double lowv = 0.0;
+  if (a.low && lane < kDiff1BR) lowv = ((const __attribute__((address_space(1))) double*)a.low)[(j0 - 1 + lane > 0) ? j0 - 1 + lane : 0];
+  double d[kDiff1BR], tot[2] = {0.0, 0.0};
+  if (rowsok) coldiff1_local(a, j0, ic, d, tot, [&](int u) { return col1_lane(lowv, u); });
+  lt[w][0][lane] = tot[0]; lt[w][1][lane] = tot[1];
+  __syncthreads();
+  double in[2] = {0.0, 0.0};
+  for (int u = kDiff1W - 1; u > w; --u) { in[0] += lt[u][0][lane]; in[1] += lt[u][1][lane]; }
+  if (w == 0) {
+    double* mine = A.tot + coldiff1_tot(A, tile, q);
+    __hip_atomic_store(mine + lane, in[0] + tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + kCol1Tile + lane, in[1] + tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int* flags = A.sync + 1 + tile * A.NSB;
+    if (lane == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // lane l waits for super-block q + 1 + l
+    const int qw = q + 1 + lane;
+    int it = 0;
+    while (__builtin_amdgcn_ballot_w64(qw < A.NSB && __hip_atomic_load(flags + (qw < A.NSB ? qw : q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) != 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++it > (1 << 22)) { if (lane == 0) *A.err = 1; break; }
+    }
+    double s0 = 0.0, s1 = 0.0;
+    for (int u = q + 1; u < A.NSB; ++u) {
+      const double* th = A.tot + coldiff1_tot(A, tile, u);
+      s0 += __hip_atomic_load(th + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s1 += __hip_atomic_load(th + kCol1Tile + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sup[0][lane] = s0; sup[1][lane] = s1;
+  }
+  __syncthreads();
+  in[0] += sup[0][lane]; in[1] += sup[1][lane];
+  if (store) coldiff1_store(a, j0, i, d, in);
+}
+void launch_col_diff1(const ColDiff1Args& A, Stream& st) {
+  const ColDiffArgs& a = A.a;
+  if (a.ncols <= 0 || a.nout <= 0) return;
+  RPDE_REQUIRE(A.NSB * kDiff1Rows >= a.nout && A.NSB <= 64 && a.row0 == 0 && a.nranks <= 1, "coldiff1: one rank, at most 64 super-blocks");
+  RPDE_HIP(hipMemsetAsync(A.sync, 0, sizeof(int) * (size_t)(1 + A.tiles * A.NSB), st.s));
+  hipLaunchKernelGGL(col_diff1_kernel, dim3(A.tiles * A.NSB), dim3(kDiff1W * 64), 0, st.s, A);
   RPDE_HIP(hipGetLastError());
 }
 template <int PASS>
@@ -1244,6 +1322,45 @@ void launch_copy2d(const double* in, long ldi, double* out, long ldo, int rows, 
   for (int r = 0; r < rows; ++r)
     for (int cc = 0; cc < cols; ++cc) out[(long)r * ldo + cc] = in[(long)r * ldi + cc];
 }
+void launch_col_diff1(const ColDiff1Args& A, Stream&) {
+  // the workgroups of a column tile from the top super-block down (the ticket order of the device)
+  const ColDiffArgs& a = A.a;
+  if (a.ncols <= 0 || a.nout <= 0) return;
+  RPDE_REQUIRE(A.NSB * kDiff1Rows >= a.nout && A.NSB <= 64 && a.row0 == 0 && a.nranks <= 1, "coldiff1: one rank, at most 64 super-blocks");
+  std::vector<double> lt((size_t)kDiff1W * 2 * kCol1Tile), ds((size_t)kDiff1W * kCol1Tile * kDiff1BR);
+  for (int tile = 0; tile < A.tiles; ++tile)
+    for (int q = A.NSB - 1; q >= 0; --q) {
+      for (int w = 0; w < kDiff1W; ++w)
+        for (int lane = 0; lane < kCol1Tile; ++lane) {
+          const int j0 = (q * kDiff1W + w) * kDiff1BR, i = tile * kCol1Tile + lane;
+          double d[kDiff1BR] = {}, tot[2] = {0.0, 0.0};
+          if (j0 < a.nout && i < a.ncols) coldiff1_local(a, j0, i, d, tot, [&](int u) { return a.low[(j0 - 1 + u > 0) ? j0 - 1 + u : 0]; });
+          lt[((size_t)w * 2 + 0) * kCol1Tile + lane] = tot[0]; lt[((size_t)w * 2 + 1) * kCol1Tile + lane] = tot[1];
+          for (int u = 0; u < kDiff1BR; ++u) ds[((size_t)w * kCol1Tile + lane) * kDiff1BR + u] = d[u];
+        }
+      double* mine = A.tot + coldiff1_tot(A, tile, q);
+      for (int lane = 0; lane < kCol1Tile; ++lane)
+        for (int par = 0; par < 2; ++par) {
+          double t = 0.0;
+          for (int w = kDiff1W - 1; w >= 0; --w) t += lt[((size_t)w * 2 + par) * kCol1Tile + lane];   // (the device adds wave 0's own sum last as well)
+          mine[par * kCol1Tile + lane] = t;
+        }
+      for (int w = 0; w < kDiff1W; ++w)
+        for (int lane = 0; lane < kCol1Tile; ++lane) {
+          const int j0 = (q * kDiff1W + w) * kDiff1BR, i = tile * kCol1Tile + lane;
+          if (!(j0 < a.nout && i < a.ncols)) continue;
+          double in[2] = {0.0, 0.0}, sup[2] = {0.0, 0.0}, d[kDiff1BR];
+          for (int u = kDiff1W - 1; u > w; --u) { in[0] += lt[((size_t)u * 2 + 0) * kCol1Tile + lane]; in[1] += lt[((size_t)u * 2 + 1) * kCol1Tile + lane]; }
+          for (int u = q + 1; u < A.NSB; ++u) {
+            const double* th = A.tot + coldiff1_tot(A, tile, u);
+            sup[0] += th[lane]; sup[1] += th[kCol1Tile + lane];
+          }
+          in[0] += sup[0]; in[1] += sup[1];
+          for (int u = 0; u < kDiff1BR; ++u) d[u] = ds[((size_t)w * kCol1Tile + lane) * kDiff1BR + u];
+          coldiff1_store(a, j0, i, d, in);
+        }
+    }
+}
 void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
   // the same per-thread functions and chains, the workgroups of a column tile one after the other: all their aggregates
   // first (what the arrival counter waits for on the device), then the inflows and the rows
@@ -1251,18 +1368,21 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0 || a.NB <= 0) return;
   RPDE_REQUIRE(A.NSB <= kCol1MaxNSB && A.W * A.NSB >= a.NB, "colhh1: super-block partition");
   const int W = A.W;
-  std::vector<double> loc((size_t)A.NSB * W * kCol1Agg * kCol1Tile), stg((size_t)A.NSB * kCol1Stg * kCol1Tile);
+  std::vector<double> loc((size_t)A.NSB * W * kCol1Agg * kCol1Tile), stg((size_t)A.NSB * kCol1Stg * kCol1Tile), tbl((size_t)A.NSB * W * kCol1TabPerBlock),
+      twl((size_t)A.NSB * kCol1TabPerBlock);
   double r[kColBR + 4];
   for (int f = 0; f < a.nf; ++f)
     for (int tile = 0; tile < A.tiles; ++tile) {
       double* ag = A.agg + col1_agg(A, f, tile, 0);
+      for (int e = 0; e < A.NSB * W * kCol1TabPerBlock; ++e) { const double* p = colhh1_block_tab(a.tab[f], e / kCol1TabPerBlock, a.NB, e % kCol1TabPerBlock); tbl[e] = p ? *p : colhh1_ident_tab(e % kCol1TabPerBlock); }
+      for (int e = 0; e < A.NSB * kCol1TabPerBlock; ++e) twl[e] = *colhh1_super_tab(A.x[f], e / kCol1TabPerBlock, e % kCol1TabPerBlock);
       for (int q = 0; q < A.NSB; ++q) {
         double* lq = loc.data() + (size_t)q * W * kCol1Agg * kCol1Tile;
         for (int w = 0; w < W; ++w)
           for (int lane = 0; lane < kCol1Tile; ++lane) {
             ColLoc L{};
             const int b = q * W + w, i = tile * kCol1Tile + lane;
-            if (b < a.NB && i < a.ncols) colhh1_local(a, f, b, i, r, L);
+            if (b < a.NB && i < a.ncols) colhh1_local(a, f, b, i, r, L, Col1TabDirect(a.tab[f], A.x[f], b * kColBR, b * kColBR - a.shift[f]));
             for (int k = 0; k < kCol1Agg; ++k) lq[(w * kCol1Agg + k) * kCol1Tile + lane] = L.v[k];
           }
         double* mine = ag + (long)q * (kCol1Agg * kCol1Tile);
@@ -1272,7 +1392,7 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
           mine[6 * kCol1Tile + lane] = d;
           for (int par = 0; par < 2; ++par) {
             double so, T0, T1;
-            colhh1_chain<true>(lq, a.tab[f], q * W, a.NB, W, par, lane, 0.0, 0.0, 0.0, so, T0, T1);
+            colhh1_chain<true>(lq, tbl.data() + (size_t)q * W * kCol1TabPerBlock, W, par, lane, 0.0, 0.0, 0.0, so, T0, T1);
             mine[par * kCol1Tile + lane] = so; mine[(2 + 2 * par) * kCol1Tile + lane] = T0; mine[(3 + 2 * par) * kCol1Tile + lane] = T1;
           }
         }
@@ -1283,7 +1403,7 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
         for (int k = 0; k < kCol1Stg; ++k)
           for (int lane = 0; lane < kCol1Tile; ++lane) stg[((size_t)u * kCol1Stg + k) * kCol1Tile + lane] = ag[((long)u * kCol1Agg + k) * kCol1Tile + lane];
       for (int lane = 0; lane < kCol1Tile; ++lane) {
-        for (int par = 0; par < 2; ++par) colhh1_sweep(stg.data(), A.x[f], A.NSB, par, lane);
+        for (int par = 0; par < 2; ++par) colhh1_sweep(stg.data(), twl.data(), A.NSB, par, lane);
         if (a.tab[f].w) for (int u = 0; u < A.NSB; ++u) kap[lane] += ag[((long)u * kCol1Agg + 6) * kCol1Tile + lane];
       }
       for (int u = 0; u < A.NSB; ++u)
@@ -1296,7 +1416,7 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
         for (int lane = 0; lane < kCol1Tile; ++lane)
           for (int par = 0; par < 2; ++par) {
             double so, T0, T1;
-            colhh1_chain<false>(lq, a.tab[f], q * W, a.NB, W, par, lane, mine[par * kCol1Tile + lane], mine[(2 + 2 * par) * kCol1Tile + lane],
+            colhh1_chain<false>(lq, tbl.data() + (size_t)q * W * kCol1TabPerBlock, W, par, lane, mine[par * kCol1Tile + lane], mine[(2 + 2 * par) * kCol1Tile + lane],
                                 mine[(3 + 2 * par) * kCol1Tile + lane], so, T0, T1);
           }
         for (int w = 0; w < W; ++w)
@@ -1304,10 +1424,11 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
             const int b = q * W + w, i = tile * kCol1Tile + lane;
             if (!(b < a.NB && i < a.ncols)) continue;
             ColLoc L{};
-            colhh1_local(a, f, b, i, r, L);     // the rows again (registers on the device)
+            const Col1TabDirect tabs(a.tab[f], A.x[f], b * kColBR, b * kColBR - a.shift[f]);
+            colhh1_local(a, f, b, i, r, L, tabs);     // the rows again (registers on the device)
             double in6[kCol1Inf];
             for (int k = 0; k < kCol1Inf; ++k) in6[k] = lq[(w * kCol1Agg + k) * kCol1Tile + lane];
-            colhh1_final(a, A.x[f], f, b, i, r, in6, ag[6 * kCol1Tile + lane]);
+            colhh1_final(a, f, b, i, r, in6, ag[6 * kCol1Tile + lane], tabs, true);
           }
       }
     }

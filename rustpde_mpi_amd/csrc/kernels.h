@@ -80,6 +80,7 @@ void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st);
 void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st);
 // single-pass form (colscan1.h): one kernel behind a memset node that clears the ticket / arrival counters
 void launch_col_hholtz1(const ColHh1Args& a, Stream& st);
+void launch_col_diff1(const ColDiff1Args& a, Stream& st);   // colscan1.h: the y-derivative in one pass (one rank)
 inline void launch_col_hholtz(const ColHhArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_hholtz_phase(a, ph, st); }   // one rank
 inline void launch_col_diff(const ColDiffArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_diff_phase(a, ph, st); }
 
