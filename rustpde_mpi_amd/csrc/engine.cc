@@ -707,6 +707,29 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   return true;
 }
 
+bool Navier2DEngine::add_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, const char* tag) {
+  // periodic S1: c2r of a spectral state line and of its x-derivative in one launch (rfft_line.h)
+  if (!whole_line_on("RPDE_S1_LINE") || !whole_line_len(a0.N) || !rfft_line_ok(a0) || !rfft_line_ok(a1)) return false;
+  Launch l;
+  l.type = Launch::kRfftPair;
+  l.rf = a0; l.rf2 = a1;
+  l.tag = tag;
+  l.bytes = 8.0 * ((double)(a0.N + 2) + 2.0 * a0.N) * a0.nlines;
+  step_.push_back(l);
+  return true;
+}
+bool Navier2DEngine::add_four_rhs(const FourRhsArgs& a, const char* tag) {
+  // periodic S3: forward real FFT, 2/3 rule, right-hand side, diagonal Helmholtz factor in x (rfft_line.h)
+  if (!whole_line_on("RPDE_S3_LINE") || !whole_line_len(a.f.N) || !four_rhs_ok(a)) return false;
+  Launch l;
+  l.type = Launch::kFourRhs;
+  l.fr = a;
+  l.tag = tag;
+  const double nc = a.f.N + 2;   // doubles of a spectral line
+  l.bytes = 8.0 * ((double)a.f.N + nc * (a.which == 1 ? 7.0 : (a.which == 0 ? 4.0 : 4.0))) * a.f.nlines;   // conv line; state rows j, j-2 (+ p | gy, temp rows j, j-2, tbc | tbc2); out
+  step_.push_back(l);
+  return true;
+}
 bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   // a whole convection term per y-line (dct_line.h conv_line: three transforms per line in registers)
   if (!whole_line_on("RPDE_CONV_LINE") || !whole_line_len(c.N) || !conv_line_ok(c)) return false;
@@ -982,6 +1005,8 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
     case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
     case Launch::kDivLine: RPDE_REQUIRE(launch_div_line(l.dvl, st_), "internal: div line shape"); break;
+    case Launch::kRfftPair: RPDE_REQUIRE(launch_rfft_pair(l.rf, l.rf2, st_), "internal: rfft pair shape"); break;
+    case Launch::kFourRhs: RPDE_REQUIRE(launch_four_rhs(l.fr, st_), "internal: fourier rhs shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
     case Launch::kPdmaCols: launch_pdma_cols(l.pc, st_); break;
     case Launch::kPdmaLines: launch_pdma_lines(l.pl, st_); break;
@@ -1154,7 +1179,8 @@ std::string Navier2DEngine::describe_step() const {
     const int ndisp = (l.type == Launch::kColHholtz || l.type == Launch::kColDiff) ? (onepass ? 1 : 3) : 1;   // kernels behind the launch
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
-                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x"};
+                                        "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x",
+                                        "whole-line transform pair", "whole-line rhs + hholtz-x"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -2021,7 +2047,13 @@ void Navier2DEngine::build_periodic() {
   // ---- S1: spectral x-lines -> physical x (value and x-derivative)
   struct { DBuf* st; DBuf* w0; DBuf* w1; int rows; } s1[3] = {
       {&U_, &Y_[0], &Y_[1], my}, {&V_, &Y_[2], &Y_[3], my}, {hc ? &TO_ : &T_, &Y_[4], &Y_[5], tr}};
-  for (auto& f : s1)
+  for (auto& f : s1) {
+    {   // value and x-derivative of a line in one launch (rfft_line.h) where the kernel covers the line length
+      RfftLineArgs v{yx(*f.st), ldx, yx(*f.w0), ldx, ylines(f.rows), nx, xF.tw.p, xF.tw2.p, 1.0};
+      RfftLineArgs d = v;
+      d.out = yx(*f.w1); d.cik = 1; d.kscale = 1.0 / sx_;
+      if (xF.fft_n * 2 == nx && add_rfft_pair(v, d, "S1 x: state -> phys-x + d/dx")) continue;
+    }
     for (int deriv = 0; deriv < 2; ++deriv) {
       ProgramBuilder pb = ypb(1, f.rows);
       pb.set_fft(xF);
@@ -2031,6 +2063,7 @@ void Navier2DEngine::build_periodic() {
       pb.store(0, pb.arr(yx(*(deriv ? f.w1 : f.w0)), ldx), nx);
       add_line(pb, deriv ? "S1 x: state -> d/dx, phys-x" : "S1 x: state -> phys-x");
     }
+  }
   for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, k >= 4 ? tr : my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
@@ -2082,6 +2115,22 @@ void Navier2DEngine::build_periodic() {
   auto rhs = [&](int which, const char* tag) {
     DBuf& state = which == 0 ? U_ : which == 1 ? V_ : T_;
     HholtzAdiOp& hh = which == 2 ? *hh_temp_ : *hh_vel_;
+    {   // the whole-line kernel (rfft_line.h four_rhs_line) where it covers the line length
+      FourRhsArgs a{};
+      a.f = RfftLineArgs{yx(Y_[which]), ldx, yx(Y_[3 + which]), ldx, ylines(my), nx, xF.tw.p, xF.tw2.p, 1.0};
+      a.which = which; a.cut = cut_x; a.dt = dt; a.line0 = yb_; a.rows = my; a.ld = ldx;
+      const bool tortho = hc && which == 2;             // "hc": orthonormal-y rows of the step's first launch
+      a.state = tortho ? yx(TO_) : yx(state); a.low = tortho ? nullptr : yD.low.p;
+      if (which == 0) { a.p = yx(P_); a.pk = -dt / sx_; }
+      if (which == 1) {
+        a.gy = yx(GY_);
+        a.tsrc = hc ? yx(TO_) : yx(T_); a.tlow = hc ? nullptr : yD.low.p;
+        a.tbc = yx(TBC_); a.ctbc = dt;
+      }
+      if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; }
+      a.diag = hh.diag0.p;
+      if (xF.fft_n * 2 == nx && add_four_rhs(a, tag)) return;
+    }
     // one LDS slot (the 16384-point configuration has no second one): every further term is
     // accumulated straight from HBM
     ProgramBuilder pb = ypb(1, my);

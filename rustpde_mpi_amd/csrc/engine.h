@@ -210,7 +210,9 @@ class Navier2DEngine {
   // the step as a list of launches
   struct Launch {
     enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine,
-                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine } type;
+                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine, kRfftPair, kFourRhs } type;
+    RfftLineArgs rf{}, rf2{};    // kRfftPair (periodic S1: value and x-derivative of a spectral line, rfft_line.h)
+    FourRhsArgs fr{};            // kFourRhs  (periodic S3)
     DivLineArgs dvl{};           // kDivLine
     PdmaLinesArgs pl{};          // kPdmaLines ("hc", pencil-sharded: Helmholtz-y of the temperature on the y-lines of an x-pencil)
     CorrLineArgs crl{};          // kCorrLine
@@ -268,6 +270,8 @@ class Navier2DEngine {
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
+  bool add_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, const char* tag);
+  bool add_four_rhs(const FourRhsArgs& a, const char* tag);
   bool add_conv_line(const ConvLineArgs& c, const char* tag);
   bool add_rhs_line(RhsLineArgs a, int which, const char* tag);   // S3 as one kernel per field (rhs_line.h)
   bool add_corr_line(CorrLineArgs a, const char* tag);            // S8 as one kernel (corr_line.h)

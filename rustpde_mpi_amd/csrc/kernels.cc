@@ -833,6 +833,24 @@ __global__ __launch_bounds__(N / 8, 4) void hdct_pair_kernel(const DctLineArgs a
   if (line >= a0.nlines) return;
   hdct_pair_line<N>(line, rpde_lds, a0, a1);
 }
+// rfft_line.h: S1 and S3 of the periodic step
+template <int N>
+__global__ __launch_bounds__(N / 8, 4) void rfft_pair_kernel(const RfftLineArgs a0, const RfftLineArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  rfft_pair_line<N>(line, rpde_lds, a0, a1);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void four_rhs_kernel(const FourRhsArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.f.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  four_rhs_line<N>(blk, a);
+}
 template <int N, int WPC>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
@@ -888,8 +906,8 @@ __global__ __launch_bounds__(N / 8, 4) void hdct_pair_batch_kernel(const Dct2Bat
   if (line >= a0.nlines) return;
   hdct_pair_line<N>(line, rpde_lds, a0, a1);
 }
-template <int N>
-__global__ __launch_bounds__(N / 16, 1) void hconv_line_batch_kernel(const ConvBatch b) {
+template <int N, int WPC>
+__global__ __launch_bounds__(N / 16, WPC) void hconv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
   RPDE_BATCH_LINE(c.nlines);
   hconv_line<N>(blk, c);
@@ -931,7 +949,9 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
     else hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
   } else if (b.kind == 2) {
     ConvBatch k; for (int i = 0; i < b.n; ++i) k.c[i] = b.c[i];
-    hipLaunchKernelGGL(hconv_line_batch_kernel<N>, grid, block, 0, st.s, k);
+    // one wave per SIMD (416 VGPRs): budgets of two / three waves spill 159 / 274 registers and measured 0.110 / 0.156 ms
+    // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10)
+    hipLaunchKernelGGL((hconv_line_batch_kernel<N, 1>), grid, block, 0, st.s, k);
   } else {
     RhsBatch k; for (int i = 0; i < b.n; ++i) k.r[i] = b.r[i];
     hipLaunchKernelGGL(rhs_line_batch_kernel<N>, grid, block, 0, st.s, k);
@@ -1026,6 +1046,34 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   }
   // 4097-point lines: the full-length core (168 VGPRs, three workgroups per CU); on the half-length core the term spills
   hipLaunchKernelGGL(conv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+bool launch_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, Stream& st) {
+  if (a0.N != a1.N || a0.nlines != a1.nlines || !rfft_line_ok(a0) || !rfft_line_ok(a1) || (a0.N != 4096 && a0.N != 1024)) return false;
+  if (a0.nlines <= 0) return true;
+  const dim3 grid(8 * ((a0.nlines + 7) / 8));
+  const size_t bytes = 2 * sizeof(double) * hdct_lds_doubles(a0.N);
+  if (a0.N == 1024) hipLaunchKernelGGL(rfft_pair_kernel<1024>, grid, dim3(128), bytes, st.s, a0, a1);
+  else {
+    static std::atomic<int> configured[32];               // dynamic-LDS permission above 64 KB, per device
+    int dev = 0;
+    RPDE_HIP(hipGetDevice(&dev));
+    if (!configured[dev & 31].load(std::memory_order_acquire)) {
+      RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfft_pair_kernel<4096>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      configured[dev & 31].store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(rfft_pair_kernel<4096>, grid, dim3(512), bytes, st.s, a0, a1);
+  }
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+bool launch_four_rhs(const FourRhsArgs& a, Stream& st) {
+  if (!four_rhs_ok(a) || (a.f.N != 4096 && a.f.N != 1024)) return false;
+  if (a.f.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.f.nlines + 7) / 8));
+  if (a.f.N == 1024) hipLaunchKernelGGL(four_rhs_kernel<1024>, grid, dim3(64), 0, st.s, a);
+  else hipLaunchKernelGGL(four_rhs_kernel<4096>, grid, dim3(256), 0, st.s, a);
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1494,6 +1542,31 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
     Blk blk{line, 0, c.N / 16, base};
     if (c.N == 1024) hconv_line<1024>(blk, c);
     else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);   // the device's choice of core per length
+  }
+  return true;
+}
+bool launch_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, Stream&) {
+  if (a0.N != a1.N || a0.nlines != a1.nlines || !rfft_line_ok(a0) || !rfft_line_ok(a1)) return false;
+  std::vector<double> lds(2 * hdct_lds_doubles(a0.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a0.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    if (a0.N == 4096) rfft_pair_line<4096>(line, base, a0, a1);
+    else if (a0.N == 1024) rfft_pair_line<1024>(line, base, a0, a1);
+    else rfft_pair_line<256>(line, base, a0, a1);
+  }
+  return true;
+}
+bool launch_four_rhs(const FourRhsArgs& a, Stream&) {
+  if (!four_rhs_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.f.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.f.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.f.N / 16, base};
+    if (a.f.N == 4096) four_rhs_line<4096>(blk, a);
+    else if (a.f.N == 1024) four_rhs_line<1024>(blk, a);
+    else four_rhs_line<256>(blk, a);
   }
   return true;
 }

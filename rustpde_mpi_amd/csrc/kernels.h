@@ -2,6 +2,7 @@
 #pragma once
 #include "colscan.h"
 #include "colscan1.h"
+#include "rfft_line.h"
 #include "line_vm.h"
 #include "pdma.h"
 #include "rhs_line.h"
@@ -91,6 +92,9 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace = nullpt
 // two transforms of the same input lines in one launch (value and x-derivative of a state line, S1 of the step):
 // the second read of a line comes from L2
 bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st);
+// rfft_line.h: the Fourier lines of the periodic step.  false: shape not covered (the caller runs the line programs)
+bool launch_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, Stream& st);   // S1: value and x-derivative of a spectral line
+bool launch_four_rhs(const FourRhsArgs& a, Stream& st);                               // S3: forward FFT + right-hand side + diagonal factor
 // Small grids (lines of 1025 points, one wave per line): a launch of one field's lines leaves most of the chip idle and
 // costs a kernel's latency; the launches of the three fields of a stage go out as ONE launch (blockIdx.y = field).
 constexpr int kLineBatch = 3;

@@ -72,6 +72,8 @@ struct Blk {          // one workgroup
 #define RPDE_MARK(blk, id) ((void)0)
 #define RPDE_TLS(blk, type, name, K) std::vector<type> name##_st((size_t)(blk).T * (K)); const int name##_K = (K)
 #define RPDE_T(name) (&name##_st[(size_t)tid * name##_K])
+#define RPDE_TLS_PTR(name) (name##_st.data())          // a thread-local array handed to a function ...
+#define RPDE_TPK(base, K) ((base) + (size_t)tid * (K))   // ... and the current thread's part of it inside a phase of that function
 #else
 #define RPDE_HD __host__ __device__
 #define RPDE_DEV __device__ __forceinline__
@@ -107,6 +109,8 @@ __device__ __forceinline__ int rpde_tid() {
 #define RPDE_SYNC(blk) do { __syncthreads(); RPDE_MARK(blk, -1); } while (0)
 #define RPDE_TLS(blk, type, name, K) type name[K]
 #define RPDE_T(name) name
+#define RPDE_TLS_PTR(name) (name)
+#define RPDE_TPK(base, K) (base)
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
     for case in cases:
         periodic, nx, ny, ra, dt, steps, aspect = case[:7]
         bc = case[7] if len(case) > 7 else "rbc"       # "hc": horizontal convection (three-term temperature base along y)
+        vs_single = len(case) > 8 and case[8] == "single"   # compare with the one-rank engine (same setup code) instead of the oracle
         ctor = "new_periodic" if periodic else "new_confined"
         nav = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, library=lib, comm=comm)
         nav.set_velocity(0.2, 1.0, 1.0)
@@ -41,7 +42,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         st = R.Statistics.new(nav, 1.0, 1.0)   # collective too: every rank gathers, reduces and keeps the same statistics
         st.update()
         got["stat_temp"], got["stat_nusselt"] = st.t_avg.vhat, st.nusselt.vhat
-        if rank == 0 and nx * ny > 1500 * 1500:
+        if rank == 0 and (nx * ny > 1500 * 1500 or vs_single):
             # big grids: compare with the single-device engine instead of the (slow) oracle
             one = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
             one.set_velocity(0.2, 1.0, 1.0)

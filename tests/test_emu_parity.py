@@ -107,6 +107,26 @@ def test_column_scans_in_one_pass(emu_lib, monkeypatch, periodic, nx, ny):
         assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-12), k
 
 
+@pytest.mark.parametrize("nx,ny,bc", [(256, 17, "rbc"), (256, 33, "rbc"), (1024, 17, "rbc"), (256, 33, "hc")])
+def test_periodic_step_fourier_lines_through_the_whole_line_kernels(emu_lib, monkeypatch, nx, ny, bc):
+    """S1 (spectral line -> physical values and x-derivative, two inverse real FFTs per workgroup) and S3 (forward real FFT,
+    2/3 rule, right-hand side, diagonal Helmholtz factor) of the periodic step as whole-line kernels (csrc/rfft_line.h)
+    against the oracle, and against the line programs of the stages (RPDE_S1_LINE=0 / RPDE_S3_LINE=0: the A/B switches)."""
+    K.check_step_parity(emu_lib, True, nx, ny, 1e5, 0.01, 3, check_at=[1, 3], bc=bc)
+    nav, _ = K.make_pair(emu_lib, True, nx, ny, 1e5, 1.0, 0.01, 1.0, bc=bc)
+    kinds = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert kinds["S1 x: state -> phys-x + d/dx"].startswith("whole-line transform pair"), kinds
+    assert all(kinds[f"S3 x: rhs + hholtz-x {f}"].startswith("whole-line rhs") for f in ("velx", "vely", "temp")), kinds
+    nav.update(3)
+    monkeypatch.setenv("RPDE_S1_LINE", "0")
+    monkeypatch.setenv("RPDE_S3_LINE", "0")
+    ref, _ = K.make_pair(emu_lib, True, nx, ny, 1e5, 1.0, 0.01, 1.0, bc=bc)
+    assert _has_line_program(ref, "S1 x") and _has_line_program(ref, "S3 x")
+    ref.update(3)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-11), k
+
+
 @pytest.mark.parametrize("nx,ny,eig", [(257, 17, "parity"), (257, 33, "parity"), (1025, 17, "shared")])
 def test_confined_step_s5_through_the_whole_line_kernel(emu_lib, monkeypatch, nx, ny, eig):
     """Divergence + x preconditioner of the Poisson solve (csrc/div_line.h) against the oracle, and against the line program
