@@ -533,6 +533,12 @@ class Statistics:
     def __init__(self, navier, save_stat, write_stat):
         self._nav = navier
         self.save_stat, self.write_stat = float(save_stat), float(write_stat)
+        # the engine keeps ONE set of statistics fields (the reference's Statistics is a value of its own,
+        # statistics.rs:11-108): a second Statistics for the same solver would reset and alias the first one's data
+        if getattr(navier, "_statistics_owner", None) is not None and navier._statistics_owner() is not None:
+            raise RpdeError("this Navier2D already has a Statistics object; the engine keeps one set of statistics per solver")
+        import weakref
+        navier._statistics_owner = weakref.ref(self)
         navier._lib.call("rpde_navier2d_statistics_enable", navier._h, self.save_stat, self.write_stat)
         # Statistics::new does not touch the solver: the hook is `navier.statistics = Some(..)` (the setter above)
         navier._lib.call("rpde_navier2d_statistics_attach", navier._h, 0)

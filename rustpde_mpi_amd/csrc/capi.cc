@@ -731,8 +731,7 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
       for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
       in.upload(hbuf);
     }
-    int nslots = 4;
-    if (const char* e = std::getenv("RPDE_MB_SLOTS")) nslots = std::atoi(e);
+    const int nslots = 4;
     ProgramBuilder pb(nslots, ax.slot_len, nlines, 1);
     pb.set_fft(ax);
     const int ai = pb.arr(in.p, ld), ao = pb.arr(out.p, ld);

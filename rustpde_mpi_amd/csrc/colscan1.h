@@ -91,10 +91,7 @@ struct Col1TabDirect {
   double h(int u) const { return h_[j0 + u]; }
 };
 #ifndef RPDE_EMU
-__device__ __forceinline__ double col1_lane(double v, int l) {   // the value lane l holds, as a wave-uniform number
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
+__device__ __forceinline__ double col1_lane(double v, int l) { return rpde_lane_f64(v, l); }   // the value lane l holds, wave-uniform
 struct Col1TabLanes {
   double a, b, c, d, e, g, k;          // lanes 0 .. 31 | 32 .. 63:  t0 | t1,  t2 | q1,  p2 | q2,  r2 | -,  w (36 lanes),  F | H0,  H1 | h
   __device__ __forceinline__ Col1TabLanes(const ColHhTabs& t, const ColHh1Tabs& x, int j0, int jr, int lane) {

@@ -409,8 +409,7 @@ void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int c
                                     bool to_xy, bool spec) {
   const int P = comm_.size, me = comm_.rank;
   if (P == 1) {
-    static const bool batch = [] { const char* e = std::getenv("RPDE_TP_BATCH"); return !e || std::atoi(e) != 0; }();
-    bool same = batch && xs.size() > 1 && xs.size() <= (size_t)kMaxTransposeBatch;
+    bool same = xs.size() > 1 && xs.size() <= (size_t)kMaxTransposeBatch;
     for (const Xfer& x : xs) same = same && x.ldi == xs[0].ldi && x.ldo == xs[0].ldo;
     if (same) {   // one launch for all arrays of the batch
       TransposeBatch b{};
@@ -1015,25 +1014,6 @@ void Navier2DEngine::run_launch(const Launch& l) {
 
 void Navier2DEngine::update(int nsteps) {
   RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
-#ifndef RPDE_EMU
-  {
-    // diagnostics (tools/fault_hunt_r04c.sh): RPDE_PROBE_ALLOC=1 RPDE_LOG_ALLOC=1 -- before the first step, one shader read of
-    // every live buffer, each named and waited for: is a buffer dead BEFORE the step touches it?
-    static const bool probe = [] { const char* e = std::getenv("RPDE_PROBE_ALLOC"); return e && std::atoi(e) != 0; }();
-    if (probe && !probed_) {
-      probed_ = true;
-      std::vector<std::pair<void*, size_t>> v;
-      { std::lock_guard<std::mutex> lk(DevLive::get().mu); v.assign(DevLive::get().live.begin(), DevLive::get().live.end()); }
-      for (auto& a : v) {
-        if (a.second < 8) continue;
-        fprintf(stderr, "[probe] %p %zu ...", a.first, a.second); fflush(stderr);
-        launch_probe(static_cast<const double*>(a.first), (long)(a.second / 8), colkap_.p, st_);
-        (void)hipStreamSynchronize(st_.s);
-        fprintf(stderr, " ok\n"); fflush(stderr);
-      }
-    }
-  }
-#endif
   if (nsteps > 0) dirty_ = false;
   if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
 #ifndef RPDE_EMU
@@ -1737,7 +1717,7 @@ void Navier2DEngine::build_confined() {
   // ---- S1: x-lines of the state -> (phys-x, composite-y) values and x-derivatives
   struct { DBuf* st; AxisTables* ax; DBuf* w0; DBuf* w1; int rows; } s1[3] = {
       {&U_, &xD, &Y_[0], &Y_[1], my}, {&V_, &xD, &Y_[2], &Y_[3], my}, {hc ? &TO_ : &T_, &xN, &Y_[4], &Y_[5], tr}};
-  static const bool s1_merge = [] { const char* e = std::getenv("RPDE_S1_MERGE"); return !e || std::atoi(e) != 0; }();   // default on (measured: 0.257 vs 0.282 ms per field)
+  const bool s1_merge = true;   // the line-program form of S1 reads the state line once (measured: 0.257 vs 0.282 ms per field with two programs)
   for (auto& f : s1) {
     {   // whole-line kernel, two transforms per line: Dirichlet stencil in x for the velocities, the Neumann table for T
       const bool dir = f.ax == &xD;

@@ -263,7 +263,6 @@ class Navier2DEngine {
   void add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale, const char* tag);
   void add_col_corr(const double* ps, int half, double* outa, double* outb, int ncols, const char* tag);
   ColHhDev colcorr_a_, colcorr_b_;   // column problems of the velocity correction (confined, one GPU)
-  bool probed_ = false;              // diagnostics (RPDE_PROBE_ALLOC)
   DBuf coldot_, colkap_;             // rank-one sums of the column scans
   int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
   bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)

@@ -3,6 +3,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -156,7 +157,10 @@ void write_file(const std::string& filename, const Tree& tree) {
 
   // crash safety: everything goes to <filename>.tmp, which replaces the target by rename() only after a complete,
   // flushed write -- an interrupted write never costs the previous snapshot / statistics file
-  const std::string tmpname = filename + ".tmp";
+  // (a name of its own per writer: two writers of one target -- two processes, a callback and a statistics write -- must not
+  // truncate each other's temporary file)
+  static std::atomic<unsigned long> serial{0};
+  const std::string tmpname = filename + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
   struct FileGuard {
     FILE* fp; std::string tmp;
     ~FileGuard() { if (fp) { std::fclose(fp); std::remove(tmp.c_str()); } }   // reached with fp set only on a throw
@@ -202,7 +206,7 @@ void write_file(const std::string& filename, const Tree& tree) {
   std::fseek(fp, 0, SEEK_SET);
   RPDE_REQUIRE(std::fwrite(f.b.data(), 1, 96, fp) == 96, "h5lite: short write");
   RPDE_REQUIRE(std::fflush(fp) == 0, "h5lite: flush failed for " + tmpname);
-  (void)fsync(fileno(fp));
+  RPDE_REQUIRE(fsync(fileno(fp)) == 0, "h5lite: fsync failed for " + tmpname);
   guard.fp = nullptr;
   RPDE_REQUIRE(std::fclose(fp) == 0, "h5lite: close failed for " + tmpname);
   if (std::rename(tmpname.c_str(), filename.c_str()) != 0) {

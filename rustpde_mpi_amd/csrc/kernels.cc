@@ -154,12 +154,7 @@ void launch_transpose_batch(const TransposeBatch& b, int n, long ldi, long ldo, 
 void launch_transpose(const double* in, long ldi, double* out, long ldo, int rows, int cols,
                       int elem, Stream& st) {
   if (rows <= 0 || cols <= 0) return;
-  static const int tile = [] { const char* e = std::getenv("RPDE_TP_TILE"); return e ? std::atoi(e) : 64; }();
-  if (elem == 1 && tile == 32) {
-    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-    hipLaunchKernelGGL((transpose_kernel<double, 32>), grid, dim3(256), 0, st.s, in, ldi, out, ldo,
-                       rows, cols);
-  } else if (elem == 1) {
+  if (elem == 1) {
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     hipLaunchKernelGGL((transpose_kernel<double, 64>), grid, dim3(256), 0, st.s, in, ldi, out, ldo,
                        rows, cols);
@@ -517,7 +512,7 @@ void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0) return;
   // the carry kernels are serial chains over the blocks, one thread per (column, parity): small workgroups spread
   // the few thousand threads over all CUs
-  static const int ct = [] { const char* e = std::getenv("RPDE_COL_CARRY_T"); const int v = e ? std::atoi(e) : 64; return (v == 64 || v == 128 || v == 256) ? v : 64; }();
+  constexpr int ct = 64;   // (128 / 256 threads per workgroup measured 3 % slower: DESIGN.md section 8)
   const int tiles = (a.ncols + 255) / 256;
   const dim3 blk(256), gb(a.pair ? 16 * ((tiles + 7) / 8) : tiles, std::max(a.NB, 1), a.pair ? 1 : a.nf), cblk(ct), gc((a.ncols + ct - 1) / ct, 2, a.nf);
   if (phase == 0) { if (a.NB > 0) hipLaunchKernelGGL(col_hholtz_kernel<0>, gb, blk, 0, st.s, a); }
@@ -784,7 +779,7 @@ __global__ __launch_bounds__(256) void col_diff_kernel(const ColDiffArgs a) {
 }
 void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st) {
   if (a.ncols <= 0 || a.nout <= 0) return;
-  static const int ct = [] { const char* e = std::getenv("RPDE_COL_CARRY_T"); const int v = e ? std::atoi(e) : 64; return (v == 64 || v == 128 || v == 256) ? v : 64; }();
+  constexpr int ct = 64;   // (128 / 256 threads per workgroup measured 3 % slower: DESIGN.md section 8)
   const dim3 blk(256), gb((a.ncols + 255) / 256, std::max(a.NB, 1)), cblk(ct), gc((a.ncols + ct - 1) / ct, 2);
   if (phase == 0) { if (a.NB > 0) hipLaunchKernelGGL(col_diff_kernel<0>, gb, blk, 0, st.s, a); }
   else if (phase == 1) {
@@ -1235,12 +1230,6 @@ void launch_pdma_lines(const PdmaLinesArgs& a, Stream& st) {
 }
 
 __global__ void set_element_kernel(double* p, long idx, double v) { p[idx] = v; }
-// diagnostics: one shader read of the first and the last double of a buffer (tools/fault_hunt_r04c.sh)
-__global__ void probe_kernel(const double* p, long n, double* sink) { if (p[0] + p[n - 1] == 1.2345e300) *sink = 1.0; }
-void launch_probe(const double* p, long n, double* sink, Stream& st) {
-  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(1), 0, st.s, p, n, sink);
-  RPDE_HIP(hipGetLastError());
-}
 void launch_set_element(double* p, long idx, double value, Stream& st) {
   hipLaunchKernelGGL(set_element_kernel, dim3(1), dim3(1), 0, st.s, p, idx, value);
   RPDE_HIP(hipGetLastError());
@@ -1482,7 +1471,6 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream&) {
     }
 }
 void launch_set_element(double* p, long idx, double value, Stream&) { p[idx] = value; }
-void launch_probe(const double*, long, double*, Stream&) {}
 void launch_sten3_rows(const Sten3RowsArgs& a, Stream&) {
   for (int j = a.row0; j < a.row0 + a.nrows; ++j)
     for (int c = 0; c < a.ncols; ++c) sten3_rows_point(a, j, c);

@@ -135,7 +135,6 @@ void launch_pdma_lines(const PdmaLinesArgs& a, Stream& st);
 
 // p[idx] = value (single element; used for pseu[0,0] = 0)
 void launch_set_element(double* p, long idx, double value, Stream& st);
-void launch_probe(const double* p, long n, double* sink, Stream& st);   // diagnostics
 
 // sum of squares + NaN flag of a pitched 2-D array into out[0] (sum), out[1] (nan count)
 void launch_sumsq(const double* a, long ld, int rows, int cols, double* out2, Stream& st);

@@ -101,6 +101,11 @@ __device__ __forceinline__ int rpde_tid() {
   __builtin_assume(t >= 0 && t < 1024);
   return t;
 }
+// the value lane l of the wave holds, as a wave-uniform number (two v_readlane_b32)
+__device__ __forceinline__ double rpde_lane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 #define RPDE_PHASE(blk, tid) for (int tid = rpde_tid() - (blk).t0, _once = 1; _once; _once = 0)
 // A value loaded from global memory is pinned where all loads of the phase have been issued: the compiler
 // may not sink the load into the (per-lane predicated) block of its only user, where it would be followed by
@@ -202,12 +207,7 @@ class DevArena {
   std::vector<Slab> slabs_;
   std::map<char*, Used> used_;
 };
-// diagnostics (RPDE_LOG_ALLOC=1): the live allocations of the process, for the probe of tools/fault_hunt_r04c.sh
-struct DevLive {
-  std::mutex mu; std::map<void*, size_t> live;
-  static DevLive& get() { static DevLive d; return d; }
-};
-inline bool dev_arena_on() {   // A/B only (tools/fault_hunt_r04c.sh): RPDE_ARENA=0 = one hipMalloc per buffer, as rounds 1-3
+inline bool dev_arena_on() {   // A/B only (tools/archive/fault_hunt_r04c.sh): RPDE_ARENA=0 = one hipMalloc per buffer, as rounds 1-3
   static const bool on = [] { const char* e = std::getenv("RPDE_ARENA"); return !e || std::atoi(e) != 0; }();
   return on;
 }
@@ -230,13 +230,6 @@ inline void* dev_alloc(size_t bytes) {
     RPDE_HIP(hipMalloc(&p, bytes ? bytes : 8));
   }
   RPDE_HIP(hipMemset(p, 0, bytes ? bytes : 8));
-  // diagnostics: RPDE_LOG_ALLOC=1 prints every allocation, so that a fault address can be placed
-  static const bool log = [] { const char* e = std::getenv("RPDE_LOG_ALLOC"); return e && std::atoi(e) != 0; }();
-  if (log) {
-    fprintf(stderr, "[alloc] %p %zu\n", p, bytes);
-    std::lock_guard<std::mutex> lk(DevLive::get().mu);
-    DevLive::get().live[p] = bytes;
-  }
   return p;
 #endif
 }
@@ -245,7 +238,6 @@ inline void dev_free(void* p) {
   if (p) std::free(static_cast<char*>(p) - kEmuGuardBytes);
 #else
   if (!p) return;
-  { std::lock_guard<std::mutex> lk(DevLive::get().mu); DevLive::get().live.erase(p); }
   if (dev_arena_on()) DevArena::get().free(p);
   else (void)hipFree(p);
 #endif

@@ -344,6 +344,31 @@ def check_independent_golden(lib, n):
             assert err < independent_golden_bound(fvp), (n, s, k, err, fvp)
 
 
+def check_ab_switch(lib, switch, nx, ny, steps, tol=1e-11):
+    """The confined step with an A/B switch of the engine on (default) and off (<switch>=0): same engine, same setup data."""
+    import rustpde_mpi_amd as R
+    fields, kinds = {}, {}
+    for flag in ("1", "0"):
+        if flag == "1":
+            os.environ.pop(switch, None)
+        else:
+            os.environ[switch] = "0"
+        nav = R.Navier2D.new_confined(nx, ny, 1e7, 1.0, 1e-3, 1.0, "rbc", library=lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(steps)
+        fields[flag] = nav.physical_fields()
+        kinds[flag] = sorted({kind for _, _, _, _, kind in nav.schedule() if kind.startswith("whole-line")})
+        del nav
+    os.environ.pop(switch, None)
+    assert kinds["1"], kinds
+    if switch == "RPDE_WHOLE_LINE":
+        assert not kinds["0"], kinds
+    for k in fields["0"]:
+        e = rel(fields["1"][k], fields["0"][k])
+        assert e < tol, (switch, k, e)
+    print(switch, kinds)
+
+
 def run_isolated(call, timeout=900):
     """Run `checks.<call>` (an expression like "check_config2_golden(lib)", with lib = the product library) in a child
     process: a large engine gets a fresh HIP context and its HBM back at exit, and a device fault -- which ends the process

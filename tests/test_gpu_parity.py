@@ -220,6 +220,33 @@ def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
         assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (stage, k)
 
 
+@pytest.mark.parametrize("switch", ["RPDE_WHOLE_LINE", "RPDE_LINE_BATCH", "RPDE_S1_PAIR"])
+def test_whole_line_kernels_equal_line_programs_1025(hip_lib, monkeypatch, switch):
+    """1025 x 1025 (BASELINE configs[1]): the whole-line kernels of 1025-point lines (one wave per line, the half-length core,
+    the batched launches of a stage's three fields, the pair form of S1) against the line programs (RPDE_WHOLE_LINE=0),
+    against one launch per field (RPDE_LINE_BATCH=0) and against two transforms in a row (RPDE_S1_PAIR=0): same engine, same
+    setup data, three steps.  In a child process, like every engine of this size (tests/checks.py run_isolated)."""
+    K.run_isolated(f"check_ab_switch(lib, '{switch}', 1025, 1025, 3)")
+
+
+@pytest.mark.parametrize("nx,ny", [(4096, 129), (1024, 257)])
+def test_periodic_fourier_whole_line_kernels_equal_line_programs(hip_lib, monkeypatch, nx, ny):
+    """Periodic step: S1 / S3 as whole-line Fourier kernels (csrc/rfft_line.h: 4096 and 1024 reals per x-line) against the line
+    programs of the stages (RPDE_S1_LINE=0 RPDE_S3_LINE=0), three steps; the oracle comparisons are the periodic step tests."""
+    fields, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RPDE_S1_LINE", flag); monkeypatch.setenv("RPDE_S3_LINE", flag)
+        nav = R.Navier2D.new_periodic(nx, ny, 1e7, 1.0, 1e-3, 1.0, "rbc", library=hip_lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(3)
+        fields[flag] = nav.physical_fields()
+        kinds[flag] = {t: kind for t, _, _, _, kind in nav.schedule() if t.startswith("S1 x") or t.startswith("S3 x")}
+        del nav
+    assert all(k.startswith("whole-line") for k in kinds["1"].values()) and all(k.startswith("line program") for k in kinds["0"].values()), kinds
+    for k in fields["0"]:
+        assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (k, K.rel(fields["1"][k], fields["0"][k]))
+
+
 @pytest.mark.parametrize("nx,ny", [(65, 4097), (1025, 1025), (2049, 513), (4097, 257)])
 def test_column_scans_in_one_pass_equal_three_kernels(hip_lib, monkeypatch, nx, ny):
     """The single-pass column scans (csrc/colscan1.h, the default on one GPU) against the three kernels of colscan.h

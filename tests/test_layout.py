@@ -54,3 +54,31 @@ def test_bench_uses_the_oracle_only_as_cpu_baseline_and_checker():
 def test_entry_uses_the_oracle_only_in_smoke():
     fns, top = _functions_importing(os.path.join(ROOT, "__graft_entry__.py"), "oracle")
     assert not top and fns <= {"smoke"}, (fns, top)
+
+
+# Every environment switch the product reads.  A/B switches exist only where a test exercises both sides (named next to them);
+# INTEGRATION.md section 4 documents the same list.
+ENV_SWITCHES = {
+    "RPDE_LAPACK_LIB", "RPDE_RCCL_LIB",            # run-time libraries
+    "RPDE_GRAPH",                                   # hipGraph replay on / off              (test_gpu_parity.test_graph_*)
+    "RPDE_SYNC_LAUNCHES",                           # diagnostics: every launch named and waited for
+    "RPDE_ARENA",                                   # device memory from slabs / one hipMalloc per buffer
+    "RPDE_WHOLE_LINE", "RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE",
+                                                    # whole-line kernel / line program per stage (test_whole_line_stage_*, test_emu_parity)
+    "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
+    "RPDE_COL_ONEPASS", "RPDE_COL1_W",              # column scans: one pass / three kernels, blocks per workgroup (test_column_scans_in_one_pass*)
+    "RPDE_COL_PAIR", "RPDE_GEMM_SWIZZLE",           # XCD pairing of the three-kernel correction-y, GEMM tile order (tests/test_gpu_parity)
+}
+
+
+def test_environment_switches_are_the_documented_list():
+    found = set()
+    for path in _sources(os.path.join(ROOT, "rustpde_mpi_amd"), (".cc", ".h", ".py")):
+        src = open(path).read()
+        found |= set(re.findall(r'getenv\("(RPDE_[A-Z0-9_]+)"\)', src))
+        found |= set(re.findall(r'whole_line_on\("(RPDE_[A-Z0-9_]+)"\)', src))
+        found |= set(re.findall(r'environ(?:\.get)?\(?\[?"(RPDE_[A-Z0-9_]+)"', src))
+    assert found == ENV_SWITCHES, (sorted(found - ENV_SWITCHES), sorted(ENV_SWITCHES - found))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in ENV_SWITCHES:
+        assert name in doc, f"{name} is not documented in INTEGRATION.md"
