@@ -163,7 +163,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     };
     up(colhh_vel_, build_colhh_tables(pinv_tables(by), hh_vel_->host[1], kColBlockRows, yb_, jend, rk));
     if (!hc_) up(colhh_temp_, build_colhh_tables(pinv_tables(by), hh_temp_->host[1], kColBlockRows, yb_, jend, rk));
-    if (!periodic) {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables)
+    {   // y part of the velocity correction as column problems (hostmath.h build_colcorr_tables), confined and periodic
       const ColCorrHost cc = build_colcorr_tables(sp_vel_->base(1), sp_pseu_->base(1), -1.0 / sy_, kColBlockRows, yb_, jend, rk);
       up(colcorr_a_, cc.a); up(colcorr_b_, cc.b);
     }
@@ -2178,23 +2178,12 @@ void Navier2DEngine::build_periodic() {
     for (int e = 0; e < 2; ++e) {
       Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.rows = e; l.tag = "pseu[0,0]=0"; step_.push_back(l);
     }
-  // ---- S7: y part of the velocity correction
-  {
-    ProgramBuilder pb = xpb(2, kx, true);
-    pb.set_fft(yN);
-    pb.load(0, pb.arr(PS_.p, ldy, 2, 1), my);
-    pb.to_ortho(0, yN);
-    pb.cdiff(1, 0, ny, -1.0 / sy_);
-    pb.from_ortho(0, yD);
-    pb.store(0, pb.arr(X_[2].p, ldy, 2, 1), my);
-    pb.from_ortho(1, yD);
-    pb.store(1, pb.arr(X_[3].p, ldy, 2, 1), my);
-    add_line(pb, "S7 y: correction-y");
-  }
-  Tc(X_[2].p, yx(Y_[2]), kx, my, false, "T5");
-  Tc(X_[3].p, yx(Y_[3]), kx, my, false, "T5");
+  // ---- C7: y part of the velocity correction as column scans on the YX pseudo-pressure (colscan.h / colscan1.h, as in the
+  // confined step: from_ortho_y(to_ortho_y ps) and from_ortho_y(-d/dy to_ortho_y ps); the interleaved re / im columns are
+  // independent columns) -- replaces the y-line program S7 and two of its three transposes
   Tc(PS_.p, yx(Y_[4]), kx, my, false, "T5");
-  add_halo({yx(Y_[4])}, 2, 0, "H2 halo pseu");
+  add_halo({yx(Y_[4])}, 2, 4, "H2 halo pseu");
+  add_col_corr(yx(Y_[4]), 0, yx(Y_[2]), yx(Y_[3]), nc, "C7 y: correction-y (column scan)");
   // ---- S8: x part of the velocity correction
   {
     ProgramBuilder pb = ypb(1, my);
