@@ -14,6 +14,8 @@ L = len(owner)
 path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
 disp = defaultdict(lambda: defaultdict(float))
 for r in csv.DictReader(open(path)):
+    if "fillBuffer" in r["Kernel_Name"] or "__amd_rocclr" in r["Kernel_Name"]:
+        continue   # blit kernels of the runtime (the memset nodes in front of the single-pass column scans)
     disp[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
 ids = sorted(disp)[-steps * L:]
 assert len(ids) == steps * L

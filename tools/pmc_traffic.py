@@ -35,8 +35,8 @@ def per_position(dirname, counter, steps, L):
     assert path, f"no counter_collection.csv under {dirname}"
     disp = {}
     for r in csv.DictReader(open(path[0])):
-        if r["Counter_Name"] != counter:
-            continue
+        if r["Counter_Name"] != counter or "fillBuffer" in r["Kernel_Name"] or "__amd_rocclr" in r["Kernel_Name"]:
+            continue   # (blit kernels of the runtime: the memset nodes in front of the single-pass column scans)
         d = int(r["Dispatch_Id"])
         disp[d] = (r["Kernel_Name"], disp.get(d, ("", 0.0))[1] + float(r["Counter_Value"]))
     seq = [disp[k] for k in sorted(disp)][-steps * L:]
