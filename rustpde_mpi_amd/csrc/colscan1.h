@@ -53,8 +53,10 @@ struct ColHh1Args {
   int W, NSB, tiles;                   // blocks per workgroup, super-blocks per column, column tiles of 64
   double* agg;                         // [nf][tiles][NSB][7][64] aggregates of the super-blocks, then (in place) their inflow states;
                                        // slot 6 of super-block 0 becomes the rank-one sum of the column
-  int* sync;                           // [0]: ticket counter, [1 + f * tiles + tile]: arrivals; zero before the launch
-  int* ready;                          // [f * tiles + tile]: the inflow states of the tile are published; zero before the launch
+  // Synchronisation area of THIS launch site, never reset: counters only grow, a launch is an epoch.  Workgroup number t
+  // (over all launches of the site) belongs to epoch t / gridDim.x + 1 and is ticket t mod gridDim.x of its launch.
+  unsigned long long* sync;            // [0]: ticket counter; [1 + f * tiles + tile]: arrivals (NSB per epoch);
+                                       // [1 + kColMaxFields * tiles + f * tiles + tile]: epoch whose inflow states are published
   int* err;                            // raised when a wait ran out
   long long* trace = nullptr;          // diagnostics (Navier2DEngine::trace_launch): per workgroup, clock values of thread 0 at the phase boundaries
 };
@@ -269,10 +271,8 @@ RPDE_HD inline void colhh1_sweep(double* stg, const double* tw, int NSB, int par
   }
 }
 
-// ints of the synchronisation area for `tiles` column tiles and up to kColMaxFields fields:
-// [0] ticket counter | arrivals per (field, tile) | ready flags per (field, tile) | [col1_err_index] error flag
-RPDE_HD inline int col1_err_index(int tiles) { return 1 + 2 * kColMaxFields * tiles; }
-RPDE_HD inline size_t col1_sync_ints(int tiles) { return (size_t)col1_err_index(tiles) + 1; }
+// 64-bit words of the synchronisation area of a launch site with `tiles` column tiles and up to kColMaxFields fields
+RPDE_HD inline size_t col1_sync_words(int tiles) { return (size_t)1 + 2 * (size_t)kColMaxFields * tiles; }
 
 // dynamic LDS of the kernel (doubles): the blocks' states, the staged aggregates of the tile, the rank-one sums
 RPDE_HD inline size_t col1_lds_doubles(int W, int NSB) {
@@ -291,7 +291,8 @@ struct ColDiff1Args {
   ColDiffArgs a;                       // one rank: row0 = 0, jend = nout
   int NSB, tiles;                      // super-blocks per column, column tiles of 64
   double* tot;                         // [tiles][NSB][2][64] sums of the super-blocks, per parity
-  int* sync;                           // [0] ticket counter, [1 + tile * NSB + q] "the sums of super-block q are published"; zero before the launch
+  unsigned long long* sync;            // this launch site's area, never reset (see ColHh1Args): [0] ticket counter,
+                                       // [1 + tile * NSB + q]: epoch whose sums of super-block q are published
   int* err;                            // raised when a wait ran out
 };
 RPDE_HD inline long coldiff1_tot(const ColDiff1Args& A, int tile, int q) { return ((long)tile * A.NSB + q) * (2 * kCol1Tile); }

@@ -170,9 +170,9 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     if (col1_W_) {
       const int dnsb = (ny_ + kDiff1Rows - 1) / kDiff1Rows;
       coldtot_.alloc((size_t)col1_tiles_ * dnsb * 2 * kCol1Tile);
-      coldsync_.alloc(((size_t)col1_tiles_ * dnsb + 2) / 2 + 1);
       colagg_.alloc((size_t)3 * col1_tiles_ * col1_NSB_ * kCol1Agg * kCol1Tile);
-      colsync_.alloc((col1_sync_ints(col1_tiles_) + 1) / 2 + 1);   // ints: ticket, arrivals, ready flags, error flag (colscan1.h)
+      colsync_.alloc(2);                                           // the error flag of the single-pass scans (an int)
+      gy_site_ = new_col_site(1 + (size_t)col1_tiles_ * dnsb);
     }
     if (P > 1) {
       const size_t cnt = (size_t)3 * kColSumm * ldx_;
@@ -477,17 +477,20 @@ void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
 
 // Column scans when the rows are split over the ranks (colscan.h): block summaries, this rank's summary, ONE small
 // exchange that gives every rank everybody's summary, inflow of the own rows from them, final pass.
-void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1, long long* trace) {
+unsigned long long* Navier2DEngine::new_col_site(size_t words) {
+  col_sites_.push_back(std::make_unique<DBuf>(words));   // zeroed: epoch 0
+  return reinterpret_cast<unsigned long long*>(col_sites_.back()->p);
+}
+void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1, unsigned long long* site, long long* trace) {
   const int P = comm_.size;
-  if (P == 1 && col1_W_ && x1 && x1[0].F) {
+  if (P == 1 && col1_W_ && x1 && x1[0].F && site) {
     ColHh1Args A;
     A.a = a;
     for (int f = 0; f < a.nf; ++f) A.x[f] = x1[f];
     A.W = col1_W_; A.NSB = col1_NSB_; A.tiles = (a.ncols + kCol1Tile - 1) / kCol1Tile;
     A.agg = colagg_.p;
-    A.sync = reinterpret_cast<int*>(colsync_.p);
-    A.ready = A.sync + 1 + kColMaxFields * A.tiles;
-    A.err = A.sync + col1_err_index(col1_tiles_);
+    A.sync = site;
+    A.err = reinterpret_cast<int*>(colsync_.p);
     A.trace = trace;
     launch_col_hholtz1(A, st_);
     return;
@@ -503,15 +506,15 @@ void Navier2DEngine::run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1, long long
   launch_col_hholtz_phase(a, 2, st_);
   launch_col_hholtz_phase(a, 3, st_);
 }
-void Navier2DEngine::run_col_diff(ColDiffArgs a) {
+void Navier2DEngine::run_col_diff(ColDiffArgs a, unsigned long long* site) {
   const int P = comm_.size;
-  if (P == 1 && col1_W_ && (a.nout + kDiff1Rows - 1) / kDiff1Rows <= 64) {
+  if (P == 1 && col1_W_ && site && (a.nout + kDiff1Rows - 1) / kDiff1Rows <= 64) {
     ColDiff1Args A;
     A.a = a;
     A.NSB = (a.nout + kDiff1Rows - 1) / kDiff1Rows; A.tiles = (a.ncols + kCol1Tile - 1) / kCol1Tile;
     RPDE_REQUIRE((size_t)A.tiles * A.NSB * 2 * kCol1Tile <= coldtot_.n, "coldiff1: buffer");
-    A.tot = coldtot_.p; A.sync = reinterpret_cast<int*>(coldsync_.p);
-    A.err = reinterpret_cast<int*>(colsync_.p) + col1_err_index(col1_tiles_);
+    A.tot = coldtot_.p; A.sync = site;
+    A.err = reinterpret_cast<int*>(colsync_.p);
     launch_col_diff1(A, st_);
     return;
   }
@@ -834,6 +837,7 @@ void Navier2DEngine::add_col_hholtz(const double* const in[3], double* const out
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = flagp();
   l.bytes = nf * 2.0 * 8.0 * (double)ylines(my_) * ncols;   // algorithmic: the three arrays read once and written once (the summary pass reads them a second time)
+  if (comm_.size == 1 && col1_W_) l.site = new_col_site(col1_sync_words((ncols + kCol1Tile - 1) / kCol1Tile));
   step_.push_back(l);
 }
 void Navier2DEngine::add_hc_to_ortho(int ncols) {
@@ -894,6 +898,7 @@ void Navier2DEngine::add_col_corr(const double* ps, int half, double* outa, doub
   a.v1 = colv1_.p; a.s1 = cols1_.p; a.v2 = colv2_.p; a.s2 = cols2_.p; a.dotp = coldot_.p; a.kap = colkap_.p;
   a.nanflag = nullptr;
   l.bytes = 3.0 * 8.0 * (double)ylines(my_) * ncols;  // algorithmic: the pseudo-pressure once, two arrays out
+  if (comm_.size == 1 && col1_W_) l.site = new_col_site(col1_sync_words((ncols + kCol1Tile - 1) / kCol1Tile));
   step_.push_back(l);
 }
 void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const double* low, int ncols, double scale,
@@ -906,7 +911,9 @@ void Navier2DEngine::add_col_diff(const double* in, double* out, int m_in, const
   a.ldi = ldx_; a.ldo = ldx_; a.in = in; a.out = out; a.low = low; a.scale = scale;
   a.vd = coldv_.p; a.sd = colds_.p;
   a.row0 = yb_; a.jend = ye_; a.nranks = comm_.size; a.rank = comm_.rank;
-  l.bytes = 8.0 * ncols * (2.0 * ylines(m_in) + nyl_);   // the input twice (block sums, final pass), the output once
+  // algorithmic: the input once, the output once (the three-kernel form of pencil-sharded runs reads the input twice)
+  l.bytes = 8.0 * ncols * ((comm_.size == 1 && col1_W_ ? 1.0 : 2.0) * ylines(m_in) + nyl_);
+  if (comm_.size == 1 && col1_W_) l.site = new_col_site(1 + (size_t)((ncols + kCol1Tile - 1) / kCol1Tile) * ((ny_ + kDiff1Rows - 1) / kDiff1Rows));
   step_.push_back(l);
 }
 #ifndef RPDE_EMU
@@ -996,11 +1003,11 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kGemmPairNT: launch_gemm_pair(false, l.gp[0], l.gp[1], st_); break;
     case Launch::kGemmPairNN: launch_gemm_pair(true, l.gp[0], l.gp[1], st_); break;
     case Launch::kSetElem: launch_set_element(l.out, l.rows, 0.0, st_); break;
-    case Launch::kColHholtz: run_col_hholtz(l.ch, l.ch1); break;
+    case Launch::kColHholtz: run_col_hholtz(l.ch, l.ch1, l.site); break;
     case Launch::kDctLine: RPDE_REQUIRE(launch_dct_line(l.dl, st_), "internal: dct line shape"); break;
     case Launch::kConvLine: RPDE_REQUIRE(launch_conv_line(l.cl, st_), "internal: conv line shape"); break;
     case Launch::kDctLine2: RPDE_REQUIRE(launch_dct_line2(l.dl, l.dl2, st_), "internal: dct line shape"); break;
-    case Launch::kColDiff: run_col_diff(l.cd); break;
+    case Launch::kColDiff: run_col_diff(l.cd, l.site); break;
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
     case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
     case Launch::kDivLine: RPDE_REQUIRE(launch_div_line(l.dvl, st_), "internal: div line shape"); break;
@@ -1204,7 +1211,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   for (size_t i = 0; i < step_.size(); ++i) {
     if (i != which) { run_launch(step_[i]); continue; }
     if (prog) run_launch(l);
-    else if (col1) run_col_hholtz(l.ch, l.ch1, trec);
+    else if (col1) run_col_hholtz(l.ch, l.ch1, l.site, trec);
     else if (l.type == Launch::kRhsLine) RPDE_REQUIRE(launch_rhs_line(l.rl, st_, trec), "trace: rhs line");
     else RPDE_REQUIRE(launch_dct_line(l.dl, st_, trec), "trace: dct line");
   }
@@ -1277,7 +1284,7 @@ double Navier2DEngine::div_norm() {
 bool Navier2DEngine::read_nanflag() {
 #ifndef RPDE_EMU
   RPDE_HIP(hipMemcpyAsync(hflag_, nanflag_.p, sizeof(int), hipMemcpyDeviceToHost, st_.s));
-  if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p) + col1_err_index(col1_tiles_), sizeof(int), hipMemcpyDeviceToHost, st_.s));
+  if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p), sizeof(int), hipMemcpyDeviceToHost, st_.s));
   RPDE_HIP(hipStreamSynchronize(st_.s));
   // a single-pass column scan whose wait for its partner workgroups ran out (colscan1.h): the step's results are wrong
   RPDE_REQUIRE(!col1_W_ || hflag_[1] == 0, "column scan: a workgroup waited for its partners in vain (RPDE_COL_ONEPASS=0 selects the three-kernel form)");
@@ -1665,7 +1672,7 @@ void Navier2DEngine::refresh_gy() {
     a.ldi = ldx_; a.ldo = ldx_; a.in = yx(P_); a.out = yx(GY_); a.low = nullptr; a.scale = 1.0 / sy_;
     a.vd = coldv_.p; a.sd = colds_.p;
     a.row0 = yb_; a.jend = ye_; a.nranks = comm_.size; a.rank = comm_.rank;
-    run_col_diff(a);
+    run_col_diff(a, gy_site_);
     dev_sync(st_);
   }
 }

@@ -162,7 +162,8 @@ class Navier2DEngine {
   // halo rows of up to three YX arrays in one exchange: `front` rows in front of the local rows (from rank - 1), `tail`
   // rows behind them (from rank + 1)
   void halo_rows(double* const* arr, int n, int front, int tail);
-  void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr, long long* trace = nullptr);   // column scans, one rank or rows split over the ranks (colscan.h)
+  void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr, unsigned long long* site = nullptr, long long* trace = nullptr);
+  void run_col_diff(ColDiffArgs a, unsigned long long* site);   // column scans, one rank or rows split over the ranks (colscan.h)
   void run_col_diff(ColDiffArgs a);
   ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
   DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;
@@ -202,8 +203,11 @@ class Navier2DEngine {
   DBuf postcut_x_, postcut_y_;   // forward-DCT scaling with the 2/3 dealiasing cut folded in
   DBuf UP_, VP_;                 // physical velocities of the step (XY), shared by the three conv programs
   DBuf colv1_, cols1_, colv2_, cols2_, coldv_, colds_;   // block carries of the column scans (colscan.h)
-  DBuf coldtot_, coldsync_;      // single-pass y-derivative (colscan1.h): super-block sums; ticket + flags
-  DBuf colagg_, colsync_;        // single-pass column scans (colscan1.h): super-block aggregates; ticket / arrival counters + error flag
+  DBuf coldtot_;                 // single-pass y-derivative (colscan1.h): super-block sums
+  DBuf colagg_, colsync_;        // single-pass column scans (colscan1.h): super-block aggregates; the error flag
+  std::vector<std::unique_ptr<DBuf>> col_sites_;   // one synchronisation area per launch site of a single-pass column scan (never reset: epochs)
+  unsigned long long* new_col_site(size_t words);
+  unsigned long long* gy_site_ = nullptr;          // refresh_gy's column scan
   int col1_W_ = 0, col1_NSB_ = 0, col1_tiles_ = 0;   // 0: the three-kernel form
   std::map<std::string, std::unique_ptr<Field>> fields_;
 
@@ -223,6 +227,7 @@ class Navier2DEngine {
     DctLineArgs dl{}, dl2{};     // kDctLine; kDctLine2: two transforms of the same lines in one launch
     GemmProblem gp[2];           // kGemmPair*
     ColHhArgs ch{};              // kColHholtz
+    unsigned long long* site = nullptr;   // kColHholtz / kColDiff on one rank: the launch site's synchronisation area (colscan1.h)
     ColHh1Tabs ch1[kColMaxFields]{};   // kColHholtz on one rank: the tables of the single-pass form (colscan1.h)
     ColDiffArgs cd{};            // kColDiff
     bool to_xy = true, spec = false;

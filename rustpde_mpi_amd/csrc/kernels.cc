@@ -542,7 +542,7 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   double* kapl = stg + A.NSB * kCol1Stg * kCol1Tile;     // [64]
   double* tbl = kapl + kCol1Tile;                        // [W][14] transfers of this super-block's blocks
   double* twl = tbl + W * kCol1TabPerBlock;              // [NSB][14] transfers of the tile's super-blocks
-  __shared__ int tk;
+  __shared__ int tk, tke[2];
   const ColHhArgs& a = A.a;
   const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   long long* trc = TRACE ? A.trace + (long)blockIdx.x * kTraceStride : nullptr;
@@ -550,10 +550,15 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
 #define RPDE_C1_MARK(id) do { if (TRACE && tid == 0 && nm < kTraceMarks) { trc[4 + 2 * nm] = (id); trc[5 + 2 * nm] = (long long)clock64(); ++nm; } } while (0)
   if (TRACE && tid == 0) trc[0] = (long long)wall_clock64();
   RPDE_C1_MARK(0);
-  if (tid == 0) tk = atomicAdd(&A.sync[0], 1);
+  if (tid == 0) {   // ticket and epoch of this workgroup (the counters of a launch site are never reset)
+    const unsigned long long t = atomicAdd(&A.sync[0], 1ull), ep = t / gridDim.x + 1ull;
+    tk = (int)(t - (ep - 1ull) * gridDim.x);
+    tke[0] = (int)(unsigned)ep; tke[1] = (int)(unsigned)(ep >> 32);
+  }
   __syncthreads();
   RPDE_C1_MARK(1);
   const int ticket = __builtin_amdgcn_readfirstlane(tk);
+  const unsigned long long epoch = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tke[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tke[0]);
   // ticket -> (field, tile, super-block): the super-blocks of a tile are consecutive; with `pair` the two fields that read
   // the same rows sit eight tickets apart (workgroups go to the XCDs round robin: same L2)
   // (integer division runs on the vector unit: every quotient goes back into a scalar register BEFORE anything branches
@@ -610,9 +615,9 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have arrived
   RPDE_C1_MARK(4);
   __syncthreads();
-  int* arrivals = A.sync + 1 + f * A.tiles + tile;
-  int* ready = A.ready + f * A.tiles + tile;
-  if (tid == 0) tk = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long* arrivals = A.sync + 1 + f * A.tiles + tile;
+  unsigned long long* ready = A.sync + 1 + kColMaxFields * A.tiles + f * A.tiles + tile;
+  if (tid == 0) tk = (int)(__hip_atomic_fetch_add(arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % (unsigned long long)A.NSB);
   __syncthreads();
   const bool last = __builtin_amdgcn_readfirstlane(tk) == A.NSB - 1;
   RPDE_C1_MARK(5);
@@ -649,11 +654,11 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
     if (w == W - 1) __hip_atomic_store(ag + 6 * kCol1Tile + lane, kapl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(ready, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     if (w == 0) {
       int it = 0;
-      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
         __builtin_amdgcn_s_sleep(8);
         if (++it > (1 << 22)) { if (lane == 0) *A.err = 1; break; }
       }
@@ -686,8 +691,7 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
   const ColHhArgs& a = A.a;
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0 || a.NB <= 0) return;
   RPDE_REQUIRE(A.NSB <= kCol1MaxNSB && A.W * A.NSB >= a.NB, "colhh1: super-block partition");
-  RPDE_REQUIRE(A.W >= 8 && A.ready == A.sync + 1 + kColMaxFields * A.tiles, "colhh1: layout of the synchronisation area");
-  RPDE_HIP(hipMemsetAsync(A.sync, 0, sizeof(int) * (size_t)col1_err_index(A.tiles), st.s));
+  RPDE_REQUIRE(A.W >= 8 && A.sync != nullptr, "colhh1: synchronisation area of the launch site");
   const int per = A.NSB * A.tiles;
   const int wgs = (a.pair && a.nf == 2) ? 16 * ((per + 7) / 8) : per * a.nf;
   const size_t bytes = sizeof(double) * col1_lds_doubles(A.W, A.NSB);
@@ -712,12 +716,17 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
 __global__ __launch_bounds__(kDiff1W * 64, 8) void col_diff1_kernel(const ColDiff1Args A) {   // eight waves per SIMD: 64 VGPRs
   __shared__ double lt[kDiff1W][2][kCol1Tile];          // the blocks' sums
   __shared__ double sup[2][kCol1Tile];                  // the sums of the super-blocks above
-  __shared__ int tk;
+  __shared__ int tk, tke[2];
   const ColDiffArgs& a = A.a;
   const int tid = (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) tk = atomicAdd(&A.sync[0], 1);
+  if (tid == 0) {   // ticket and epoch of this workgroup (the counters of a launch site are never reset)
+    const unsigned long long t = atomicAdd(&A.sync[0], 1ull), ep = t / gridDim.x + 1ull;
+    tk = (int)(t - (ep - 1ull) * gridDim.x);
+    tke[0] = (int)(unsigned)ep; tke[1] = (int)(unsigned)(ep >> 32);
+  }
   __syncthreads();
   const int ticket = __builtin_amdgcn_readfirstlane(tk);
+  const unsigned long long epoch = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(tke[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(tke[0]);
   const int tile = __builtin_amdgcn_readfirstlane(ticket / A.NSB);
   const int q = __builtin_amdgcn_readfirstlane(A.NSB - 1 - (ticket - tile * A.NSB));   // from the top
   if (tile >= A.tiles) return;
@@ -738,12 +747,12 @@ __global__ __launch_bounds__(kDiff1W * 64, 8) void col_diff1_kernel(const ColDif
     __hip_atomic_store(mine + lane, in[0] + tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + kCol1Tile + lane, in[1] + tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int* flags = A.sync + 1 + tile * A.NSB;
-    if (lane == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* flags = A.sync + 1 + tile * A.NSB;
+    if (lane == 0) __hip_atomic_store(flags + q, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // lane l waits for super-block q + 1 + l
     const int qw = q + 1 + lane;
     int it = 0;
-    while (__builtin_amdgcn_ballot_w64(qw < A.NSB && __hip_atomic_load(flags + (qw < A.NSB ? qw : q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) != 0) {
+    while (__builtin_amdgcn_ballot_w64(qw < A.NSB && __hip_atomic_load(flags + (qw < A.NSB ? qw : q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) != 0) {
       __builtin_amdgcn_s_sleep(4);
       if (++it > (1 << 22)) { if (lane == 0) *A.err = 1; break; }
     }
@@ -763,7 +772,7 @@ void launch_col_diff1(const ColDiff1Args& A, Stream& st) {
   const ColDiffArgs& a = A.a;
   if (a.ncols <= 0 || a.nout <= 0) return;
   RPDE_REQUIRE(A.NSB * kDiff1Rows >= a.nout && A.NSB <= 64 && a.row0 == 0 && a.nranks <= 1, "coldiff1: one rank, at most 64 super-blocks");
-  RPDE_HIP(hipMemsetAsync(A.sync, 0, sizeof(int) * (size_t)(1 + A.tiles * A.NSB), st.s));
+  RPDE_REQUIRE(A.sync != nullptr, "coldiff1: synchronisation area of the launch site");
   hipLaunchKernelGGL(col_diff1_kernel, dim3(A.tiles * A.NSB), dim3(kDiff1W * 64), 0, st.s, A);
   RPDE_HIP(hipGetLastError());
 }

@@ -114,8 +114,9 @@ def test_config2_golden_1025_200_steps(hip_lib):
 def test_headline_independent_reference_setup(hip_lib, n):
     """The engine with its OWN setup (C++ band matrices, one dgeev per parity block) against the oracle run in the
     REFERENCE's setup (one dgeev of the whole operator), n x n, Ra = 1e8, dt = 2e-4 (n = 4097: the bench workload), up to
-    200 steps -- committed samples, tests/golden/make_headline_golden.py.  The bar per snapshot and field is 1e-10 once the
-    oracle's own two eigenbases agree to 1e-11, the documented transient bound before (checks.independent_golden_bound)."""
+    200 steps -- committed samples, tests/golden/make_headline_golden.py.  The bar per snapshot and field is 1e-10 once five times the
+    distance of the oracle's own two eigenbases is below that, the transient envelope before (checks.independent_golden_bound: the
+    effective bar per size is listed there)."""
     import os
     path = os.path.join(K.GOLDEN, f"headline_{n}_full.npz")
     if not os.path.exists(path):

@@ -25,7 +25,7 @@ def kind_of_tag(tag):
 def kind_of_kernel(name):
     for k in ("transpose", "gemm", "set_element", "line_kernel", "copy2d", "col_hholtz", "col_diff"):
         if k in name: return k
-    if "_line" in name: return "line_kernel"   # whole-line kernels: hdct_line2_kernel, conv_line_kernel, rhs_line_kernel ...
+    if "_line" in name or "hdct_pair" in name or "rfft_pair" in name or "four_rhs" in name: return "line_kernel"   # whole-line kernels: hdct_pair_kernel, conv_line_kernel, rhs_line_kernel ...
     return "other"
 
 
