@@ -686,6 +686,8 @@ static bool whole_line_len(int N) { return N == 256 || N == 1024 || N == 4096; }
 static bool whole_line_len(int N) { return N == 1024 || N == 4096; }   // 1024: the kernels on the half-length core (no convection term)
 #endif
 
+static bool rfft_line_len(int N) { return whole_line_len(N) || N == 8192 || N == 16384; }   // Fourier lines (rfft_line.h)
+
 bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   if (!whole_line_on("RPDE_DCT_LINE") || !whole_line_len(a.N) || !dct_line_ok(a)) return false;
   Launch l;
@@ -711,7 +713,7 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
 
 bool Navier2DEngine::add_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, const char* tag) {
   // periodic S1: c2r of a spectral state line and of its x-derivative in one launch (rfft_line.h)
-  if (!whole_line_on("RPDE_S1_LINE") || !whole_line_len(a0.N) || !rfft_line_ok(a0) || !rfft_line_ok(a1)) return false;
+  if (!whole_line_on("RPDE_S1_LINE") || !rfft_line_len(a0.N) || !rfft_line_ok(a0) || !rfft_line_ok(a1)) return false;
   Launch l;
   l.type = Launch::kRfftPair;
   l.rf = a0; l.rf2 = a1;
@@ -722,7 +724,7 @@ bool Navier2DEngine::add_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a
 }
 bool Navier2DEngine::add_four_rhs(const FourRhsArgs& a, const char* tag) {
   // periodic S3: forward real FFT, 2/3 rule, right-hand side, diagonal Helmholtz factor in x (rfft_line.h)
-  if (!whole_line_on("RPDE_S3_LINE") || !whole_line_len(a.f.N) || !four_rhs_ok(a)) return false;
+  if (!whole_line_on("RPDE_S3_LINE") || !rfft_line_len(a.f.N) || !four_rhs_ok(a)) return false;
   Launch l;
   l.type = Launch::kFourRhs;
   l.fr = a;

@@ -848,12 +848,32 @@ __global__ __launch_bounds__(N / 8, 4) void rfft_pair_kernel(const RfftLineArgs 
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void four_rhs_kernel(const FourRhsArgs a) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];   // N + N / 16 + 64 doubles (140 KB at N = 16384)
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.f.nlines) return;
-  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  Blk blk{line, 0, N / 16, rpde_lds, nullptr, 0};
   four_rhs_line<N>(blk, a);
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void rfft_seq2_kernel(const RfftLineArgs a0, const RfftLineArgs a1) {
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a0.nlines) return;
+  Blk blk{line, 0, N / 16, rpde_lds, nullptr, 0};
+  rfft_seq2_line<N>(blk, a0, a1);
+}
+// dynamic LDS above 64 KB needs the permission once per kernel and device
+template <class K>
+static void lds_permission(K kernel, size_t bytes) {
+  static std::atomic<size_t> have[32];
+  int dev = 0;
+  RPDE_HIP(hipGetDevice(&dev));
+  if (bytes > have[dev & 31].load(std::memory_order_acquire)) {
+    RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have[dev & 31].store(bytes, std::memory_order_release);
+  }
 }
 template <int N, int WPC>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
@@ -1054,30 +1074,35 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   return true;
 }
 bool launch_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, Stream& st) {
-  if (a0.N != a1.N || a0.nlines != a1.nlines || !rfft_line_ok(a0) || !rfft_line_ok(a1) || (a0.N != 4096 && a0.N != 1024)) return false;
+  const int N = a0.N;
+  if (N != a1.N || a0.nlines != a1.nlines || !rfft_line_ok(a0) || !rfft_line_ok(a1) || N == 256) return false;
   if (a0.nlines <= 0) return true;
   const dim3 grid(8 * ((a0.nlines + 7) / 8));
-  const size_t bytes = 2 * sizeof(double) * hdct_lds_doubles(a0.N);
-  if (a0.N == 1024) hipLaunchKernelGGL(rfft_pair_kernel<1024>, grid, dim3(128), bytes, st.s, a0, a1);
-  else {
-    static std::atomic<int> configured[32];               // dynamic-LDS permission above 64 KB, per device
-    int dev = 0;
-    RPDE_HIP(hipGetDevice(&dev));
-    if (!configured[dev & 31].load(std::memory_order_acquire)) {
-      RPDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfft_pair_kernel<4096>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      configured[dev & 31].store(1, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(rfft_pair_kernel<4096>, grid, dim3(512), bytes, st.s, a0, a1);
+  const size_t one = sizeof(double) * hdct_lds_doubles(N);
+  if (N == 1024) hipLaunchKernelGGL(rfft_pair_kernel<1024>, grid, dim3(128), 2 * one, st.s, a0, a1);
+  else if (N == 4096) {
+    lds_permission(rfft_pair_kernel<4096>, 2 * one);
+    hipLaunchKernelGGL(rfft_pair_kernel<4096>, grid, dim3(512), 2 * one, st.s, a0, a1);
+  } else if (N == 8192) {   // long lines: the two transforms in a row in one buffer (rfft_seq2_line)
+    lds_permission(rfft_seq2_kernel<8192>, one);
+    hipLaunchKernelGGL(rfft_seq2_kernel<8192>, grid, dim3(512), one, st.s, a0, a1);
+  } else {
+    lds_permission(rfft_seq2_kernel<16384>, one);
+    hipLaunchKernelGGL(rfft_seq2_kernel<16384>, grid, dim3(1024), one, st.s, a0, a1);
   }
   RPDE_HIP(hipGetLastError());
   return true;
 }
 bool launch_four_rhs(const FourRhsArgs& a, Stream& st) {
-  if (!four_rhs_ok(a) || (a.f.N != 4096 && a.f.N != 1024)) return false;
+  const int N = a.f.N;
+  if (!four_rhs_ok(a) || N == 256) return false;
   if (a.f.nlines <= 0) return true;
   const dim3 grid(8 * ((a.f.nlines + 7) / 8));
-  if (a.f.N == 1024) hipLaunchKernelGGL(four_rhs_kernel<1024>, grid, dim3(64), 0, st.s, a);
-  else hipLaunchKernelGGL(four_rhs_kernel<4096>, grid, dim3(256), 0, st.s, a);
+  const size_t one = sizeof(double) * hdct_lds_doubles(N);
+  if (N == 1024) hipLaunchKernelGGL(four_rhs_kernel<1024>, grid, dim3(64), one, st.s, a);
+  else if (N == 4096) hipLaunchKernelGGL(four_rhs_kernel<4096>, grid, dim3(256), one, st.s, a);
+  else if (N == 8192) { lds_permission(four_rhs_kernel<8192>, one); hipLaunchKernelGGL(four_rhs_kernel<8192>, grid, dim3(512), one, st.s, a); }
+  else { lds_permission(four_rhs_kernel<16384>, one); hipLaunchKernelGGL(four_rhs_kernel<16384>, grid, dim3(1024), one, st.s, a); }
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1548,7 +1573,10 @@ bool launch_rfft_pair(const RfftLineArgs& a0, const RfftLineArgs& a1, Stream&) {
   double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
   for (int line = 0; line < a0.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
-    if (a0.N == 4096) rfft_pair_line<4096>(line, base, a0, a1);
+    Blk blk{line, 0, a0.N / 16, base};
+    if (a0.N == 16384) rfft_seq2_line<16384>(blk, a0, a1);
+    else if (a0.N == 8192) rfft_seq2_line<8192>(blk, a0, a1);
+    else if (a0.N == 4096) rfft_pair_line<4096>(line, base, a0, a1);
     else if (a0.N == 1024) rfft_pair_line<1024>(line, base, a0, a1);
     else rfft_pair_line<256>(line, base, a0, a1);
   }
@@ -1561,7 +1589,9 @@ bool launch_four_rhs(const FourRhsArgs& a, Stream&) {
   for (int line = 0; line < a.f.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.f.N / 16, base};
-    if (a.f.N == 4096) four_rhs_line<4096>(blk, a);
+    if (a.f.N == 16384) four_rhs_line<16384>(blk, a);
+    else if (a.f.N == 8192) four_rhs_line<8192>(blk, a);
+    else if (a.f.N == 4096) four_rhs_line<4096>(blk, a);
     else if (a.f.N == 1024) four_rhs_line<1024>(blk, a);
     else four_rhs_line<256>(blk, a);
   }

@@ -1,8 +1,8 @@
 // Whole-line real FFTs of the periodic step (round 4): the Fourier axis of Navier2D::new_periodic (funspace fourier_r2c,
 // src/navier_stokes/navier.rs:336-428, called through src/field.rs:103-110) on lines of N = 4096 / 1024 reals that stay
 // in registers, like the Chebyshev lines of hdct_line.h: T = N / 16 threads, M = N / 2 = 8 T complex points, eight per
-// thread, radix passes 8 x 8 x 8 x 4 (N = 4096), 8 x 8 x 8 (1024), 8 x 8 x 2 (256: emulation build), both components in the
-// exchange buffer at once.
+// thread, radix passes 8 x 8 x 8 x 4 (N = 4096), 8 x 8 x 8 (1024), 8 x 8 x 8 x 8 (8192), 8 x 8 x 8 x 8 x 2 (16384: 1024 threads,
+// 140 KB of LDS, one workgroup per CU), 8 x 8 x 2 (256: emulation build), both components in the exchange buffer at once.
 //
 //   backward (complex -> real, rustfft inverse / n: oracle/bases.py:131, the line program's OP_RFFT_B):
 //     Z_k = ((X_k + conj X_{M-k}) + i conj(w_k) (X_k - conj X_{M-k})) / 2,  w_k = exp(-2 pi i k / N),  0 <= k < M
@@ -23,14 +23,14 @@ struct RfftLineArgs {
   const double* in; long ldi;      // backward: lines of N / 2 + 1 interleaved complex numbers; forward: lines of N reals
   double* out; long ldo;           // backward: lines of N reals; forward: lines of N / 2 + 1 interleaved complex numbers
   int nlines;
-  int N;                           // reals per line: 4096 or 1024 (256: emulation build)
+  int N;                           // reals per line: 16384, 8192, 4096 or 1024 (256: emulation build)
   const double* tw;                // fft_twiddles(N / 2): (cos, -sin)(2 pi k / (N / 2))             (AxisTables::tw of the Fourier axis)
   const double* tw2;               // rfft_split_twiddles(N): (cos, sin)(2 pi k / N), k = 0 .. N / 2   (AxisTables::tw2)
   double scale = 1.0;              // multiplies the result (backward: on top of 1 / N)
   int cik = 0; double kscale = 0;  // backward: transform i k kscale X_k instead of X_k (OP_CIK with power 1)
 };
 RPDE_HD inline bool rfft_line_ok(const RfftLineArgs& a) {
-  return (a.N == 4096 || a.N == 1024 || a.N == 256) && (((size_t)a.in | (size_t)a.out) & 15) == 0 && (a.ldi & 1) == 0 && (a.ldo & 1) == 0;
+  return (a.N == 16384 || a.N == 8192 || a.N == 4096 || a.N == 1024 || a.N == 256) && (((size_t)a.in | (size_t)a.out) & 15) == 0 && (a.ldi & 1) == 0 && (a.ldo & 1) == 0;
 }
 
 // the passes behind the first radix-8 pass of an M = N / 2 point FFT (hdct_core's, with the twiddles of a Fourier axis:
@@ -38,7 +38,7 @@ RPDE_HD inline bool rfft_line_ok(const RfftLineArgs& a) {
 template <int N>
 RPDE_DEV void rfft_passes(Blk& blk, double* re_b, double* im_b, lds_t pre, lds_t pim, tab_t tw) {
   constexpr int T = N / 16, M = N / 2;
-  static_assert(N == 4096 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 4, 8 x 8 x 8 or 8 x 8 x 2");
+  static_assert(N == 16384 || N == 8192 || N == 4096 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 8 x 2, 8 x 8 x 8 x 8, 8 x 8 x 8 x 4, 8 x 8 x 8 or 8 x 8 x 2");
   auto exchange = [&](auto LG, auto RR) {
     constexpr int LGNS = decltype(LG)::value, Ns = 1 << LGNS, R = decltype(RR)::value, B = 8 / R;
     constexpr int LGR = (R == 8) ? 3 : (R == 4) ? 2 : 1;
@@ -106,7 +106,15 @@ RPDE_DEV void rfft_passes(Blk& blk, double* re_b, double* im_b, lds_t pre, lds_t
   exchange(integral_constant<int, 0>{}, integral_constant<int, 8>{});
   pass(integral_constant<int, 3>{}, integral_constant<int, 8>{});
   exchange(integral_constant<int, 3>{}, integral_constant<int, 8>{});
-  if constexpr (N == 4096) {
+  if constexpr (N == 16384 || N == 8192) {
+    pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
+    exchange(integral_constant<int, 6>{}, integral_constant<int, 8>{});
+    pass(integral_constant<int, 9>{}, integral_constant<int, 8>{});
+    if constexpr (N == 16384) {
+      exchange(integral_constant<int, 9>{}, integral_constant<int, 8>{});
+      pass(integral_constant<int, 12>{}, integral_constant<int, 2>{});
+    }
+  } else if constexpr (N == 4096) {
     pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     exchange(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     pass(integral_constant<int, 9>{}, integral_constant<int, 4>{});
@@ -250,6 +258,15 @@ RPDE_DEV void rfft_pair_line(int line, double* lds, const RfftLineArgs& a0, cons
   Blk blk{line, 0, T, lds + half * LB, nullptr, 0, half * T};
   rfft_bwd_line<N>(blk, half ? a1 : a0);
 #endif
+}
+
+// The same two transforms one after the other in ONE buffer: lines of 8192 / 16384 reals, whose exchange buffer (70 / 140 KB)
+// does not fit twice into the LDS of a CU next to a second workgroup.  The line is read twice (the second time from the L2).
+template <int N>
+RPDE_DEV void rfft_seq2_line(Blk& blk, const RfftLineArgs& a0, const RfftLineArgs& a1) {
+  rfft_bwd_line<N>(blk, a0);
+  RPDE_SYNC(blk);
+  rfft_bwd_line<N>(blk, a1);
 }
 
 // S3 of the periodic step (navier_eq.rs solve_velx / solve_vely / solve_temp with the Fourier axis: the x part of HholtzAdi is

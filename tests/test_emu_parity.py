@@ -222,10 +222,23 @@ def test_periodic_step(emu_lib, nx, ny, steps, aspect):
 
 
 @pytest.mark.parametrize("nx", [8192, 16384])
-def test_periodic_step_long_fourier_lines(emu_lib, nx):
+def test_periodic_step_long_fourier_lines(emu_lib, monkeypatch, nx):
     """nx = 16384 (BASELINE config 5's line length) and 8192: the one-slot 1024-thread configuration
     with a 4096- / 8192-point complex FFT per x-line; aspect 8 as in that config."""
     K.check_step_parity(emu_lib, True, nx, 9, 1e5, 0.01, 2, aspect=8.0, check_at=[1, 2])
+    # round 4: these lines run through the whole-line Fourier kernels as well (rfft_line.h: 8 x 8 x 8 x 8 (x 2) passes, the two
+    # transforms of S1 one after the other in one buffer); A/B against the line programs
+    nav, _ = K.make_pair(emu_lib, True, nx, 9, 1e5, 1.0, 0.01, 8.0)
+    kinds = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert kinds["S1 x: state -> phys-x + d/dx"].startswith("whole-line transform pair") and kinds["S3 x: rhs + hholtz-x vely"].startswith("whole-line rhs"), kinds
+    nav.update(2)
+    monkeypatch.setenv("RPDE_S1_LINE", "0")
+    monkeypatch.setenv("RPDE_S3_LINE", "0")
+    ref, _ = K.make_pair(emu_lib, True, nx, 9, 1e5, 1.0, 0.01, 8.0)
+    assert _has_line_program(ref, "S1 x") and _has_line_program(ref, "S3 x")
+    ref.update(2)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(ref, k).vhat) < (1e-10 if k == "pres" else 1e-11), k
 
 
 def test_errors_mirror_reference_panics(emu_lib):
