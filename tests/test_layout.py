@@ -82,3 +82,21 @@ def test_environment_switches_are_the_documented_list():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in ENV_SWITCHES:
         assert name in doc, f"{name} is not documented in INTEGRATION.md"
+
+
+def test_committed_pmc_evidence_belongs_to_these_kernel_sources():
+    """profiles/r04_pmc_traffic.json (rocprofv3 --pmc passes of the round's evidence run) carries a sha256 over
+    rustpde_mpi_amd/csrc/*.{h,cc}; bench.py reports roofline.traffic_source.stale = true when the running sources hash
+    differently.  The committed evidence of the latest round has to belong to the committed kernels."""
+    import glob
+    import hashlib
+    import json
+    root = os.path.join(ROOT, "rustpde_mpi_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".h", ".cc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))[-1]
+    d = json.load(open(latest))
+    assert d.get("csrc_sha256") == h.hexdigest(), f"{os.path.basename(latest)} was collected on other kernel sources"
