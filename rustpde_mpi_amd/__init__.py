@@ -26,7 +26,7 @@ import numpy as np
 
 from ._capi import Lib, RpdeError, as_f64, ptr
 
-__all__ = ["Navier2D", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
+__all__ = ["Navier2D", "Navier2DMpi", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
            "chebyshev", "cheb_dirichlet", "cheb_neumann", "cheb_dirichlet_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
@@ -503,6 +503,24 @@ class h5:
         a = as_f64(array)
         dims = (C.c_uint64 * 2)(*a.shape)
         library.call("rpde_h5_write", str(filename).encode(), path.encode(), a.ndim, dims, ptr(a))
+
+
+class Navier2DMpi:
+    """The reference's `Navier2DMpi` (src/navier_stokes_mpi/navier.rs:216-225, 364-373): the same constructors with the
+    communicator in front -- `universe` is what the reference calls its `&Universe`, here a `rustpde_mpi_amd.dist.TorchComm`
+    (callback transport over torch.distributed) or `RcclComm` (native RCCL transport).  One process per GPU; every rank
+    passes the same arguments.  The object returned is a pencil-sharded `Navier2D`: `update()`, `exit()`, `callback()`,
+    `write()` / `read()`, the field views and `Statistics` behave as on one GPU (collective where the reference's are)."""
+
+    @staticmethod
+    def new_confined(universe, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, init_random=0.1, seed=0):
+        return Navier2D.new_confined(nx, ny, ra, pr, dt, aspect, bc, device=device, library=library, comm=universe,
+                                     init_random=init_random, seed=seed)
+
+    @staticmethod
+    def new_periodic(universe, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, init_random=0.1, seed=0):
+        return Navier2D.new_periodic(nx, ny, ra, pr, dt, aspect, bc, device=device, library=library, comm=universe,
+                                     init_random=init_random, seed=seed)
 
 
 class _StatField:

@@ -31,7 +31,8 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         bc = case[7] if len(case) > 7 else "rbc"       # "hc": horizontal convection (three-term temperature base along y)
         vs_single = len(case) > 8 and case[8] == "single"   # compare with the one-rank engine (same setup code) instead of the oracle
         ctor = "new_periodic" if periodic else "new_confined"
-        nav = getattr(R.Navier2D, ctor)(nx, ny, ra, 1.0, dt, aspect, bc, library=lib, comm=comm)
+        # the reference's spelling of the sharded constructors: Navier2DMpi::new_confined(&universe, nx, ny, ...)
+        nav = getattr(R.Navier2DMpi, ctor)(comm, nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
         nav.set_velocity(0.2, 1.0, 1.0)
         nav.set_temperature(0.2, 1.0, 1.0)
         nav.update(steps)
