@@ -9,6 +9,7 @@ eigenbases of the same matrix are apart at each snapshot (the start-up transient
     python tests/golden/make_headline_golden.py run 4097 full   &     (about 1.5 h on 4 cores)
     python tests/golden/make_headline_golden.py run 4097 parity &
     python tests/golden/make_headline_golden.py combine 4097
+    python tests/golden/make_headline_golden.py compare 4097 <dir A> <dir B> out.json     (two "full" runs against each other)
 
 `run` leaves stride-8 samples of every snapshot in /tmp/rpde_golden; `combine` writes the committed
 file: stride-64 samples (65 x 65 per field) and full-field norms of the "full" run, and the relative L2
@@ -75,13 +76,35 @@ def combine(n):
             out[f"{k}_{s}_full_vs_parity"] = np.array(np.linalg.norm(a[k] - b[k]) / np.linalg.norm(a[k]) if b is not None else np.nan)
         out[f"div_norm_{s}"] = a["div_norm"]
         print(s, {k: float(out[f"{k}_{s}_full_vs_parity"]) for k in FIELDS})
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"headline_{n}_full.npz")
+    # RPDE_GOLDEN_OUT: another file name (the extended 4097 run of round 4 is committed NEXT to the golden the tests read:
+    # headline_4097_full_extended.npz -- its snapshots behind step 200 have no "parity" partner and no engine comparison yet)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("RPDE_GOLDEN_OUT", f"headline_{n}_full.npz"))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path))
+
+
+def compare(n, dir_a, dir_b, out):
+    """Two runs of the SAME oracle setup (mode "full": the reference's one dgeev of the whole operator) in two processes --
+    e.g. with different BLAS thread counts: relative L2 of their stride-8 samples per snapshot.  dgeev's output is not
+    reproducible across thread counts, and the Poisson solve amplifies its round-off by 1e10 (poisson.rs:84-87): this is how
+    far the REFERENCE ALGORITHM sits from itself."""
+    import json
+    rows = []
+    for s in SNAPS:
+        fa, fb = os.path.join(dir_a, f"{n}_full_{s}.npz"), os.path.join(dir_b, f"{n}_full_{s}.npz")
+        if not (os.path.exists(fa) and os.path.exists(fb)):
+            continue
+        a, b = np.load(fa), np.load(fb)
+        rows.append({"steps": s, "rel_l2": {k: float(np.linalg.norm(a[k] - b[k]) / np.linalg.norm(a[k])) for k in FIELDS}})
+        print(s, {k: f"{v:.2e}" for k, v in rows[-1]["rel_l2"].items()})
+    json.dump({"n": n, "ra": RA, "dt": DT, "what": "oracle eig_mode=full, run A vs run B (two processes, different BLAS thread counts)",
+               "snapshots": rows}, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]), sys.argv[3])
+    elif sys.argv[1] == "compare":      # compare <n> <dir of run A> <dir of run B> <out.json>
+        compare(int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5])
     else:
         combine(int(sys.argv[2]))
