@@ -40,6 +40,18 @@ const char* rpde_version(void);
 /* 1 when the library was built for the GPU (HIP, gfx950); the test-only host emulation build reports 0 */
 int rpde_is_device_build(void);
 int rpde_device_count(int* count);
+/* Device memory bookkeeping (no counterpart in the reference: ndarray owns host memory).  The library takes its HBM in
+ * slabs per DEVICE (csrc/platform.h ArenaT): a handle created with `device` = d only ever gets memory of device d, also when
+ * one process drives several GPUs.  rpde_device_memory: bytes held in slabs / bytes in live buffers on `device` (-1: all).
+ * rpde_device_trim: slabs without a live buffer go back to the driver (the destroy functions call it; a host that wants the
+ * memory back for another library at another time calls it itself).  rpde_arena_check: with RPDE_ARENA_GUARD=1 in the
+ * environment every buffer is followed by a guard granule; *violations = buffers whose guard was overwritten since the last
+ * call (0 without guards).  rpde_arena_selftest: the keying logic on a host backend with two pretended devices (runs
+ * without a GPU); 0 = pass. */
+int rpde_device_memory(int device, size_t* slab_bytes, size_t* used_bytes);
+int rpde_device_trim(int device, size_t* released_bytes);
+int rpde_arena_check(long* violations);
+int rpde_arena_selftest(void);
 
 /* ---- engine level: what `impl Integrate for Navier2D` does ----------------------------------- */
 /* Navier2D::new_confined(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes/navier.rs:215-308 */

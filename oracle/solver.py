@@ -304,7 +304,13 @@ class Poisson:
     """c D2 vhat = A f via eigen-decomposition in x and banded row solves in y
     (``poisson.rs:54-94,195-236``; tensor data ``fdma_tensor.rs:74-154``)."""
 
+    # (the tensor Helmholtz solver of hholtz.rs is the same construction with other constants: class Hholtz below)
+    LAPLACIAN_SIGN = 1.0      # laplacian = +mat_b * c          (poisson.rs:68)
+    ALPHA = 0.0               # FdmaTensor::from_matrix(.., 0.) (poisson.rs:82)
+    SINGULARITY_FIX = True    # poisson.rs:84-87
+
     def __init__(self, space: Space2, c, eig_mode="full", eig_override=None):
+        c = [self.LAPLACIAN_SIGN * ci for ci in c]
         b0, b1 = space.bases
         self.matvec = []
         ing = []
@@ -332,9 +338,9 @@ class Poisson:
         assert kind1 == "band"
         self.fdma_a = Fdma(*lap1, sweep=False)
         self.fdma_c = Fdma(*mass1, sweep=False)
-        self.alpha = 0.0
+        self.alpha = self.ALPHA
         # singularity fix, poisson.rs:84-87 (shifts the WHOLE eigenvalue vector)
-        if abs(self.lam[0]) < 1e-10:
+        if self.SINGULARITY_FIX and abs(self.lam[0]) < 1e-10:
             self.lam = self.lam - 1e-10
 
     def row_bands(self):
@@ -358,6 +364,16 @@ class Poisson:
             if self.bwd is not None:
                 out = self.bwd @ out
         return out
+
+
+class Hholtz(Poisson):
+    """(I - c D2) vhat = A f with the tensor solver (``src/solver/hholtz.rs:72-106``): the construction of ``Poisson`` with
+    laplacian = -mat_b * c (``hholtz.rs:86``), alpha = 1 (``hholtz.rs:100``: the identity becomes alpha * (Cx x Cy)) and no
+    singularity fix; ``solve`` = preconditioner along both axes, then ``FdmaTensor::solve`` (``hholtz.rs:176-186``).
+    Used by ``Navier2DAdjoint`` as the norm of the residual (``steady_adjoint.rs:296-318``)."""
+    LAPLACIAN_SIGN = -1.0
+    ALPHA = 1.0
+    SINGULARITY_FIX = False
 
 
 class Poisson1:

@@ -22,6 +22,10 @@ SIGNATURES = {
     "rpde_version": (C.c_char_p, []),
     "rpde_is_device_build": (C.c_int, []),
     "rpde_device_count": (C.c_int, [_ip]),
+    "rpde_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rpde_device_trim": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
+    "rpde_arena_check": (C.c_int, [C.POINTER(C.c_long)]),
+    "rpde_arena_selftest": (C.c_int, []),
     "rpde_navier2d_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                 C.c_double, C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "rpde_navier2d_create_periodic": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,

@@ -69,6 +69,90 @@ int rpde_device_count(int* count) {
   })
 }
 
+int rpde_device_memory(int device, size_t* slab_bytes, size_t* used_bytes) {
+  RPDE_TRY({
+    RPDE_REQUIRE(slab_bytes && used_bytes, "null pointer");
+#ifdef RPDE_EMU
+    (void)device; *slab_bytes = 0; *used_bytes = 0;
+#else
+    *slab_bytes = DevArena::get().slab_bytes(device);
+    *used_bytes = DevArena::get().used_bytes(device);
+#endif
+  })
+}
+int rpde_device_trim(int device, size_t* released_bytes) {
+  RPDE_TRY({
+    size_t r = 0;
+#ifndef RPDE_EMU
+    if (dev_arena_on()) r = DevArena::get().trim(device);
+#else
+    (void)device;
+#endif
+    if (released_bytes) *released_bytes = r;
+  })
+}
+int rpde_arena_check(long* violations) {
+  RPDE_TRY({
+    RPDE_REQUIRE(violations, "null pointer");
+#ifdef RPDE_EMU
+    *violations = 0;
+#else
+    *violations = dev_arena_on() ? DevArena::get().check() : 0;
+#endif
+  })
+}
+int rpde_arena_selftest(void) {
+  RPDE_TRY({
+    using A = ArenaT<ArenaHostBackend>;
+    int& cur = ArenaHostBackend::current();
+    const int saved = cur;
+    struct Restore { int& c; int v; ~Restore() { c = v; } } restore{cur, saved};
+    {
+      A a(false);
+      cur = 0;
+      void* p0 = a.alloc(1000);
+      void* q0 = a.alloc(5 << 20);
+      RPDE_REQUIRE(p0 && q0 && a.device_of(p0) == 0 && a.device_of(q0) == 0, "device 0 blocks");
+      RPDE_REQUIRE(a.slab_bytes(0) == A::kFirstSlabBytes && a.slab_bytes(1) == 0, "one small first slab on device 0");
+      a.free(q0);                                      // 5 MB free on a device-0 slab ...
+      cur = 1;
+      void* p1 = a.alloc(5 << 20);                     // ... which an allocation for device 1 must not take
+      RPDE_REQUIRE(p1 && a.device_of(p1) == 1, "a device-1 block lies in a device-1 slab");
+      RPDE_REQUIRE(a.slab_bytes(1) == A::kFirstSlabBytes && a.slab_bytes(0) == A::kFirstSlabBytes, "device 1 got its own slab");
+      RPDE_REQUIRE(a.used_bytes(0) == 4096 && a.used_bytes(1) == (size_t(5) << 20), "per-device accounting");
+      a.free(p0);                                      // freed while ANOTHER device is current: back to its own slab
+      RPDE_REQUIRE(a.used_bytes(0) == 0 && a.used_bytes(1) == (size_t(5) << 20), "free finds the owning slab");
+      RPDE_REQUIRE(a.trim(1) == 0, "a slab with a live block stays");
+      RPDE_REQUIRE(a.trim(0) == A::kFirstSlabBytes && a.slab_bytes(0) == 0, "trim(0) releases device 0 only");
+      cur = 0;
+      void* r0 = a.alloc(size_t(300) << 20);           // larger than the first slab: a slab of its own size
+      RPDE_REQUIRE(r0 && a.device_of(r0) == 0 && a.slab_bytes(0) == (size_t(300) << 20), "oversized request");
+      void* s0 = a.alloc(1 << 20);                     // second slab of the device: the large size
+      RPDE_REQUIRE(s0 && a.slab_bytes(0) == (size_t(300) << 20) + A::kSlabBytes, "second slab");
+      a.free(r0); a.free(s0); a.free(p1);
+      RPDE_REQUIRE(a.trim(-1) == (size_t(300) << 20) + A::kSlabBytes + A::kFirstSlabBytes && a.slab_bytes(-1) == 0, "trim(-1)");
+    }
+    {
+      A g(true);                                       // guards: a write behind a block is counted, a write inside is not
+      cur = 0;
+      char* p = static_cast<char*>(g.alloc(1000));
+      char* q = static_cast<char*>(g.alloc(8192));
+      RPDE_REQUIRE(p && q, "guarded blocks");
+      std::memset(p, 0, 1000); std::memset(q, 0, 8192);
+      RPDE_REQUIRE(g.check() == 0, "clean guards");
+      p[1000] = 0;                                     // first byte behind the 1000 requested
+      RPDE_REQUIRE(g.check() == 1, "overrun by one byte");
+      q[8192 + 4095] = 1;                              // last byte of the guard granule
+      RPDE_REQUIRE(g.check() == 2, "overrun into the guard granule");
+      g.free(p);
+      RPDE_REQUIRE(g.check() == 2, "free() counts the block it releases, check() the live one");
+      g.free(q);
+      RPDE_REQUIRE(g.check() == 1 && g.check() == 0, "counted once");
+      g.trim(-1);
+    }
+  })
+}
+
 static int create_engine(int nx, int ny, double ra, double pr, double dt, double aspect,
                          const char* bc, int device, bool periodic, rpde_navier2d** out) {
   RPDE_TRY({
@@ -166,7 +250,7 @@ int rpde_navier2d_comm_stats(rpde_navier2d* h, double* bytes_per_step, int* exch
 }
 int rpde_navier2d_destroy(rpde_navier2d* h) {
   RPDE_TRY({
-    if (h) { select_device(h->device); delete h->e; delete h; }
+    if (h) { select_device(h->device); delete h->e; delete h; dev_trim(); }
   })
 }
 int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n) {
@@ -425,7 +509,7 @@ int rpde_space2_create(int kind0, int n0, int kind1, int n1, int device, rpde_sp
   })
 }
 int rpde_space2_destroy(rpde_space2* s) {
-  RPDE_TRY({ if (s) { select_device(s->device); delete s->sp; delete s; } })
+  RPDE_TRY({ if (s) { select_device(s->device); delete s->sp; delete s; dev_trim(); } })
 }
 static void shape_of(Space2Ops& sp, int which, int* r, int* c, int* e) {
   switch (which) {

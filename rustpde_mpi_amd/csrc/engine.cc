@@ -156,6 +156,20 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
       while (col1_W_ < kCol1MaxW && (nb + col1_W_ - 1) / col1_W_ > kCol1MaxNSB) col1_W_ *= 2;
       col1_NSB_ = (nb + col1_W_ - 1) / col1_W_;
       if (col1_NSB_ > kCol1MaxNSB) col1_W_ = col1_NSB_ = col1_tiles_ = 0;   // taller than 16384 rows: the three kernels
+#ifndef RPDE_EMU
+      // the single-pass scans WAIT for partner workgroups (colscan1.h): a tile's NSB super-blocks of up to two paired fields
+      // plus the tickets handed out in between must be resident together.  On a partitioned or CU-masked device that may
+      // not hold: ask the runtime how many workgroups of the kernel the device keeps resident and use the three kernels if
+      // that is not comfortably more (RPDE_COL1_FORCE=1: skip the test, A/B only)
+      if (col1_W_ && !std::getenv("RPDE_COL1_FORCE")) {
+        const int resident = col_hholtz1_resident_workgroups(col1_W_, col1_NSB_);
+        if (resident < 2 * col1_NSB_ + 16) {
+          std::fprintf(stderr, "rustpde_hip: %d resident workgroups of the single-pass column scan (< %d): using the three-kernel form\n",
+                       resident, 2 * col1_NSB_ + 16);
+          col1_W_ = col1_NSB_ = col1_tiles_ = 0;
+        }
+      }
+#endif
     }
     auto up = [&](ColHhDev& d, const ColHhHost& h) {
       d.upload(h);
@@ -1289,6 +1303,10 @@ bool Navier2DEngine::read_nanflag() {
   if (col1_W_) RPDE_HIP(hipMemcpyAsync(hflag_ + 1, reinterpret_cast<int*>(colsync_.p), sizeof(int), hipMemcpyDeviceToHost, st_.s));
   RPDE_HIP(hipStreamSynchronize(st_.s));
   // a single-pass column scan whose wait for its partner workgroups ran out (colscan1.h): the step's results are wrong
+  if (col1_W_ && hflag_[1] != 0) {   // report it once: the flag is cleared, the engine stays usable (the state of this step is not)
+    RPDE_HIP(hipMemsetAsync(colsync_.p, 0, sizeof(int), st_.s));
+    RPDE_HIP(hipStreamSynchronize(st_.s));
+  }
   RPDE_REQUIRE(!col1_W_ || hflag_[1] == 0, "column scan: a workgroup waited for its partners in vain (RPDE_COL_ONEPASS=0 selects the three-kernel form)");
 #else
   *hflag_ = *flagp();

@@ -164,7 +164,6 @@ class Navier2DEngine {
   void halo_rows(double* const* arr, int n, int front, int tail);
   void run_col_hholtz(ColHhArgs a, const ColHh1Tabs* x1 = nullptr, unsigned long long* site = nullptr, long long* trace = nullptr);
   void run_col_diff(ColDiffArgs a, unsigned long long* site);   // column scans, one rank or rows split over the ranks (colscan.h)
-  void run_col_diff(ColDiffArgs a);
   ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
   DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;
   void scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols);

@@ -591,7 +591,10 @@ __global__ __launch_bounds__(W * 64, 4) void col_hholtz1_kernel(const ColHh1Args
   ColLoc L;
 #pragma unroll
   for (int k = 0; k < kCol1Agg; ++k) L.v[k] = 0.0;
-  const Col1TabLanes tabs(t, x, b * kColBR, b * kColBR - a.shift[f], lane);   // (tables are padded: reads behind the last block are harmless)
+  // a wave whose block does not exist (super-blocks behind the last block) fetches block 0's coefficients and never uses
+  // them: the tables are padded for one block behind the last row, not for W of them
+  const int bt = rowsok ? b : 0;
+  const Col1TabLanes tabs(t, x, bt * kColBR, bt * kColBR - a.shift[f], lane);
   if (rowsok) colhh1_local(a, f, b, ic, r, L, tabs);
   if (tfetch) tbl[tid] = tv;                             // (twl follows tbl)
   RPDE_C1_MARK(2);
@@ -692,6 +695,7 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
   if (a.ncols <= 0 || a.n <= 0 || a.nf <= 0 || a.NB <= 0) return;
   RPDE_REQUIRE(A.NSB <= kCol1MaxNSB && A.W * A.NSB >= a.NB, "colhh1: super-block partition");
   RPDE_REQUIRE(A.W >= 8 && A.sync != nullptr, "colhh1: synchronisation area of the launch site");
+  RPDE_REQUIRE((A.W + A.NSB) * kCol1TabPerBlock <= 64 * A.W, "colhh1: one thread per transfer coefficient (W + NSB blocks of 14)");
   const int per = A.NSB * A.tiles;
   const int wgs = (a.pair && a.nf == 2) ? 16 * ((per + 7) / 8) : per * a.nf;
   const size_t bytes = sizeof(double) * col1_lds_doubles(A.W, A.NSB);
@@ -711,6 +715,16 @@ void launch_col_hholtz1(const ColHh1Args& A, Stream& st) {
   else if (A.W == 8) go(col_hholtz1_kernel<8>, 8);
   else fail("colhh1: 8 or 16 blocks per workgroup");
   RPDE_HIP(hipGetLastError());
+}
+int col_hholtz1_resident_workgroups(int W, int NSB) {
+  int dev = 0, cus = 0, per_cu = 0;
+  RPDE_HIP(hipGetDevice(&dev));
+  RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const size_t bytes = sizeof(double) * col1_lds_doubles(W, NSB);
+  const void* k = (W == 16) ? reinterpret_cast<const void*>(col_hholtz1_kernel<16>) : reinterpret_cast<const void*>(col_hholtz1_kernel<8>);
+  RPDE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  RPDE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * W, bytes));
+  return per_cu * cus;
 }
 // single-pass y-derivative (colscan1.h)
 __global__ __launch_bounds__(kDiff1W * 64, 8) void col_diff1_kernel(const ColDiff1Args A) {   // eight waves per SIMD: 64 VGPRs

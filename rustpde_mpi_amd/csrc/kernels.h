@@ -79,8 +79,12 @@ void launch_xchg_unpack(const XchgDesc& d, const double* recv, Stream& st);
 // summaries (sharded only, after the exchange); 3: final pass
 void launch_col_hholtz_phase(const ColHhArgs& a, int phase, Stream& st);
 void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st);
-// single-pass form (colscan1.h): one kernel behind a memset node that clears the ticket / arrival counters
+// single-pass form (colscan1.h): one kernel; every launch site owns its ticket / arrival counters and never resets them
+// (64-bit, a launch is an epoch)
 void launch_col_hholtz1(const ColHh1Args& a, Stream& st);
+// workgroups of that kernel the current device keeps resident at once (occupancy per CU x CUs): the engine's ctor compares it
+// with what a tile's partners need before it chooses the single-pass form
+int col_hholtz1_resident_workgroups(int W, int NSB);
 void launch_col_diff1(const ColDiff1Args& a, Stream& st);   // colscan1.h: the y-derivative in one pass (one rank)
 inline void launch_col_hholtz(const ColHhArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_hholtz_phase(a, ph, st); }   // one rank
 inline void launch_col_diff(const ColDiffArgs& a, Stream& st) { for (int ph : {0, 1, 3}) launch_col_diff_phase(a, ph, st); }

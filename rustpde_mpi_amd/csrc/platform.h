@@ -130,28 +130,44 @@ struct Stream {
 
 constexpr size_t kEmuGuardBytes = 256;
 
-#ifndef RPDE_EMU
-// Device memory of every engine and operator of the process comes out of a few large slabs: one hipMalloc of
-// kSlabBytes (a multiple of the 2 MB a page-table block covers; a larger request gets a slab of its own size) that is
-// mapped ONCE, and a best-fit free list with coalescing on top of it.  Nothing this library allocates shares a
-// 2 MB block of the runtime's own small-allocation heap (ROCr packs hipMalloc requests below 2 MB into 2 MB blocks it
-// also uses for its internal objects, and gives such blocks back piecemeal), no mapping appears or disappears while a
-// step runs, and an engine's 300 tables cost 300 free-list operations instead of 300 driver calls.  Slabs go back to
-// the driver only when an allocation fails (trim()) -- DESIGN.md section 10-0 has the measurements that led here.
-class DevArena {
+// Device memory of every engine and operator of the process comes out of a few large slabs: one raw allocation (hipMalloc)
+// of a multiple of the 2 MB a page-table block covers, mapped ONCE, and a best-fit free list with coalescing on top of it.
+// Nothing this library allocates shares a 2 MB block of the runtime's own small-allocation heap (ROCr packs hipMalloc requests
+// below 2 MB into 2 MB blocks it also uses for its internal objects, and gives such blocks back piecemeal), no mapping
+// appears or disappears while a step runs, and an engine's 300 tables cost 300 free-list operations instead of 300 driver
+// calls (DESIGN.md section 10-0 has the measurements that led here).
+//  * **Keyed by device** (round 5): a slab belongs to the device that was current when it was allocated; an allocation only
+//    ever takes space from slabs of the device that is current NOW (every C-ABI entry selects its handle's device first), and
+//    a block goes back to the slab it came from whatever device is current at free time.
+//  * trim(device): slabs nobody uses go back to the driver -- called when an engine / operator set is destroyed and when an
+//    allocation fails.  The first slab of a device is small (256 MB), later ones 1 GB.
+//  * Guards (RPDE_ARENA_GUARD=1, tests): every block is followed by one granule filled with a byte pattern, the unused tail
+//    of its last granule as well; check() / free() count blocks whose pattern was overwritten -- a contiguous slab turns
+//    an overrun into a silent hit on the neighbour, the guards keep WRITES beyond a block detectable (reads beyond a block
+//    stay invisible here: RPDE_ARENA=0 gives every buffer its own mapping for that).
+// The bookkeeping is a template over the raw allocator so that the keying logic runs in a unit test without a second GPU
+// (rpde_arena_selftest: a host backend with two pretended devices).
+template <class Backend>
+class ArenaT {
  public:
   static constexpr size_t kPage = 4096;
   static constexpr size_t kHuge = size_t(2) << 20;
+  static constexpr size_t kFirstSlabBytes = size_t(256) << 20;
   static constexpr size_t kSlabBytes = size_t(1) << 30;
-  static DevArena& get() { static DevArena a; return a; }
+  static constexpr unsigned char kGuardByte = 0xA5;
+  explicit ArenaT(bool guard = false) : guard_(guard) {}
+  ~ArenaT() = default;   // process exit: the driver reclaims the slabs (no HIP calls from static destructors)
   void* alloc(size_t bytes) {
-    const size_t n = round_up(bytes ? bytes : 8, kPage);
+    const size_t want = bytes ? bytes : 8;
+    const size_t n = round_up(want, kPage) + (guard_ ? kPage : 0);
+    const int dev = Backend::current_device();
     std::lock_guard<std::mutex> lk(mu_);
-    void* p = take(n);
+    void* p = take(n, want, dev);
     if (!p) {
-      if (!add_slab(n)) { trim(); if (!add_slab(n)) return nullptr; }
-      p = take(n);
+      if (!add_slab(n, dev)) { trim_locked(-1); if (!add_slab(n, dev)) return nullptr; }
+      p = take(n, want, dev);
     }
+    if (p && guard_) Backend::fill(static_cast<char*>(p) + want, kGuardByte, n - want, dev);
     return p;
   }
   void free(void* p) {
@@ -159,6 +175,7 @@ class DevArena {
     std::lock_guard<std::mutex> lk(mu_);
     auto u = used_.find(static_cast<char*>(p));
     if (u == used_.end()) return;
+    if (guard_ && !guard_intact(u->first, u->second)) ++violations_;
     Slab& sl = slabs_[u->second.slab];
     char* a = u->first; size_t n = u->second.bytes;
     used_.erase(u);
@@ -170,48 +187,136 @@ class DevArena {
     }
     sl.free[a] = n;
   }
-  size_t slab_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t t = 0; for (auto& s : slabs_) t += s.size; return t; }
-  size_t used_bytes() { std::lock_guard<std::mutex> lk(mu_); size_t t = 0; for (auto& u : used_) t += u.second.bytes; return t; }
+  // slabs of `device` (-1: of every device) that hold no block go back to the driver; returns the bytes released
+  size_t trim(int device = -1) { std::lock_guard<std::mutex> lk(mu_); return trim_locked(device); }
+  // blocks in use whose guard pattern was overwritten (+ those found at free time since the last call); 0 without guards
+  long check() {
+    std::lock_guard<std::mutex> lk(mu_);
+    long bad = violations_;
+    violations_ = 0;
+    if (guard_) for (auto& u : used_) if (!guard_intact(u.first, u.second)) ++bad;
+    return bad;
+  }
+  bool guarded() const { return guard_; }
+  size_t slab_bytes(int device = -1) {
+    std::lock_guard<std::mutex> lk(mu_); size_t t = 0;
+    for (auto& s : slabs_) if (s.base && (device < 0 || s.device == device)) t += s.size;
+    return t;
+  }
+  size_t used_bytes(int device = -1) {
+    std::lock_guard<std::mutex> lk(mu_); size_t t = 0;
+    for (auto& u : used_) if (device < 0 || slabs_[u.second.slab].device == device) t += u.second.bytes;
+    return t;
+  }
+  int device_of(void* p) {   // the device whose slab holds p; -1: not ours
+    std::lock_guard<std::mutex> lk(mu_);
+    auto u = used_.find(static_cast<char*>(p));
+    return u == used_.end() ? -1 : slabs_[u->second.slab].device;
+  }
   template <class F> void for_each_used(F f) { std::lock_guard<std::mutex> lk(mu_); for (auto& u : used_) f(u.first, u.second.bytes); }
 
  private:
-  struct Slab { char* base = nullptr; size_t size = 0; std::map<char*, size_t> free; };
-  struct Used { size_t bytes; size_t slab; };
+  struct Slab { char* base = nullptr; size_t size = 0; int device = -1; std::map<char*, size_t> free; };
+  struct Used { size_t bytes; size_t slab; size_t want; };
   static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-  void* take(size_t n) {                                      // best fit over all slabs
+  void* take(size_t n, size_t want, int dev) {                // best fit over the slabs of THIS device
     size_t bs = 0; std::map<char*, size_t>::iterator bi; bool found = false;
-    for (size_t k = 0; k < slabs_.size(); ++k)
+    for (size_t k = 0; k < slabs_.size(); ++k) {
+      if (!slabs_[k].base || slabs_[k].device != dev) continue;
       for (auto it = slabs_[k].free.begin(); it != slabs_[k].free.end(); ++it)
         if (it->second >= n && (!found || it->second < bi->second)) { bs = k; bi = it; found = true; }
+    }
     if (!found) return nullptr;
     char* a = bi->first; const size_t rest = bi->second - n;
     slabs_[bs].free.erase(bi);
     if (rest) slabs_[bs].free[a + n] = rest;
-    used_[a] = Used{n, bs};
+    used_[a] = Used{n, bs, want};
     return a;
   }
-  bool add_slab(size_t n) {
-    const size_t size = std::max(kSlabBytes, round_up(n, kHuge));
-    void* p = nullptr;
-    if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return false; }
-    for (auto& s : slabs_) if (!s.base) { s.base = static_cast<char*>(p); s.size = size; s.free.clear(); s.free[s.base] = size; return true; }
-    slabs_.emplace_back();
-    slabs_.back().base = static_cast<char*>(p); slabs_.back().size = size; slabs_.back().free[slabs_.back().base] = size;
+  bool add_slab(size_t n, int dev) {
+    bool first = true;
+    for (auto& s : slabs_) if (s.base && s.device == dev) first = false;
+    const size_t size = std::max(first ? kFirstSlabBytes : kSlabBytes, round_up(n, kHuge));
+    void* p = Backend::raw_alloc(size, dev);
+    if (!p) return false;
+    Slab* sl = nullptr;
+    for (auto& s : slabs_) if (!s.base) { sl = &s; break; }
+    if (!sl) { slabs_.emplace_back(); sl = &slabs_.back(); }
+    sl->base = static_cast<char*>(p); sl->size = size; sl->device = dev; sl->free.clear(); sl->free[sl->base] = size;
     return true;
   }
-  void trim() {                                               // slabs nobody uses go back to the driver
+  size_t trim_locked(int device) {
+    size_t released = 0;
     for (auto& s : slabs_)
-      if (s.base && s.free.size() == 1 && s.free.begin()->second == s.size) { (void)hipFree(s.base); s.base = nullptr; s.size = 0; s.free.clear(); }
+      if (s.base && (device < 0 || s.device == device) && s.free.size() == 1 && s.free.begin()->second == s.size) {
+        Backend::raw_free(s.base, s.device);
+        released += s.size;
+        s.base = nullptr; s.size = 0; s.device = -1; s.free.clear();
+      }
+    return released;
   }
+  bool guard_intact(char* a, const Used& u) {
+    const size_t len = u.bytes - u.want;
+    scratch_.resize(len);
+    Backend::read(scratch_.data(), a + u.want, len, slabs_[u.slab].device);
+    for (size_t i = 0; i < len; ++i) if (scratch_[i] != kGuardByte) return false;
+    return true;
+  }
+  const bool guard_;
   std::mutex mu_;
   std::vector<Slab> slabs_;
   std::map<char*, Used> used_;
+  std::vector<unsigned char> scratch_;
+  long violations_ = 0;
+};
+
+// the backend of rpde_arena_selftest: host memory, `device` is whatever the test pretends is current
+struct ArenaHostBackend {
+  static int& current() { static thread_local int d = 0; return d; }
+  static int current_device() { return current(); }
+  static void* raw_alloc(size_t n, int) { return std::malloc(n); }
+  static void raw_free(void* p, int) { std::free(p); }
+  static void fill(void* p, unsigned char b, size_t n, int) { std::memset(p, b, n); }
+  static void read(void* dst, const void* src, size_t n, int) { std::memcpy(dst, src, n); }
+};
+
+#ifndef RPDE_EMU
+struct ArenaHipBackend {
+  static int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+  static void* raw_alloc(size_t n, int) {      // the device is current (alloc() read it from the runtime)
+    void* p = nullptr;
+    if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+  }
+  struct OnDevice {                            // run a few runtime calls with `dev` current, then restore
+    int prev = 0; bool sw = false;
+    explicit OnDevice(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) sw = hipSetDevice(dev) == hipSuccess; }
+    ~OnDevice() { if (sw) (void)hipSetDevice(prev); }
+  };
+  static void raw_free(void* p, int dev) { OnDevice g(dev); (void)hipFree(p); }
+  static void fill(void* p, unsigned char b, size_t n, int dev) { OnDevice g(dev); (void)hipMemset(p, b, n); }
+  static void read(void* dst, const void* src, size_t n, int dev) { OnDevice g(dev); (void)hipDeviceSynchronize(); (void)hipMemcpy(dst, src, n, hipMemcpyDeviceToHost); }
+};
+class DevArena {
+ public:
+  static ArenaT<ArenaHipBackend>& get() {
+    static ArenaT<ArenaHipBackend> a([] { const char* e = std::getenv("RPDE_ARENA_GUARD"); return e && std::atoi(e) != 0; }());
+    return a;
+  }
 };
 inline bool dev_arena_on() {   // A/B only (tools/archive/fault_hunt_r04c.sh): RPDE_ARENA=0 = one hipMalloc per buffer, as rounds 1-3
   static const bool on = [] { const char* e = std::getenv("RPDE_ARENA"); return !e || std::atoi(e) != 0; }();
   return on;
 }
 #endif
+// give unused slabs of the current device back to the driver (after an engine / operator set has been destroyed)
+inline size_t dev_trim() {
+#ifdef RPDE_EMU
+  return 0;
+#else
+  return dev_arena_on() ? DevArena::get().trim(ArenaHipBackend::current_device()) : 0;
+#endif
+}
 
 inline void* dev_alloc(size_t bytes) {
 #ifdef RPDE_EMU

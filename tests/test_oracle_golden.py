@@ -47,6 +47,52 @@ def test_poisson_2d(mode, cplx):
     assert np.abs(x - ref).max() < 2e-6  # printed digits
 
 
+@pytest.mark.parametrize("mode", ["full", "parity"])
+def test_hholtz_tensor_analytic(mode):
+    """The reference's own tests of the tensor Helmholtz solver, src/solver/hholtz.rs:226-255 (cheb_dirichlet x
+    cheb_dirichlet, 64 x 64, alpha = 1) and 257-286 (fourier_r2c x cheb_dirichlet, 16 x 7, alpha = 1e-5): analytic
+    fields cos(n x) cos(n y) / cos(x) cos(n y), the reference's tolerance 1e-3 -- and far below it, the spectral
+    accuracy of the discretisation (the solver is exact for the discrete operator)."""
+    n = np.pi / 2
+    # test_hholtz2d_cd_cd
+    alpha = 1.0
+    sp = B.Space2(B.cheb_dirichlet(64), B.cheb_dirichlet(64))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(n * x)[:, None] * np.cos(n * y)[None, :]
+    exp = f.v / (1 + alpha * n * n * 2)
+    f.forward(); f.vhat = S.Hholtz(sp, [alpha, alpha], eig_mode=mode).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+    assert np.abs(f.v - exp).max() < 1e-12
+    # test_hholtz2d_fo_cd
+    alpha = 1e-5
+    sp = B.Space2(B.fourier_r2c(16), B.cheb_dirichlet(7))
+    f = N.Field2(sp)
+    x, y = f.x
+    f.v = np.cos(x)[:, None] * np.cos(n * y)[None, :]
+    exp = f.v / (1 + alpha * n * n + alpha)
+    f.forward(); f.vhat = S.Hholtz(sp, [alpha, alpha]).solve(f.to_ortho()); f.backward()
+    assert np.abs(f.v - exp).max() < TOL_REF
+    assert np.abs(f.v - exp).max() < 1e-6     # 7 Chebyshev points resolve cos(pi y / 2) to 1e-7
+
+
+def test_hholtz_tensor_equals_adi_without_splitting_error():
+    """(I - c D2) as a tensor solve and as the ADI product (1 - c Dxx)(1 - c Dyy) differ by the splitting term
+    c^2 Dxx Dyy: for a small c the two solvers of the reference agree to O(c^2) -- a cross-check of Hholtz against the
+    solver that the known-answer vectors pin (hholtz_adi.rs:192-246)."""
+    sp = B.Space2(B.cheb_dirichlet(24), B.cheb_dirichlet(20))
+    rng = np.random.default_rng(3)
+    f = N.Field2(sp)
+    f.vhat = rng.standard_normal(sp.shape_spectral) / (1 + np.arange(sp.shape_spectral[0]))[:, None] ** 3 / (1 + np.arange(sp.shape_spectral[1]))[None, :] ** 3
+    rhs = f.to_ortho()
+    errs = []
+    for c in (1e-4, 1e-5):
+        a = S.Hholtz(sp, [c, c]).solve(rhs)
+        b = S.HholtzAdi(sp, [c, c]).solve(rhs)
+        errs.append(np.abs(a - b).max() / np.abs(a).max())
+    assert errs[0] < 1e-3 and errs[1] < errs[0] / 50, errs      # O(c^2)
+
+
 def test_analytic_roundtrips():
     n = np.pi / 2
     alpha = 1e-5
