@@ -201,6 +201,45 @@ def parity_independent_golden(make, args):
             "tol": PARITY_TOL, "ok": all(r["ok"] for r in rows)}
 
 
+def parity_shared_basis_golden(args, library, device):
+    """SAME INPUTS over the full horizon: the engine is created with the x eigenvalues of the committed golden
+    (tests/golden/make_shared_basis_golden.py: `x_spectrum=` -- the library rebuilds the oracle's eigenbasis bit for bit,
+    no LAPACK), runs this workload for the golden's 200 steps, and every snapshot is compared with the CPU oracle's samples:
+    plain tol (1e-10) on u, v, T and p from the first step.  None when no golden exists for the workload."""
+    import numpy as np
+    import rustpde_mpi_amd as R
+    tag = "" if (args.ra == 1e8 and args.dt == 2e-4) else f"_ra{args.ra:g}_dt{args.dt:g}"
+    path = os.path.join(ROOT, "tests", "golden", f"shared_basis_{args.nx}{tag}.npz")
+    if args.periodic or args.nx != args.ny or abs(args.aspect - 1.0) > 0 or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if abs(float(g["ra"]) - args.ra) > 0 or abs(float(g["dt"]) - args.dt) > 0:
+        return None
+    stride = int(g["stride"])
+    nav = R.Navier2D.new_confined(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", device=device, library=library,
+                                  init_random=None, x_spectrum=np.ascontiguousarray(g["x_spectrum"]))
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    rows, done = [], 0
+    for s in [int(v) for v in g["snaps"]]:
+        if f"velx_{s}" not in g.files:
+            continue
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        rel = {k: float(np.linalg.norm(f[k][::stride, ::stride] - g[f"{k}_{s}"]) / np.linalg.norm(g[f"{k}_{s}"]))
+               for k in ("velx", "vely", "temp", "pres")}
+        nrm = {k: float(abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) / float(g[f"{k}_{s}_norm"])) for k in rel}
+        rows.append({"steps": s, "rel_l2": rel, "full_field_norm_rel_diff": nrm,
+                     "ok": all(v < PARITY_TOL for v in rel.values()) and all(v < PARITY_TOL for v in nrm.values())})
+    del nav
+    return {"golden": os.path.relpath(path, ROOT), "sample_stride": stride, "tol": PARITY_TOL,
+            "setup": "both sides on the eigenbasis the library rebuilds from the golden's x eigenvalues (bit-identical, no LAPACK)",
+            "snapshots": rows, "steps": rows[-1]["steps"] if rows else 0,
+            "worst_rel_l2": {k: max(r["rel_l2"][k] for r in rows) for k in ("velx", "vely", "temp", "pres")} if rows else None,
+            "ok": bool(rows) and all(r["ok"] for r in rows)}
+
+
 def pmc_traffic(workload, tag):
     """HBM bytes per launch of kernel `tag` from the committed rocprofv3 --pmc passes
     (tools/pmc_step.py + tools/pmc_traffic.py -> profiles/*pmc_traffic*.json, FETCH_SIZE and
@@ -440,6 +479,9 @@ def main():
         del nav   # free the timed engine's HBM before the parity engine is built
         out["cpu_baseline"], ora, osteps = cpu_baseline(args, eig)
         out["parity"] = parity_vs_oracle(make, ora, osteps, shared=eig is not None)
+        shared_gold = parity_shared_basis_golden(args, library, local_rank)
+        if shared_gold is not None:
+            out["parity_shared_basis_golden"] = shared_gold
         gold = parity_independent_golden(make, args)
         if gold is not None:
             out["parity_independent_golden"] = gold
@@ -451,6 +493,9 @@ def main():
     print(json.dumps(out))
     if "parity" in out and not out["parity"]["ok"]:
         sys.exit(f"parity vs the oracle above {PARITY_TOL}: {out['parity']['rel_l2']}")
+    if "parity_shared_basis_golden" in out and not out["parity_shared_basis_golden"]["ok"]:
+        bad = [r for r in out["parity_shared_basis_golden"]["snapshots"] if not r["ok"]]
+        sys.exit(f"parity vs the same-inputs golden above {PARITY_TOL}: {bad}")
     if "parity_independent_golden" in out and not out["parity_independent_golden"]["ok"]:
         bad = [r for r in out["parity_independent_golden"]["snapshots"] if not r["ok"]]
         sys.exit(f"parity vs the independent-setup golden above its bound: {bad}")

@@ -28,6 +28,8 @@ extern "C" {
 typedef struct rpde_navier2d rpde_navier2d;   /* Navier2D<f64|Complex<f64>, Space2>  src/navier_stokes/navier.rs:49-89 */
 typedef struct rpde_space2 rpde_space2;       /* funspace Space2<B0,B1>              src/bases.rs:11-19, src/field.rs:59-72 */
 typedef struct rpde_hholtz_adi rpde_hholtz_adi; /* HholtzAdi<f64,2>                  src/solver/hholtz_adi.rs:31-39 */
+typedef struct rpde_hholtz rpde_hholtz;       /* Hholtz<f64,2>                       src/solver/hholtz.rs:29-37 */
+typedef struct rpde_adjoint2d rpde_adjoint2d; /* Navier2DAdjoint<f64|Complex<f64>, Space2>  src/navier_stokes/steady_adjoint.rs:67-113 */
 typedef struct rpde_poisson rpde_poisson;     /* Poisson<f64,2>                      src/solver/poisson.rs:33-40 */
 
 /* base kinds (funspace BaseKind, used at src/field.rs:172-179) */
@@ -60,6 +62,16 @@ int rpde_navier2d_create_confined(int nx, int ny, double ra, double pr, double d
 /* Navier2D::new_periodic(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes/navier.rs:336-428 */
 int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
                                   const char* bc, int device, rpde_navier2d** out);
+/* The same constructor with the x eigenvalues of the Poisson solver supplied by the host (m = nx - 2 doubles in the order
+ * rpde_poisson_x_spectrum returns them): the eigenbasis is then built WITHOUT LAPACK and bit-reproducibly
+ * (rpde_poisson_x_eigenbasis_from_spectrum) instead of by dgeev (FdmaTensor::from_matrix, src/solver/fdma_tensor.rs:123-127,
+ * src/solver/utils.rs:67-99).  Two uses: a host that caches the spectrum skips the O(n^3) setup of every later run, and a
+ * checker on another machine can run the reference algorithm on EXACTLY the engine's setup data -- dgeev's output is not
+ * reproducible across thread counts or CPU models and Poisson::new's -1e-10 shift (poisson.rs:84-87) amplifies the
+ * difference by 1e10 (tests/golden/make_shared_basis_golden.py). */
+int rpde_navier2d_create_confined_with_spectrum(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                                const char* bc, int device, const double* lam, size_t m,
+                                                rpde_navier2d** out);
 /* Pencil-sharded engine = Navier2DMpi (src/navier_stokes_mpi/navier.rs:216-336, 364-486): rank r of
  * nranks owns a slab of every field; layout changes call `alltoallv` (the role of funspace's
  * Decomp2d::transpose_x_to_y / transpose_y_to_x = MPI_Alltoallv, src/field_mpi.rs:456-477).
@@ -175,6 +187,36 @@ int rpde_h5_list(const char* filename, char* buf, size_t len);   /* newline-sepa
 /* integrate(&mut pde, max_time, None) without callbacks      src/lib.rs:187-219 ; returns steps taken */
 int rpde_navier2d_integrate(rpde_navier2d* h, double max_time, int exit_check_every, long* steps);
 
+/* ---- adjoint descent to steady states: what `impl Integrate for Navier2DAdjoint` does ------------------------------ *
+ * (first slice.)  Fields stay in HBM; one update = a forward step with DT_NAVIER for the residual,  *
+ * three tensor Helmholtz solves for its norm, an explicit adjoint step.  bc = "rbc" only (see csrc/adjoint.h).             */
+/* Navier2DAdjoint::new_confined(nx, ny, ra, pr, dt, aspect, bc)   src/navier_stokes/steady_adjoint.rs:215-370 */
+int rpde_adjoint2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                   const char* bc, int device, rpde_adjoint2d** out);
+/* Navier2DAdjoint::new_periodic(nx, ny, ra, pr, dt, aspect, bc)   src/navier_stokes/steady_adjoint.rs:372-531 */
+int rpde_adjoint2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                   const char* bc, int device, rpde_adjoint2d** out);
+int rpde_adjoint2d_destroy(rpde_adjoint2d* h);
+int rpde_adjoint2d_set_velocity(rpde_adjoint2d* h, double amp, double m, double n);      /* steady_adjoint.rs:183-186 */
+int rpde_adjoint2d_set_temperature(rpde_adjoint2d* h, double amp, double m, double n);   /* steady_adjoint.rs:190-192 */
+int rpde_adjoint2d_reset_time(rpde_adjoint2d* h);                                        /* steady_adjoint.rs:207-209 */
+/* name in {"velx","vely","temp","pres","pseu","velx_adj","vely_adj","temp_adj","pres_adj","tempbc"} = the public Field2
+ * members (steady_adjoint.rs:69-91); "tempbc" is read-only */
+int rpde_adjoint2d_spectral_shape(rpde_adjoint2d* h, const char* name, int* rows, int* cols, int* is_complex);
+int rpde_adjoint2d_set_field(rpde_adjoint2d* h, const char* name, int space, const double* data, size_t len);
+int rpde_adjoint2d_get_field(rpde_adjoint2d* h, const char* name, int space, double* data, size_t len);
+/* n x Integrate::update()                                         src/navier_stokes/steady_adjoint.rs:541-608 */
+int rpde_adjoint2d_update(rpde_adjoint2d* h, int nsteps);
+int rpde_adjoint2d_time(rpde_adjoint2d* h, double* time);          /* Integrate::get_time */
+int rpde_adjoint2d_dt(rpde_adjoint2d* h, double* dt);              /* Integrate::get_dt */
+int rpde_adjoint2d_param(rpde_adjoint2d* h, const char* key, double* value);   /* params: "ra" "pr" "nu" "ka" */
+/* Integrate::exit(): NaN divergence, or (|velx_adj| + |vely_adj| + |temp_adj|) / 3 < RES_TOL = 1e-7 ("Steady state
+ * converged!")                                                    src/navier_stokes/steady_adjoint.rs:624-638 */
+int rpde_adjoint2d_exit(rpde_adjoint2d* h, int* stop);
+/* DivNorm::div_norm / DivNorm::norm_residual -> [|velx_adj|, |vely_adj|, |temp_adj|]   steady_adjoint_eq.rs:36-50 */
+int rpde_adjoint2d_div_norm(rpde_adjoint2d* h, double* norm);
+int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3);
+
 /* ---- operator level: funspace Space2 methods as called by rustpde ---------------------------- */
 /* Space2::new(&base0(n0), &base1(n1)); base1 must be a Chebyshev-family base                     */
 int rpde_space2_create(int kind0, int n0, int kind1, int n1, int device, rpde_space2** out);
@@ -199,6 +241,25 @@ int rpde_hholtz_adi_destroy(rpde_hholtz_adi* hs);
 int rpde_poisson_create(rpde_space2* s, double c0, double c1, rpde_poisson** out);
 int rpde_poisson_solve(rpde_poisson* ps, const double* in_ortho, size_t nin, double* out, size_t nout);
 int rpde_poisson_destroy(rpde_poisson* ps);
+/* Host-only setup mathematics of Poisson::new for a Chebyshev x axis of n points (base_kind RPDE_CHEB_DIRICHLET or
+ * RPDE_CHEB_NEUMANN; c0 as in rpde_poisson_create): no device is touched.
+ *  rpde_poisson_x_spectrum: the m = n - 2 eigenvalues of inv(C_x) A_x (LAPACK dgeev, values only), order [even-parity
+ *    block | odd-parity block], each descending, before the -1e-10 shift.
+ *  rpde_poisson_x_eigenbasis_from_spectrum: lam -> lam_refined, fwd = Q^-1 C^-1 and bwd = Q (dense m x m, row-major,
+ *    natural coefficient index; row / column k belongs to lam[k]) by Rayleigh-quotient / inverse iteration on the BANDED
+ *    pencil A_x - lam C_x, bit-reproducible (no LAPACK, fixed operation order): what an engine created with the same
+ *    spectrum uses.  `lam` only has to identify the eigenvalues (dgeev on the dense inv(C) A is 1e-7 relative at n = 1025
+ *    for the small ones); lam_refined are the eigenvalues of the pencil to round-off.     src/solver/fdma_tensor.rs:106-154 */
+int rpde_poisson_x_spectrum(int base_kind, int n, double c0, double* lam, size_t m);
+int rpde_poisson_x_eigenbasis_from_spectrum(int base_kind, int n, double c0, const double* lam, size_t m,
+                                            double* lam_refined, double* fwd, double* bwd);
+/* Poisson::new with a supplied x spectrum (see rpde_navier2d_create_confined_with_spectrum) */
+int rpde_poisson_create_with_spectrum(rpde_space2* s, double c0, double c1, const double* lam, size_t m, rpde_poisson** out);
+/* Hholtz::new(&field, [c0, c1]) / Solve::solve: (I - c0 Dxx - c1 Dyy) vhat = A f with the TENSOR solver (x diagonalised,
+ * one banded solve per x-row) -- the norm of Navier2DAdjoint's residual          src/solver/hholtz.rs:72-106, 164-187 */
+int rpde_hholtz_create(rpde_space2* s, double c0, double c1, rpde_hholtz** out);
+int rpde_hholtz_solve(rpde_hholtz* hs, const double* in_ortho, size_t nin, double* out, size_t nout);
+int rpde_hholtz_destroy(rpde_hholtz* hs);
 /* The x eigen-decomposition Poisson::new builds once (FdmaTensor::from_matrix,                     *
  * src/solver/fdma_tensor.rs:123-127; LAPACK dgeev/dgetri, src/solver/utils.rs:67-107): m = nx - 2    *
  * eigenvalues `lam` (before the -1e-10 shift of poisson.rs:84-87), fwd = Q^-1 C^-1 and bwd = Q as     *

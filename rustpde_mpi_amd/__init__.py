@@ -26,7 +26,7 @@ import numpy as np
 
 from ._capi import Lib, RpdeError, as_f64, ptr
 
-__all__ = ["Navier2D", "Navier2DMpi", "Space2", "HholtzAdi", "Poisson", "integrate", "lib", "RpdeError",
+__all__ = ["Navier2D", "Navier2DMpi", "Navier2DAdjoint", "Space2", "HholtzAdi", "Poisson", "Hholtz", "integrate", "lib", "RpdeError",
            "chebyshev", "cheb_dirichlet", "cheb_neumann", "cheb_dirichlet_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
@@ -62,14 +62,14 @@ class _FieldView:
 
     def _shape(self):
         r, c, z = C.c_int(), C.c_int(), C.c_int()
-        self._nav._lib.call("rpde_navier2d_spectral_shape", self._nav._h, self._name.encode(),
+        self._nav._lib.call(self._nav._prefix + "_spectral_shape", self._nav._h, self._name.encode(),
                             C.byref(r), C.byref(c), C.byref(z))
         return r.value, c.value, bool(z.value)
 
     @property
     def v(self):
         out = np.empty((self._nav.nx, self._nav.ny))
-        self._nav._lib.call("rpde_navier2d_get_field", self._nav._h, self._name.encode(), PHYSICAL,
+        self._nav._lib.call(self._nav._prefix + "_get_field", self._nav._h, self._name.encode(), PHYSICAL,
                             ptr(out), out.size)
         return out
 
@@ -78,14 +78,14 @@ class _FieldView:
         a = as_f64(value)
         if a.shape != (self._nav.nx, self._nav.ny):
             raise RpdeError(f"physical field must have shape {(self._nav.nx, self._nav.ny)}")
-        self._nav._lib.call("rpde_navier2d_set_field", self._nav._h, self._name.encode(), PHYSICAL,
+        self._nav._lib.call(self._nav._prefix + "_set_field", self._nav._h, self._name.encode(), PHYSICAL,
                             ptr(a), a.size)
 
     @property
     def vhat(self):
         r, c, z = self._shape()
         out = np.empty((r, c * (2 if z else 1)))
-        self._nav._lib.call("rpde_navier2d_get_field", self._nav._h, self._name.encode(), SPECTRAL,
+        self._nav._lib.call(self._nav._prefix + "_get_field", self._nav._h, self._name.encode(), SPECTRAL,
                             ptr(out), out.size)
         return out.view(np.complex128) if z else out
 
@@ -95,7 +95,7 @@ class _FieldView:
         a = as_f64(np.asarray(value, dtype=np.complex128 if z else np.float64))
         if a.shape != (r, c * (2 if z else 1)):
             raise RpdeError(f"spectral field {self._name} must have shape {(r, c)}")
-        self._nav._lib.call("rpde_navier2d_set_field", self._nav._h, self._name.encode(), SPECTRAL,
+        self._nav._lib.call(self._nav._prefix + "_set_field", self._nav._h, self._name.encode(), SPECTRAL,
                             ptr(a), a.size)
 
     @property
@@ -110,6 +110,7 @@ class _FieldView:
 
 class Navier2D:
     """Device-resident `Navier2D` (2-D Rayleigh-Benard convection, f64)."""
+    _prefix = "rpde_navier2d"      # C-ABI family of this handle (the field views call <prefix>_get_field ...)
 
     def __init__(self, handle, nx, ny, periodic, library):
         self._h, self.nx, self.ny, self.periodic, self._lib = handle, nx, ny, periodic, library
@@ -117,10 +118,17 @@ class Navier2D:
             setattr(self, name, _FieldView(self, name))
 
     @classmethod
-    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic, comm=None):
+    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic, comm=None, x_spectrum=None):
         library = library or lib()
         h = C.c_void_p()
-        if comm is not None and comm.size > 1 and getattr(comm, "native_rccl", False):
+        if x_spectrum is not None:
+            # the Poisson solver's x eigenvalues supplied by the host: eigenbasis without LAPACK, bit-reproducible
+            if periodic or (comm is not None and comm.size > 1):
+                raise RpdeError("x_spectrum: confined, one device")
+            lam = as_f64(np.asarray(x_spectrum, dtype=np.float64))
+            library.call("rpde_navier2d_create_confined_with_spectrum", int(nx), int(ny), float(ra), float(pr), float(dt),
+                         float(aspect), str(bc).encode(), int(device), ptr(lam), lam.size, C.byref(h))
+        elif comm is not None and comm.size > 1 and getattr(comm, "native_rccl", False):
             # pencil-sharded engine, native transport: grouped ncclSend/ncclRecv on the engine's stream
             library.call("rpde_navier2d_create_sharded_rccl", int(periodic), int(nx), int(ny), float(ra),
                          float(pr), float(dt), float(aspect), str(bc).encode(), int(device),
@@ -144,9 +152,10 @@ class Navier2D:
     # itself); this mirror does what the reference does, with a fixed seed so that runs are reproducible.
     # Pass init_random=None to keep the zero state.
     @classmethod
-    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None, init_random=0.1, seed=0):
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, comm=None, init_random=0.1, seed=0,
+                     x_spectrum=None):
         obj = cls._new("rpde_navier2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device,
-                       library, False, comm)
+                       library, False, comm, x_spectrum)
         if init_random is not None:
             obj.init_random(init_random, seed)
         return obj
@@ -448,12 +457,139 @@ class Poisson(_Solver):
     """`Poisson::new(&field, [c0, c1])` + `solve` (src/solver/poisson.rs:54-94,195-236)."""
     _create, _solve, _destroy = "rpde_poisson_create", "rpde_poisson_solve", "rpde_poisson_destroy"
 
+    def __init__(self, space: Space2, c, x_spectrum=None):
+        if x_spectrum is None:
+            super().__init__(space, c)
+            return
+        self._space, self._lib = space, space._lib
+        self._h = C.c_void_p()
+        lam = as_f64(np.asarray(x_spectrum, dtype=np.float64))
+        self._lib.call("rpde_poisson_create_with_spectrum", space._h, float(c[0]), float(c[1]), ptr(lam), lam.size, C.byref(self._h))
+
     def eigenbasis(self):
         """(lam, fwd, bwd) of the x eigen-decomposition (fdma_tensor.rs:123-127)."""
         m = self._space.shape("spectral")[0]
         lam, fwd, bwd = np.empty(m), np.empty((m, m)), np.empty((m, m))
         self._lib.call("rpde_poisson_eigenbasis", self._h, ptr(lam), ptr(fwd), ptr(bwd), m)
         return lam, fwd, bwd
+
+
+def poisson_x_spectrum(base, c0, library=None):
+    """The n - 2 x eigenvalues `Poisson::new` computes for a Chebyshev axis `base` = (kind, n) (host only: LAPACK dgeev,
+    values only); order [even block | odd block], each descending."""
+    library = library or lib()
+    kind, n = base
+    lam = np.empty(n - 2)
+    library.call("rpde_poisson_x_spectrum", int(kind), int(n), float(c0), ptr(lam), lam.size)
+    return lam
+
+
+def poisson_x_eigenbasis_from_spectrum(base, c0, lam, library=None):
+    """(refined lam, fwd, bwd) for given (approximate) eigenvalues: the bit-reproducible eigenbasis an engine created with `x_spectrum=lam` uses
+    (host only, no LAPACK) -- the format of `Navier2D.poisson_eigenbasis()` / the oracle's `eig_override`."""
+    library = library or lib()
+    kind, n = base
+    lam = as_f64(np.asarray(lam, dtype=np.float64))
+    m = n - 2
+    ref, fwd, bwd = np.empty(m), np.empty((m, m)), np.empty((m, m))
+    library.call("rpde_poisson_x_eigenbasis_from_spectrum", int(kind), int(n), float(c0), ptr(lam), lam.size, ptr(ref), ptr(fwd), ptr(bwd))
+    return ref, fwd, bwd
+
+
+class Hholtz(_Solver):
+    """`Hholtz::new(&field, [c0, c1])` + `solve`: (I - c D2) vhat = A f with the tensor solver (src/solver/hholtz.rs:72-106,164-187)."""
+    _create, _solve, _destroy = "rpde_hholtz_create", "rpde_hholtz_solve", "rpde_hholtz_destroy"
+
+
+class Navier2DAdjoint:
+    """Device-resident `Navier2DAdjoint` (src/navier_stokes/steady_adjoint.rs): adjoint descent to steady states.
+    Same spelling as the reference: `new_confined / new_periodic`, `set_velocity`, `set_temperature`, `update()`, `exit()`,
+    `.velx.vhat` ... `.temp_adj.v`, `div_norm()`, `norm_residual()`; `integrate(pde, max_time, None)` drives it."""
+    _prefix = "rpde_adjoint2d"
+    FIELDS = ("velx", "vely", "temp", "pres", "pseu", "velx_adj", "vely_adj", "temp_adj", "pres_adj", "tempbc")
+
+    def __init__(self, handle, nx, ny, periodic, library):
+        self._h, self.nx, self.ny, self.periodic, self._lib = handle, nx, ny, periodic, library
+        for name in self.FIELDS:
+            setattr(self, name, _FieldView(self, name))
+
+    @classmethod
+    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic):
+        library = library or lib()
+        h = C.c_void_p()
+        library.call(fn, int(nx), int(ny), float(ra), float(pr), float(dt), float(aspect), str(bc).encode(), int(device), C.byref(h))
+        return cls(h, nx, ny, periodic, library)
+
+    @classmethod
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+        return cls._new("rpde_adjoint2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device, library, False)
+
+    @classmethod
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None):
+        return cls._new("rpde_adjoint2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device, library, True)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.call("rpde_adjoint2d_destroy", self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_velocity(self, amp, m, n):
+        self._lib.call("rpde_adjoint2d_set_velocity", self._h, float(amp), float(m), float(n))
+
+    def set_temperature(self, amp, m, n):
+        self._lib.call("rpde_adjoint2d_set_temperature", self._h, float(amp), float(m), float(n))
+
+    def reset_time(self):
+        self._lib.call("rpde_adjoint2d_reset_time", self._h)
+
+    def update(self, nsteps: int = 1):
+        self._lib.call("rpde_adjoint2d_update", self._h, int(nsteps))
+
+    def get_time(self):
+        t = C.c_double()
+        self._lib.call("rpde_adjoint2d_time", self._h, C.byref(t))
+        return t.value
+
+    def get_dt(self):
+        t = C.c_double()
+        self._lib.call("rpde_adjoint2d_dt", self._h, C.byref(t))
+        return t.value
+
+    def exit(self):
+        f = C.c_int()
+        self._lib.call("rpde_adjoint2d_exit", self._h, C.byref(f))
+        return bool(f.value)
+
+    def callback(self):   # snapshots of the adjoint solver (steady_adjoint_io.rs) are not part of this slice
+        pass
+
+    def div_norm(self):
+        d = C.c_double()
+        self._lib.call("rpde_adjoint2d_div_norm", self._h, C.byref(d))
+        return d.value
+
+    def norm_residual(self):
+        r = (C.c_double * 3)()
+        self._lib.call("rpde_adjoint2d_norm_residual", self._h, r)
+        return [r[0], r[1], r[2]]
+
+    @property
+    def params(self):
+        out = {}
+        for k in ("ra", "pr", "nu", "ka"):
+            v = C.c_double()
+            self._lib.call("rpde_adjoint2d_param", self._h, k.encode(), C.byref(v))
+            out[k] = v.value
+        return out
+
+    def physical_fields(self, names=("velx", "vely", "temp", "pres")):
+        return {k: getattr(self, k).v for k in names}
+
+    def spectral_fields(self, names=FIELDS[:9]):
+        return {k: getattr(self, k).vhat for k in names}
 
 
 def transpose(a, device=0, library=None):

@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librustpde_hip.so")
-SOURCES = ["kernels.cc", "hostmath.cc", "ops.cc", "rccl_transport.cc", "h5lite.cc", "engine.cc", "capi.cc"]
+SOURCES = ["kernels.cc", "gemm.cc", "hostmath.cc", "ops.cc", "rccl_transport.cc", "h5lite.cc", "engine.cc", "adjoint.cc", "capi.cc"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,422 @@
+// Navier2DAdjointEngine: see adjoint.h.  Reference: src/navier_stokes/steady_adjoint.rs, steady_adjoint_eq.rs.
+#include "adjoint.h"
+
+#include <cmath>
+
+namespace rpde {
+
+// ------------------------------------------------------------------------------------------------
+// element-wise kernels on pitched 2-D arrays of doubles (complex arrays: twice the columns)
+#ifndef RPDE_EMU
+// out = a x + b y  (x, y may alias out)
+__global__ __launch_bounds__(256) void adj_lincomb_kernel(double* out, long ldo, double a, const double* x, long ldx, double b,
+                                                          const double* y, long ldy, int rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    double v = 0.0;
+    if (x) v += a * x[(long)r * ldx + c];
+    if (y) v += b * y[(long)r * ldy + c];
+    out[(long)r * ldo + c] = v;
+  }
+}
+// out = (acc ? out : 0) + s x y
+__global__ __launch_bounds__(256) void adj_muladd_kernel(double* out, long ldo, double s, const double* x, long ldx, const double* y,
+                                                         long ldy, int rows, int cols, int acc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const double v = s * x[(long)r * ldx + c] * y[(long)r * ldy + c];
+    double* o = out + (long)r * ldo + c;
+    *o = acc ? *o + v : v;
+  }
+}
+// the 2/3 rule (functions.rs:72-82): rows >= r0 and columns >= c0 (in doubles) become zero
+__global__ __launch_bounds__(256) void adj_dealias_kernel(double* a, long ld, int rows, int cols, int r0, int c0) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y)
+    if (r >= r0 || c >= c0) a[(long)r * ld + c] = 0.0;
+}
+static dim3 ew_grid(int rows, int cols) { return dim3((cols + 255) / 256, rows < 2048 ? rows : 2048); }
+static void ew_lincomb(double* out, long ldo, double a, const double* x, long ldx, double b, const double* y, long ldy, int rows, int cols, Stream& st) {
+  hipLaunchKernelGGL(adj_lincomb_kernel, ew_grid(rows, cols), dim3(256), 0, st.s, out, ldo, a, x, ldx, b, y, ldy, rows, cols);
+  RPDE_HIP(hipGetLastError());
+}
+static void ew_muladd(double* out, long ldo, double s, const double* x, long ldx, const double* y, long ldy, int rows, int cols, bool acc, Stream& st) {
+  hipLaunchKernelGGL(adj_muladd_kernel, ew_grid(rows, cols), dim3(256), 0, st.s, out, ldo, s, x, ldx, y, ldy, rows, cols, acc ? 1 : 0);
+  RPDE_HIP(hipGetLastError());
+}
+static void ew_dealias(double* a, long ld, int rows, int cols, int r0, int c0, Stream& st) {
+  hipLaunchKernelGGL(adj_dealias_kernel, ew_grid(rows, cols), dim3(256), 0, st.s, a, ld, rows, cols, r0, c0);
+  RPDE_HIP(hipGetLastError());
+}
+#else
+static void ew_lincomb(double* out, long ldo, double a, const double* x, long ldx, double b, const double* y, long ldy, int rows, int cols, Stream&) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      double v = 0.0;
+      if (x) v += a * x[(long)r * ldx + c];
+      if (y) v += b * y[(long)r * ldy + c];
+      out[(long)r * ldo + c] = v;
+    }
+}
+static void ew_muladd(double* out, long ldo, double s, const double* x, long ldx, const double* y, long ldy, int rows, int cols, bool acc, Stream&) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const double v = s * x[(long)r * ldx + c] * y[(long)r * ldy + c];
+      double* o = out + (long)r * ldo + c;
+      *o = acc ? *o + v : v;
+    }
+}
+static void ew_dealias(double* a, long ld, int rows, int cols, int r0, int c0, Stream&) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c)
+      if (r >= r0 || c >= c0) a[(long)r * ld + c] = 0.0;
+}
+#endif
+
+static double get_nu(double ra, double pr, double h) { return std::sqrt(pr / (ra / std::pow(h, 3.0))); }
+static double get_ka(double ra, double pr, double h) { return std::sqrt(1.0 / ((ra / std::pow(h, 3.0)) * pr)); }
+
+// ------------------------------------------------------------------------------------------------
+Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                             const std::string& bc, bool periodic)
+    : nx_(nx), ny_(ny), ex_(periodic ? 2 : 1), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
+  RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");
+  RPDE_REQUIRE(bc == "rbc", "Navier2DAdjoint with bc = \"hc\": the reference builds its four-diagonal tensor solver Hholtz on the "
+                            "three-term base cheb_dirichlet_neumann (steady_adjoint.rs:312-318), which Fdma cannot hold -- not supported");
+  RPDE_REQUIRE(nx >= 8 && ny >= 8, "grid too small");
+  RPDE_REQUIRE(!periodic || nx % 2 == 0, "fourier_r2c needs an even number of points");
+#ifndef RPDE_EMU
+  RPDE_HIP(hipStreamCreate(&st_.s));
+#endif
+  nu_ = get_nu(ra, pr, sy_ * 2.0);
+  ka_ = get_ka(ra, pr, sy_ * 2.0);
+  const BaseKind bx_vel = periodic ? kFourierR2c : kChebDirichlet;
+  const BaseKind bx_tmp = periodic ? kFourierR2c : kChebNeumann;
+  const BaseKind bx_ort = periodic ? kFourierR2c : kChebyshev;
+  sp_vel_ = std::make_unique<Space2Ops>(make_base(bx_vel, nx), make_base(kChebDirichlet, ny));
+  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebDirichlet, ny));
+  sp_ortho_ = std::make_unique<Space2Ops>(make_base(bx_ort, nx), make_base(kChebyshev, ny));
+  sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
+  // the Helmholtz solvers of the FORWARD step run on DT_NAVIER (steady_adjoint.rs:273-295)
+  hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, kDtNavier * nu_ / (sx_ * sx_), kDtNavier * nu_ / (sy_ * sy_));
+  hh_temp_ = std::make_unique<HholtzAdiOp>(*sp_temp_, kDtNavier * ka_ / (sx_ * sx_), kDtNavier * ka_ / (sy_ * sy_));
+  pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_));
+  // smoother (1 - weight D2) (steady_adjoint.rs:300-322): velx and vely live in the same space -> one solver serves both
+  norm_vel_ = std::make_unique<TensorHholtzOp>(*sp_vel_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
+  norm_temp_ = std::make_unique<TensorHholtzOp>(*sp_temp_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
+
+  auto mk = [&](const char* name, Space2Ops* sp) {
+    F f{sp, Arr2(sp->spec_rows(), sp->spec_cols(), ex_)};
+    f_.emplace(name, std::move(f));
+  };
+  mk("velx", sp_vel_.get()); mk("vely", sp_vel_.get()); mk("temp", sp_temp_.get());
+  mk("pres", sp_ortho_.get()); mk("pseu", sp_pseu_.get());
+  mk("velx_adj", sp_vel_.get()); mk("vely_adj", sp_vel_.get()); mk("temp_adj", sp_temp_.get());
+  mk("pres_adj", sp_ortho_.get()); mk("tempbc", sp_ortho_.get());
+
+  const int ro = sp_ortho_->ortho_rows(), co = sp_ortho_->ortho_cols();
+  for (Arr2* a : {&rhs_, &div_, &t0_, &t1_, &old_[0], &old_[1], &old_[2], &cv_}) a->alloc(ro, co, ex_);
+  for (Arr2* a : {&ux_, &uy_, &ta_, &ph_, &conv_, &cp_}) a->alloc(nx, ny, 1);
+  red_.alloc(2);
+
+  {  // the lift bc_rbc (boundary_conditions.rs:18-36 / 143-161): T = +0.5 (bottom) ... -0.5 (top), forward transformed
+    const Vec y = base_coords(sp_ortho_->base(1));
+    const double x1 = y.front(), x2 = y.back(), y1 = 0.5, y2 = -0.5;
+    const double m = (y2 - y1) / (x2 - x1), n = (y1 * x2 - y2 * x1) / (x2 - x1);
+    Vec prof((size_t)nx * ny);
+    for (int i = 0; i < nx; ++i)
+      for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = m * y[j] + n;
+    dev_upload2d(ph_.p(), ph_.ld, prof.data(), nx, ny);
+    sp_ortho_->forward(ph_, field("tempbc").vhat, st_);
+  }
+  dev_sync(st_);
+}
+
+Navier2DAdjointEngine::~Navier2DAdjointEngine() {
+#ifndef RPDE_EMU
+  if (st_.s) { (void)hipStreamSynchronize(st_.s); (void)hipStreamDestroy(st_.s); }
+#endif
+}
+
+double Navier2DAdjointEngine::param(const std::string& key) const {
+  if (key == "ra") return ra_;
+  if (key == "pr") return pr_;
+  if (key == "nu") return nu_;
+  if (key == "ka") return ka_;
+  fail("unknown parameter " + key);
+}
+
+Navier2DAdjointEngine::F& Navier2DAdjointEngine::field(const std::string& name) {
+  auto it = f_.find(name);
+  RPDE_REQUIRE(it != f_.end(), "unknown field " + name + " (velx vely temp pres pseu velx_adj vely_adj temp_adj pres_adj tempbc)");
+  return it->second;
+}
+
+void Navier2DAdjointEngine::spectral_shape(const std::string& name, int* rows, int* cols, int* elem) {
+  F& f = field(name);
+  *rows = f.vhat.rows; *cols = f.vhat.cols; *elem = f.vhat.elem;
+}
+
+void Navier2DAdjointEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
+  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
+  F& f = field(name);
+  RPDE_REQUIRE(len == (size_t)f.vhat.rows * f.vhat.cols * f.vhat.elem, "set_field: wrong length for the spectral shape of " + name);
+  dev_sync(st_);
+  dev_upload2d(f.vhat.p(), f.vhat.ld, host, f.vhat.rows, (long)f.vhat.cols * f.vhat.elem);
+}
+
+void Navier2DAdjointEngine::get_field_spectral(const std::string& name, double* host, size_t len) {
+  F& f = field(name);
+  RPDE_REQUIRE(len == (size_t)f.vhat.rows * f.vhat.cols * f.vhat.elem, "get_field: wrong length for the spectral shape of " + name);
+  dev_sync(st_);
+  dev_download2d(host, f.vhat.p(), f.vhat.ld, f.vhat.rows, (long)f.vhat.cols * f.vhat.elem);
+}
+
+void Navier2DAdjointEngine::set_field_physical(const std::string& name, const double* host, size_t len) {
+  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
+  F& f = field(name);
+  RPDE_REQUIRE(len == (size_t)nx_ * ny_, "set_field: physical arrays are nx*ny doubles");
+  dev_sync(st_);
+  dev_upload2d(ph_.p(), ph_.ld, host, nx_, ny_);
+  f.sp->forward(ph_, f.vhat, st_);
+  dev_sync(st_);
+}
+
+void Navier2DAdjointEngine::get_field_physical(const std::string& name, double* host, size_t len) {
+  F& f = field(name);
+  RPDE_REQUIRE(len == (size_t)nx_ * ny_, "get_field: physical arrays are nx*ny doubles");
+  f.sp->backward(f.vhat, ph_, st_);
+  dev_sync(st_);
+  dev_download2d(host, ph_.p(), ph_.ld, nx_, ny_);
+}
+
+static void sincos_field(const Base& b0, const Base& b1, double sx, double sy, double amp, double m, double n, bool sin_cos, Vec& out) {
+  // functions.rs:85-126 (coordinates normalised by x[last] - x[0])
+  Vec x = base_coords(b0), y = base_coords(b1);
+  for (double& v : x) v *= sx;
+  for (double& v : y) v *= sy;
+  const double x0 = x.front(), xl = x.back() - x.front(), y0 = y.front(), yl = y.back() - y.front();
+  out.resize(x.size() * y.size());
+  for (size_t i = 0; i < x.size(); ++i)
+    for (size_t j = 0; j < y.size(); ++j) {
+      const double xa = M_PI * m * ((x[i] - x0) / xl), ya = M_PI * n * ((y[j] - y0) / yl);
+      out[i * y.size() + j] = sin_cos ? amp * std::sin(xa) * std::cos(ya) : amp * std::cos(xa) * std::sin(ya);
+    }
+}
+
+void Navier2DAdjointEngine::set_velocity(double amp, double m, double n) {
+  Vec v;
+  sincos_field(sp_vel_->base(0), sp_vel_->base(1), sx_, sy_, amp, m, n, true, v);
+  set_field_physical("velx", v.data(), v.size());
+  sincos_field(sp_vel_->base(0), sp_vel_->base(1), sx_, sy_, -amp, m, n, false, v);
+  set_field_physical("vely", v.data(), v.size());
+}
+
+void Navier2DAdjointEngine::set_temperature(double amp, double m, double n) {
+  Vec v;
+  sincos_field(sp_temp_->base(0), sp_temp_->base(1), sx_, sy_, -amp, m, n, false, v);
+  set_field_physical("temp", v.data(), v.size());
+}
+
+// ------------------------------------------------------------------------------------------------
+void Navier2DAdjointEngine::zero(Arr2& a) { dev_zero(a.p(), a.bytes(), st_); }
+
+void Navier2DAdjointEngine::lincomb(Arr2& out, double a, const Arr2& x, double b, const Arr2& y) {
+  RPDE_REQUIRE(out.rows == x.rows && out.cols == x.cols && out.elem == x.elem && y.rows == x.rows && y.cols == x.cols && y.elem == x.elem,
+               "lincomb: shapes differ");
+  ew_lincomb(out.p(), out.ld, a, x.p(), x.ld, b, y.p(), y.ld, out.rows, out.cols * out.elem, st_);
+}
+
+void Navier2DAdjointEngine::acc_to_ortho(F& f, double s, Arr2& out) {
+  f.sp->to_ortho(f.vhat, t0_, st_);
+  lincomb(out, 1.0, out, s, t0_);
+}
+
+void Navier2DAdjointEngine::acc_gradient(F& f, int d0, int d1, double s, Arr2& out) {
+  f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
+  lincomb(out, 1.0, out, s, t0_);
+}
+
+void Navier2DAdjointEngine::backward(F& f, Arr2& phys) { f.sp->backward(f.vhat, phys, st_); }
+
+void Navier2DAdjointEngine::conv_term(const Arr2& u, F& f, int d0, int d1, double s, bool first) {
+  f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
+  sp_ortho_->backward(t0_, cp_, st_);
+  ew_muladd(conv_.p(), conv_.ld, s, u.p(), u.ld, cp_.p(), cp_.ld, nx_, ny_, !first, st_);
+}
+
+void Navier2DAdjointEngine::conv_finish(Arr2& out) {
+  sp_ortho_->forward(conv_, out, st_);
+  ew_dealias(out.p(), out.ld, out.rows, out.cols * out.elem, out.rows * 2 / 3, (out.cols * 2 / 3) * out.elem, st_);
+}
+
+void Navier2DAdjointEngine::div(Arr2& out) {   // steady_adjoint_eq.rs:19-24
+  F &u = field("velx"), &v = field("vely");
+  u.sp->gradient(u.vhat, 1, 0, sx_, sy_, out, st_);
+  v.sp->gradient(v.vhat, 0, 1, sx_, sy_, t0_, st_);
+  lincomb(out, 1.0, out, 1.0, t0_);
+}
+
+void Navier2DAdjointEngine::solve_pres(const Arr2& d) {   // steady_adjoint_eq.rs:226-231
+  F& ps = field("pseu");
+  pois_->solve(d, ps.vhat, st_);
+  launch_set_element(ps.vhat.p(), 0, 0.0, st_);
+  if (ex_ == 2) launch_set_element(ps.vhat.p(), 1, 0.0, st_);
+}
+
+void Navier2DAdjointEngine::correct_velocity(double c) {   // steady_adjoint_eq.rs:183-192
+  F &ps = field("pseu"), &u = field("velx"), &v = field("vely");
+  Arr2 tmp(u.vhat.rows, u.vhat.cols, ex_);
+  ps.sp->gradient(ps.vhat, 1, 0, sx_, sy_, t0_, st_);
+  u.sp->from_ortho(t0_, tmp, st_);
+  lincomb(u.vhat, 1.0, u.vhat, -c, tmp);
+  ps.sp->gradient(ps.vhat, 0, 1, sx_, sy_, t0_, st_);
+  v.sp->from_ortho(t0_, tmp, st_);
+  lincomb(v.vhat, 1.0, v.vhat, -c, tmp);
+  dev_sync(st_);          // tmp goes out of scope
+}
+
+double Navier2DAdjointEngine::norm(const Arr2& a) {   // functions.rs:24-35
+  launch_sumsq(a.p(), a.ld, a.rows, a.cols * a.elem, red_.p, st_);
+  dev_sync(st_);
+  double h[2];
+  dev_download(h, red_.p, sizeof(h));
+  if (h[1] > 0) return std::nan("");
+  return std::sqrt(h[0]);
+}
+
+double Navier2DAdjointEngine::div_norm() {
+  div(div_);
+  return norm(div_);
+}
+
+void Navier2DAdjointEngine::norm_residual(double out[3]) {
+  out[0] = norm(field("velx_adj").vhat);
+  out[1] = norm(field("vely_adj").vhat);
+  out[2] = norm(field("temp_adj").vhat);
+}
+
+bool Navier2DAdjointEngine::exit() {
+  if (std::isnan(div_norm())) return true;
+  double r[3];
+  norm_residual(r);
+  return (r[0] + r[1] + r[2]) / 3.0 < kResTol;
+}
+
+// ------------------------------------------------------------------------------------------------
+void Navier2DAdjointEngine::update(int nsteps) {
+  F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
+  F &velx_adj = field("velx_adj"), &vely_adj = field("vely_adj"), &temp_adj = field("temp_adj"), &pres_adj = field("pres_adj");
+  F& tempbc = field("tempbc");
+  const double dtn = kDtNavier, dt = dt_;
+  for (int step = 0; step < nsteps; ++step) {
+    // ================= forward step for the residual (steady_adjoint.rs:547-585) =================
+    backward(velx, ux_);
+    backward(vely, uy_);
+    velx.sp->to_ortho(velx.vhat, old_[0], st_);
+    vely.sp->to_ortho(vely.vhat, old_[1], st_);
+    temp.sp->to_ortho(temp.vhat, old_[2], st_);
+    // solve_velx (steady_adjoint_eq.rs:134-144)
+    lincomb(rhs_, 1.0, old_[0], 0.0, old_[0]);
+    acc_gradient(pres, 1, 0, -dtn, rhs_);
+    conv_term(ux_, velx, 1, 0, 1.0, true);
+    conv_term(uy_, velx, 0, 1, 1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+    hh_vel_->solve(rhs_, velx.vhat, st_);
+    // solve_vely (steady_adjoint_eq.rs:147-160): buoyancy = temp.to_ortho() * dt, without the lift
+    lincomb(rhs_, 1.0, old_[1], dtn, old_[2]);
+    acc_gradient(pres, 0, 1, -dtn, rhs_);
+    conv_term(ux_, vely, 1, 0, 1.0, true);
+    conv_term(uy_, vely, 0, 1, 1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+    hh_vel_->solve(rhs_, vely.vhat, st_);
+    // projection (steady_adjoint.rs:563-567)
+    div(div_);
+    solve_pres(div_);
+    correct_velocity(1.0);
+    // update_pres (steady_adjoint_eq.rs:194-201): pres += -nu div + pseu.to_ortho() / dt
+    lincomb(pres.vhat, 1.0, pres.vhat, -nu_, div_);
+    acc_to_ortho(pseu, 1.0 / dtn, pres.vhat);
+    // solve_temp (steady_adjoint_eq.rs:166-180)
+    lincomb(rhs_, 1.0, old_[2], 0.0, old_[2]);
+    acc_gradient(tempbc, 2, 0, dtn * ka_, rhs_);
+    acc_gradient(tempbc, 0, 2, dtn * ka_, rhs_);
+    conv_term(ux_, temp, 1, 0, 1.0, true);
+    conv_term(uy_, temp, 0, 1, 1.0, false);
+    conv_term(ux_, tempbc, 1, 0, 1.0, false);
+    conv_term(uy_, tempbc, 0, 1, 1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+    hh_temp_->solve(rhs_, temp.vhat, st_);
+    // residual (steady_adjoint.rs:572-575) in the norm of solver_norm, sign flipped (577-584)
+    velx.sp->to_ortho(velx.vhat, t1_, st_);
+    lincomb(t1_, -1.0 / dtn, t1_, 1.0 / dtn, old_[0]);      // -(new - old) / dt
+    norm_vel_->solve(t1_, velx_adj.vhat, st_);
+    vely.sp->to_ortho(vely.vhat, t1_, st_);
+    lincomb(t1_, -1.0 / dtn, t1_, 1.0 / dtn, old_[1]);
+    norm_vel_->solve(t1_, vely_adj.vhat, st_);
+    temp.sp->to_ortho(temp.vhat, t1_, st_);
+    lincomb(t1_, -1.0 / dtn, t1_, 1.0 / dtn, old_[2]);
+    norm_temp_->solve(t1_, temp_adj.vhat, st_);
+    // ================= adjoint step (steady_adjoint.rs:588-607) =================
+    backward(velx, ux_);
+    backward(vely, uy_);
+    backward(temp_adj, ta_);
+    // solve_velx_adj (steady_adjoint_eq.rs:338-359)
+    zero(rhs_);
+    acc_to_ortho(velx, 1.0, rhs_);
+    acc_gradient(pres_adj, 1, 0, -dt, rhs_);
+    conv_term(ux_, velx_adj, 1, 0, 1.0, true);     // conv_velx_adjoint (steady_adjoint_eq.rs:236-262)
+    conv_term(uy_, velx_adj, 0, 1, 1.0, false);
+    conv_term(ux_, velx_adj, 1, 0, 1.0, false);
+    conv_term(uy_, vely_adj, 1, 0, 1.0, false);
+    conv_term(ta_, temp, 1, 0, -1.0, false);
+    conv_term(ta_, tempbc, 1, 0, -1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    acc_gradient(velx_adj, 2, 0, dt * nu_, rhs_);
+    acc_gradient(velx_adj, 0, 2, dt * nu_, rhs_);
+    // (vely's right-hand side needs velx.to_ortho() no more, but conv_vely_adjoint reads velx_adj / vely_adj only: velx may change now)
+    velx.sp->from_ortho(rhs_, velx.vhat, st_);
+    // solve_vely_adj (steady_adjoint_eq.rs:362-388)
+    zero(rhs_);
+    acc_to_ortho(vely, 1.0, rhs_);
+    acc_gradient(pres_adj, 0, 1, -dt, rhs_);
+    conv_term(ux_, vely_adj, 1, 0, 1.0, true);     // conv_vely_adjoint (steady_adjoint_eq.rs:265-293)
+    conv_term(uy_, vely_adj, 0, 1, 1.0, false);
+    conv_term(ux_, velx_adj, 0, 1, 1.0, false);
+    conv_term(uy_, vely_adj, 0, 1, 1.0, false);
+    conv_term(ta_, temp, 0, 1, -1.0, false);
+    conv_term(ta_, tempbc, 0, 1, -1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    acc_gradient(vely_adj, 2, 0, dt * nu_, rhs_);
+    acc_gradient(vely_adj, 0, 2, dt * nu_, rhs_);
+    vely.sp->from_ortho(rhs_, vely.vhat, st_);
+    // projection (steady_adjoint.rs:598-602); update_pres_adj (steady_adjoint_eq.rs:203-210)
+    div(div_);
+    solve_pres(div_);
+    correct_velocity(1.0);
+    acc_to_ortho(pseu, 1.0 / dt, pres_adj.vhat);
+    // solve_temp_adj (steady_adjoint_eq.rs:395-424)
+    zero(rhs_);
+    acc_to_ortho(temp, 1.0, rhs_);
+    conv_term(ux_, temp_adj, 1, 0, 1.0, true);     // conv_temp_adjoint (steady_adjoint_eq.rs:296-314)
+    conv_term(uy_, temp_adj, 0, 1, 1.0, false);
+    conv_finish(cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    acc_to_ortho(vely_adj, dt, rhs_);
+    acc_gradient(temp_adj, 2, 0, dt * ka_, rhs_);
+    acc_gradient(temp_adj, 0, 2, dt * ka_, rhs_);
+    temp.sp->from_ortho(rhs_, temp.vhat, st_);
+    time_ += dt_;
+  }
+  dev_sync(st_);
+}
+
+}  // namespace rpde

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "engine.h"
+#include "adjoint.h"
 #include "dct_line.h"
 #include "h5lite.h"
 #include "rccl_transport.h"
@@ -18,6 +19,8 @@ struct rpde_navier2d { Navier2DEngine* e; int device; };
 struct rpde_space2 { Space2Ops* sp; Stream st; int device; };
 struct rpde_hholtz_adi { HholtzAdiOp* op; rpde_space2* s; };
 struct rpde_poisson { PoissonOp* op; rpde_space2* s; };
+struct rpde_hholtz { TensorHholtzOp* op; rpde_space2* s; };
+struct rpde_adjoint2d { Navier2DAdjointEngine* e; int device; };
 
 static void select_device(int device) {
 #ifndef RPDE_EMU
@@ -172,6 +175,14 @@ int rpde_navier2d_create_confined(int nx, int ny, double ra, double pr, double d
                                   const char* bc, int device, rpde_navier2d** out) {
   return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, false, out);
 }
+int rpde_navier2d_create_confined_with_spectrum(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                                const char* bc, int device, const double* lam, size_t m,
+                                                rpde_navier2d** out) {
+  if (!lam) { g_err = "null pointer"; return 1; }
+  const Vec spectrum(lam, lam + m);
+  struct Pending { explicit Pending(const Vec* v) { set_pending_x_spectrum(v); } ~Pending() { set_pending_x_spectrum(nullptr); } } guard(&spectrum);
+  return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, false, out);
+}
 int rpde_navier2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect,
                                   const char* bc, int device, rpde_navier2d** out) {
   return create_engine(nx, ny, ra, pr, dt, aspect, bc, device, true, out);
@@ -253,6 +264,87 @@ int rpde_navier2d_destroy(rpde_navier2d* h) {
     if (h) { select_device(h->device); delete h->e; delete h; dev_trim(); }
   })
 }
+// ---- Navier2DAdjoint (adjoint.h)
+static int create_adjoint(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc, int device,
+                          bool periodic, rpde_adjoint2d** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out && bc, "null pointer");
+    select_device(device);
+    auto* h = new rpde_adjoint2d{nullptr, device};
+    try {
+      h->e = new Navier2DAdjointEngine(nx, ny, ra, pr, dt, aspect, bc, periodic);
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  })
+}
+int rpde_adjoint2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc, int device,
+                                   rpde_adjoint2d** out) {
+  return create_adjoint(nx, ny, ra, pr, dt, aspect, bc, device, false, out);
+}
+int rpde_adjoint2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc, int device,
+                                   rpde_adjoint2d** out) {
+  return create_adjoint(nx, ny, ra, pr, dt, aspect, bc, device, true, out);
+}
+int rpde_adjoint2d_destroy(rpde_adjoint2d* h) {
+  RPDE_TRY({ if (h) { select_device(h->device); delete h->e; delete h; dev_trim(); } })
+}
+int rpde_adjoint2d_set_velocity(rpde_adjoint2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_velocity(amp, m, n); })
+}
+int rpde_adjoint2d_set_temperature(rpde_adjoint2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_temperature(amp, m, n); })
+}
+int rpde_adjoint2d_reset_time(rpde_adjoint2d* h) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); h->e->reset_time(); }) }
+int rpde_adjoint2d_spectral_shape(rpde_adjoint2d* h, const char* name, int* rows, int* cols, int* is_complex) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && rows && cols && is_complex, "null pointer");
+    int e = 1;
+    h->e->spectral_shape(name, rows, cols, &e);
+    *is_complex = e == 2;
+  })
+}
+int rpde_adjoint2d_set_field(rpde_adjoint2d* h, const char* name, int space, const double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->set_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->set_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_adjoint2d_get_field(rpde_adjoint2d* h, const char* name, int space, double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->get_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->get_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_adjoint2d_update(rpde_adjoint2d* h, int nsteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(nsteps >= 0, "negative step count"); select_device(h->device); h->e->update(nsteps); })
+}
+int rpde_adjoint2d_time(rpde_adjoint2d* h, double* time) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(time, "null pointer"); *time = h->e->time(); }) }
+int rpde_adjoint2d_dt(rpde_adjoint2d* h, double* dt) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(dt, "null pointer"); *dt = h->e->dt(); }) }
+int rpde_adjoint2d_param(rpde_adjoint2d* h, const char* key, double* value) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(key && value, "null pointer"); *value = h->e->param(key); })
+}
+int rpde_adjoint2d_exit(rpde_adjoint2d* h, int* stop) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(stop, "null pointer"); select_device(h->device); *stop = h->e->exit() ? 1 : 0; })
+}
+int rpde_adjoint2d_div_norm(rpde_adjoint2d* h, double* norm) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(norm, "null pointer"); select_device(h->device); *norm = h->e->div_norm(); })
+}
+int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(res3, "null pointer"); select_device(h->device); h->e->norm_residual(res3); })
+}
+
 int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_velocity(amp, m, n); })
 }
@@ -625,6 +717,70 @@ int rpde_poisson_solve(rpde_poisson* ps, const double* in, size_t nin, double* o
     Arr2 b = alloc_shape(*ps->s->sp, 1, out, nout, "Poisson output");
     ps->op->solve(a, b, ps->s->st); dev_sync(ps->s->st); download(b, out);
   })
+}
+static void x_operator_bands(int base_kind, int n, double c0, Bands& ax, Bands& cx) {
+  RPDE_REQUIRE(base_kind == RPDE_CHEB_DIRICHLET || base_kind == RPDE_CHEB_NEUMANN, "x spectrum: a composite Chebyshev base with a two-term stencil");
+  RPDE_REQUIRE(n >= 4, "x spectrum: at least four points");
+  const Base b = make_base((BaseKind)base_kind, n);
+  ax = bands_axpy(Bands{Vec(b.m, 0.0), Vec(b.m, 0.0), Vec(b.m, 0.0), Vec(b.m, 0.0)}, c0, hholtz_mat_b(b));
+  cx = hholtz_mat_a(b);
+}
+int rpde_poisson_x_spectrum(int base_kind, int n, double c0, double* lam, size_t m) {
+  RPDE_TRY({
+    RPDE_REQUIRE(lam && (int)m == n - 2, "x spectrum: m must be n - 2");
+    Bands ax, cx;
+    x_operator_bands(base_kind, n, c0, ax, cx);
+    const Vec l = eigen_spectrum_parity(ax, cx);
+    std::copy(l.begin(), l.end(), lam);
+  })
+}
+int rpde_poisson_x_eigenbasis_from_spectrum(int base_kind, int n, double c0, const double* lam, size_t m,
+                                            double* lam_refined, double* fwd, double* bwd) {
+  RPDE_TRY({
+    RPDE_REQUIRE(lam && lam_refined && fwd && bwd && (int)m == n - 2, "eigenbasis from spectrum: m must be n - 2");
+    Bands ax, cx;
+    x_operator_bands(base_kind, n, c0, ax, cx);
+    const EigenX eg = eigenbasis_from_spectrum(ax, cx, Vec(lam, lam + m));
+    std::copy(eg.lam.begin(), eg.lam.end(), lam_refined);
+    // the layout of PoissonOp::export_eigenbasis: dense m x m over the natural coefficient index
+    std::fill(fwd, fwd + m * m, 0.0);
+    std::fill(bwd, bwd + m * m, 0.0);
+    size_t moff = 0;
+    for (int par = 0; par < 2; ++par) {
+      const int mb = par ? eg.mo : eg.me, off = par ? eg.me : 0;
+      for (int k = 0; k < mb; ++k)
+        for (int i = 0; i < mb; ++i) {
+          fwd[(size_t)(off + k) * m + (par + 2 * i)] = eg.fwd[moff + (size_t)k * mb + i];
+          bwd[(size_t)(par + 2 * i) * m + (off + k)] = eg.bwd[moff + (size_t)i * mb + k];
+        }
+      moff += (size_t)mb * mb;
+    }
+  })
+}
+int rpde_poisson_create_with_spectrum(rpde_space2* s, double c0, double c1, const double* lam, size_t m, rpde_poisson** out) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); RPDE_REQUIRE(out && lam, "null pointer"); select_device(s->device);
+    const Vec spectrum(lam, lam + m);
+    struct Pending { explicit Pending(const Vec* v) { set_pending_x_spectrum(v); } ~Pending() { set_pending_x_spectrum(nullptr); } } guard(&spectrum);
+    *out = new rpde_poisson{new PoissonOp(*s->sp, c0, c1), s};
+  })
+}
+int rpde_hholtz_create(rpde_space2* s, double c0, double c1, rpde_hholtz** out) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(s); RPDE_REQUIRE(out, "null pointer"); select_device(s->device);
+    *out = new rpde_hholtz{new TensorHholtzOp(*s->sp, c0, c1), s};
+  })
+}
+int rpde_hholtz_solve(rpde_hholtz* hs, const double* in, size_t nin, double* out, size_t nout) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(hs); select_device(hs->s->device);
+    Arr2 a = upload_shape(*hs->s->sp, 2, in, nin, "Hholtz input");
+    Arr2 b = alloc_shape(*hs->s->sp, 1, out, nout, "Hholtz output");
+    hs->op->solve(a, b, hs->s->st); dev_sync(hs->s->st); download(b, out);
+  })
+}
+int rpde_hholtz_destroy(rpde_hholtz* hs) {
+  RPDE_TRY({ if (hs) { delete hs->op; delete hs; } })
 }
 int rpde_poisson_eigenbasis(rpde_poisson* ps, double* lam, double* fwd, double* bwd, size_t m) {
   RPDE_TRY({

@@ -59,7 +59,6 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   lds_t buf = (lds_t)blk.lds;
   lds2_t buf2 = (lds2_t)blk.lds;
   const int line = blk.line;
-  cgmem2_t src2 = (cgmem2_t)(a.in + (long)line * a.ldi);
   tab_t tw = (tab_t)a.tw;
   tab_t tw2 = (tab_t)a.tw2;
   const int n_in = a.n_in;
@@ -70,13 +69,16 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   // ---- stage the line two doubles into the buffer: xs[m + 2] = x[m] (m < n_in), zeros in front and behind, so that
   // the stencil tap x[m - 2] and the tail m >= n_in need no selects.  Pair p holds xs[2p], xs[2p + 1] = x[2p - 2], x[2p - 1].
   if (!staged) {
+  // through a buffer descriptor that ends behind the pair holding the last coefficient: a pair outside the line reads zero,
+  // no bounds test, no branch, one 32-bit offset per thread (round 5, as hdct_core)
+  const RowBuf rb = row_buf(a.in + (long)line * a.ldi, 8L * ((n_in + 1) & ~1));
   RPDE_PHASE(blk, tid) {
     constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);   // pairs per thread: 2 T QP >= N + 4
     dbl2 v[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
-      const int p = tid + q * T, k = 2 * p - 2;
-      v[q] = (k >= 0 && k < n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
+      const int p = tid + q * T;                          // pair p = elements 2 p - 2, 2 p - 1 at byte 16 (p - 1)
+      v[q] = row_ld2(rb, 16 * (p - 1), 0);
     }
 #pragma unroll
     for (int q = 0; q < QP; ++q) {

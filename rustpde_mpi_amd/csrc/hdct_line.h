@@ -49,8 +49,19 @@ struct HdctStoreEmit {
 // needs in flight.
 // PAIR: the line runs in one half of a workgroup whose other half runs another transform of the same length
 // (hdct_pair_line): every barrier is met by both halves, so the barriers of the derivative are passed without it too.
-template <int N, class Fetch, class Emit, bool PAIR = false>
+// MODE: what the caller knows at compile time about a.fwd / a.deriv / a.sten (kHdctFwd | kHdctDeriv | kHdctSten2 | kHdctSten1),
+// -1 = nothing (every flag is tested at run time).  The step's launches have fixed flags: with them as constants the
+// selects of the staging, of the pre-step's prefactors and of the output scaling (2/3 rule) and the code of the branches
+// not taken disappear (round 5, profiles/r05_isa_census.md).
+constexpr int kHdctFwd = 1, kHdctDeriv = 2, kHdctSten2 = 4, kHdctSten1 = 8;
+RPDE_HD inline int hdct_mode_of(const DctLineArgs& a) {
+  return (a.fwd ? kHdctFwd : 0) | (a.deriv ? kHdctDeriv : 0) | (a.sten == 2 ? kHdctSten2 : 0) | (a.sten == 1 ? kHdctSten1 : 0);
+}
+template <int N, class Fetch, class Emit, bool PAIR = false, int MODE = -1>
 RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch& fetch, const Emit& emit) {
+  const bool a_fwd = MODE >= 0 ? (MODE & kHdctFwd) != 0 : a.fwd != 0;
+  const bool a_deriv = MODE >= 0 ? (MODE & kHdctDeriv) != 0 : a.deriv != 0;
+  const int a_sten = MODE >= 0 ? ((MODE & kHdctSten2) ? 2 : (MODE & kHdctSten1) ? 1 : 0) : a.sten;
   using G = HdctGeom<N>;
   constexpr int T = G::T, M = G::M, PL = G::PL, NW = G::NW;
   static_assert(N == 4096 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 4, 8 x 8 x 8 or 8 x 8 x 2");
@@ -72,16 +83,19 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   // Dirichlet stencil (sten == 2: c_m = a_m - a_{m-2}) is applied on the way: the second pair of a thread is the first
   // pair of its neighbour, an L1 hit.
   if (!staged) {
-    cgmem2_t src2 = (cgmem2_t)(a.in + (long)blk.line * a.ldi);
-    const bool dsten = a.sten == 2;
+    // through a buffer descriptor that ends behind the pair holding the last coefficient: a pair outside the line (the one
+    // in front of it, everything behind it) reads zero -- no bounds test, no branch, one 32-bit offset per thread (round 5;
+    // the flat form cost fourteen instructions per load: test, exec-mask branch, zeroed registers, 64-bit address)
+    const RowBuf rb = row_buf(a.in + (long)blk.line * a.ldi, 8L * ((n_in + 1) & ~1));
+    const bool dsten = a_sten == 2;
     RPDE_PHASE(blk, tid) {
       constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);   // pairs per thread: 2 T QP >= N + 4
       dbl2 v[QP], w[QP];
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
-        const int p = tid + q * T, k = 2 * p - 2;
-        v[q] = (k >= 0 && k < n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
-        w[q] = (dsten && k >= 2 && k - 2 < n_in) ? src2[(k - 2) >> 1] : dbl2{0.0, 0.0};
+        const int p = tid + q * T;                        // pair p = elements k = 2 p - 2, k + 1 at byte 16 (p - 1)
+        v[q] = row_ld2(rb, 16 * (p - 1), 0);
+        w[q] = dsten ? row_ld2(rb, 16 * (p - 2), 0) : dbl2{0.0, 0.0};
       }
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
@@ -98,7 +112,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 
   // ---- table stencil and / or derivative: the orthonormal coefficients (then their derivative) replace the staged
   // line, thread t owning the contiguous chunk k = 16 t .. 16 t + 15 (the last thread also k = N)
-  if (a.sten == 1) {
+  if (a_sten == 1) {
     tab_t low = (tab_t)a.low;
     RPDE_TLS(blk, double, c, 17);
     RPDE_PHASE(blk, tid) {
@@ -120,10 +134,10 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     }
     RPDE_SYNC(blk);
   }
-  if (PAIR || a.deriv) {
+  if (PAIR || a_deriv) {
     // d_k = dscale * sum_{j > k, j + k odd} 2 j c_j, d_0 halved (the suffix sums of scan_cheb_diff, line_vm.h): thread t
     // owns the chunk lo = 16 (T - 1 - t), so that the carry flows from thread t - 1 to thread t
-    const bool dv = a.deriv != 0;
+    const bool dv = a_deriv;
     RPDE_TLS(blk, double, zz, 16);
     RPDE_TLS(blk, double, vd, 2);
     RPDE_PHASE(blk, tid) {
@@ -164,7 +178,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
         for (int u = 0; u < wave; ++u) { S[0] += scr[8 + u]; S[1] += scr[8 + NW + u]; }
       }
 #pragma unroll
-      for (int par = 0; par < 2; ++par) vd[par] = dpp_f64<0x138, 0xF>(0.0, v[par]) + S[par];   // wave_shr:1
+      for (int par = 0; par < 2; ++par) vd[par] = dpp_f64z<0x138>(v[par]) + S[par];   // wave_shr:1
     }
 #endif
     RPDE_SYNC(blk);
@@ -197,13 +211,13 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     for (int q = 0; q < 8; ++q) { const int j = tid + q * T; xa[q] = buf[j + 2]; xb[q] = buf[N - j + 2]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { cs[q] = c0 * kC32[q] - s0 * kS32[q]; sn[q] = s0 * kC32[q] + c0 * kS32[q]; }
-    const double f = a.fwd ? 1.0 : ((tid & 1) ? -0.5 : 0.5);
+    const double f = a_fwd ? 1.0 : ((tid & 1) ? -0.5 : 0.5);
     double e1 = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = tid + q * T;
       const bool end = (q == 0 && tid == 0);               // j = 0 pairs the two ends of the line
-      const double fa = (end && !a.fwd) ? 1.0 : f;
+      const double fa = (end && !a_fwd) ? 1.0 : f;
       const double A = fa * xa[q], B = fa * xb[q];
       const double s = A + B, d = A - B;
       const double t2 = 2.0 * sn[q] * d;
@@ -211,7 +225,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
       if (!end) buf[N - j + 2] = s + t2;
       e1 += end ? d : 2.0 * cs[q] * d;
     }
-    if (tid == 0) buf[M + 2] = (a.fwd ? 2.0 : 1.0) * buf[M + 2];   // y_M = 2 f_M x_M, M even
+    if (tid == 0) buf[M + 2] = (a_fwd ? 2.0 : 1.0) * buf[M + 2];   // y_M = 2 f_M x_M, M even
     RPDE_T(e1p)[0] = e1;
   }
 #ifndef RPDE_EMU
@@ -367,14 +381,14 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   const double fn = 1.0 / (double)N;
   auto finish = [&](int tid, int u, double e0, double eo) {
     const int m = 2 * (tid + u * T);
-    if (a.fwd) {   // (-1)^k / N, both ends halved, the 2/3 rule
+    if (a_fwd) {   // (-1)^k / N, both ends halved, the 2/3 rule
       e0 = (m < a.cut) ? e0 * ((u == 0 && tid == 0) ? 0.5 * fn : fn) : 0.0;
       eo = (m + 1 < a.cut) ? -eo * fn : 0.0;
     }
     emit(tid, u, m, e0, eo);
   };
   auto finish_end = [&](int tid, double en) {
-    if (a.fwd) en = (N < a.cut) ? en * 0.5 * fn : 0.0;         // N is even
+    if (a_fwd) en = (N < a.cut) ? en * 0.5 * fn : 0.0;         // N is even
     emit(tid, 8, N, en, 0.0);
   };
 #ifdef RPDE_EMU
@@ -422,9 +436,23 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #endif
 }
 
-template <int N>
+template <int N, int MODE = -1>
 RPDE_DEV void hdct_bwd_line(Blk& blk, const DctLineArgs& a) {
-  hdct_core<N>(blk, a, false, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)blk.line * a.ldo), a.scale});
+  hdct_core<N, HdctNoFetch, HdctStoreEmit, false, MODE>(blk, a, false, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)blk.line * a.ldo), a.scale});
+}
+
+// the two flag combinations the time step launches (backward of a Dirichlet state line, and of its derivative) run code
+// compiled for them (hdct_core's MODE); everything else the generic form
+template <int N>
+RPDE_DEV void hdct_bwd_line_by_mode(Blk& blk, const DctLineArgs& a) {
+#ifdef RPDE_EMU
+  const int mode = hdct_mode_of(a);
+#else
+  const int mode = __builtin_amdgcn_readfirstlane(hdct_mode_of(a));
+#endif
+  if (mode == kHdctSten2) hdct_bwd_line<N, kHdctSten2>(blk, a);
+  else if (mode == (kHdctSten2 | kHdctDeriv)) hdct_bwd_line<N, kHdctSten2 | kHdctDeriv>(blk, a);
+  else hdct_bwd_line<N>(blk, a);
 }
 
 // S1 of the step: the physical values AND the physical derivative of one state line (a0: the series, a1: deriv = 1 of the
@@ -438,17 +466,17 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
   {
     Blk all{line, 0, T2, lds};
     lds2_t bufa = (lds2_t)lds, bufb = (lds2_t)(lds + LB);
-    cgmem2_t src2 = (cgmem2_t)(a0.in + (long)line * a0.ldi);
     const bool dsten = a0.sten == 2;
     const int n_in = a0.n_in;
+    const RowBuf rb = row_buf(a0.in + (long)line * a0.ldi, 8L * ((n_in + 1) & ~1));   // as in hdct_core: outside the line reads zero
     RPDE_PHASE(all, tid) {
       constexpr int QP = (N + 4 + 2 * T2 - 1) / (2 * T2);   // pairs per thread: 2 T2 QP >= N + 4
       dbl2 v[QP], w[QP];
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
-        const int p = tid + q * T2, k = 2 * p - 2;
-        v[q] = (k >= 0 && k < n_in) ? src2[k >> 1] : dbl2{0.0, 0.0};
-        w[q] = (dsten && k >= 2 && k - 2 < n_in) ? src2[(k - 2) >> 1] : dbl2{0.0, 0.0};
+        const int p = tid + q * T2;
+        v[q] = row_ld2(rb, 16 * (p - 1), 0);
+        w[q] = dsten ? row_ld2(rb, 16 * (p - 2), 0) : dbl2{0.0, 0.0};
       }
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
@@ -465,16 +493,27 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
 #ifdef RPDE_EMU
   {
     Blk b0{line, 0, T, lds};
-    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b0, a0, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a0.out + (long)line * a0.ldo), a0.scale});
     Blk b1{line, 0, T, lds + LB};
-    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b1, a1, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a1.out + (long)line * a1.ldo), a1.scale});
+    if (a0.sten != 1) {
+      hdct_core<N, HdctNoFetch, HdctStoreEmit, true, 0>(b0, a0, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a0.out + (long)line * a0.ldo), a0.scale});
+      hdct_core<N, HdctNoFetch, HdctStoreEmit, true, kHdctDeriv>(b1, a1, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a1.out + (long)line * a1.ldo), a1.scale});
+    } else {
+      hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b0, a0, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a0.out + (long)line * a0.ldo), a0.scale});
+      hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(b1, a1, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a1.out + (long)line * a1.ldo), a1.scale});
+    }
   }
 #else
   {
     const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >= T ? 1 : 0);
     Blk blk{line, 0, T, lds + half * LB, nullptr, 0, half * T};
-    const DctLineArgs& a = half ? a1 : a0;
-    hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(blk, a, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)line * a.ldo), a.scale});
+    // hdct_pair_ok: both backward, the first the series, the second its derivative; the stencil is applied by the staging above
+    if (a0.sten != 1) {
+      if (half) hdct_core<N, HdctNoFetch, HdctStoreEmit, true, kHdctDeriv>(blk, a1, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a1.out + (long)line * a1.ldo), a1.scale});
+      else hdct_core<N, HdctNoFetch, HdctStoreEmit, true, 0>(blk, a0, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a0.out + (long)line * a0.ldo), a0.scale});
+    } else {
+      const DctLineArgs& a = half ? a1 : a0;
+      hdct_core<N, HdctNoFetch, HdctStoreEmit, true>(blk, a, true, HdctNoFetch{}, HdctStoreEmit{(gmem_t)(a.out + (long)line * a.ldo), a.scale});
+    }
   }
 #endif
 }

@@ -597,4 +597,198 @@ EigenX eigen_decomposition_parity(const Bands& a, const Bands& c) {
   return out;
 }
 
+Vec eigen_spectrum_parity(const Bands& a, const Bands& c) {
+  Lapack& L = lapack();
+  const int m = (int)a.dia.size();
+  const int me = (m + 1) / 2, mo = m / 2;
+  Vec lam(m);
+  int loff = 0;
+  for (int par = 0; par < 2; ++par) {
+    const int mb = par == 0 ? me : mo;
+    auto dense_cm = [&](const Bands& bd) {
+      Vec d((size_t)mb * mb, 0.0);
+      for (int r = 0; r < mb; ++r) {
+        const int R = par + 2 * r;
+        auto put = [&](int cc, double v) { if (cc >= 0 && cc < mb) d[(size_t)cc * mb + r] = v; };
+        put(r - 1, bd.low[R]); put(r, bd.dia[R]); put(r + 1, bd.up1[R]); put(r + 2, bd.up2[R]);
+      }
+      return d;
+    };
+    Vec cinv = dense_cm(c);
+    invert_cm(L, cinv, mb);
+    Vec x = matmul_cm(L, cinv, dense_cm(a), mb);
+    Vec wr(mb), wi(mb);
+    int info = 0, lwork = -1, one = 1;
+    double wq = 0;
+    L.dgeev("N", "N", &mb, x.data(), &mb, wr.data(), wi.data(), nullptr, &one, nullptr, &one, &wq, &lwork, &info, 1, 1);
+    lwork = (int)wq + 1;
+    Vec work(lwork);
+    L.dgeev("N", "N", &mb, x.data(), &mb, wr.data(), wi.data(), nullptr, &one, nullptr, &one, work.data(), &lwork, &info, 1, 1);
+    RPDE_REQUIRE(info == 0, "dgeev failed");
+    double wmax = 0.0, imax = 0.0;
+    for (int k = 0; k < mb; ++k) { wmax = std::max(wmax, std::fabs(wr[k])); imax = std::max(imax, std::fabs(wi[k])); }
+    RPDE_REQUIRE(imax <= 1e-8 * std::max(wmax, 1.0), "Poisson eigen-decomposition: complex eigenvalues");
+    std::stable_sort(wr.begin(), wr.end(), [](double x0, double x1) { return x0 > x1; });
+    std::copy(wr.begin(), wr.end(), lam.begin() + loff);
+    loff += mb;
+  }
+  return lam;
+}
+
+namespace {
+// LU with partial pivoting of an n x n band matrix (kl sub-, ku super-diagonals), row storage with room for the fill:
+// row i holds columns i - kl .. i + ku + kl at ab[i * w + (j - i + kl)], w = 2 kl + ku + 1.  Rows are swapped physically
+// (a pivot row reaches at most kl rows down).  A pivot that vanishes against the matrix norm is replaced by `tiny`:
+// the matrix is singular ON PURPOSE (inverse iteration at an eigenvalue), the solve then returns the null direction.
+struct BandLU {
+  int n = 0, kl = 0, ku = 0, w = 0;
+  Vec ab;                  // factorised in place: U in the row, multipliers in mult
+  Vec mult;                // mult[i * kl + (r - i - 1)]: multiplier of row r (after the swap of step i)
+  std::vector<int> piv;    // row swapped with row i in step i
+  double& at(int i, int j) { return ab[(size_t)i * w + (j - i + kl)]; }
+  void factor(double tiny) {
+    mult.assign((size_t)n * std::max(kl, 1), 0.0);
+    piv.assign(n, 0);
+    for (int i = 0; i < n; ++i) {
+      int p = i;
+      double best = std::fabs(at(i, i));
+      for (int r = i + 1; r <= std::min(n - 1, i + kl); ++r) {
+        const double v = std::fabs(ab[(size_t)r * w + (i - r + kl)]);
+        if (v > best) { best = v; p = r; }
+      }
+      piv[i] = p;
+      const int jmax = std::min(n - 1, i + ku + kl);
+      if (p != i)
+        for (int j = i; j <= jmax; ++j) std::swap(at(i, j), ab[(size_t)p * w + (j - p + kl)]);
+      if (std::fabs(at(i, i)) < tiny) at(i, i) = at(i, i) < 0.0 ? -tiny : tiny;
+      const double d = at(i, i);
+      for (int r = i + 1; r <= std::min(n - 1, i + kl); ++r) {
+        double& e = ab[(size_t)r * w + (i - r + kl)];
+        const double f = e / d;
+        mult[(size_t)i * kl + (r - i - 1)] = f;
+        e = 0.0;
+        if (f != 0.0)
+          for (int j = i + 1; j <= jmax; ++j) ab[(size_t)r * w + (j - r + kl)] -= f * at(i, j);
+      }
+    }
+  }
+  void solve(Vec& x) {     // in place
+    for (int i = 0; i < n; ++i) {
+      if (piv[i] != i) std::swap(x[i], x[piv[i]]);
+      for (int r = i + 1; r <= std::min(n - 1, i + kl); ++r) x[r] -= mult[(size_t)i * kl + (r - i - 1)] * x[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = x[i];
+      const int jmax = std::min(n - 1, i + ku + kl);
+      for (int j = i + 1; j <= jmax; ++j) v -= at(i, j) * x[j];
+      x[i] = v / at(i, i);
+    }
+  }
+};
+}  // namespace
+
+EigenX eigenbasis_from_spectrum(const Bands& a, const Bands& c, const Vec& lam) {
+  const int m = (int)a.dia.size();
+  RPDE_REQUIRE((int)lam.size() == m, "eigenbasis_from_spectrum: one eigenvalue per coefficient");
+  EigenX out;
+  out.me = (m + 1) / 2;
+  out.mo = m / 2;
+  out.lam = lam;
+  out.fwd.assign((size_t)out.me * out.me + (size_t)out.mo * out.mo, 0.0);
+  out.bwd.assign(out.fwd.size(), 0.0);
+  size_t moff = 0;
+  int loff = 0;
+  for (int par = 0; par < 2; ++par) {
+    const int mb = par == 0 ? out.me : out.mo;
+    // entries of row r of a parity block: columns r - 1, r, r + 1, r + 2
+    auto ent = [&](const Bands& bd, int r, int off) {
+      const int R = par + 2 * r;
+      return off == -1 ? bd.low[R] : off == 0 ? bd.dia[R] : off == 1 ? bd.up1[R] : bd.up2[R];
+    };
+    double norm = 0.0;
+    for (int r = 0; r < mb; ++r)
+      for (int off = -1; off <= 2; ++off) norm = std::max(norm, std::fabs(ent(a, r, off)));
+    auto band_mul = [&](const Bands& bd, const Vec& x, Vec& y) {   // y = (block of bd) x
+      for (int r = 0; r < mb; ++r) {
+        double v = 0.0;
+        for (int off = -1; off <= 2; ++off) { const int jc = r + off; if (jc >= 0 && jc < mb) v += ent(bd, r, off) * x[jc]; }
+        y[r] = v;
+      }
+    };
+    Vec q(mb), f(mb), aq(mb), cq(mb);
+    for (int k = 0; k < mb; ++k) {
+      // Rayleigh-quotient iteration on the banded pencil: dgeev works on the dense inv(C) A, whose norm grows like n^4, and
+      // returns the small eigenvalues with an ABSOLUTE error of eps * n^4 (1e-7 relative at n = 1025); against the pencil
+      // itself the generalised Rayleigh quotient rho = (f A q) / (f C q) of a left / right pair converges in two or three
+      // rounds to the eigenvalue the operator has (residual |A q - rho C q| at round-off level)
+      double l = lam[loff + k];
+      for (int round = 0; round < 6; ++round) {
+        double mnorm = norm;
+        for (int r = 0; r < mb; ++r)
+          for (int off = -1; off <= 2; ++off) mnorm = std::max(mnorm, std::fabs(l * ent(c, r, off)));
+        const double tiny = 2.220446049250313e-16 * mnorm;
+        BandLU R_, L_;                                // M = A - l C (kl 1, ku 2) and its transpose (kl 2, ku 1)
+        R_.n = L_.n = mb;
+        R_.kl = 1; R_.ku = 2; R_.w = 2 * R_.kl + R_.ku + 1; R_.ab.assign((size_t)mb * R_.w, 0.0);
+        L_.kl = 2; L_.ku = 1; L_.w = 2 * L_.kl + L_.ku + 1; L_.ab.assign((size_t)mb * L_.w, 0.0);
+        for (int r = 0; r < mb; ++r)
+          for (int off = -1; off <= 2; ++off) {
+            const int jc = r + off;
+            if (jc < 0 || jc >= mb) continue;
+            const double v = ent(a, r, off) - l * ent(c, r, off);
+            R_.at(r, jc) = v;
+            L_.at(jc, r) = v;
+          }
+        R_.factor(tiny);
+        L_.factor(tiny);
+        auto iterate = [&](BandLU& lu, Vec& x, int its) {
+          if (round == 0)
+            for (int i = 0; i < mb; ++i) x[i] = 1.0 / (1.0 + (double)((i * 7 + 3) % 11));   // a fixed start with every component
+          for (int it = 0; it < its; ++it) {
+            lu.solve(x);
+            double mx = 0.0;
+            for (double v : x) mx = std::max(mx, std::fabs(v));
+            RPDE_REQUIRE(mx > 0.0 && mx == mx && mx < 1e300, "inverse iteration failed");
+            for (double& v : x) v /= mx;
+          }
+        };
+        iterate(R_, q, round == 0 ? 3 : 1);
+        iterate(L_, f, round == 0 ? 3 : 1);
+        band_mul(a, q, aq);
+        band_mul(c, q, cq);
+        double faq = 0.0, fcq = 0.0;
+        for (int r = 0; r < mb; ++r) { faq += f[r] * aq[r]; fcq += f[r] * cq[r]; }
+        RPDE_REQUIRE(fcq != 0.0 && fcq == fcq, "left and right eigenvector are orthogonal in the C inner product");
+        const double rho = faq / fcq;
+        const bool done = std::fabs(rho - l) <= 8.0 * 2.220446049250313e-16 * std::max(std::fabs(l), 1e-3 * norm / std::max(1.0, (double)mb));
+        // a refined value must stay the eigenvalue it started from: well inside the gap to its neighbours
+        l = rho;
+        if (done || round == 5) break;
+      }
+      out.lam[loff + k] = l;
+      {  // q: unit 2-norm, its largest component positive
+        double s2 = 0.0, big = 0.0;
+        int ib = 0;
+        for (int i = 0; i < mb; ++i) { s2 += q[i] * q[i]; if (std::fabs(q[i]) > big) { big = std::fabs(q[i]); ib = i; } }
+        const double sc = (q[ib] < 0.0 ? -1.0 : 1.0) / std::sqrt(s2);
+        for (double& v : q) v *= sc;
+      }
+      {  // f: f C q = 1
+        band_mul(c, q, cq);
+        double dot = 0.0;
+        for (int r = 0; r < mb; ++r) dot += f[r] * cq[r];
+        RPDE_REQUIRE(dot != 0.0 && dot == dot, "left and right eigenvector are orthogonal in the C inner product");
+        for (double& v : f) v /= dot;
+      }
+      for (int i = 0; i < mb; ++i) {
+        out.bwd[moff + (size_t)i * mb + k] = q[i];   // Q(i, k)
+        out.fwd[moff + (size_t)k * mb + i] = f[i];   // F(k, i)
+      }
+    }
+    moff += (size_t)mb * mb;
+    loff += mb;
+  }
+  return out;
+}
+
 }  // namespace rpde

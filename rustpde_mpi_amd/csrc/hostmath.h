@@ -126,5 +126,16 @@ struct EigenX {
 // coefficients decouple exactly).  Throws if LAPACK cannot be loaded.
 EigenX eigen_decomposition_parity(const Bands& a, const Bands& c);
 std::string lapack_library_path();
+// The eigenvalues alone (dgeev without vectors), same order as EigenX::lam.
+Vec eigen_spectrum_parity(const Bands& a, const Bands& c);
+// The eigenbasis that belongs to GIVEN eigenvalues, without LAPACK and bit-reproducible: per eigenvalue one right and one
+// left null vector of the banded pencil A - lam C of a parity block (inverse iteration on a banded LU with partial pivoting:
+// O(m) per vector), bwd = the right vectors (unit 2-norm, largest component positive), fwd = the left vectors scaled to
+// fwd C bwd = I (the rows of Q^-1 C^-1 ARE the left eigenvectors of the pencil: F A = Lam F C).  Plain scalar loops in a
+// fixed order: the same library binary returns the same bits on any host -- which is what lets a checker on another
+// machine run the reference algorithm on EXACTLY the engine's setup data (tests/golden/make_shared_basis_golden.py): dgeev's
+// own output is not reproducible across thread counts or CPU models, and the Poisson solve amplifies that by 1e10
+// (DESIGN.md section 4).  `lam`: m values in EigenX order.
+EigenX eigenbasis_from_spectrum(const Bands& a, const Bands& c, const Vec& lam);
 
 }  // namespace rpde

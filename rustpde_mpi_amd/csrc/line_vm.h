@@ -857,11 +857,20 @@ __device__ __forceinline__ Affine<ORDER> affine_wave_scan(Affine<ORDER> inc) {
   inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x143, 0xC>(inc));
   return inc;
 }
+// the same with zeros shifted in (bound_ctrl) and every row enabled: no `old` operand, i.e. no two v_mov in front of the pair
+// of DPP moves (shifts inside a row and the wave shift; the row broadcasts keep rows masked and need `old`)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64z(double x) {
+  const long long xb = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)xb, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(xb >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ __forceinline__ double sum_wave_scan(double v) {
-  v += dpp_f64<0x111, 0xF>(0.0, v);
-  v += dpp_f64<0x112, 0xF>(0.0, v);
-  v += dpp_f64<0x114, 0xF>(0.0, v);
-  v += dpp_f64<0x118, 0xF>(0.0, v);
+  v += dpp_f64z<0x111>(v);
+  v += dpp_f64z<0x112>(v);
+  v += dpp_f64z<0x114>(v);
+  v += dpp_f64z<0x118>(v);
   v += dpp_f64<0x142, 0xA>(0.0, v);
   v += dpp_f64<0x143, 0xC>(0.0, v);
   return v;
@@ -1078,7 +1087,7 @@ RPDE_DEVN void scan_cheb_diff(Blk& blk, lds_t dst, clds_t src, int n, lds_t carr
       for (int u = 0; u < wave; ++u) { S[0] += carry[u]; S[1] += carry[NW + u]; }
     }
 #pragma unroll
-    for (int par = 0; par < 2; ++par) vv[par] = dpp_f64<0x138, 0xF>(0.0, v[par]) + S[par];   // wave_shr:1
+    for (int par = 0; par < 2; ++par) vv[par] = dpp_f64z<0x138>(v[par]) + S[par];   // wave_shr:1
   }
 #endif
   RPDE_SYNC(blk);   // every thread has consumed its inputs (in-place operation is allowed)

@@ -535,7 +535,10 @@ static Arr2 upload_dense(const double* src, int rows, int cols) {
   return a;
 }
 
-PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_end) : sp(s) {
+static thread_local const Vec* g_pending_x_spectrum = nullptr;
+void set_pending_x_spectrum(const Vec* lam) { g_pending_x_spectrum = lam; }
+
+PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_end, double alpha, bool singular_fix) : sp(s) {
   const Base& b0 = sp.base(0);
   const Base& b1 = sp.base(1);
   RPDE_REQUIRE(b1.is_two_term(), "Poisson: axis 1 must be a composite Chebyshev base with a two-term stencil");
@@ -545,7 +548,10 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
     Bands ax = bands_axpy(Bands{Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0), Vec(m0, 0.0)}, c0,
                           hholtz_mat_b(b0));
     Bands cx = hholtz_mat_a(b0);
-    EigenX eg = eigen_decomposition_parity(ax, cx);
+    const Vec* given = (alpha == 0.0 && singular_fix) ? g_pending_x_spectrum : nullptr;
+    if (given) RPDE_REQUIRE((int)given->size() == m0, "the supplied x spectrum must hold nx - 2 eigenvalues ([even block | odd block])");
+    from_spectrum = given != nullptr;
+    EigenX eg = given ? eigenbasis_from_spectrum(ax, cx, *given) : eigen_decomposition_parity(ax, cx);
     me = eg.me; mo = eg.mo;
     lam = eg.lam;
     fwd_e = upload_dense(eg.fwd.data(), me, me);
@@ -560,7 +566,7 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
   lam_raw = lam;
   // singularity fix (src/solver/poisson.rs:84-87): lam[0] of the descending list is the largest
   const double lmax = *std::max_element(lam.begin(), lam.end());
-  if (std::fabs(lmax) < 1e-10)
+  if (singular_fix && std::fabs(lmax) < 1e-10)
     for (double& l : lam) l -= 1e-10;
   // per-row factorised y systems (A_y + lam_r C_y)
   const Bands ay = bands_axpy(Bands{Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0)}, c1,
@@ -572,7 +578,7 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
   const size_t nr = (size_t)std::max(0, re - rb);
   Vec q1(nr * ld, 0.0), p2(nr * ld, 0.0), q2(nr * ld, 0.0), r2(nr * ld, 0.0);
   for (int r = rb; r < re; ++r) {
-    Bands mtx = bands_axpy(ay, lam[r], cy);
+    Bands mtx = bands_axpy(ay, lam[r] + alpha, cy);   // (A_y + (lam_i + alpha) C_y), fdma_tensor.rs:219-221
     fdma_sweep(mtx);
     FdmaTables t = fdma_tables(mtx);
     const Vec a = chunk_major(t.q1, lc, +1), b = chunk_major(t.p2, lc, -1, 1.0),

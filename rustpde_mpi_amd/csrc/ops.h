@@ -200,18 +200,28 @@ class HholtzAdiOp {
   Space2Ops& sp;
 };
 
+// Setup data supplied by the host: the x eigenvalues of the next PLAIN Poisson solver built on this thread (alpha = 0; the
+// tensor Helmholtz solvers ignore it).  With it PoissonOp builds its eigenbasis with hostmath's eigenbasis_from_spectrum
+// (bit-reproducible, no LAPACK) instead of dgeev.  Null clears.  The C ABI sets it around the construction of one engine
+// (rpde_navier2d_create_confined_with_spectrum) or operator (rpde_poisson_create_with_spectrum).
+void set_pending_x_spectrum(const Vec* lam);
+
 // Poisson (src/solver/poisson.rs:54-94,195-236) on canonical arrays
 class PoissonOp {
  public:
   // row_begin / row_end: the x-rows (eigen index, or wavenumber when periodic) whose factorised y-systems
   // are kept on this device; the default keeps all of them.  A pencil-sharded rank only solves its own rows.
-  PoissonOp(Space2Ops& sp, double c0, double c1, int row_begin = 0, int row_end = -1);
+  // alpha / singular_fix: the same tensor construction serves `Hholtz` (src/solver/hholtz.rs:72-106:
+  // (I - c D2) vhat = A f, i.e. laplacian = -c mat_b, alpha = 1, no singularity shift) -- TensorHholtzOp below
+  PoissonOp(Space2Ops& sp, double c0, double c1, int row_begin = 0, int row_end = -1, double alpha = 0.0,
+            bool singular_fix = true);
   void solve(const Arr2& in_ortho, Arr2& out, Stream& st);
   Space2Ops& sp;
   // x direction
   int me = 0, mo = 0, half = 0;  // parity block sizes; column offset of the odd block in split arrays
   Vec lam;                       // eigenvalues (after the singularity shift), engine order
   Vec lam_raw;                   // the same before the shift (what LAPACK returned)
+  bool from_spectrum = false;    // the eigenbasis was built from host-supplied eigenvalues (set_pending_x_spectrum)
   // the x eigen-decomposition in the reference's form (fdma_tensor.rs:123-127): m eigenvalues
   // (unshifted, order [even block | odd block]), fwd = Q^-1 C^-1 and bwd = Q as dense m x m row-major
   // matrices over the natural coefficient index.  Setup data, exported so that a checker can run
@@ -221,6 +231,14 @@ class PoissonOp {
   Arr2 fwd_e, fwd_o, bwd_e, bwd_o;
   // y direction: per-x-row swept tables, row index = eigen index (confined) or wavenumber (periodic)
   FdmaDev rows;
+};
+
+// Hholtz<f64, 2> (src/solver/hholtz.rs:29-37, 72-106, 164-187): (I - c0 Dxx - c1 Dyy) vhat = A f by diagonalising x --
+// FdmaTensor::from_matrix(laplacians = -c mat_b, masses = mat_a, alpha = 1).  solve(): preconditioner along both axes,
+// eigen-transform (two parity GEMMs), one banded solve per x-row with pre-factorised rows, back-transform.
+class TensorHholtzOp : public PoissonOp {
+ public:
+  TensorHholtzOp(Space2Ops& sp, double c0, double c1) : PoissonOp(sp, -c0, -c1, 0, -1, 1.0, false) {}
 };
 
 }  // namespace rpde

@@ -330,6 +330,42 @@ def check_independent_golden(lib, n):
             assert err < independent_golden_bound(fvp), (n, s, k, err, fvp)
 
 
+def check_shared_basis_golden(lib, path, tol=1e-10, max_steps=None):
+    """The SAME-INPUTS comparison over the full horizon (tests/golden/make_shared_basis_golden.py): the engine is created with
+    the x eigenvalues the golden file carries (`x_spectrum=`: the library rebuilds the oracle's eigenbasis bit for bit, no
+    LAPACK), runs the golden's workload, and EVERY snapshot is held to the plain `tol` (BASELINE.json: 1e-10) on u, v, T and p
+    -- sample points and full-field norms.  Returns {step: {field: rel L2}}."""
+    g = np.load(path)
+    n, stride = int(g["nx"]), int(g["stride"])
+    lam_in = np.ascontiguousarray(g["x_spectrum"])
+    # the reproducibility the golden rests on: the same refined eigenvalues from the same input, bit for bit
+    ref, _, _ = R.poisson_x_eigenbasis_from_spectrum((R.CHEB_NEUMANN, n), 1.0, lam_in, library=lib) if n <= 1100 else (None, None, None)
+    if ref is not None and lib.is_device_build and str(g["library_version"]) == lib.version:
+        assert np.array_equal(ref, g["x_spectrum_refined"]), "the library does not reproduce the golden's eigenvalues bit for bit"
+    nav = R.Navier2D.new_confined(n, int(g["ny"]), float(g["ra"]), float(g["pr"]), float(g["dt"]), 1.0, "rbc", library=lib,
+                                  init_random=None, x_spectrum=lam_in)
+    nav.set_velocity(0.2, 1.0, 1.0)
+    nav.set_temperature(0.2, 1.0, 1.0)
+    out, done = {}, 0
+    for s in [int(v) for v in g["snaps"]]:
+        if f"velx_{s}" not in g.files or (max_steps is not None and s > max_steps):
+            continue
+        nav.update(s - done)
+        done = s
+        f = nav.physical_fields()
+        out[s] = {}
+        for k in ("velx", "vely", "temp", "pres"):
+            want = g[f"{k}_{s}"]
+            e = float(np.linalg.norm(f[k][::stride, ::stride] - want) / np.linalg.norm(want))
+            out[s][k] = e
+            assert e < tol, (n, s, k, e)
+            assert abs(np.linalg.norm(f[k]) - float(g[f"{k}_{s}_norm"])) < tol * float(g[f"{k}_{s}_norm"]), (n, s, k, "norm")
+        assert abs(nav.div_norm() - float(g[f"div_norm_{s}"])) < 1e-8 * max(1.0, float(g[f"div_norm_{s}"]))
+        print(s, {k: f"{e:.1e}" for k, e in out[s].items()})
+    assert out, "no snapshot compared"
+    return out
+
+
 def check_extended_golden(lib, n=4097):
     """The engine (own setup) against the EXTENDED golden tests/golden/headline_<n>_full_extended.npz: a second run of the
     oracle in the reference's one-dgeev setup, carried on to step 800 (make_headline_golden.py, RPDE_GOLDEN_SNAPS).  The bar

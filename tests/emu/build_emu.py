@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "..", "rustpde_mpi_amd", "csrc"))
 OUT = os.path.join(HERE, "librustpde_emu.so")
-SOURCES = ["kernels.cc", "hostmath.cc", "ops.cc", "rccl_transport.cc", "h5lite.cc", "engine.cc", "capi.cc"]
+SOURCES = ["kernels.cc", "gemm.cc", "hostmath.cc", "ops.cc", "rccl_transport.cc", "h5lite.cc", "engine.cc", "adjoint.cc", "capi.cc"]
 
 
 def build(force=False):

@@ -1,0 +1,187 @@
+"""Navier2DAdjoint (first slice): the adjoint-descent solver of src/navier_stokes/steady_adjoint.rs.
+
+oracle/adjoint.py restates `update()` (steady_adjoint.rs:541-608) and its equations (steady_adjoint_eq.rs); the tensor
+Helmholtz solver behind the residual norm (src/solver/hholtz.rs) is pinned by the reference's own analytic tests
+(tests/test_oracle_golden.py::test_hholtz_tensor_analytic).  The reference holds no golden for the adjoint step; what pins
+the oracle's step beyond its solvers is the property the method is built on: the descent reduces the residual norm
+(Farazmand 2016), and a steady state (conduction, below the critical Rayleigh number) is a fixed point.
+
+Engine (csrc/adjoint.cc, C ABI rpde_adjoint2d_*) against that oracle: emulation build on the CPU, HIP build on the GPU
+(129^2, 257^2, 1025^2, periodic 256 x 129)."""
+import numpy as np
+import pytest
+
+import rustpde_mpi_amd as R
+from oracle import adjoint as A, bases as B, navier as N, solver as S
+
+FIELDS = ("velx", "vely", "temp", "pres", "velx_adj", "vely_adj", "temp_adj", "pres_adj", "pseu")
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def check_adjoint_parity(lib, nx, ny, periodic, steps, ra=1e4, dt=0.005, tol=1e-10, tol_p=1e-8):
+    """Engine vs oracle after every update: u, v, T and the three adjoint fields to `tol` (BASELINE's 1e-10), the pressures
+    (pres, pres_adj, pseu: they carry the Poisson solve's amplified eigenvector round-off) to `tol_p`;
+    div_norm, norm_residual and exit() agree."""
+    mk_e = R.Navier2DAdjoint.new_periodic if periodic else R.Navier2DAdjoint.new_confined
+    mk_o = A.Navier2DAdjoint.new_periodic if periodic else A.Navier2DAdjoint.new_confined
+    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, "rbc", library=lib)
+    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    for z in (nav, ora):
+        z.set_velocity(0.1, 1.0, 1.0)
+        z.set_temperature(0.1, 1.0, 1.0)
+    worst = {}
+    for s in range(steps):
+        nav.update(1)
+        ora.update()
+        got, want = nav.spectral_fields(FIELDS), ora.spectral_fields(FIELDS)
+        for k in FIELDS:
+            e = rel(got[k], want[k])
+            worst[k] = max(worst.get(k, 0.0), e)
+            assert e < (tol_p if k in ("pres", "pres_adj", "pseu") else tol), (nx, ny, periodic, s, k, e)
+    assert abs(nav.get_time() - ora.time) < 1e-12 and abs(nav.get_time() - steps * dt) < 1e-12
+    ro, rn = ora.norm_residual(), nav.norm_residual()
+    for a, b in zip(rn, ro):
+        assert abs(a - b) < 1e-9 * max(b, 1e-30), (rn, ro)
+    assert abs(nav.div_norm() - ora.div_norm()) < 1e-8 * max(ora.div_norm(), 1e-12)
+    assert nav.exit() == ora.exit()
+    phys_e, phys_o = nav.physical_fields(), ora.physical_fields()
+    for k in ("velx", "vely", "temp"):
+        assert rel(phys_e[k], phys_o[k]) < tol, k
+    print(nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
+    return worst
+
+
+def check_hholtz_operator(lib, n0=33, n1=29):
+    """rpde_hholtz_* against the oracle's Hholtz on random smooth data, and the reference's analytic test
+    (hholtz.rs:226-255) through the device operator."""
+    rng = np.random.default_rng(5)
+    for base0, ob0 in (((R.CHEB_DIRICHLET, n0), B.cheb_dirichlet(n0)), ((R.CHEB_NEUMANN, n0), B.cheb_neumann(n0)),
+                       ((R.FOURIER_R2C, n0 - 1), B.fourier_r2c(n0 - 1))):
+        sp = R.Space2(base0, (R.CHEB_DIRICHLET, n1), library=lib)
+        osp = B.Space2(ob0, B.cheb_dirichlet(n1))
+        f = N.Field2(osp)
+        f.v = rng.standard_normal(f.v.shape)
+        f.forward()
+        rhs = f.to_ortho()
+        for c in ([1e-1, 1e-1], [2.5e-2, 1e-1]):
+            want = S.Hholtz(osp, c, eig_mode="parity").solve(rhs)
+            got = R.Hholtz(sp, c).solve(rhs)
+            assert rel(got, want) < 1e-11, (base0, c, rel(got, want))
+    # hholtz.rs:226-255 (64 x 64, alpha = 1): cos(pi x / 2) cos(pi y / 2) / (1 + 2 alpha (pi / 2)^2)
+    n, alpha, k = 64, 1.0, np.pi / 2
+    sp = R.Space2((R.CHEB_DIRICHLET, n), (R.CHEB_DIRICHLET, n), library=lib)
+    x = N.Field2(B.Space2(B.cheb_dirichlet(n), B.cheb_dirichlet(n))).x[0]
+    v = np.cos(k * x)[:, None] * np.cos(k * x)[None, :]
+    out = sp.backward(R.Hholtz(sp, [alpha, alpha]).solve(sp.to_ortho(sp.forward(v))))
+    assert np.abs(out - v / (1 + alpha * k * k * 2)).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ oracle
+def test_oracle_descent_reduces_the_residual():
+    """33 x 33, Ra = 1e4, dt = 5e-3 (inside the explicit scheme's stability bound 0.2 DT_NAVIER / nu): the residual norm of u,
+    v and T falls monotonically over 40 updates -- adjoint descent does what it is built for."""
+    nav = A.Navier2DAdjoint.new_confined(33, 33, 1e4, 1.0, 0.005, 1.0, "rbc", eig_mode="parity")
+    nav.set_velocity(0.1, 1.0, 1.0)
+    nav.set_temperature(0.1, 1.0, 1.0)
+    hist = []
+    for _ in range(40):
+        nav.update()
+        hist.append(sum(nav.norm_residual()))
+    assert all(b < a for a, b in zip(hist[2:], hist[3:])), hist
+    assert hist[-1] < 0.5 * hist[2]
+    assert not nav.exit()
+
+
+def test_oracle_conduction_state_is_a_fixed_point():
+    """Zero perturbation = the conduction state: no residual, nothing moves, exit() reports convergence
+    (steady_adjoint.rs:631-635)."""
+    nav = A.Navier2DAdjoint.new_confined(17, 17, 1e3, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    nav.update()
+    assert max(nav.norm_residual()) < 1e-12
+    for k in ("velx", "vely", "temp"):
+        assert np.abs(getattr(nav, k).vhat).max() < 1e-12
+    assert nav.exit()
+
+
+def test_oracle_rejects_unknown_bc():
+    with pytest.raises(ValueError):
+        A.Navier2DAdjoint.new_confined(17, 17, 1e3, 1.0, 0.01, 1.0, "xx")
+
+
+# ------------------------------------------------------------------------------------------------ emulation build (CPU)
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (65, 33, False), (32, 33, True), (64, 17, True)])
+def test_emu_adjoint_step_parity(emu_lib, nx, ny, periodic):
+    check_adjoint_parity(emu_lib, nx, ny, periodic, steps=4)
+
+
+def test_emu_hholtz_operator(emu_lib):
+    check_hholtz_operator(emu_lib)
+
+
+def test_emu_adjoint_errors_and_fields(emu_lib):
+    with pytest.raises(R.RpdeError, match="not supported"):
+        R.Navier2DAdjoint.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "hc", library=emu_lib)
+    with pytest.raises(R.RpdeError, match="not recognized"):
+        R.Navier2DAdjoint.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "xx", library=emu_lib)
+    nav = R.Navier2DAdjoint.new_confined(17, 19, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib)
+    ora = A.Navier2DAdjoint.new_confined(17, 19, 1e4, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    assert rel(nav.tempbc.vhat, ora.tempbc.vhat) < 1e-13                       # the lift
+    p = nav.params
+    assert abs(p["nu"] - ora.params["nu"]) < 1e-15 and abs(p["ka"] - ora.params["ka"]) < 1e-15
+    assert nav.get_dt() == 0.01 and nav.get_time() == 0.0
+    with pytest.raises(R.RpdeError, match="tempbc is fixed"):
+        nav.tempbc.vhat = ora.tempbc.vhat
+    with pytest.raises(R.RpdeError, match="unknown field"):
+        R._FieldView(nav, "nope").vhat
+    # spectral and physical set / get round trip, conduction state is a fixed point, exit() = converged
+    nav.update(1)
+    assert max(nav.norm_residual()) < 1e-12 and nav.exit()
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((17, 19))
+    nav.velx.v = v
+    ora.set_field_physical("velx", v)
+    assert rel(nav.velx.vhat, ora.velx.vhat) < 1e-12
+    nav.reset_time()
+    assert nav.get_time() == 0.0
+
+
+def test_emu_integrate_drives_the_adjoint_solver(emu_lib):
+    """rustpde::integrate(&mut navier_adjoint, max_time, None) (examples/navier_rbc_steady.rs): update / exit loop."""
+    nav = R.Navier2DAdjoint.new_confined(17, 17, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+    nav.set_velocity(0.1, 1.0, 1.0)
+    nav.set_temperature(0.1, 1.0, 1.0)
+    R.integrate(nav, 0.05, None)
+    assert abs(nav.get_time() - 0.05) < 1e-9
+    assert np.isfinite(nav.div_norm())
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (257, 257, False, 4), (256, 129, True, 4), (1025, 1025, False, 2)])
+def test_gpu_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
+    """Ra = 1e6 at 1025^2 keeps dt = 0.002 inside 0.2 DT_NAVIER / nu."""
+    if nx >= 1025:
+        check_adjoint_parity(hip_lib, nx, ny, periodic, steps, ra=1e6, dt=0.002)
+    else:
+        check_adjoint_parity(hip_lib, nx, ny, periodic, steps)
+
+
+@pytest.mark.gpu
+def test_gpu_hholtz_operator(hip_lib):
+    check_hholtz_operator(hip_lib)
+    check_hholtz_operator(hip_lib, 129, 65)
+
+
+@pytest.mark.gpu
+def test_gpu_descent_reduces_the_residual(hip_lib):
+    nav = R.Navier2DAdjoint.new_confined(65, 65, 1e4, 1.0, 0.002, 1.0, "rbc", library=hip_lib)
+    nav.set_velocity(0.1, 1.0, 1.0)
+    nav.set_temperature(0.1, 1.0, 1.0)
+    hist = []
+    for _ in range(30):
+        nav.update(1)
+        hist.append(sum(nav.norm_residual()))
+    assert all(b < a for a, b in zip(hist[2:], hist[3:])), hist

@@ -127,6 +127,53 @@ def test_headline_independent_reference_setup(hip_lib, n):
         K.check_independent_golden(hip_lib, n)
 
 
+@pytest.mark.parametrize("name", ["shared_basis_4097", "shared_basis_2049", "shared_basis_1025", "shared_basis_1025_ra1e+07_dt0.001"])
+def test_shared_basis_golden(hip_lib, name):
+    """Same inputs over the FULL horizon: the engine on the golden's x spectrum (bit-identical eigenbasis, no LAPACK on
+    either side's vectors) against the CPU oracle's committed samples, 200 steps, the plain 1e-10 on u, v, T AND p at EVERY
+    snapshot from step 1 -- no envelope, no transient (4097^2: the bench workload; 1025^2 with Ra = 1e7, dt = 1e-3:
+    BASELINE config 2).  tests/golden/make_shared_basis_golden.py."""
+    import os
+    path = os.path.join(K.GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.npz not generated (tests/golden/make_shared_basis_golden.py)")
+    if "4097" in name:
+        res = K.check_shared_basis_golden(hip_lib, path)
+    else:
+        K.run_isolated(f"check_shared_basis_golden(lib, {path!r})")
+        return
+    assert max(res) >= 200 or os.environ.get("RPDE_ALLOW_PARTIAL_GOLDEN"), f"golden ends at step {max(res)}"
+
+
+@pytest.mark.parametrize("switch", ["RPDE_GEMM_R4", "RPDE_S1_SPLIT"])
+def test_round5_ab_switches(hip_lib, switch):
+    """The A/B switches of round 5 select another FORM of the same arithmetic (the round-4 steady-state loop of the GEMM; value
+    and derivative of a state line as two launches instead of the pair kernel): a 4097 x 129 confined run (4096-point x-lines,
+    2048 / 2047-wide parity GEMMs through the 128-tiles) must give bit-identical fields either way.  The switches are read
+    once per process, so each side runs in its own."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = ("import hashlib, numpy as np, rustpde_mpi_amd as R\n"
+            "nav = R.Navier2D.new_confined(4097, 129, 1e7, 1.0, 1e-3, 1.0, 'rbc', init_random=None)\n"
+            "nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0); nav.update(3)\n"
+            "f = nav.physical_fields()\n"
+            "print('HASH', hashlib.sha256(b''.join(np.ascontiguousarray(f[k]).tobytes() for k in sorted(f))).hexdigest(), float(np.abs(f['pres']).max()))\n")
+    out = {}
+    for flag in ("", "1"):
+        env = dict(os.environ)
+        env.pop(switch, None)
+        if flag:
+            env[switch] = flag
+        r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(K.GOLDEN)), env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    print(switch, out)
+    assert out[""] == out["1"], out
+
+
 def test_headline_extended_golden_800_steps(hip_lib):
     """4097 x 4097 (the bench workload) for 800 steps against the second, longer run of the oracle in the reference's
     one-dgeev setup (tests/golden/headline_4097_full_extended.npz): the PLAIN 1e-10 bar on u, v, T AND p, no envelope --

@@ -62,11 +62,12 @@ ENV_SWITCHES = {
     "RPDE_LAPACK_LIB", "RPDE_RCCL_LIB",            # run-time libraries
     "RPDE_GRAPH",                                   # hipGraph replay on / off              (test_gpu_parity.test_graph_*)
     "RPDE_SYNC_LAUNCHES",                           # diagnostics: every launch named and waited for
-    "RPDE_ARENA",                                   # device memory from slabs / one hipMalloc per buffer
+    "RPDE_ARENA", "RPDE_ARENA_GUARD",               # device memory from slabs / one hipMalloc per buffer; guard granules (tests/test_arena.py)
     "RPDE_WHOLE_LINE", "RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE",
                                                     # whole-line kernel / line program per stage (test_whole_line_stage_*, test_emu_parity)
     "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
-    "RPDE_COL_ONEPASS", "RPDE_COL1_W",              # column scans: one pass / three kernels, blocks per workgroup (test_column_scans_in_one_pass*)
+    "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
+    "RPDE_S1_SPLIT", "RPDE_GEMM_R4",                # A/B of round 5: S1 as two launches, the round-4 GEMM loop (test_gpu_parity.test_round5_ab_switches)
     "RPDE_COL_PAIR", "RPDE_GEMM_SWIZZLE",           # XCD pairing of the three-kernel correction-y, GEMM tile order (tests/test_gpu_parity)
 }
 

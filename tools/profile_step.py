@@ -7,7 +7,18 @@ import rustpde_mpi_amd as R
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 ny = int(sys.argv[2]) if len(sys.argv) > 2 else 4097
 per = len(sys.argv) > 3 and sys.argv[3] == "periodic"
-nav = (R.Navier2D.new_periodic if per else R.Navier2D.new_confined)(nx, ny, 1e8, 1.0, 2e-4, 1.0, "rbc")
+# RPDE_TOOLS_SPECTRUM=<file.npy>: the x eigenvalues are computed once (rpde_poisson_x_spectrum) and kept in that file; later
+# runs create the engine from them (no dgeev: seconds instead of a minute at 4097^2) -- A/B runs of one gpurun call
+spec = None
+if os.environ.get("RPDE_TOOLS_SPECTRUM") and not per:
+    import numpy as np
+    path = os.environ["RPDE_TOOLS_SPECTRUM"]
+    if not os.path.exists(path):
+        np.save(path, R.poisson_x_spectrum((R.CHEB_NEUMANN, nx), 1.0))
+    spec = np.load(path)
+    assert spec.size == nx - 2
+kw = {"x_spectrum": spec} if spec is not None else {}
+nav = (R.Navier2D.new_periodic if per else R.Navier2D.new_confined)(nx, ny, 1e8, 1.0, 2e-4, 1.0, "rbc", **kw)
 nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
 nav.profile(2)
 rows = nav.profile(5)
