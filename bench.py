@@ -164,7 +164,7 @@ def parity_independent_golden(make, args):
         rel = {k: float(np.linalg.norm(f[k][::stride, ::stride] - g[f"{k}_{s}"]) / np.linalg.norm(g[f"{k}_{s}"]))
                for k in ("velx", "vely", "temp", "pres")}
         fvp = {k: float(g[f"{k}_{s}_full_vs_parity"]) for k in rel}
-        bound = {k: independent_golden_bound(fvp[k]) for k in rel}
+        bound = {k: independent_golden_bound(fvp[k], n=args.nx, step=s, field=k) for k in rel}
         fvp = {k: (v if v == v else None) for k, v in fvp.items()}     # not measured: null (NaN is not JSON)
         rows.append({"steps": s, "rel_l2": rel, "oracle_full_vs_parity": fvp, "bound": bound,
                      "ok": all(rel[k] < bound[k] for k in rel)})

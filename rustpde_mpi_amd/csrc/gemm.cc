@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 // TM x TM block tile (128 or 64), 4 waves in a 2 x 2 grid, each wave MT x MT MFMA tiles (MT = TM / 32).  The
 // 64-tile serves problems that would not give every CU a 128-tile (small grids; the local products of a
 // pencil-sharded run, 512 x 2048 x 2048 per GPU at 4097^2 on 8 GPUs).
-template <bool NN, int TM, bool OLD = false>
+template <bool NN, int TM, bool OLD = true>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
                                                  int tile_m, int tile_n, bool ct = false) {
@@ -218,7 +218,7 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
     double a0[MT], b0[MT], a1[MT], b1[MT];
     frag(0, 0, a0, b0);
     // steady state: stage t stores the operands of stage t + 1 and loads those of stage t + 2, all three full stages
-    if (!OLD && vec16)   // (OLD: the round-4 loop -- every stage through the bounds-tested form below; A/B switch RPDE_GEMM_R4=1)
+    if (!OLD && vec16)   // (OLD: the round-4 loop -- every stage through the bounds-tested form below; the default, see launch_gemm_pair)
       for (; k0 + 3 * BK <= K; k0 += BK, st ^= 1) {
         frag(st, 1, a1, b1);
         mma(a0, b0);
@@ -284,13 +284,13 @@ __global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
 template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
-  constexpr int TM = DB == 2 ? 64 : 128;   // DB 3: the 128-tile with the round-4 loop (A/B only)
+  constexpr int TM = DB == 2 ? 64 : 128;   // DB 3: the 128-tile with the round-4 loop (the default; DB 1: the peeled loop, A/B)
   int tx, ty;
   gemm_tile_of_block(z, tx, ty);
   if (ty * TM >= g.M || tx * TM >= g.N) return;
   if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else if constexpr (DB == 3) gemm_f64_db_tile<NN, 128, true>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else gemm_f64_db_tile<NN, 128>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+  else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
 }
 
 // the steady-state loop addresses its operands with 32-bit byte offsets from a scalar base (gemm_f64_db_tile)
@@ -338,8 +338,11 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
   } else {
     const GemmSwizzle z = gemm_swizzle((int)grid.x, (int)grid.y);
-    static const bool r4 = [] { const char* e = std::getenv("RPDE_GEMM_R4"); return e && std::atoi(e) != 0; }();
-    if (r4) {
+    // RPDE_GEMM_PEEL=1 (A/B): the steady-state loop without bounds tests and 64-bit vector addresses (gemm_f64_db_tile<.., OLD =
+    // false>).  Measured in round 5 (profiles/r05_experiments): G1 / G2 1.081 / 1.100 ms with it, 1.071 / 1.092 without -- the
+    // 375 instructions around the 64 MFMAs of a stage were never what kept the pipe at 0.81; the round-4 loop stays the default
+    static const bool peel = [] { const char* e = std::getenv("RPDE_GEMM_PEEL"); return e && std::atoi(e) != 0; }();
+    if (!peel) {
       if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 3>), grid, dim3(256), 0, st.s, g0, g1, z);
       else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 3>), grid, dim3(256), 0, st.s, g0, g1, z);
     } else if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1, z);

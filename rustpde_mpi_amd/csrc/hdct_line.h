@@ -31,6 +31,7 @@ struct HdctGeom {
   static constexpr int NW = (T + 63) / 64; // waves
   static constexpr int SCR = 2 * PL + 8;   // scratch: [0, NW) partial sums of E_1, [8, 8 + 8 NW) wave totals of the row scans
                                            // (8 doubles behind the planes stay free: the padded line of rhs_line.h ends there)
+  static constexpr int LDS = N + N / 16 + 64;   // doubles per line buffer
 };
 RPDE_HD inline size_t hdct_lds_doubles(int N) { return (size_t)N + N / 16 + 64; }
 
@@ -418,6 +419,8 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #pragma unroll
     for (int x = 0; x < NW; ++x) e1 += scr[x];
     double run = e1;                                           // E_1 - (rows before u) - (waves before this one in row u)
+    // (a window of wave totals behind NW - 1 zeros, read at a wave-uniform address, would replace the selects below -- tried
+    // in round 5: 50 vector instructions fewer per transform, but the S3 kernel spills 44 registers more with it; not kept)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       double before = 0.0, row = 0.0;

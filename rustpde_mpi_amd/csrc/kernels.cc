@@ -553,7 +553,7 @@ void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream& st) {
 // hdct_line.h: the same transforms through the half-length FFT (8 complex points per thread)
 template <int N, bool TRACE = false>
 __global__ __launch_bounds__(N / 16, 4) void hdct_line_kernel(const DctLineArgs a, long long* trace) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.nlines) return;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(N / 16, 4) void hdct_line_kernel(const DctLineArgs 
 }
 template <int N, int WPC = 4>
 __global__ __launch_bounds__(N / 16, WPC) void hdct_line2_kernel(const DctLineArgs a0, const DctLineArgs a1) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a0.nlines) return;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(N / 8, 4) void rfft_pair_kernel(const RfftLineArgs 
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void four_rhs_kernel(const FourRhsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];   // N + N / 16 + 64 doubles (140 KB at N = 16384)
+  extern __shared__ __attribute__((aligned(16))) double rpde_lds[];   // hdct_lds_doubles(N) (140 KB at N = 16384)
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.f.nlines) return;
@@ -621,7 +621,7 @@ static void lds_permission(K kernel, size_t bytes) {
 }
 template <int N, int WPC>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineA
 }
 template <int N, int WHICH, bool TRACE = false, int WPC = 3>
 __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.nlines) return;
@@ -644,7 +644,7 @@ struct Dct2Batch { DctLineArgs a0[kLineBatch], a1[kLineBatch]; };
 struct ConvBatch { ConvLineArgs c[kLineBatch]; };
 struct RhsBatch { RhsLineArgs r[kLineBatch]; };
 #define RPDE_BATCH_LINE(nl) \
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64]; \
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS]; \
   const int chunk = (int)gridDim.x >> 3; \
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3); \
   if (line >= (nl)) return; \
@@ -728,7 +728,7 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void div_line_kernel(const DivLineArgs a) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.nlines) return;
@@ -746,7 +746,7 @@ bool launch_div_line(const DivLineArgs& a, Stream& st) {
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void corr_line_kernel(const CorrLineArgs a) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16 + 64];
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.nlines) return;

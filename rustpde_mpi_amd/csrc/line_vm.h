@@ -835,14 +835,25 @@ __device__ __forceinline__ double dpp_f64(double old, double x) {
   const int hi = __builtin_amdgcn_update_dpp((int)(ob >> 32), (int)(xb >> 32), CTRL, ROW_MASK, 0xF, false);
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
+// the same with zeros shifted in (bound_ctrl) and every row enabled: no `old` operand, i.e. no two v_mov in front of the pair
+// of DPP moves (shifts inside a row and the wave shift; the row broadcasts keep rows masked and need `old`)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64z(double x) {
+  const long long xb = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)xb, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(xb >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
 template <int ORDER, int CTRL, int ROW_MASK>
 __device__ __forceinline__ Affine<ORDER> affine_dpp(const Affine<ORDER>& a) {
   Affine<ORDER> r = affine_identity<ORDER>();
+  // the entries whose identity value is zero take the zero-fill form where every row takes part (no `old` operand)
+  auto z = [](double x) { if constexpr (ROW_MASK == 0xF) return dpp_f64z<CTRL>(x); else return dpp_f64<CTRL, ROW_MASK>(0.0, x); };
   r.m11 = dpp_f64<CTRL, ROW_MASK>(1.0, a.m11);
-  r.v1 = dpp_f64<CTRL, ROW_MASK>(0.0, a.v1);
+  r.v1 = z(a.v1);
   if constexpr (ORDER == 2) {
-    r.m12 = dpp_f64<CTRL, ROW_MASK>(0.0, a.m12); r.m21 = dpp_f64<CTRL, ROW_MASK>(0.0, a.m21);
-    r.m22 = dpp_f64<CTRL, ROW_MASK>(1.0, a.m22); r.v2 = dpp_f64<CTRL, ROW_MASK>(0.0, a.v2);
+    r.m12 = z(a.m12); r.m21 = z(a.m21);
+    r.m22 = dpp_f64<CTRL, ROW_MASK>(1.0, a.m22); r.v2 = z(a.v2);
   }
   return r;
 }
@@ -856,15 +867,6 @@ __device__ __forceinline__ Affine<ORDER> affine_wave_scan(Affine<ORDER> inc) {
   inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x142, 0xA>(inc));
   inc = affine_compose<ORDER>(inc, affine_dpp<ORDER, 0x143, 0xC>(inc));
   return inc;
-}
-// the same with zeros shifted in (bound_ctrl) and every row enabled: no `old` operand, i.e. no two v_mov in front of the pair
-// of DPP moves (shifts inside a row and the wave shift; the row broadcasts keep rows masked and need `old`)
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64z(double x) {
-  const long long xb = __double_as_longlong(x);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)xb, CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(xb >> 32), CTRL, 0xF, 0xF, true);
-  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 __device__ __forceinline__ double sum_wave_scan(double v) {
   v += dpp_f64z<0x111>(v);

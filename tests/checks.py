@@ -305,7 +305,7 @@ def check_config2_golden(lib):
         for k in ("velx", "vely", "temp", "pres"):
             want = g[f"{k}_{s}"]
             got = f[k][::stride, ::stride]
-            tol = independent_golden_bound(float(g[f"{k}_{s}_full_vs_parity"]))
+            tol = independent_golden_bound(float(g[f"{k}_{s}_full_vs_parity"]), n=nx)   # (own pair x the spread ratio measured at this size)
             if s >= 100:
                 assert tol == 1e-10, (k, s, tol)     # the golden itself must have left the transient: the 1e-10 bar is exercised
             err = np.linalg.norm(got - want) / np.linalg.norm(want)
@@ -327,7 +327,8 @@ def check_independent_golden(lib, n):
     print({s: {k: f"{e:.1e} (oracle full vs parity {b:.1e})" for k, (e, b) in r.items()} for s, r in res.items()})
     for s, r in res.items():
         for k, (err, fvp) in r.items():
-            assert err < independent_golden_bound(fvp), (n, s, k, err, fvp)
+            bound = independent_golden_bound(fvp, n=n, step=s, field=k)
+            assert err < bound, (n, s, k, err, bound, fvp)
 
 
 def check_shared_basis_golden(lib, path, tol=1e-10, max_steps=None):
