@@ -216,6 +216,11 @@ int rpde_adjoint2d_exit(rpde_adjoint2d* h, int* stop);
 /* DivNorm::div_norm / DivNorm::norm_residual -> [|velx_adj|, |vely_adj|, |temp_adj|]   steady_adjoint_eq.rs:36-50 */
 int rpde_adjoint2d_div_norm(rpde_adjoint2d* h, double* norm);
 int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3);
+/* Navier2DAdjoint::write / read: ux uy temp pres tempbc + time + params in the reference's HDF5 layout; read takes ux, uy,
+ * temp and time, also from a snapshot written by Navier2D (the restart.h5 of examples/navier_rbc_steady.rs) and at another
+ * resolution                                                        src/navier_stokes/steady_adjoint_io.rs:22-33, 48-71 */
+int rpde_adjoint2d_write(rpde_adjoint2d* h, const char* filename);
+int rpde_adjoint2d_read(rpde_adjoint2d* h, const char* filename);
 
 /* ---- operator level: funspace Space2 methods as called by rustpde ---------------------------- */
 /* Space2::new(&base0(n0), &base1(n1)); base1 must be a Chebyshev-family base                     */

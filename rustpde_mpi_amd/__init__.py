@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -563,8 +564,42 @@ class Navier2DAdjoint:
         self._lib.call("rpde_adjoint2d_exit", self._h, C.byref(f))
         return bool(f.value)
 
-    def callback(self):   # snapshots of the adjoint solver (steady_adjoint_io.rs) are not part of this slice
-        pass
+    def write(self, filename):
+        """`Navier2DAdjoint::write` (steady_adjoint_io.rs:48-71)."""
+        self._lib.call("rpde_adjoint2d_write", self._h, str(filename).encode())
+
+    def read(self, filename):
+        """`Navier2DAdjoint::read` (steady_adjoint_io.rs:22-33): ux, uy, temp, time -- also from a `Navier2D` snapshot."""
+        self._lib.call("rpde_adjoint2d_read", self._h, str(filename).encode())
+        print(f" <== {str(filename)!r}")
+
+    def write_unwrap(self, filename):
+        try:
+            self.write(filename)
+        except RpdeError as e:
+            print(f"Error while writing file {str(filename)!r}. Error: {e}", file=sys.stderr)
+
+    def read_unwrap(self, filename):
+        try:
+            self.read(filename)
+            print(f"Reading file {str(filename)!r} was successfull.")
+        except RpdeError as e:
+            print(f"Error while reading file {str(filename)!r}. Error: {e}", file=sys.stderr)
+
+    write_intervall = None
+
+    def callback(self):
+        """`Integrate::callback` (steady_adjoint.rs:616-620) -> `callback_from_filename` (steady_adjoint_io.rs:84-143):
+        data/adjoint{time:0>8.2}.h5 on `write_intervall`, |div| and the residual norms on stdout.  (The Nu / Nuv / Re columns
+        of data/info_adjoint.txt need the diagnostics reductions of Navier2D; not part of this slice.)"""
+        os.makedirs("data", exist_ok=True)
+        t, dt = self.get_time(), self.get_dt()
+        name = "data/adjoint{:0>8.2f}.h5".format(t)
+        if self.write_intervall is None or (t + dt / 2.0) % self.write_intervall < dt:
+            self.write_unwrap(name)
+        ru, rv, rt = self.norm_residual()
+        print("time = {:4.2f}      |div| = {:4.2e}".format(t, self.div_norm()))
+        print("|U| = {:10.2e}\n|V| = {:10.2e}\n|T| = {:10.2e}".format(ru, rv, rt))
 
     def div_norm(self):
         d = C.c_double()

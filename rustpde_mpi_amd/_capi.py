@@ -58,6 +58,8 @@ SIGNATURES = {
     "rpde_adjoint2d_exit": (C.c_int, [_vp, _ip]),
     "rpde_adjoint2d_div_norm": (C.c_int, [_vp, _dp]),
     "rpde_adjoint2d_norm_residual": (C.c_int, [_vp, _dp]),
+    "rpde_adjoint2d_write": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_adjoint2d_read": (C.c_int, [_vp, C.c_char_p]),
     "rpde_navier2d_create_confined_with_spectrum": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                                               C.c_char_p, C.c_int, _dp, C.c_size_t, C.POINTER(_vp)]),
     "rpde_poisson_x_spectrum": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp, C.c_size_t]),

@@ -3,6 +3,8 @@
 
 #include <cmath>
 
+#include "h5lite.h"
+
 namespace rpde {
 
 // ------------------------------------------------------------------------------------------------
@@ -219,6 +221,75 @@ void Navier2DAdjointEngine::set_temperature(double amp, double m, double n) {
   Vec v;
   sincos_field(sp_temp_->base(0), sp_temp_->base(1), sx_, sy_, -amp, m, n, false, v);
   set_field_physical("temp", v.data(), v.size());
+}
+
+// ------------------------------------------------------------------------------------------------
+void Navier2DAdjointEngine::grid(int axis, double* x, size_t len) const {
+  const Base& b = sp_vel_->base(axis);
+  RPDE_REQUIRE((int)len == b.n, "grid: wrong length");
+  const Vec c = base_coords(b);
+  const double sc = axis == 0 ? sx_ : sy_;
+  for (int i = 0; i < b.n; ++i) x[i] = c[i] * sc;
+}
+
+static const char* const kAdjSnapFields[5][2] = {{"velx", "ux"}, {"vely", "uy"}, {"temp", "temp"}, {"pres", "pres"}, {"tempbc", "tempbc"}};
+
+void Navier2DAdjointEngine::write(const std::string& filename) {
+  h5::Tree t;
+  Vec x((size_t)nx_), y((size_t)ny_);
+  grid(0, x.data(), x.size());
+  grid(1, y.data(), y.size());
+  for (const auto& fg : kAdjSnapFields) {
+    const std::string g = fg[1];
+    t[g + "/x"] = h5::Dataset{{(uint64_t)nx_}, x};       // field/io.rs:96-99: `dx` / `dy` are written from the coordinates
+    t[g + "/dx"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/y"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[g + "/dy"] = h5::Dataset{{(uint64_t)ny_}, y};
+    h5::Dataset v{{(uint64_t)nx_, (uint64_t)ny_}, Vec((size_t)nx_ * ny_)};
+    get_field_physical(fg[0], v.data.data(), v.data.size());
+    t[g + "/v"] = std::move(v);
+    int r, c, e;
+    spectral_shape(fg[0], &r, &c, &e);
+    Vec vh((size_t)r * c * e);
+    get_field_spectral(fg[0], vh.data(), vh.size());
+    if (e == 1) {
+      t[g + "/vhat"] = h5::Dataset{{(uint64_t)r, (uint64_t)c}, std::move(vh)};
+    } else {   // read_write_hdf5.rs:171-188: complex arrays as two real datasets
+      h5::Dataset re{{(uint64_t)r, (uint64_t)c}, Vec((size_t)r * c)}, im = re;
+      for (size_t k = 0; k < (size_t)r * c; ++k) { re.data[k] = vh[2 * k]; im.data[k] = vh[2 * k + 1]; }
+      t[g + "/vhat_re"] = std::move(re);
+      t[g + "/vhat_im"] = std::move(im);
+    }
+  }
+  t["time"] = h5::Dataset{{1}, {time_}};
+  for (const char* k : {"ra", "pr", "nu", "ka"}) t[k] = h5::Dataset{{1}, {param(k)}};
+  h5::update_file(filename, t);
+}
+
+void Navier2DAdjointEngine::read(const std::string& filename) {
+  h5::Reader rd(filename);
+  for (int k = 0; k < 3; ++k) {    // steady_adjoint_io.rs:23-25: ux, uy, temp
+    const std::string name = kAdjSnapFields[k][0], g = kAdjSnapFields[k][1];
+    int r, c, e;
+    spectral_shape(name, &r, &c, &e);
+    Vec neu((size_t)r * c * e, 0.0);
+    uint64_t ro = 0, co = 0;
+    auto place = [&](const h5::Dataset& d, int comp) {
+      RPDE_REQUIRE(d.dims.size() == 2, "snapshot: " + g + "/vhat must be two-dimensional");
+      ro = d.dims[0]; co = d.dims[1];
+      const uint64_t rm = std::min<uint64_t>(ro, r), cm = std::min<uint64_t>(co, c);
+      for (uint64_t i = 0; i < rm; ++i)
+        for (uint64_t j = 0; j < cm; ++j) neu[(i * c + j) * e + comp] = d.data[i * co + j];
+    };
+    if (e == 1) place(rd.read(g + "/vhat"), 0);
+    else { place(rd.read(g + "/vhat_re"), 0); place(rd.read(g + "/vhat_im"), 1); }
+    if (((int)ro != r || (int)co != c) && periodic_) {   // field/io.rs:167-175: the unnormalised Fourier coefficients scale with the number of points
+      const double norm = (double)(r - 1) / (double)(ro - 1);
+      for (double& v : neu) v *= norm;
+    }
+    set_field_spectral(name, neu.data(), neu.size());
+  }
+  time_ = rd.read("time").data.at(0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,6 +46,13 @@ class Navier2DAdjointEngine {
   void get_field_spectral(const std::string& name, double* host, size_t len);
   void set_field_physical(const std::string& name, const double* host, size_t len);
   void get_field_physical(const std::string& name, double* host, size_t len);
+  // Navier2DAdjoint::write / read (steady_adjoint_io.rs:48-71, 22-33) in the reference's HDF5 layout (csrc/h5lite): write =
+  // ux, uy, temp, pres, tempbc as Field2 groups (x, dx, y, dy, v, vhat) + time + params; read = vhat of ux, uy, temp (other
+  // resolutions by truncation / zero padding like field/io.rs:151-176) + time -- also from a snapshot a Navier2D run wrote
+  // (examples/navier_rbc_steady.rs starts from one)
+  void write(const std::string& filename);
+  void read(const std::string& filename);
+  void grid(int axis, double* x, size_t len) const;
   Stream& stream() { return st_; }
 
  private:

@@ -341,6 +341,12 @@ int rpde_adjoint2d_exit(rpde_adjoint2d* h, int* stop) {
 int rpde_adjoint2d_div_norm(rpde_adjoint2d* h, double* norm) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(norm, "null pointer"); select_device(h->device); *norm = h->e->div_norm(); })
 }
+int rpde_adjoint2d_write(rpde_adjoint2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->write(filename); })
+}
+int rpde_adjoint2d_read(rpde_adjoint2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->read(filename); })
+}
 int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(res3, "null pointer"); select_device(h->device); h->e->norm_residual(res3); })
 }

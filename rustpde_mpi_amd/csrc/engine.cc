@@ -61,6 +61,17 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   // release_device_objects() from the destructor AND from the constructor's catch-all
   RPDE_HIP(hipStreamCreate(&st_.s));
 #endif
+  if (comm_.size > 1) {
+    const char* e = std::getenv("RPDE_OVERLAP");
+    overlap_ = !e || std::atoi(e) != 0;
+  }
+#ifndef RPDE_EMU
+  if (overlap_) {
+    RPDE_HIP(hipStreamCreate(&st2_.s));
+    RPDE_HIP(hipEventCreateWithFlags(&xprod_, hipEventDisableTiming));
+    for (auto& ev : xdone_) RPDE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+#endif
   try {
     construct(nx, ny, ra, pr, dt, aspect, periodic);
   } catch (...) {
@@ -73,6 +84,9 @@ void Navier2DEngine::release_device_objects() {
 #ifndef RPDE_EMU
   if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
   if (st_.s) (void)hipStreamSynchronize(st_.s);
+  if (st2_.s) { (void)hipStreamSynchronize(st2_.s); (void)hipStreamDestroy(st2_.s); st2_.s = nullptr; }
+  if (xprod_) { (void)hipEventDestroy(xprod_); xprod_ = nullptr; }
+  for (auto& ev : xdone_) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   rccl_comm_destroy(comm_.rccl); comm_.rccl = nullptr;
   if (ev0_) { (void)hipEventDestroy(ev0_); ev0_ = nullptr; }
   if (ev1_) { (void)hipEventDestroy(ev1_); ev1_ = nullptr; }
@@ -270,6 +284,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     dev_sync(st_);
   }
   if (periodic) build_periodic(); else build_confined();
+  if (overlap_) overlap_ = apply_overlap_order();
   if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos + column-scan summaries
     xchg_count_ = 0;
     for (size_t i = 0; i < step_.size();) {
@@ -280,7 +295,8 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
       size_t j = i; int n = 0;
       while (j < step_.size() && n < kMaxBatch && step_[j].type == Launch::kTranspose &&
              step_[j].rows == step_[i].rows && step_[j].cols == step_[i].cols &&
-             step_[j].elem == step_[i].elem && step_[j].to_xy == step_[i].to_xy && step_[j].spec == step_[i].spec) { ++j; ++n; }
+             step_[j].elem == step_[i].elem && step_[j].to_xy == step_[i].to_xy && step_[j].spec == step_[i].spec &&
+             step_[j].async_id == step_[i].async_id) { ++j; ++n; }
       ++xchg_count_;
       i = j;
     }
@@ -378,13 +394,13 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
 
 // ------------------------------------------------------------------------------------------
 // communication helpers
-void Navier2DEngine::alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv,
-                               const std::vector<int64_t>& rc) {
+void Navier2DEngine::alltoallv_on(Stream& s, const double* send, const std::vector<int64_t>& sc, double* recv,
+                                  const std::vector<int64_t>& rc) {
   if (comm_.rccl) {   // stream-ordered: pack, exchange and unpack queue up without a host round trip
-    rccl_alltoallv(comm_.rccl, send, sc.data(), recv, rc.data(), st_);
+    rccl_alltoallv(comm_.rccl, send, sc.data(), recv, rc.data(), s);
     return;
   }
-  dev_sync(st_);
+  dev_sync(s);
   const int rcode = comm_.fn(comm_.user, send, sc.data(), recv, rc.data());
   RPDE_REQUIRE(rcode == 0, "all-to-all callback failed");
 }
@@ -419,8 +435,8 @@ void Navier2DEngine::gather_rows(const double* local, long ld, int rows_global,
   dev_sync(st_);   // the RCCL transport is stream-ordered; `snd` dies here and callers read `full`
 }
 
-void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem,
-                                    bool to_xy, bool spec) {
+void Navier2DEngine::exchange_batch_on(Stream& st_, const std::vector<Xfer>& xs, int rows, int cols, int elem,
+                                       bool to_xy, bool spec) {   // (`st_` shadows the member: the stream of THIS exchange)
   const int P = comm_.size, me = comm_.rank;
   if (P == 1) {
     bool same = xs.size() > 1 && xs.size() <= (size_t)kMaxTransposeBatch;
@@ -462,8 +478,65 @@ void Navier2DEngine::exchange_batch(const std::vector<Xfer>& xs, int rows, int c
   d.c0[P] = std::min(outpart[P], cols);
   d.r0[P] = std::min(inpart[P], rows);
   launch_xchg_pack(d, sendbuf_.p, st_);          // one launch: all destinations, all arrays
-  alltoallv(sendbuf_.p, sc, recvbuf_.p, rc);
+  alltoallv_on(st_, sendbuf_.p, sc, recvbuf_.p, rc);
   launch_xchg_unpack(d, recvbuf_.p, st_);        // one launch: all sources, all arrays
+}
+
+bool Navier2DEngine::apply_overlap_order() {
+  auto starts = [](const Launch& l, const char* pre) { return std::string(l.tag).rfind(pre, 0) == 0; };
+  size_t b = 0, e = 0;
+  while (b < step_.size() && !starts(step_[b], "S1 x:")) ++b;
+  for (size_t k = b; k < step_.size(); ++k) if (starts(step_[k], "S3 x:")) e = k + 1;
+  if (b >= step_.size() || e <= b) return false;
+  std::vector<size_t> s1, t1, t2, s3, up, vp, cu, cv, ct;
+  for (size_t k = b; k < e; ++k) {
+    const Launch& l = step_[k];
+    const std::string t = l.tag;
+    if (starts(l, "S1 x:")) s1.push_back(k);
+    else if (t == "T1" && l.type == Launch::kTranspose) t1.push_back(k);
+    else if (t == "T2" && l.type == Launch::kTranspose) t2.push_back(k);
+    else if (starts(l, "S3 x:")) s3.push_back(k);
+    else if (t == "S2 y: velx -> phys") up.push_back(k);
+    else if (t == "S2 y: vely -> phys") vp.push_back(k);
+    else if (t == "S2 y: conv_velx") cu.push_back(k);
+    else if (t == "S2 y: conv_vely") cv.push_back(k);
+    else if (t == "S2 y: conv_temp") ct.push_back(k);
+    else return false;                                   // something else lives between S1 and S3: keep the serial order
+  }
+  if (t1.size() != 6 || t2.size() != 3 || s3.size() != 3 || (s1.size() != 3 && s1.size() != 6) ||
+      up.size() != 1 || vp.size() != 1 || cu.size() != 1 || cv.size() != 1 || ct.size() != 1) return false;
+  const size_t per = s1.size() / 3;
+  std::vector<Launch> out(step_.begin(), step_.begin() + (long)b);
+  auto push = [&](size_t k, int async_id, unsigned wait) {
+    Launch l = step_[k];
+    l.async_id = async_id; l.wait_mask |= wait;
+    out.push_back(l);
+  };
+  for (int f = 0; f < 3; ++f) {
+    for (size_t i = 0; i < per; ++i) push(s1[f * per + i], -1, 0);
+    push(t1[2 * f], f, 0); push(t1[2 * f + 1], f, 0);
+  }
+  push(up[0], -1, 1u << 0);
+  push(vp[0], -1, 1u << 1);
+  push(cu[0], -1, (1u << 0) | (1u << 1)); push(t2[0], 3, 0);
+  push(cv[0], -1, (1u << 0) | (1u << 1)); push(t2[1], 4, 0);
+  push(ct[0], -1, 1u << 2); push(t2[2], 5, 0);
+  for (int f = 0; f < 3; ++f) push(s3[f], -1, 1u << (3 + f));
+  out.insert(out.end(), step_.begin() + (long)e, step_.end());
+  // whatever follows may read any of the exchanged arrays: it starts behind all six exchanges (S3 temp has waited for the
+  // last one, and exchanges complete in program order on their stream)
+  step_.swap(out);
+  return true;
+}
+
+void Navier2DEngine::after_exchange(unsigned wait_mask) {
+#ifndef RPDE_EMU
+  if (!overlap_) return;
+  for (int id = 0; id < kMaxAsync; ++id)
+    if ((wait_mask >> id) & 1) RPDE_HIP(hipStreamWaitEvent(st_.s, xdone_[id], 0));
+#else
+  (void)wait_mask;    // the emulation runs the launches in program order on the host: an exchange has landed when it returns
+#endif
 }
 
 void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
@@ -958,7 +1031,7 @@ size_t Navier2DEngine::group_end(size_t i) const {
   while (j < step_.size() && (int)(j - i) < kMaxBatch) {
     const Launch& m = step_[j];
     if (m.type != Launch::kTranspose || m.rows != l.rows || m.cols != l.cols || m.elem != l.elem ||
-        m.to_xy != l.to_xy || m.spec != l.spec || m.ldi != l.ldi || m.ldo != l.ldo) break;
+        m.to_xy != l.to_xy || m.spec != l.spec || m.ldi != l.ldi || m.ldo != l.ldo || m.async_id != l.async_id) break;
     ++j;
   }
   return j;
@@ -993,6 +1066,11 @@ size_t Navier2DEngine::run_from(size_t i) {
   } sync_after{this, sync_each && hipStreamIsCapturingNow(st_.s) == false};
   if (sync_after.on) { fprintf(stderr, "[launch] %s ...", group_tag(i, j).c_str()); fflush(stderr); }
 #endif
+  {
+    unsigned wm = 0;
+    for (size_t k = i; k < j; ++k) wm |= step_[k].wait_mask;
+    if (wm) after_exchange(wm);
+  }
   if (line_batch_kind(l) >= 0 && j - i > 1) {
     LineBatch b;
     b.kind = line_batch_kind(l);
@@ -1007,6 +1085,19 @@ size_t Navier2DEngine::run_from(size_t i) {
   if (l.type != Launch::kTranspose) { run_launch(l); return i + 1; }
   std::vector<Xfer> xs;
   for (size_t k = i; k < j; ++k) xs.push_back(Xfer{step_[k].in, step_[k].ldi, step_[k].out, step_[k].ldo});
+  if (overlap_ && comm_.size > 1 && l.async_id >= 0) {
+    // on the exchange stream, behind everything the main stream has been given so far (the producer of these arrays; also
+    // every earlier reader of the arrays the unpack overwrites); exchanges follow each other in program order on st2_
+#ifndef RPDE_EMU
+    RPDE_HIP(hipEventRecord(xprod_, st_.s));
+    RPDE_HIP(hipStreamWaitEvent(st2_.s, xprod_, 0));
+    exchange_batch_on(st2_, xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
+    RPDE_HIP(hipEventRecord(xdone_[l.async_id], st2_.s));
+#else
+    exchange_batch_on(st2_, xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
+#endif
+    return j;
+  }
   exchange_batch(xs, l.rows, l.cols, l.elem, l.to_xy, l.spec);
   return j;
 }

@@ -145,11 +145,29 @@ class Navier2DEngine {
     return clampi((e < rows ? e : rows) - b, 0, rows);
   }
   int xb(bool spec) const { return (spec ? kpart_ : xpart_)[comm_.rank]; }
-  void alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv, const std::vector<int64_t>& rc);
+  void alltoallv(const double* send, const std::vector<int64_t>& sc, double* recv, const std::vector<int64_t>& rc) { alltoallv_on(st_, send, sc, recv, rc); }
+  void alltoallv_on(Stream& s, const double* send, const std::vector<int64_t>& sc, double* recv, const std::vector<int64_t>& rc);
   // out = in^T across ranks.  to_xy: input YX (rows split by ypart_), output XY (rows split by
   // xpart_/kpart_); otherwise the reverse.  rows/cols are the GLOBAL logical sizes of the input.
   struct Xfer { const double* in; long ldi; double* out; long ldo; };
-  void exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem, bool to_xy, bool spec);
+  void exchange_batch(const std::vector<Xfer>& xs, int rows, int cols, int elem, bool to_xy, bool spec) { exchange_batch_on(st_, xs, rows, cols, elem, to_xy, spec); }
+  void exchange_batch_on(Stream& s, const std::vector<Xfer>& xs, int rows, int cols, int elem, bool to_xy, bool spec);
+  // ---- overlap of the array transposes of a pencil-sharded step with the compute of the neighbouring fields (round 5):
+  // the transposes T1 / T2 of ONE field go out as soon as that field's producer has run, on a second stream (pack, all-to-all,
+  // unpack), while the main stream computes the next field; a consumer waits for the event of the exchange it reads.
+  // RPDE_OVERLAP=0: the serial order of rounds 2-4 (every exchange on the main stream, T1 as one batch of six arrays).
+  static constexpr int kMaxAsync = 8;
+  bool overlap_ = false;
+  Stream st2_;                 // the exchange stream
+#ifndef RPDE_EMU
+  hipEvent_t xdone_[kMaxAsync] = {}, xprod_ = nullptr;   // exchange `id` has landed; the producer of an exchange has run
+#endif
+  void after_exchange(unsigned wait_mask);   // the main stream waits for the exchanges of `wait_mask`
+  // re-orders step_ for the overlap (the builders emit the serial order: S1 x3, T1 x6, S2 x5, T2 x3, S3 x3): S1(u), T1(u)*,
+  // S1(v), T1(v)*, S1(T), T1(T)*, S2 u -> phys [waits T1(u)], v -> phys [T1(v)], conv_velx, T2(velx)*, conv_vely, T2(vely)*,
+  // conv_temp [T1(T)], T2(temp)*, S3 velx [T2(velx)], S3 vely [T2(vely)], S3 temp [T2(temp)]  (* = on the exchange stream);
+  // false (and the serial order stays) if the step does not have that shape
+  bool apply_overlap_order();
   void exchange(const double* in, long ldi, double* out, long ldo, int rows, int cols, int elem,
                 bool to_xy, bool spec) {
     exchange_batch({Xfer{in, ldi, out, ldo}}, rows, cols, elem, to_xy, spec);
@@ -238,6 +256,8 @@ class Navier2DEngine {
     long ldi = 0, ldo = 0;
     int rows = 0, cols = 0, elem = 1;
     const char* tag = "";
+    int async_id = -1;           // kTranspose, overlap_: the exchange of this group runs on st2_ and signals xdone_[async_id]
+    unsigned wait_mask = 0;      // any launch: before it, the main stream waits for these exchanges
     double bytes = 0.0;          // algorithmic HBM bytes of one launch (reads + writes)
     double flops = 0.0;          // floating point operations of one launch (GEMMs)
   };

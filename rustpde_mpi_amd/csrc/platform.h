@@ -318,6 +318,27 @@ inline size_t dev_trim() {
 #endif
 }
 
+#ifdef RPDE_EMU
+// RPDE_ALLOC_LOG=<file> (emulation build only): the sequence of device allocations / uploads / frees an engine performs, one
+// line each ("A id bytes", "U id bytes", "F id") -- tools/fault_repro replays it with bare HIP calls on a GPU
+inline void alloc_log(char op, const void* p, size_t bytes) {
+  static const char* path = std::getenv("RPDE_ALLOC_LOG");
+  if (!path) return;
+  static std::map<const void*, long> ids;
+  static long next = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  long id;
+  if (op == 'A') { id = next++; ids[p] = id; }
+  else {
+    auto it = ids.upper_bound(p);            // an upload may target the middle of a buffer
+    if (it == ids.begin()) return;
+    id = std::prev(it)->second;
+    if (op == 'F') ids.erase(std::prev(it));
+  }
+  if (FILE* f = std::fopen(path, "a")) { std::fprintf(f, "%c %ld %zu\n", op, id, bytes); std::fclose(f); }
+}
+#endif
 inline void* dev_alloc(size_t bytes) {
 #ifdef RPDE_EMU
   // a NaN-filled guard in front of every buffer: a read below the start of a table or array
@@ -325,6 +346,7 @@ inline void* dev_alloc(size_t bytes) {
   char* raw = static_cast<char*>(std::calloc(bytes + kEmuGuardBytes + 1, 1));
   RPDE_REQUIRE(raw, "host allocation failed");
   std::memset(raw, 0xFF, kEmuGuardBytes);
+  alloc_log('A', raw + kEmuGuardBytes, bytes);
   return raw + kEmuGuardBytes;
 #else
   void* p = nullptr;
@@ -340,7 +362,7 @@ inline void* dev_alloc(size_t bytes) {
 }
 inline void dev_free(void* p) {
 #ifdef RPDE_EMU
-  if (p) std::free(static_cast<char*>(p) - kEmuGuardBytes);
+  if (p) { alloc_log('F', p, 0); std::free(static_cast<char*>(p) - kEmuGuardBytes); }
 #else
   if (!p) return;
   if (dev_arena_on()) DevArena::get().free(p);
@@ -349,6 +371,7 @@ inline void dev_free(void* p) {
 }
 inline void dev_upload(void* dst, const void* src, size_t bytes) {
 #ifdef RPDE_EMU
+  alloc_log('U', dst, bytes);
   std::memcpy(dst, src, bytes);
 #else
   RPDE_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));

@@ -30,6 +30,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         periodic, nx, ny, ra, dt, steps, aspect = case[:7]
         bc = case[7] if len(case) > 7 else "rbc"       # "hc": horizontal convection (three-term temperature base along y)
         vs_single = len(case) > 8 and case[8] == "single"   # compare with the one-rank engine (same setup code) instead of the oracle
+        ab_overlap = len(case) > 8 and case[8] == "overlap_ab"   # the same run with RPDE_OVERLAP=0: fields must be bit-identical
         ctor = "new_periodic" if periodic else "new_confined"
         # the reference's spelling of the sharded constructors: Navier2DMpi::new_confined(&universe, nx, ny, ...)
         nav = getattr(R.Navier2DMpi, ctor)(comm, nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
@@ -40,6 +41,20 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         got["pseu"] = nav.pseu.vhat
         divn = nav.div_norm()
         stats = nav.comm_stats()
+        serial = None
+        if ab_overlap:
+            os.environ["RPDE_OVERLAP"] = "0"
+            try:
+                nav0 = getattr(R.Navier2DMpi, ctor)(comm, nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
+            finally:
+                os.environ.pop("RPDE_OVERLAP", None)
+            nav0.set_velocity(0.2, 1.0, 1.0)
+            nav0.set_temperature(0.2, 1.0, 1.0)
+            nav0.update(steps)
+            f0 = nav0.physical_fields()
+            f0["pseu"] = nav0.pseu.vhat
+            serial = {"bitwise_equal": bool(all(np.array_equal(got[k], f0[k]) for k in f0)), "comm": nav0.comm_stats()}
+            del nav0
         st = R.Statistics.new(nav, 1.0, 1.0)   # collective too: every rank gathers, reduces and keeps the same statistics
         st.update()
         got["stat_temp"], got["stat_nusselt"] = st.t_avg.vhat, st.nusselt.vhat
@@ -69,7 +84,7 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
             want["stat_temp"], want["stat_nusselt"] = so.t_avg.vhat, so.nusselt.vhat
             err = {k: float(np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-300)) for k in want}
             results.append({"case": [periodic, nx, ny, steps], "err": err, "div": [divn, ora.div_norm()],
-                            "comm": stats, "calls": comm.calls})
+                            "comm": stats, "calls": comm.calls, "serial": serial})
         del nav
     if rank == 0:
         with open(out_path, "w") as f:

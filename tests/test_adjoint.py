@@ -185,3 +185,74 @@ def test_gpu_descent_reduces_the_residual(hip_lib):
         nav.update(1)
         hist.append(sum(nav.norm_residual()))
     assert all(b < a for a, b in zip(hist[2:], hist[3:])), hist
+
+
+# ------------------------------------------------------------------------------------------------ snapshots (steady_adjoint_io.rs)
+@pytest.mark.parametrize("periodic", [False, True])
+def test_emu_adjoint_write_read(emu_lib, tmp_path, periodic):
+    """Navier2DAdjoint::write / read: the Field2 layout of Navier2D::write (independent parser tests/h5classic.py); read takes
+    ux, uy, temp and time; a restart continues bit-identically in u, v, T (pres / pres_adj are not part of the file's
+    restart set, steady_adjoint_io.rs:22-33)."""
+    from tests.h5classic import File
+    mk = R.Navier2DAdjoint.new_periodic if periodic else R.Navier2DAdjoint.new_confined
+    nx = 16 if periodic else 17
+    nav = mk(nx, 17, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+    nav.set_velocity(0.1, 1.0, 1.0)
+    nav.set_temperature(0.1, 1.0, 1.0)
+    nav.update(2)
+    fn = str(tmp_path / "adjoint.h5")
+    nav.write(fn)
+    f = File(fn).datasets
+    groups = ("ux", "uy", "temp", "pres", "tempbc")
+    spec = ("vhat_re", "vhat_im") if periodic else ("vhat",)
+    assert sorted(f) == sorted([f"{g}/{d}" for g in groups for d in ("x", "dx", "y", "dy", "v") + spec] + ["time", "ra", "pr", "nu", "ka"])
+    for g, name in zip(groups, ("velx", "vely", "temp", "pres", "tempbc")):
+        fld = getattr(nav, name)
+        assert np.array_equal(f[g + "/v"], fld.v)
+        if periodic:
+            assert np.array_equal(f[g + "/vhat_re"], fld.vhat.real) and np.array_equal(f[g + "/vhat_im"], fld.vhat.imag)
+        else:
+            assert np.array_equal(f[g + "/vhat"], fld.vhat)
+    assert f["time"][0] == nav.get_time() and f["ra"][0] == 1e4
+    nav2 = mk(nx, 17, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+    nav2.read(fn)
+    assert nav2.get_time() == nav.get_time()
+    for k in ("velx", "vely", "temp"):
+        assert np.array_equal(getattr(nav, k).vhat, getattr(nav2, k).vhat), k
+    with pytest.raises(R.RpdeError):
+        nav2.read(str(tmp_path / "missing.h5"))
+
+
+def test_emu_adjoint_starts_from_a_navier2d_snapshot(emu_lib, tmp_path):
+    """examples/navier_rbc_steady.rs: `navier.read_unwrap("restart.h5")` of a file Navier2D wrote, also at another
+    resolution (field/io.rs:151-176), then descent; the oracle starts from the same coefficients."""
+    src = R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, init_random=None)
+    src.set_velocity(0.1, 1.0, 1.0)
+    src.set_temperature(0.1, 1.0, 1.0)
+    src.update(5)
+    fn = str(tmp_path / "restart.h5")
+    src.write(fn)
+    nav = R.Navier2DAdjoint.new_confined(33, 33, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+    nav.read_unwrap(fn)
+    nav.reset_time()
+    old = src.temp.vhat
+    assert np.array_equal(nav.temp.vhat[:old.shape[0], :old.shape[1]], old) and not nav.temp.vhat[old.shape[0]:].any()
+    ora = A.Navier2DAdjoint.new_confined(33, 33, 1e4, 1.0, 0.005, 1.0, "rbc", eig_mode="parity")
+    for k in ("velx", "vely", "temp"):
+        getattr(ora, k).vhat = getattr(nav, k).vhat.copy()
+    nav.update(3)
+    for _ in range(3):
+        ora.update()
+    for k in ("velx", "vely", "temp", "velx_adj", "temp_adj"):
+        assert rel(getattr(nav, k).vhat, getattr(ora, k).vhat) < 1e-10, k
+
+
+def test_emu_adjoint_callback_writes_the_flow_file(emu_lib, tmp_path, monkeypatch, capfd):
+    monkeypatch.chdir(tmp_path)
+    nav = R.Navier2DAdjoint.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib)
+    nav.set_velocity(0.1, 1.0, 1.0)
+    nav.update(3)
+    nav.callback()
+    assert (tmp_path / "data" / "adjoint00000.03.h5").exists()
+    out = capfd.readouterr().out
+    assert "|div| =" in out and "|U| =" in out and "|T| =" in out

@@ -61,7 +61,9 @@ def test_entry_uses_the_oracle_only_in_smoke():
 ENV_SWITCHES = {
     "RPDE_LAPACK_LIB", "RPDE_RCCL_LIB",            # run-time libraries
     "RPDE_GRAPH",                                   # hipGraph replay on / off              (test_gpu_parity.test_graph_*)
+    "RPDE_OVERLAP",                                 # pencil-sharded: transposes of one field on a second stream under the next field's compute (test_sharded.test_overlap_*)
     "RPDE_SYNC_LAUNCHES",                           # diagnostics: every launch named and waited for
+    "RPDE_ALLOC_LOG",                               # emulation build only: allocation trace for tools/fault_repro
     "RPDE_ARENA", "RPDE_ARENA_GUARD",               # device memory from slabs / one hipMalloc per buffer; guard granules (tests/test_arena.py)
     "RPDE_WHOLE_LINE", "RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE",
                                                     # whole-line kernel / line program per stage (test_whole_line_stage_*, test_emu_parity)

@@ -60,7 +60,27 @@ def test_sharded_column_scans_and_whole_line_kernels_emulation(world, tmp_path, 
     for r in res:
         for k, e in r["err"].items():
             assert e < (1e-10 if k == "pseu" else 1e-12), (r["case"], k, e)
-        assert r["comm"][1] == 13
+        assert r["comm"][1] == 17   # 13 of the serial order + 4: T1 and T2 as three exchanges each (RPDE_OVERLAP, the default)
+
+
+CASES_OVERLAP = [(False, 33, 33, 1e5, 0.01, 4, 1.0, "rbc", "overlap_ab"), (True, 32, 33, 1e5, 0.01, 4, 1.0, "rbc", "overlap_ab"),
+                 (False, 129, 129, 1e5, 0.01, 3, 1.0, "rbc", "overlap_ab"), (False, 33, 33, 1e5, 0.01, 4, 1.0, "hc", "overlap_ab")]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlap_order_equals_serial_order_emulation(world, tmp_path, emu_lib):
+    """RPDE_OVERLAP (round 5): the transposes of one field leave as soon as that field's producer has run (three T1 and three
+    T2 exchanges instead of one batch each, on a second stream in the HIP build) and the consumers wait for the exchange they
+    read.  Same arithmetic, another order of launches: the fields must be BIT-identical to the serial order, and both meet
+    the oracle.  17 exchanges per step instead of 13 (six array exchanges instead of two)."""
+    res = _spawn(world, emu_lib.path, False, CASES_OVERLAP, tmp_path)
+    assert len(res) == len(CASES_OVERLAP)
+    for r in res:
+        for k, e in r["err"].items():
+            assert e < 1e-10, (r["case"], k, e)
+        assert r["serial"]["bitwise_equal"], r["case"]
+        # "rbc": T1 and T2 were one batch each (2 -> 6 exchanges); "hc": T1 already went out as two batches (3 -> 6)
+        assert r["comm"][1] - r["serial"]["comm"][1] in (3, 4), (r["comm"], r["serial"]["comm"])
 
 
 # "hc": the three-term stencil of the temperature reads two halo rows, its seven-diagonal Helmholtz solve along y goes
@@ -78,7 +98,7 @@ def test_sharded_hc_matches_oracle_emulation(world, tmp_path, emu_lib):
             assert e < 1e-10, (r["case"], k, e)
         # the "rbc" count + T3 / T4 of the temperature + one more for T1 (the temperature arrays have ny rows instead of my:
         # two batches)
-        assert r["comm"][1] == 16
+        assert r["comm"][1] == 19   # (16 in the serial order, RPDE_OVERLAP=0)
 
 
 # BASELINE configs[3] / [4] run on 8 GPUs: 4097 = 8 * 512 + 1 rows is a ragged 8-way partition with several column-scan
@@ -98,7 +118,7 @@ def test_sharded_world_size_8_emulation(tmp_path, emu_lib):
         for k, e in r["err"].items():
             assert e < (1e-10 if r["case"][0] else 1e-11), (r["case"], k, e)
         assert abs(r["div"][0] - r["div"][1]) < 1e-9 * max(1.0, r["div"][1])
-        assert r["comm"][1] == 13
+        assert r["comm"][1] == 17
 
 
 def test_sharded_long_fourier_lines_emulation(tmp_path, emu_lib):
@@ -117,6 +137,22 @@ def test_sharded_matches_oracle_hip(world, tmp_path, hip_lib):
     for r in res:
         for k, e in r["err"].items():
             assert e < 1e-10, (r["case"], k, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlap_order_equals_serial_order_hip(world, tmp_path, hip_lib):
+    """The same A/B on the device: the per-field exchanges run on the engine's second stream behind an event of their
+    producer, the consumers wait for the exchange's event (ranks share the one GPU of the test box; gloo callback
+    transport) -- bit-identical to RPDE_OVERLAP=0, and both meet the oracle.  Includes a 1025-wide case (whole-line kernels on
+    the local lines, several column-scan blocks per rank)."""
+    cases = CASES_OVERLAP + [(False, 1025, 257, 1e6, 1e-3, 3, 1.0, "rbc", "overlap_ab")]
+    res = _spawn(world, hip_lib.path, True, cases, tmp_path)
+    assert len(res) == len(cases)
+    for r in res:
+        for k, e in r["err"].items():
+            assert e < 1e-10, (r["case"], k, e)
+        assert r["serial"]["bitwise_equal"], r["case"]
 
 
 @pytest.mark.gpu
