@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--dt", type=float, default=2e-4)
     p.add_argument("--periodic", action="store_true")
     p.add_argument("--aspect", type=float, default=1.0)
+    p.add_argument("--bc", default="rbc", choices=["rbc", "hc"], help="boundary condition of the temperature (navier.rs:245-248)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=2)
     p.add_argument("--profile-steps", type=int, default=3)
@@ -62,7 +63,7 @@ def cpu_baseline(args, eig=None):
     ctor = N.Navier2D.new_periodic if args.periodic else N.Navier2D.new_confined
     t0 = time.perf_counter()
     kw = {"eig_mode": "parity"} if eig is None else {"eig_override": eig}
-    ora = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", **kw)
+    ora = ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, args.bc, **kw)
     ora.set_velocity(0.2, 1.0, 1.0)
     ora.set_temperature(0.2, 1.0, 1.0)
     setup = time.perf_counter() - t0
@@ -145,7 +146,7 @@ def parity_independent_golden(make, args):
     exists for the workload."""
     import numpy as np
     path = os.path.join(ROOT, "tests", "golden", f"headline_{args.nx}_full.npz")
-    if args.periodic or args.nx != args.ny or not os.path.exists(path):
+    if args.periodic or args.bc != "rbc" or args.nx != args.ny or not os.path.exists(path):
         return None
     g = np.load(path)
     if abs(float(g["ra"]) - args.ra) > 0 or abs(float(g["dt"]) - args.dt) > 0 or abs(args.aspect - 1.0) > 0:
@@ -210,7 +211,7 @@ def parity_shared_basis_golden(args, library, device):
     import rustpde_mpi_amd as R
     tag = "" if (args.ra == 1e8 and args.dt == 2e-4) else f"_ra{args.ra:g}_dt{args.dt:g}"
     path = os.path.join(ROOT, "tests", "golden", f"shared_basis_{args.nx}{tag}.npz")
-    if args.periodic or args.nx != args.ny or abs(args.aspect - 1.0) > 0 or not os.path.exists(path):
+    if args.periodic or args.bc != "rbc" or args.nx != args.ny or abs(args.aspect - 1.0) > 0 or not os.path.exists(path):
         return None
     g = np.load(path)
     if abs(float(g["ra"]) - args.ra) > 0 or abs(float(g["dt"]) - args.dt) > 0:
@@ -302,7 +303,7 @@ def main():
         library = Lib(build_emu())
 
     def make(comm):
-        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", device=local_rank, comm=comm,
+        return ctor(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, args.bc, device=local_rank, comm=comm,
                     library=library)
 
     if world > 1:
@@ -456,7 +457,7 @@ def main():
         "data": ("DRY RUN on the host emulation build -- NOT a measurement" if args.dry_run_emu else
                  "synthetic (deterministic IC of examples/navier_rbc.rs: set_velocity(0.2,1,1), set_temperature(0.2,1,1))"),
         "config": {"workload": f"Navier2D::new_{'periodic' if args.periodic else 'confined'} "
-                               f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect={args.aspect:g} bc=rbc",
+                               f"{args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect={args.aspect:g} bc={args.bc}",
                    "parallelism": "single GPU" if world == 1 else
                                   f"pencil-sharded over {world} GPUs (x-/y-pencils, all-to-all over RCCL, transport {transport})"},
         "roofline": roof,

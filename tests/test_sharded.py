@@ -166,7 +166,7 @@ def test_config4_geometry_sharded_equals_single_device(tmp_path, hip_lib, n, wor
         # across the ranks) and the GEMM tile shapes differ; pseu is the raw output of the Poisson solve, which
         # amplifies such round-off (measured 1.4e-11)
         assert e < (1e-9 if k == "pseu" else 1e-11), (k, e)
-    assert res[0]["comm"][1] == 13   # 4 batched all-to-alls (T1, T2, T4b, T4c) + 5 halo exchanges + 4 column-scan summaries per step
+    assert res[0]["comm"][1] == 17   # 8 array all-to-alls (T1 x3, T2 x3: one per field, RPDE_OVERLAP; T4b, T4c) + 5 halo exchanges + 4 column-scan summaries per step
 
 
 def _nccl_single(rank, port, out):
