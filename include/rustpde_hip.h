@@ -29,6 +29,7 @@ typedef struct rpde_navier2d rpde_navier2d;   /* Navier2D<f64|Complex<f64>, Spac
 typedef struct rpde_space2 rpde_space2;       /* funspace Space2<B0,B1>              src/bases.rs:11-19, src/field.rs:59-72 */
 typedef struct rpde_hholtz_adi rpde_hholtz_adi; /* HholtzAdi<f64,2>                  src/solver/hholtz_adi.rs:31-39 */
 typedef struct rpde_hholtz rpde_hholtz;       /* Hholtz<f64,2>                       src/solver/hholtz.rs:29-37 */
+typedef struct rpde_lnse2d rpde_lnse2d;       /* Navier2DLnse<f64|Complex<f64>, Space2>     src/navier_stokes_lnse/lnse.rs:24-63 */
 typedef struct rpde_adjoint2d rpde_adjoint2d; /* Navier2DAdjoint<f64|Complex<f64>, Space2>  src/navier_stokes/steady_adjoint.rs:67-113 */
 typedef struct rpde_poisson rpde_poisson;     /* Poisson<f64,2>                      src/solver/poisson.rs:33-40 */
 
@@ -221,6 +222,39 @@ int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3);
  * resolution                                                        src/navier_stokes/steady_adjoint_io.rs:22-33, 48-71 */
 int rpde_adjoint2d_write(rpde_adjoint2d* h, const char* filename);
 int rpde_adjoint2d_read(rpde_adjoint2d* h, const char* filename);
+
+/* ---- linearised Navier-Stokes about mean fields: what `impl Integrate for Navier2DLnse` does -------------------- *
+ * (second slice: the forward LNSE step; the adjoint-gradient drivers of src/navier_stokes_lnse are   *
+ * not built.)  bc = "rbc".                                                                                                   */
+/* Navier2DLnse::new_confined / new_periodic(nx, ny, ra, pr, dt, aspect, bc)     src/navier_stokes_lnse/lnse.rs:98-176, 196-253
+ * mean_file: the snapshot MeanFields::read_from_* takes the mean flow from ("ux/v", "uy/v", "temp/v" + "tempbc/v"; NULL = the
+ * reference's "mean.h5"); if it does not exist: the boundary condition's default mean (no flow, conduction profile),
+ * src/navier_stokes_lnse/meanfield.rs:28-49, 92-127.  (The reference also writes "mean_field.h5" from its constructor; a
+ * host that wants it calls rpde_lnse2d_get_mean.) */
+int rpde_lnse2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                const char* mean_file, int device, rpde_lnse2d** out);
+int rpde_lnse2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                const char* mean_file, int device, rpde_lnse2d** out);
+int rpde_lnse2d_destroy(rpde_lnse2d* h);
+int rpde_lnse2d_set_velocity(rpde_lnse2d* h, double amp, double m, double n);       /* functions.rs:85-126 on velx / vely */
+int rpde_lnse2d_set_temperature(rpde_lnse2d* h, double amp, double m, double n);
+int rpde_lnse2d_reset_time(rpde_lnse2d* h);
+/* name in {"velx","vely","temp","pres","pseu","tempbc"} (lnse.rs:26-37) */
+int rpde_lnse2d_spectral_shape(rpde_lnse2d* h, const char* name, int* rows, int* cols, int* is_complex);
+int rpde_lnse2d_set_field(rpde_lnse2d* h, const char* name, int space, const double* data, size_t len);
+int rpde_lnse2d_get_field(rpde_lnse2d* h, const char* name, int space, double* data, size_t len);
+/* MeanFields: name in {"velx","vely","temp"}, physical (nx x ny) arrays; set = assign + forward (meanfield.rs:237-259) */
+int rpde_lnse2d_set_mean(rpde_lnse2d* h, const char* name, const double* data, size_t len);
+int rpde_lnse2d_get_mean(rpde_lnse2d* h, const char* name, double* data, size_t len);
+/* n x Integrate::update()                                         src/navier_stokes_lnse/lnse.rs:263-288 */
+int rpde_lnse2d_update(rpde_lnse2d* h, int nsteps);
+int rpde_lnse2d_time(rpde_lnse2d* h, double* time);
+int rpde_lnse2d_dt(rpde_lnse2d* h, double* dt);
+int rpde_lnse2d_param(rpde_lnse2d* h, const char* key, double* value);
+int rpde_lnse2d_exit(rpde_lnse2d* h, int* stop);                   /* NaN divergence, lnse.rs:305-313 */
+int rpde_lnse2d_div_norm(rpde_lnse2d* h, double* norm);            /* lnse_eq.rs:36-41 */
+int rpde_lnse2d_write(rpde_lnse2d* h, const char* filename);       /* the Field2 snapshot layout (ux uy temp pres tempbc + time + params) */
+int rpde_lnse2d_read(rpde_lnse2d* h, const char* filename);
 
 /* ---- operator level: funspace Space2 methods as called by rustpde ---------------------------- */
 /* Space2::new(&base0(n0), &base1(n1)); base1 must be a Chebyshev-family base                     */

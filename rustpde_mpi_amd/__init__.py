@@ -27,7 +27,7 @@ import numpy as np
 
 from ._capi import Lib, RpdeError, as_f64, ptr
 
-__all__ = ["Navier2D", "Navier2DMpi", "Navier2DAdjoint", "Space2", "HholtzAdi", "Poisson", "Hholtz", "integrate", "lib", "RpdeError",
+__all__ = ["Navier2D", "Navier2DMpi", "Navier2DAdjoint", "Navier2DLnse", "Space2", "HholtzAdi", "Poisson", "Hholtz", "integrate", "lib", "RpdeError",
            "chebyshev", "cheb_dirichlet", "cheb_neumann", "cheb_dirichlet_neumann", "fourier_r2c", "LIB_PATH", "Statistics"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librustpde_hip.so")
@@ -532,45 +532,45 @@ class Navier2DAdjoint:
     def __del__(self):
         try:
             if self._h:
-                self._lib.call("rpde_adjoint2d_destroy", self._h)
+                self._lib.call(self._prefix + "_destroy", self._h)
                 self._h = None
         except Exception:
             pass
 
     def set_velocity(self, amp, m, n):
-        self._lib.call("rpde_adjoint2d_set_velocity", self._h, float(amp), float(m), float(n))
+        self._lib.call(self._prefix + "_set_velocity", self._h, float(amp), float(m), float(n))
 
     def set_temperature(self, amp, m, n):
-        self._lib.call("rpde_adjoint2d_set_temperature", self._h, float(amp), float(m), float(n))
+        self._lib.call(self._prefix + "_set_temperature", self._h, float(amp), float(m), float(n))
 
     def reset_time(self):
-        self._lib.call("rpde_adjoint2d_reset_time", self._h)
+        self._lib.call(self._prefix + "_reset_time", self._h)
 
     def update(self, nsteps: int = 1):
-        self._lib.call("rpde_adjoint2d_update", self._h, int(nsteps))
+        self._lib.call(self._prefix + "_update", self._h, int(nsteps))
 
     def get_time(self):
         t = C.c_double()
-        self._lib.call("rpde_adjoint2d_time", self._h, C.byref(t))
+        self._lib.call(self._prefix + "_time", self._h, C.byref(t))
         return t.value
 
     def get_dt(self):
         t = C.c_double()
-        self._lib.call("rpde_adjoint2d_dt", self._h, C.byref(t))
+        self._lib.call(self._prefix + "_dt", self._h, C.byref(t))
         return t.value
 
     def exit(self):
         f = C.c_int()
-        self._lib.call("rpde_adjoint2d_exit", self._h, C.byref(f))
+        self._lib.call(self._prefix + "_exit", self._h, C.byref(f))
         return bool(f.value)
 
     def write(self, filename):
         """`Navier2DAdjoint::write` (steady_adjoint_io.rs:48-71)."""
-        self._lib.call("rpde_adjoint2d_write", self._h, str(filename).encode())
+        self._lib.call(self._prefix + "_write", self._h, str(filename).encode())
 
     def read(self, filename):
         """`Navier2DAdjoint::read` (steady_adjoint_io.rs:22-33): ux, uy, temp, time -- also from a `Navier2D` snapshot."""
-        self._lib.call("rpde_adjoint2d_read", self._h, str(filename).encode())
+        self._lib.call(self._prefix + "_read", self._h, str(filename).encode())
         print(f" <== {str(filename)!r}")
 
     def write_unwrap(self, filename):
@@ -603,12 +603,12 @@ class Navier2DAdjoint:
 
     def div_norm(self):
         d = C.c_double()
-        self._lib.call("rpde_adjoint2d_div_norm", self._h, C.byref(d))
+        self._lib.call(self._prefix + "_div_norm", self._h, C.byref(d))
         return d.value
 
     def norm_residual(self):
         r = (C.c_double * 3)()
-        self._lib.call("rpde_adjoint2d_norm_residual", self._h, r)
+        self._lib.call(self._prefix + "_norm_residual", self._h, r)
         return [r[0], r[1], r[2]]
 
     @property
@@ -616,7 +616,7 @@ class Navier2DAdjoint:
         out = {}
         for k in ("ra", "pr", "nu", "ka"):
             v = C.c_double()
-            self._lib.call("rpde_adjoint2d_param", self._h, k.encode(), C.byref(v))
+            self._lib.call(self._prefix + "_param", self._h, k.encode(), C.byref(v))
             out[k] = v.value
         return out
 
@@ -624,6 +624,63 @@ class Navier2DAdjoint:
         return {k: getattr(self, k).v for k in names}
 
     def spectral_fields(self, names=FIELDS[:9]):
+        return {k: getattr(self, k).vhat for k in names}
+
+
+class Navier2DLnse(Navier2DAdjoint):
+    """Device-resident `Navier2DLnse` (src/navier_stokes_lnse/lnse.rs): the Navier-Stokes step linearised about mean fields.
+    `new_confined / new_periodic(nx, ny, ra, pr, dt, aspect, bc, mean_file=None)`; `mean_file=None` looks for "mean.h5" like
+    the reference and falls back to the boundary condition's default mean; `.mean_velx.v` etc. read / assign the mean fields."""
+    _prefix = "rpde_lnse2d"
+    FIELDS = ("velx", "vely", "temp", "pres", "pseu", "tempbc")
+
+    class _Mean:
+        def __init__(self, nav, name):
+            self._nav, self._name = nav, name
+
+        @property
+        def v(self):
+            out = np.empty((self._nav.nx, self._nav.ny))
+            self._nav._lib.call("rpde_lnse2d_get_mean", self._nav._h, self._name.encode(), ptr(out), out.size)
+            return out
+
+        @v.setter
+        def v(self, value):
+            a = as_f64(value)
+            if a.shape != (self._nav.nx, self._nav.ny):
+                raise RpdeError(f"mean field must have shape {(self._nav.nx, self._nav.ny)}")
+            self._nav._lib.call("rpde_lnse2d_set_mean", self._nav._h, self._name.encode(), ptr(a), a.size)
+
+    def __init__(self, handle, nx, ny, periodic, library):
+        super().__init__(handle, nx, ny, periodic, library)
+        for name in ("velx", "vely", "temp"):
+            setattr(self, "mean_" + name, Navier2DLnse._Mean(self, name))
+
+    @classmethod
+    def _new(cls, fn, nx, ny, ra, pr, dt, aspect, bc, device, library, periodic, mean_file=None):
+        library = library or lib()
+        h = C.c_void_p()
+        library.call(fn, int(nx), int(ny), float(ra), float(pr), float(dt), float(aspect), str(bc).encode(),
+                     None if mean_file is None else str(mean_file).encode(), int(device), C.byref(h))
+        return cls(h, nx, ny, periodic, library)
+
+    @classmethod
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, mean_file=None):
+        return cls._new("rpde_lnse2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device, library, False, mean_file)
+
+    @classmethod
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, mean_file=None):
+        return cls._new("rpde_lnse2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device, library, True, mean_file)
+
+    def norm_residual(self):
+        raise RpdeError("Navier2DLnse has no residual (steady_adjoint.rs only)")
+
+    def callback(self):
+        os.makedirs("data", exist_ok=True)
+        self.write_unwrap("data/flow{:0>8.2f}.h5".format(self.get_time()))
+        print("time = {:4.2f}      |div| = {:4.2e}".format(self.get_time(), self.div_norm()))
+
+    def spectral_fields(self, names=("velx", "vely", "temp", "pres", "pseu")):
         return {k: getattr(self, k).vhat for k in names}
 
 

@@ -65,6 +65,27 @@ SIGNATURES = {
     "rpde_poisson_x_spectrum": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp, C.c_size_t]),
     "rpde_poisson_x_eigenbasis_from_spectrum": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp, C.c_size_t, _dp, _dp, _dp]),
     "rpde_poisson_create_with_spectrum": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_size_t, C.POINTER(_vp)]),
+    "rpde_lnse2d_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                              C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "rpde_lnse2d_create_periodic": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                              C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "rpde_lnse2d_destroy": (C.c_int, [_vp]),
+    "rpde_lnse2d_set_velocity": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
+    "rpde_lnse2d_set_temperature": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
+    "rpde_lnse2d_reset_time": (C.c_int, [_vp]),
+    "rpde_lnse2d_spectral_shape": (C.c_int, [_vp, C.c_char_p, _ip, _ip, _ip]),
+    "rpde_lnse2d_set_field": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp, C.c_size_t]),
+    "rpde_lnse2d_get_field": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp, C.c_size_t]),
+    "rpde_lnse2d_set_mean": (C.c_int, [_vp, C.c_char_p, _dp, C.c_size_t]),
+    "rpde_lnse2d_get_mean": (C.c_int, [_vp, C.c_char_p, _dp, C.c_size_t]),
+    "rpde_lnse2d_update": (C.c_int, [_vp, C.c_int]),
+    "rpde_lnse2d_time": (C.c_int, [_vp, _dp]),
+    "rpde_lnse2d_dt": (C.c_int, [_vp, _dp]),
+    "rpde_lnse2d_param": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "rpde_lnse2d_exit": (C.c_int, [_vp, _ip]),
+    "rpde_lnse2d_div_norm": (C.c_int, [_vp, _dp]),
+    "rpde_lnse2d_write": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_lnse2d_read": (C.c_int, [_vp, C.c_char_p]),
     "rpde_hholtz_create": (C.c_int, [_vp, C.c_double, C.c_double, C.POINTER(_vp)]),
     "rpde_hholtz_solve": (C.c_int, [_vp, _dp, C.c_size_t, _dp, C.c_size_t]),
     "rpde_hholtz_destroy": (C.c_int, [_vp]),

@@ -2,6 +2,7 @@
 #include "adjoint.h"
 
 #include <cmath>
+#include <cstdio>
 
 #include "h5lite.h"
 
@@ -82,14 +83,15 @@ static double get_nu(double ra, double pr, double h) { return std::sqrt(pr / (ra
 static double get_ka(double ra, double pr, double h) { return std::sqrt(1.0 / ((ra / std::pow(h, 3.0)) * pr)); }
 
 // ------------------------------------------------------------------------------------------------
-Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                                             const std::string& bc, bool periodic)
+GenericFlow2D::GenericFlow2D(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc, bool periodic,
+                             double dt_helmholtz, std::initializer_list<const char*> extra_fields)
     : nx_(nx), ny_(ny), ex_(periodic ? 2 : 1), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");
-  RPDE_REQUIRE(bc == "rbc", "Navier2DAdjoint with bc = \"hc\": the reference builds its four-diagonal tensor solver Hholtz on the "
-                            "three-term base cheb_dirichlet_neumann (steady_adjoint.rs:312-318), which Fdma cannot hold -- not supported");
+  RPDE_REQUIRE(bc == "rbc", "bc = \"hc\" is not supported by this solver (Navier2DAdjoint: the reference builds its four-diagonal tensor "
+                            "solver Hholtz on the three-term base cheb_dirichlet_neumann, steady_adjoint.rs:312-318, which Fdma cannot hold)");
   RPDE_REQUIRE(nx >= 8 && ny >= 8, "grid too small");
   RPDE_REQUIRE(!periodic || nx % 2 == 0, "fourier_r2c needs an even number of points");
+  RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   RPDE_HIP(hipStreamCreate(&st_.s));
 #endif
@@ -102,22 +104,22 @@ Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double p
   sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebDirichlet, ny));
   sp_ortho_ = std::make_unique<Space2Ops>(make_base(bx_ort, nx), make_base(kChebyshev, ny));
   sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
-  // the Helmholtz solvers of the FORWARD step run on DT_NAVIER (steady_adjoint.rs:273-295)
-  hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, kDtNavier * nu_ / (sx_ * sx_), kDtNavier * nu_ / (sy_ * sy_));
-  hh_temp_ = std::make_unique<HholtzAdiOp>(*sp_temp_, kDtNavier * ka_ / (sx_ * sx_), kDtNavier * ka_ / (sy_ * sy_));
+  hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, dt_helmholtz * nu_ / (sx_ * sx_), dt_helmholtz * nu_ / (sy_ * sy_));
+  hh_temp_ = std::make_unique<HholtzAdiOp>(*sp_temp_, dt_helmholtz * ka_ / (sx_ * sx_), dt_helmholtz * ka_ / (sy_ * sy_));
   pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_));
-  // smoother (1 - weight D2) (steady_adjoint.rs:300-322): velx and vely live in the same space -> one solver serves both
-  norm_vel_ = std::make_unique<TensorHholtzOp>(*sp_vel_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
-  norm_temp_ = std::make_unique<TensorHholtzOp>(*sp_temp_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
 
-  auto mk = [&](const char* name, Space2Ops* sp) {
-    F f{sp, Arr2(sp->spec_rows(), sp->spec_cols(), ex_)};
+  auto mk = [&](const std::string& name, Space2Ops* sp, bool ro = false) {
+    F f{sp, Arr2(sp->spec_rows(), sp->spec_cols(), ex_), ro};
     f_.emplace(name, std::move(f));
   };
   mk("velx", sp_vel_.get()); mk("vely", sp_vel_.get()); mk("temp", sp_temp_.get());
-  mk("pres", sp_ortho_.get()); mk("pseu", sp_pseu_.get());
-  mk("velx_adj", sp_vel_.get()); mk("vely_adj", sp_vel_.get()); mk("temp_adj", sp_temp_.get());
-  mk("pres_adj", sp_ortho_.get()); mk("tempbc", sp_ortho_.get());
+  mk("pres", sp_ortho_.get()); mk("pseu", sp_pseu_.get()); mk("tempbc", sp_ortho_.get(), true);
+  for (const char* name : extra_fields) {
+    const std::string n = name;
+    Space2Ops* sp = n.rfind("mean_", 0) == 0 ? sp_ortho_.get() : n.rfind("velx", 0) == 0 || n.rfind("vely", 0) == 0 ? sp_vel_.get()
+                    : n.rfind("temp", 0) == 0 ? sp_temp_.get() : sp_ortho_.get();
+    mk(n, sp);
+  }
 
   const int ro = sp_ortho_->ortho_rows(), co = sp_ortho_->ortho_cols();
   for (Arr2* a : {&rhs_, &div_, &t0_, &t1_, &old_[0], &old_[1], &old_[2], &cv_}) a->alloc(ro, co, ex_);
@@ -137,13 +139,23 @@ Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double p
   dev_sync(st_);
 }
 
-Navier2DAdjointEngine::~Navier2DAdjointEngine() {
+Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
+                                             const std::string& bc, bool periodic)
+    // the Helmholtz solvers of the FORWARD step run on DT_NAVIER (steady_adjoint.rs:273-295)
+    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, kDtNavier, {"velx_adj", "vely_adj", "temp_adj", "pres_adj"}) {
+  // smoother (1 - weight D2) (steady_adjoint.rs:300-322): velx and vely live in the same space -> one solver serves both
+  norm_vel_ = std::make_unique<TensorHholtzOp>(*sp_vel_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
+  norm_temp_ = std::make_unique<TensorHholtzOp>(*sp_temp_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
+  dev_sync(st_);
+}
+
+GenericFlow2D::~GenericFlow2D() {
 #ifndef RPDE_EMU
   if (st_.s) { (void)hipStreamSynchronize(st_.s); (void)hipStreamDestroy(st_.s); }
 #endif
 }
 
-double Navier2DAdjointEngine::param(const std::string& key) const {
+double GenericFlow2D::param(const std::string& key) const {
   if (key == "ra") return ra_;
   if (key == "pr") return pr_;
   if (key == "nu") return nu_;
@@ -151,35 +163,35 @@ double Navier2DAdjointEngine::param(const std::string& key) const {
   fail("unknown parameter " + key);
 }
 
-Navier2DAdjointEngine::F& Navier2DAdjointEngine::field(const std::string& name) {
+GenericFlow2D::F& GenericFlow2D::field(const std::string& name) {
   auto it = f_.find(name);
-  RPDE_REQUIRE(it != f_.end(), "unknown field " + name + " (velx vely temp pres pseu velx_adj vely_adj temp_adj pres_adj tempbc)");
+  RPDE_REQUIRE(it != f_.end(), "unknown field " + name);
   return it->second;
 }
 
-void Navier2DAdjointEngine::spectral_shape(const std::string& name, int* rows, int* cols, int* elem) {
+void GenericFlow2D::spectral_shape(const std::string& name, int* rows, int* cols, int* elem) {
   F& f = field(name);
   *rows = f.vhat.rows; *cols = f.vhat.cols; *elem = f.vhat.elem;
 }
 
-void Navier2DAdjointEngine::set_field_spectral(const std::string& name, const double* host, size_t len) {
-  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
+void GenericFlow2D::set_field_spectral(const std::string& name, const double* host, size_t len) {
   F& f = field(name);
+  RPDE_REQUIRE(!f.read_only, name + " is fixed by the boundary condition");
   RPDE_REQUIRE(len == (size_t)f.vhat.rows * f.vhat.cols * f.vhat.elem, "set_field: wrong length for the spectral shape of " + name);
   dev_sync(st_);
   dev_upload2d(f.vhat.p(), f.vhat.ld, host, f.vhat.rows, (long)f.vhat.cols * f.vhat.elem);
 }
 
-void Navier2DAdjointEngine::get_field_spectral(const std::string& name, double* host, size_t len) {
+void GenericFlow2D::get_field_spectral(const std::string& name, double* host, size_t len) {
   F& f = field(name);
   RPDE_REQUIRE(len == (size_t)f.vhat.rows * f.vhat.cols * f.vhat.elem, "get_field: wrong length for the spectral shape of " + name);
   dev_sync(st_);
   dev_download2d(host, f.vhat.p(), f.vhat.ld, f.vhat.rows, (long)f.vhat.cols * f.vhat.elem);
 }
 
-void Navier2DAdjointEngine::set_field_physical(const std::string& name, const double* host, size_t len) {
-  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
+void GenericFlow2D::set_field_physical(const std::string& name, const double* host, size_t len) {
   F& f = field(name);
+  RPDE_REQUIRE(!f.read_only, name + " is fixed by the boundary condition");
   RPDE_REQUIRE(len == (size_t)nx_ * ny_, "set_field: physical arrays are nx*ny doubles");
   dev_sync(st_);
   dev_upload2d(ph_.p(), ph_.ld, host, nx_, ny_);
@@ -187,7 +199,7 @@ void Navier2DAdjointEngine::set_field_physical(const std::string& name, const do
   dev_sync(st_);
 }
 
-void Navier2DAdjointEngine::get_field_physical(const std::string& name, double* host, size_t len) {
+void GenericFlow2D::get_field_physical(const std::string& name, double* host, size_t len) {
   F& f = field(name);
   RPDE_REQUIRE(len == (size_t)nx_ * ny_, "get_field: physical arrays are nx*ny doubles");
   f.sp->backward(f.vhat, ph_, st_);
@@ -209,7 +221,7 @@ static void sincos_field(const Base& b0, const Base& b1, double sx, double sy, d
     }
 }
 
-void Navier2DAdjointEngine::set_velocity(double amp, double m, double n) {
+void GenericFlow2D::set_velocity(double amp, double m, double n) {
   Vec v;
   sincos_field(sp_vel_->base(0), sp_vel_->base(1), sx_, sy_, amp, m, n, true, v);
   set_field_physical("velx", v.data(), v.size());
@@ -217,14 +229,14 @@ void Navier2DAdjointEngine::set_velocity(double amp, double m, double n) {
   set_field_physical("vely", v.data(), v.size());
 }
 
-void Navier2DAdjointEngine::set_temperature(double amp, double m, double n) {
+void GenericFlow2D::set_temperature(double amp, double m, double n) {
   Vec v;
   sincos_field(sp_temp_->base(0), sp_temp_->base(1), sx_, sy_, -amp, m, n, false, v);
   set_field_physical("temp", v.data(), v.size());
 }
 
 // ------------------------------------------------------------------------------------------------
-void Navier2DAdjointEngine::grid(int axis, double* x, size_t len) const {
+void GenericFlow2D::grid(int axis, double* x, size_t len) const {
   const Base& b = sp_vel_->base(axis);
   RPDE_REQUIRE((int)len == b.n, "grid: wrong length");
   const Vec c = base_coords(b);
@@ -234,7 +246,7 @@ void Navier2DAdjointEngine::grid(int axis, double* x, size_t len) const {
 
 static const char* const kAdjSnapFields[5][2] = {{"velx", "ux"}, {"vely", "uy"}, {"temp", "temp"}, {"pres", "pres"}, {"tempbc", "tempbc"}};
 
-void Navier2DAdjointEngine::write(const std::string& filename) {
+void GenericFlow2D::write(const std::string& filename) {
   h5::Tree t;
   Vec x((size_t)nx_), y((size_t)ny_);
   grid(0, x.data(), x.size());
@@ -266,7 +278,7 @@ void Navier2DAdjointEngine::write(const std::string& filename) {
   h5::update_file(filename, t);
 }
 
-void Navier2DAdjointEngine::read(const std::string& filename) {
+void GenericFlow2D::read(const std::string& filename) {
   h5::Reader rd(filename);
   for (int k = 0; k < 3; ++k) {    // steady_adjoint_io.rs:23-25: ux, uy, temp
     const std::string name = kAdjSnapFields[k][0], g = kAdjSnapFields[k][1];
@@ -293,52 +305,52 @@ void Navier2DAdjointEngine::read(const std::string& filename) {
 }
 
 // ------------------------------------------------------------------------------------------------
-void Navier2DAdjointEngine::zero(Arr2& a) { dev_zero(a.p(), a.bytes(), st_); }
+void GenericFlow2D::zero(Arr2& a) { dev_zero(a.p(), a.bytes(), st_); }
 
-void Navier2DAdjointEngine::lincomb(Arr2& out, double a, const Arr2& x, double b, const Arr2& y) {
+void GenericFlow2D::lincomb(Arr2& out, double a, const Arr2& x, double b, const Arr2& y) {
   RPDE_REQUIRE(out.rows == x.rows && out.cols == x.cols && out.elem == x.elem && y.rows == x.rows && y.cols == x.cols && y.elem == x.elem,
                "lincomb: shapes differ");
   ew_lincomb(out.p(), out.ld, a, x.p(), x.ld, b, y.p(), y.ld, out.rows, out.cols * out.elem, st_);
 }
 
-void Navier2DAdjointEngine::acc_to_ortho(F& f, double s, Arr2& out) {
+void GenericFlow2D::acc_to_ortho(F& f, double s, Arr2& out) {
   f.sp->to_ortho(f.vhat, t0_, st_);
   lincomb(out, 1.0, out, s, t0_);
 }
 
-void Navier2DAdjointEngine::acc_gradient(F& f, int d0, int d1, double s, Arr2& out) {
+void GenericFlow2D::acc_gradient(F& f, int d0, int d1, double s, Arr2& out) {
   f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
   lincomb(out, 1.0, out, s, t0_);
 }
 
-void Navier2DAdjointEngine::backward(F& f, Arr2& phys) { f.sp->backward(f.vhat, phys, st_); }
+void GenericFlow2D::backward(F& f, Arr2& phys) { f.sp->backward(f.vhat, phys, st_); }
 
-void Navier2DAdjointEngine::conv_term(const Arr2& u, F& f, int d0, int d1, double s, bool first) {
+void GenericFlow2D::conv_term(const Arr2& u, F& f, int d0, int d1, double s, bool first) {
   f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
   sp_ortho_->backward(t0_, cp_, st_);
   ew_muladd(conv_.p(), conv_.ld, s, u.p(), u.ld, cp_.p(), cp_.ld, nx_, ny_, !first, st_);
 }
 
-void Navier2DAdjointEngine::conv_finish(Arr2& out) {
+void GenericFlow2D::conv_finish(Arr2& out) {
   sp_ortho_->forward(conv_, out, st_);
   ew_dealias(out.p(), out.ld, out.rows, out.cols * out.elem, out.rows * 2 / 3, (out.cols * 2 / 3) * out.elem, st_);
 }
 
-void Navier2DAdjointEngine::div(Arr2& out) {   // steady_adjoint_eq.rs:19-24
+void GenericFlow2D::div(Arr2& out) {   // steady_adjoint_eq.rs:19-24
   F &u = field("velx"), &v = field("vely");
   u.sp->gradient(u.vhat, 1, 0, sx_, sy_, out, st_);
   v.sp->gradient(v.vhat, 0, 1, sx_, sy_, t0_, st_);
   lincomb(out, 1.0, out, 1.0, t0_);
 }
 
-void Navier2DAdjointEngine::solve_pres(const Arr2& d) {   // steady_adjoint_eq.rs:226-231
+void GenericFlow2D::solve_pres(const Arr2& d) {   // steady_adjoint_eq.rs:226-231
   F& ps = field("pseu");
   pois_->solve(d, ps.vhat, st_);
   launch_set_element(ps.vhat.p(), 0, 0.0, st_);
   if (ex_ == 2) launch_set_element(ps.vhat.p(), 1, 0.0, st_);
 }
 
-void Navier2DAdjointEngine::correct_velocity(double c) {   // steady_adjoint_eq.rs:183-192
+void GenericFlow2D::correct_velocity(double c) {   // steady_adjoint_eq.rs:183-192
   F &ps = field("pseu"), &u = field("velx"), &v = field("vely");
   Arr2 tmp(u.vhat.rows, u.vhat.cols, ex_);
   ps.sp->gradient(ps.vhat, 1, 0, sx_, sy_, t0_, st_);
@@ -350,7 +362,7 @@ void Navier2DAdjointEngine::correct_velocity(double c) {   // steady_adjoint_eq.
   dev_sync(st_);          // tmp goes out of scope
 }
 
-double Navier2DAdjointEngine::norm(const Arr2& a) {   // functions.rs:24-35
+double GenericFlow2D::norm(const Arr2& a) {   // functions.rs:24-35
   launch_sumsq(a.p(), a.ld, a.rows, a.cols * a.elem, red_.p, st_);
   dev_sync(st_);
   double h[2];
@@ -359,7 +371,7 @@ double Navier2DAdjointEngine::norm(const Arr2& a) {   // functions.rs:24-35
   return std::sqrt(h[0]);
 }
 
-double Navier2DAdjointEngine::div_norm() {
+double GenericFlow2D::div_norm() {
   div(div_);
   return norm(div_);
 }
@@ -485,6 +497,108 @@ void Navier2DAdjointEngine::update(int nsteps) {
     acc_gradient(temp_adj, 2, 0, dt * ka_, rhs_);
     acc_gradient(temp_adj, 0, 2, dt * ka_, rhs_);
     temp.sp->from_ortho(rhs_, temp.vhat, st_);
+    time_ += dt_;
+  }
+  dev_sync(st_);
+}
+
+// ================================================================================================
+// Navier2DLnse (src/navier_stokes_lnse/lnse.rs, lnse_eq.rs, meanfield.rs)
+Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc,
+                                       bool periodic, const std::string& mean_file)
+    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, dt, {"mean_velx", "mean_vely", "mean_temp"}) {
+  um_.alloc(nx, ny, 1); vm_.alloc(nx, ny, 1);
+  bool from_file = false;
+  if (!mean_file.empty()) {
+    if (FILE* f = std::fopen(mean_file.c_str(), "rb")) { std::fclose(f); from_file = true; }
+  }
+  if (from_file) {
+    // MeanFields::read (meanfield.rs:237-259): the PHYSICAL arrays of a snapshot, the lift added to the temperature
+    h5::Reader rd(mean_file);
+    const char* const grp[3][2] = {{"velx", "ux/v"}, {"vely", "uy/v"}, {"temp", "temp/v"}};
+    for (const auto& g : grp) {
+      h5::Dataset d = rd.read(g[1]);
+      RPDE_REQUIRE(d.dims.size() == 2 && (int)d.dims[0] == nx && (int)d.dims[1] == ny, std::string("mean field ") + g[1] + ": shape differs from the grid");
+      if (std::string(g[0]) == "temp") {
+        try {
+          const h5::Dataset b = rd.read("tempbc/v");
+          if (b.data.size() == d.data.size()) for (size_t i = 0; i < d.data.size(); ++i) d.data[i] += b.data[i];
+        } catch (const std::exception&) {}      // "if let Ok(x)": no lift in the file
+      }
+      set_mean_physical(g[0], d.data.data(), d.data.size());
+    }
+  } else {
+    // MeanFields::new_rbc_confined / _periodic (meanfield.rs:28-49, 130-151): no mean flow, the conduction profile
+    std::printf("File \"%s\" does not exist. Use \"%s\" meanfield.\n", mean_file.c_str(), bc.c_str());
+    const Vec y = base_coords(sp_ortho_->base(1));
+    const double height = y.back() - y.front();
+    Vec prof((size_t)nx * ny);
+    for (int i = 0; i < nx; ++i)
+      for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = -(y[j] - y.front()) / height + 0.5;
+    set_mean_physical("temp", prof.data(), prof.size());
+  }
+  refresh_mean();
+  dev_sync(st_);
+}
+
+void Navier2DLnseEngine::set_mean_physical(const std::string& name, const double* host, size_t len) {
+  RPDE_REQUIRE(name == "velx" || name == "vely" || name == "temp", "mean field: velx, vely or temp");
+  set_field_physical("mean_" + name, host, len);
+  refresh_mean();
+}
+void Navier2DLnseEngine::get_mean_physical(const std::string& name, double* host, size_t len) {
+  RPDE_REQUIRE(name == "velx" || name == "vely" || name == "temp", "mean field: velx, vely or temp");
+  get_field_physical("mean_" + name, host, len);
+}
+void Navier2DLnseEngine::refresh_mean() {
+  backward(mean("velx"), um_);
+  backward(mean("vely"), vm_);
+}
+
+void Navier2DLnseEngine::conv_lin(F& mean_f, F& f, Arr2& out) {   // lnse_eq.rs:59-110
+  conv_term(ux_, mean_f, 1, 0, 1.0, true);      // ux dM/dx + uy dM/dy
+  conv_term(uy_, mean_f, 0, 1, 1.0, false);
+  conv_term(um_, f, 1, 0, 1.0, false);          // U df/dx + V df/dy
+  conv_term(vm_, f, 0, 1, 1.0, false);
+  conv_finish(out);
+}
+
+bool Navier2DLnseEngine::exit() { return std::isnan(div_norm()); }
+
+void Navier2DLnseEngine::update(int nsteps) {
+  F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
+  const double dt = dt_;
+  for (int step = 0; step < nsteps; ++step) {
+    temp.sp->to_ortho(temp.vhat, old_[2], st_);            // buoyancy: temp.to_ortho(), no lift (lnse.rs:265)
+    backward(velx, ux_);
+    backward(vely, uy_);
+    // solve_velx (lnse_eq.rs:179-190)
+    zero(rhs_);
+    acc_to_ortho(velx, 1.0, rhs_);
+    acc_gradient(pres, 1, 0, -dt, rhs_);
+    conv_lin(mean("velx"), velx, cv_);
+    lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    hh_vel_->solve(rhs_, velx.vhat, st_);
+    // solve_vely (lnse_eq.rs:193-207)
+    zero(rhs_);
+    acc_to_ortho(vely, 1.0, rhs_);
+    acc_gradient(pres, 0, 1, -dt, rhs_);
+    lincomb(rhs_, 1.0, rhs_, dt, old_[2]);
+    conv_lin(mean("vely"), vely, cv_);
+    lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    hh_vel_->solve(rhs_, vely.vhat, st_);
+    // projection (lnse.rs:277-281); update_pres (lnse_eq.rs:140-146)
+    div(div_);
+    solve_pres(div_);
+    correct_velocity(1.0);
+    lincomb(pres.vhat, 1.0, pres.vhat, -nu_, div_);
+    acc_to_ortho(pseu, 1.0 / dt, pres.vhat);
+    // solve_temp (lnse_eq.rs:212-221)
+    zero(rhs_);
+    acc_to_ortho(temp, 1.0, rhs_);
+    conv_lin(mean("temp"), temp, cv_);
+    lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    hh_temp_->solve(rhs_, temp.vhat, st_);
     time_ += dt_;
   }
   dev_sync(st_);

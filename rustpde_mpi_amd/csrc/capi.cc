@@ -21,6 +21,7 @@ struct rpde_hholtz_adi { HholtzAdiOp* op; rpde_space2* s; };
 struct rpde_poisson { PoissonOp* op; rpde_space2* s; };
 struct rpde_hholtz { TensorHholtzOp* op; rpde_space2* s; };
 struct rpde_adjoint2d { Navier2DAdjointEngine* e; int device; };
+struct rpde_lnse2d { Navier2DLnseEngine* e; int device; };
 
 static void select_device(int device) {
 #ifndef RPDE_EMU
@@ -349,6 +350,96 @@ int rpde_adjoint2d_read(rpde_adjoint2d* h, const char* filename) {
 }
 int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(res3, "null pointer"); select_device(h->device); h->e->norm_residual(res3); })
+}
+
+// ---- Navier2DLnse (adjoint.h): the same entry points as the adjoint solver over the shared base
+static int create_lnse(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc, const char* mean_file,
+                       int device, bool periodic, rpde_lnse2d** out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(out && bc, "null pointer");
+    select_device(device);
+    auto* h = new rpde_lnse2d{nullptr, device};
+    try {
+      h->e = new Navier2DLnseEngine(nx, ny, ra, pr, dt, aspect, bc, periodic, mean_file ? mean_file : "mean.h5");
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  })
+}
+int rpde_lnse2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                const char* mean_file, int device, rpde_lnse2d** out) {
+  return create_lnse(nx, ny, ra, pr, dt, aspect, bc, mean_file, device, false, out);
+}
+int rpde_lnse2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                const char* mean_file, int device, rpde_lnse2d** out) {
+  return create_lnse(nx, ny, ra, pr, dt, aspect, bc, mean_file, device, true, out);
+}
+int rpde_lnse2d_destroy(rpde_lnse2d* h) {
+  RPDE_TRY({ if (h) { select_device(h->device); delete h->e; delete h; dev_trim(); } })
+}
+int rpde_lnse2d_set_velocity(rpde_lnse2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_velocity(amp, m, n); })
+}
+int rpde_lnse2d_set_temperature(rpde_lnse2d* h, double amp, double m, double n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_temperature(amp, m, n); })
+}
+int rpde_lnse2d_reset_time(rpde_lnse2d* h) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); h->e->reset_time(); }) }
+int rpde_lnse2d_spectral_shape(rpde_lnse2d* h, const char* name, int* rows, int* cols, int* is_complex) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && rows && cols && is_complex, "null pointer");
+    int e = 1;
+    h->e->spectral_shape(name, rows, cols, &e);
+    *is_complex = e == 2;
+  })
+}
+int rpde_lnse2d_set_field(rpde_lnse2d* h, const char* name, int space, const double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->set_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->set_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_lnse2d_get_field(rpde_lnse2d* h, const char* name, int space, double* data, size_t len) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h);
+    RPDE_REQUIRE(name && data, "null pointer");
+    select_device(h->device);
+    if (space == RPDE_PHYSICAL) h->e->get_field_physical(name, data, len);
+    else if (space == RPDE_SPECTRAL) h->e->get_field_spectral(name, data, len);
+    else fail("space must be RPDE_PHYSICAL or RPDE_SPECTRAL");
+  })
+}
+int rpde_lnse2d_set_mean(rpde_lnse2d* h, const char* name, const double* data, size_t len) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(name && data, "null pointer"); select_device(h->device); h->e->set_mean_physical(name, data, len); })
+}
+int rpde_lnse2d_get_mean(rpde_lnse2d* h, const char* name, double* data, size_t len) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(name && data, "null pointer"); select_device(h->device); h->e->get_mean_physical(name, data, len); })
+}
+int rpde_lnse2d_update(rpde_lnse2d* h, int nsteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(nsteps >= 0, "negative step count"); select_device(h->device); h->e->update(nsteps); })
+}
+int rpde_lnse2d_time(rpde_lnse2d* h, double* time) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(time, "null pointer"); *time = h->e->time(); }) }
+int rpde_lnse2d_dt(rpde_lnse2d* h, double* dt) { RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(dt, "null pointer"); *dt = h->e->dt(); }) }
+int rpde_lnse2d_param(rpde_lnse2d* h, const char* key, double* value) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(key && value, "null pointer"); *value = h->e->param(key); })
+}
+int rpde_lnse2d_exit(rpde_lnse2d* h, int* stop) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(stop, "null pointer"); select_device(h->device); *stop = h->e->exit() ? 1 : 0; })
+}
+int rpde_lnse2d_div_norm(rpde_lnse2d* h, double* norm) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(norm, "null pointer"); select_device(h->device); *norm = h->e->div_norm(); })
+}
+int rpde_lnse2d_write(rpde_lnse2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->write(filename); })
+}
+int rpde_lnse2d_read(rpde_lnse2d* h, const char* filename) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->read(filename); })
 }
 
 int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n) {

@@ -256,3 +256,115 @@ def test_emu_adjoint_callback_writes_the_flow_file(emu_lib, tmp_path, monkeypatc
     assert (tmp_path / "data" / "adjoint00000.03.h5").exists()
     out = capfd.readouterr().out
     assert "|div| =" in out and "|U| =" in out and "|T| =" in out
+
+
+# ================================================================================================ Navier2DLnse
+def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=True, tol=1e-10, tol_p=1e-8):
+    """Engine vs oracle after every update, with a non-trivial mean flow (a convection roll) on top of the conduction
+    profile: u, v, T to `tol`, pres / pseu to `tol_p` (the Poisson solve's amplified eigenvector round-off)."""
+    from oracle import lnse as L
+    mk_e = R.Navier2DLnse.new_periodic if periodic else R.Navier2DLnse.new_confined
+    mk_o = L.Navier2DLnse.new_periodic if periodic else L.Navier2DLnse.new_confined
+    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    assert rel(nav.mean_temp.v, ora.mean.temp.v) < 1e-13                  # the default mean: conduction profile, no flow
+    assert np.abs(nav.mean_velx.v).max() == 0.0
+    if mean_flow:
+        x, y = ora.velx.x
+        xs, ys = (x - x[0]) / (x[-1] - x[0]), (y - y[0]) / (y[-1] - y[0])
+        um = 0.3 * np.sin(np.pi * xs)[:, None] * np.cos(np.pi * ys)[None, :]
+        vm = -0.3 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :]
+        tm = ora.mean.temp.v + 0.1 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :]
+        for name, arr in (("velx", um), ("vely", vm), ("temp", tm)):
+            getattr(nav, "mean_" + name).v = arr
+            ora.mean.set_physical(name, arr)
+        assert rel(nav.mean_velx.v, ora.mean.velx.v) < 1e-12
+    for z in (nav, ora):
+        z.set_velocity(0.1, 2.0, 1.0)
+        z.set_temperature(0.1, 1.0, 2.0)
+    worst = {}
+    for s in range(steps):
+        nav.update(1)
+        ora.update()
+        got, want = nav.spectral_fields(), ora.spectral_fields()
+        for k in want:
+            e = rel(got[k], want[k])
+            worst[k] = max(worst.get(k, 0.0), e)
+            assert e < (tol_p if k in ("pres", "pseu") else tol), (nx, ny, periodic, s, k, e)
+    assert abs(nav.div_norm() - ora.div_norm()) < 1e-8 * max(ora.div_norm(), 1e-12)
+    assert nav.exit() == ora.exit() and abs(nav.get_time() - ora.time) < 1e-12
+    print("lnse", nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
+    return worst
+
+
+def test_oracle_lnse_is_the_linearisation_of_navier2d():
+    """What pins the oracle's LNSE step: it IS the linearisation of Navier2D::update (oracle/navier.py, itself pinned by the
+    critical Rayleigh numbers) about the conduction state (mean: no flow, T = the lift).  With N_eps = Navier2D started from
+    eps * q and N_0 = Navier2D started from rest (its lift alone: the hydrostatic part the projection absorbs), the divided
+    difference (N_eps - N_0) / eps equals the LNSE evolution of q to 1e-4 relative, and the part of the mismatch that is the
+    quadratic term halves when eps halves."""
+    from oracle import lnse as L
+    n, ra, dt, steps = 33, 1e5, 0.01, 5
+
+    def navier(eps):
+        nav = N.Navier2D.new_confined(n, n, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+        nav.set_velocity(eps, 2.0, 1.0)
+        nav.set_temperature(eps, 1.0, 2.0)
+        for _ in range(steps):
+            nav.update()
+        return {k: getattr(nav, k).vhat.copy() for k in ("velx", "vely", "temp")}
+
+    lin = L.Navier2DLnse.new_confined(n, n, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    lin.set_velocity(1.0, 2.0, 1.0)
+    lin.set_temperature(1.0, 1.0, 2.0)
+    for _ in range(steps):
+        lin.update()
+    base = navier(0.0)
+    mism = []
+    for eps in (1e-3, 5e-4):
+        ne = navier(eps)
+        mism.append({k: np.abs((ne[k] - base[k]) / eps - getattr(lin, k).vhat).max() / np.abs(getattr(lin, k).vhat).max() for k in base})
+    # measured: temp 6.4e-5 -> 3.2e-5 (the quadratic term, linear in eps); velx / vely 1.5e-5 / 1.3e-5 at both eps -- the flow
+    # Navier2D develops from rest (its lift's discrete hydrostatic imbalance, |u| ~ 1e-5) advects the perturbation, a term the
+    # linearisation about an exactly resting mean does not have
+    for k in mism[0]:
+        assert mism[0][k] < 2e-4, (k, mism)
+        assert mism[1][k] <= 1.01 * mism[0][k], (k, mism)
+    assert 1.8 < mism[0]["temp"] / mism[1]["temp"] < 2.2, mism
+
+
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (65, 33, False), (32, 33, True)])
+def test_emu_lnse_step_parity(emu_lib, nx, ny, periodic):
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=4)
+
+
+def test_emu_lnse_mean_from_a_snapshot_and_errors(emu_lib, tmp_path):
+    """MeanFields::read_from_confined (meanfield.rs:92-127, 237-259): ux/v, uy/v, temp/v + tempbc/v of a Navier2D snapshot."""
+    src = R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, init_random=None)
+    src.set_velocity(0.1, 1.0, 1.0)
+    src.set_temperature(0.1, 1.0, 1.0)
+    src.update(3)
+    fn = str(tmp_path / "mean.h5")
+    src.write(fn)
+    nav = R.Navier2DLnse.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, mean_file=fn)
+    from tests.h5classic import File
+    f = File(fn).datasets
+    assert rel(nav.mean_velx.v, f["ux/v"]) < 1e-12 and rel(nav.mean_temp.v, f["temp/v"] + f["tempbc/v"]) < 1e-12
+    nav.set_velocity(0.05, 1.0, 1.0)
+    nav.update(2)
+    assert np.isfinite(nav.div_norm()) and not nav.exit()
+    with pytest.raises(R.RpdeError, match="shape differs"):
+        R.Navier2DLnse.new_confined(33, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, mean_file=fn)
+    with pytest.raises(R.RpdeError, match="not supported"):
+        R.Navier2DLnse.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "hc", library=emu_lib, mean_file="/nonexistent")
+    with pytest.raises(R.RpdeError, match="velx, vely or temp"):
+        R.Navier2DLnse._Mean(nav, "pres").v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2)])
+def test_gpu_lnse_step_parity(hip_lib, nx, ny, periodic, steps):
+    if nx >= 1025:
+        check_lnse_parity(hip_lib, nx, ny, periodic, steps, ra=1e7, dt=1e-3)
+    else:
+        check_lnse_parity(hip_lib, nx, ny, periodic, steps)

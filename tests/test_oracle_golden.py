@@ -202,8 +202,9 @@ def test_full_and_parity_eigenbases_agree_after_transient():
         assert np.linalg.norm(fa[k] - fb[k]) / np.linalg.norm(fa[k]) < 1e-11
 
 
-def test_engine_is_as_close_to_the_reference_setup_as_that_setup_is_to_itself():
-    """Paperwork of DESIGN.md section 4.  tests/golden/headline_4097_two_reference_setups.json: the oracle in the REFERENCE's
+def test_committed_records_agree_documentation_only():
+    """NOT a parity test: it compares two committed files with each other and cannot fail from a code change.  It keeps the
+    figures DESIGN.md section 4 quotes consistent with the records they come from.  tests/golden/headline_4097_two_reference_setups.json: the oracle in the REFERENCE's
     setup (one dgeev of the whole x operator) run twice at 4097^2, in two processes with different BLAS thread counts -- the
     two runs differ from each other by p 2.1e-3 after one step and 1.7e-9 after 200 (dgeev's round-off, amplified by the 1e10
     of poisson.rs:84-87).  profiles/r04_bench.json: the engine on the GPU against run A (`parity_independent_golden`).  At
