@@ -23,54 +23,13 @@ CHEB_DIRICHLET_NEUMANN = "cheb_dirichlet_neumann"
 FOURIER_R2C = "fourier_r2c"
 
 
-_POOL = None
-_LANE_MIN = 1 << 19      # arrays below this many elements run on the calling thread
-
-
-def _lane_workers():
-    """Threads for the lane functions: the reference runs its lanes on rayon's pool (`*_par` calls of field.rs / the solvers);
-    here every lane function acts on the lanes of an array independently, so blocks of lanes go to a thread pool (NumPy
-    releases the GIL in its inner loops).  The results are bit-identical to the single-thread run: no lane sees another.
-    WORKERS = 1 (bench.py's single-thread leg) runs everything on the calling thread."""
-    import os
-    if WORKERS == 1:
-        return 1
-    n = os.cpu_count() or 1
-    return max(1, min(n if WORKERS < 0 else WORKERS, 64))
-
-
 def _axis0(fn, x, axis, *a, **k):
-    """Run lane function ``fn`` (written for axis 0) along ``axis``."""
-    nw = _lane_workers()
-    lanes = x.shape[1 - axis] if x.ndim == 2 else 0
-    if nw == 1 or x.ndim != 2 or x.size < _LANE_MIN or lanes < 4 * nw:
-        if axis == 0:
-            return fn(x, *a, **k)
-        return np.ascontiguousarray(fn(np.ascontiguousarray(x.T), *a, **k).T)
-    global _POOL
-    if _POOL is None or _POOL._max_workers < nw:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=nw)
-    edges = np.linspace(0, lanes, nw + 1).astype(int)
-    blocks = [(int(edges[i]), int(edges[i + 1])) for i in range(nw) if edges[i + 1] > edges[i]]
-
-    def run(b):
-        lo, hi = b
-        if axis == 0:
-            return fn(np.ascontiguousarray(x[:, lo:hi]), *a, **k)
-        return fn(np.ascontiguousarray(x[lo:hi].T), *a, **k)
-
-    parts = list(_POOL.map(run, blocks))
-    n_out = parts[0].shape[0]
+    """Run lane function ``fn`` (written for axis 0) along ``axis``.  (Round 5 tried blocks of lanes on a thread pool:
+    bit-identical, 10 % faster in `differentiate` on 64 cores, and five times SLOWER in the Helmholtz sweeps, whose lane
+    functions are Python loops over the line -- GIL-bound; not kept.)"""
     if axis == 0:
-        out = np.empty((n_out, lanes), dtype=parts[0].dtype)
-        for (lo, hi), r in zip(blocks, parts):
-            out[:, lo:hi] = r
-    else:
-        out = np.empty((lanes, n_out), dtype=parts[0].dtype)
-        for (lo, hi), r in zip(blocks, parts):
-            out[lo:hi] = r.T
-    return out
+        return fn(x, *a, **k)
+    return np.ascontiguousarray(fn(np.ascontiguousarray(x.T), *a, **k).T)
 
 
 class Base:

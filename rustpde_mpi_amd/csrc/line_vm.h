@@ -839,10 +839,14 @@ __device__ __forceinline__ double dpp_f64(double old, double x) {
 // of DPP moves (shifts inside a row and the wave shift; the row broadcasts keep rows masked and need `old`)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64z(double x) {
+#ifdef RPDE_DPP_OLD            // experiment build only (tools/r05_call4.sh): the form of round 4
+  return dpp_f64<CTRL, 0xF>(0.0, x);
+#else
   const long long xb = __double_as_longlong(x);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)xb, CTRL, 0xF, 0xF, true);
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(xb >> 32), CTRL, 0xF, 0xF, true);
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+#endif
 }
 template <int ORDER, int CTRL, int ROW_MASK>
 __device__ __forceinline__ Affine<ORDER> affine_dpp(const Affine<ORDER>& a) {

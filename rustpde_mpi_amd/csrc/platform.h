@@ -236,7 +236,12 @@ class ArenaT {
   bool add_slab(size_t n, int dev) {
     bool first = true;
     for (auto& s : slabs_) if (s.base && s.device == dev) first = false;
+#ifdef RPDE_FIRST_SLAB_1GB     // experiment build only (tools/r05_call4.sh): the slab sizes of round 4
+    const size_t size = std::max(kSlabBytes, round_up(n, kHuge));
+    (void)first;
+#else
     const size_t size = std::max(first ? kFirstSlabBytes : kSlabBytes, round_up(n, kHuge));
+#endif
     void* p = Backend::raw_alloc(size, dev);
     if (!p) return false;
     Slab* sl = nullptr;

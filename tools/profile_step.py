@@ -3,6 +3,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rustpde_mpi_amd as R
+if os.environ.get("RPDE_TOOLS_LIB"):      # an experiment build (rustpde_mpi_amd.build variant): librustpde_hip_<variant>.so
+    from rustpde_mpi_amd._capi import Lib
+    R._lib = Lib(os.path.join(os.path.dirname(R.LIB_PATH), os.environ["RPDE_TOOLS_LIB"]))
 
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
 ny = int(sys.argv[2]) if len(sys.argv) > 2 else 4097
