@@ -247,7 +247,7 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
       frag(st, 2, a0, b0);
       mma(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
-      if (k0 + 2 * BK < K) gload(k0 + 2 * BK);
+      if (k0 + 2 * BK < K) gload(k0 + 2 * BK);   // (one MFMA group earlier, right behind the LDS stores: 1.5 % slower, round 5 call 5)
       frag(st, 3, a1, b1);
       mma(a0, b0);
       __builtin_amdgcn_sched_barrier(0);

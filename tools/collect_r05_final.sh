@@ -8,7 +8,7 @@ for f in r05_bench.json r05_bench_profiled.json r05_kernel_stats.csv r05_trace_b
 done
 c=$(cut -c1-7 $O/commit.txt 2>/dev/null)
 cp $O/commit.txt $P/r05_commit.txt
-cp $O/pytest_gpu_final.txt $P/r05_pytest_gpu_final_${c}.txt
+cp $O/pytest_gpu_final.txt $P/r05_pytest_gpu_full_final_${c}.txt
 for f in bench bench_profiled pmc_traffic schedule; do cp $O/$f.json $P/r05_$f.json 2>/dev/null; done
 for f in pmc_traffic sq_counters profile_step kernel_resources; do cp $O/$f.txt $P/r05_$f.txt 2>/dev/null; done
 cp $O/trace_by_tag.csv $P/r05_trace_by_tag.csv 2>/dev/null

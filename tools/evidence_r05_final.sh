@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round-5 evidence, headline part, on the FINAL sources (the first evidence run, tools/evidence_r05.sh, predates the LNSE
-# solver and the completed 4097^2 same-inputs golden: its per-configuration bench lines, kernel stats of configs 2 / 3 / 5 and
-# the full GPU test pass stay valid -- the kernels of the time step did not change after it): the same-inputs goldens at
-# 4097^2 and 2049^2, PMC traffic and SQ counter passes, the bench line, rocprofv3 kernel trace + stats of the bench command.
+# solver and the completed 4097^2 same-inputs golden: its per-configuration bench lines and kernel stats of configs 2 / 3 / 5
+# stay valid -- the kernels of the time step did not change after it): the full GPU test suite (with the
+# same-inputs goldens at 4097^2 and 2049^2 and the LNSE tests), PMC traffic and SQ counter passes, the bench line, rocprofv3 kernel trace + stats of the bench command.
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/r05f
 rm -rf $O; mkdir -p $O
 cat $R/.evidence_commit > $O/commit.txt 2>/dev/null
 export EVIDENCE_COMMIT=$(cat $O/commit.txt 2>/dev/null)
-(timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_adjoint.py tests/test_arena.py -m gpu -q -s -k "shared_basis or lnse or adjoint or hholtz or arena or guard or mapping" 2>&1 | grep -v "socket.cpp\|amdgpu.ids\|Gloo\] Rank" | tail -80) > $O/pytest_gpu_final.txt
+(timeout 1800 python -m pytest tests -m gpu -q -s --durations=8 2>&1 | grep -v "socket.cpp\|amdgpu.ids\|Gloo\] Rank" | tail -150) > $O/pytest_gpu_final.txt
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_write.log 2>&1
