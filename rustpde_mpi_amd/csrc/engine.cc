@@ -951,7 +951,18 @@ void Navier2DEngine::add_hc_hholtz(const double* in, double* out, int ncols) {
   l.type = Launch::kPdmaCols;
   l.tag = "C4 y: hholtz-y temp (PdmaPlus2 columns)";
   l.pc = PdmaColsArgs{in, ldx_, out, ldx_, my_, ncols, yT.pv0.p, yT.pv1.p, yT.pv2.p, hh_temp_->pdma[1].tabs(), flagp()};
-  l.bytes = 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: one read, one write (the intermediate ze rows are written and read back)
+  // round 5: the blocked form (pdma.h: blocks of 32 rows from zero inflow + tabulated homogeneous solutions, 8320 workgroups at
+  // 4097 x 4095 instead of 65 waves); RPDE_HC_BLOCKED=0: one thread per column walking all rows (A/B, tests/test_hc.py)
+  const char* eb = std::getenv("RPDE_HC_BLOCKED");
+  if (!eb || std::atoi(eb) != 0) {
+    PdmaDev& pd = hh_temp_->pdma[1];
+    if (!pd.NB) pd.upload_blocks();
+    if (pdma_ws_.n < pdma_blk_ws_doubles(my_, ldx_)) pdma_ws_.alloc(pdma_blk_ws_doubles(my_, ldx_));
+    l.pc.blk = pd.blk();
+    l.pc.ws = pdma_ws_.p;
+    l.pc.ldw = ldx_;
+  }
+  l.bytes = 2.0 * 8.0 * (double)my_ * ncols;   // algorithmic: one read, one write (the intermediate rows are written and read back)
   step_.push_back(l);
 }
 void Navier2DEngine::add_hc_hholtz_sharded(const double* in, double* out, int rows_x, int elem, bool spec) {

@@ -184,6 +184,7 @@ class Navier2DEngine {
   void run_col_diff(ColDiffArgs a, unsigned long long* site);   // column scans, one rank or rows split over the ranks (colscan.h)
   ColHhDev colhh_vel_, colhh_temp_;   // Helmholtz-y tables of this rank's rows
   DBuf colsumm_, colsend_, colgath_, halo_s_, halo_r_;
+  DBuf pdma_ws_;                      // "hc": workspace of the blocked PdmaPlus2 column solve (pdma.h)
   void scatter_rows_yx(const double* full, long ldf, DBuf& dst, int rows, int ncols);
   void scatter_rows_xy(const double* full, long ldf, DBuf& dst, int rows, int ncols, bool spec);
   void gather_rows(const double* local, long ld, int rows_global, const std::vector<int>& part,

@@ -199,6 +199,42 @@ PdmaTables pdma_factor(const Bands7& mt) {
   return t;
 }
 
+PdmaBlockTables pdma_block_tables(const PdmaTables& t, int BR) {
+  const int n = t.n, NB = (n + BR - 1) / BR;
+  PdmaBlockTables o;
+  o.NB = NB;
+  for (Vec* v : {&o.phi1, &o.phi2, &o.psi1, &o.psi2, &o.psi3, &o.psi4}) v->assign((size_t)n + 4, 0.0);
+  o.fm.assign((size_t)4 * NB, 0.0);
+  o.bm.assign((size_t)16 * NB, 0.0);
+  for (int b = 0; b < NB; ++b) {
+    const int j0 = b * BR, j1 = std::min(n, j0 + BR);
+    // forward: z_j = (- l2_j z_{j-2} - ka_j z_{j-1}) imu_j with (z_{j0-1}, z_{j0-2}) = (1, 0) and (0, 1)
+    for (int s = 0; s < 2; ++s) {
+      Vec& phi = s == 0 ? o.phi1 : o.phi2;
+      double z1 = s == 0 ? 1.0 : 0.0, z2 = s == 0 ? 0.0 : 1.0;
+      for (int j = j0; j < j1; ++j) {
+        const double z = (-t.l2[j] * z2 - t.ka[j] * z1) * t.imu[j];
+        phi[j] = z;
+        z2 = z1; z1 = z;
+      }
+      o.fm[4 * b + 0 + s] = z1;     // z_{j1-1} (a one-row block: z_{j1-2} = z_{j0-1} = the inflow itself)
+      o.fm[4 * b + 2 + s] = z2;
+    }
+    // backward: x_i = - al_i x_{i+1} - be_i x_{i+2} - ga_i x_{i+3} - de_i x_{i+4} with x_{j1 + k} = delta_{k s}
+    for (int s = 0; s < 4; ++s) {
+      Vec& psi = s == 0 ? o.psi1 : s == 1 ? o.psi2 : s == 2 ? o.psi3 : o.psi4;
+      double x[4] = {s == 0 ? 1.0 : 0.0, s == 1 ? 1.0 : 0.0, s == 2 ? 1.0 : 0.0, s == 3 ? 1.0 : 0.0};   // x_{i+1} .. x_{i+4}
+      for (int i = j1 - 1; i >= j0; --i) {
+        const double v = -t.al[i] * x[0] - t.be[i] * x[1] - t.ga[i] * x[2] - t.de[i] * x[3];
+        psi[i] = v;
+        x[3] = x[2]; x[2] = x[1]; x[1] = x[0]; x[0] = v;
+      }
+      for (int k = 0; k < 4; ++k) o.bm[16 * b + 4 * k + s] = x[k];   // x_{j0 + k} (short blocks: the inflows shine through)
+    }
+  }
+  return o;
+}
+
 FromOrthoTables from_ortho_tables(const Base& b) {
   RPDE_REQUIRE(b.is_two_term(), "from_ortho tables of the stride-2 form need a two-term stencil");
   const int m = b.m;

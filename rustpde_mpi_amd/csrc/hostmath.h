@@ -80,6 +80,10 @@ Bands7 from_ortho7(const Base& b);                        // S^T S (offsets -2 .
 //   ze_i = (rhs_i - l2_{i-2} ze_{i-2} - ka_i ze_{i-1}) imu_i ,   x_i = ze_i - al_i x_{i+1} - be_i x_{i+2} - ga_i x_{i+3} - de_i x_{i+4}
 struct PdmaTables { int n = 0; Vec l2, ka, imu, al, be, ga, de; };   // l2 is shifted: l2[i] = a[i, i-2]
 PdmaTables pdma_factor(const Bands7& m);
+// tables of the blocked column form (pdma.h PdmaBlkTabs): homogeneous solutions of the two recurrences restarted at every block
+// of BR rows, and the block transfer matrices of the end states
+struct PdmaBlockTables { int NB = 0; Vec phi1, phi2, fm, psi1, psi2, psi3, psi4, bm; };
+PdmaBlockTables pdma_block_tables(const PdmaTables& t, int BR);
 
 // Tables of the column-scan Helmholtz solve (colscan.h) for one swept Fdma and its B2 preconditioner,
 // rows cut into blocks of BR: per-row coefficients (zero-padded to NB * BR + 4), the block transfer

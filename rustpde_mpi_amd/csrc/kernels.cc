@@ -988,8 +988,31 @@ __global__ __launch_bounds__(64) void pdma_cols_kernel(const PdmaColsArgs a) {
   if (c >= a.ncols) return;
   if (pdma_column(a, c) && a.nanflag) *a.nanflag = 1;
 }
+// blocked form (pdma.h): PH 0 forward from zero inflow, 2 forward correction + backward from zero inflow, 4 backward correction:
+// one thread per column of one block; PH 1 / 3: the serial carries, one thread per column
+template <int PH>
+__global__ __launch_bounds__(64) void pdma_cols_blk_kernel(const PdmaColsArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.ncols) return;
+  if constexpr (PH == 0) pdma_blk_fwd_local(a, (int)blockIdx.y, c);
+  else if constexpr (PH == 1) pdma_blk_fwd_carry(a, c);
+  else if constexpr (PH == 2) pdma_blk_mid(a, (int)blockIdx.y, c);
+  else if constexpr (PH == 3) pdma_blk_bwd_carry(a, c);
+  else { if (pdma_blk_final(a, (int)blockIdx.y, c) && a.nanflag) *a.nanflag = 1; }
+}
 void launch_pdma_cols(const PdmaColsArgs& a, Stream& st) {
   if (a.n <= 0 || a.ncols <= 0) return;
+  if (a.blk.phi1) {
+    RPDE_REQUIRE(a.ws && a.ldw >= a.ncols && a.blk.NB == (a.n + kPdmaBR - 1) / kPdmaBR, "pdma_cols: workspace / tables of the blocked form");
+    const dim3 tiles((a.ncols + 63) / 64), blocks((a.ncols + 63) / 64, a.blk.NB);
+    hipLaunchKernelGGL(pdma_cols_blk_kernel<0>, blocks, dim3(64), 0, st.s, a);
+    hipLaunchKernelGGL(pdma_cols_blk_kernel<1>, tiles, dim3(64), 0, st.s, a);
+    hipLaunchKernelGGL(pdma_cols_blk_kernel<2>, blocks, dim3(64), 0, st.s, a);
+    hipLaunchKernelGGL(pdma_cols_blk_kernel<3>, tiles, dim3(64), 0, st.s, a);
+    hipLaunchKernelGGL(pdma_cols_blk_kernel<4>, blocks, dim3(64), 0, st.s, a);
+    RPDE_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(pdma_cols_kernel, dim3((a.ncols + 63) / 64), dim3(64), 0, st.s, a);   // one wave per workgroup: the columns spread over as many CUs as there are waves
   RPDE_HIP(hipGetLastError());
 }
@@ -1259,6 +1282,15 @@ void launch_sten3_rows(const Sten3RowsArgs& a, Stream&) {
     for (int c = 0; c < a.ncols; ++c) sten3_rows_point(a, j, c);
 }
 void launch_pdma_cols(const PdmaColsArgs& a, Stream&) {
+  if (a.blk.phi1) {   // the blocked form, phase by phase like the device
+    RPDE_REQUIRE(a.ws && a.ldw >= a.ncols && a.blk.NB == (a.n + kPdmaBR - 1) / kPdmaBR, "pdma_cols: workspace / tables of the blocked form");
+    for (int b = 0; b < a.blk.NB; ++b) for (int c = 0; c < a.ncols; ++c) pdma_blk_fwd_local(a, b, c);
+    for (int c = 0; c < a.ncols; ++c) pdma_blk_fwd_carry(a, c);
+    for (int b = 0; b < a.blk.NB; ++b) for (int c = 0; c < a.ncols; ++c) pdma_blk_mid(a, b, c);
+    for (int c = 0; c < a.ncols; ++c) pdma_blk_bwd_carry(a, c);
+    for (int b = 0; b < a.blk.NB; ++b) for (int c = 0; c < a.ncols; ++c) if (pdma_blk_final(a, b, c) && a.nanflag) *a.nanflag = 1;
+    return;
+  }
   for (int c = 0; c < a.ncols; ++c)
     if (pdma_column(a, c) && a.nanflag) *a.nanflag = 1;
 }

@@ -50,7 +50,14 @@ AxisTables::AxisTables(const Base& b) : base(b) {
 
 void PdmaDev::upload(const PdmaTables& t) {
   n = t.n;
+  host = t;
   l2.upload(t.l2); ka.upload(t.ka); imu.upload(t.imu); al.upload(t.al); be.upload(t.be); ga.upload(t.ga); de.upload(t.de);
+}
+void PdmaDev::upload_blocks() {
+  const PdmaBlockTables b = pdma_block_tables(host, kPdmaBR);
+  NB = b.NB;
+  phi1.upload(b.phi1); phi2.upload(b.phi2); fm.upload(b.fm);
+  psi1.upload(b.psi1); psi2.upload(b.psi2); psi3.upload(b.psi3); psi4.upload(b.psi4); bm.upload(b.bm);
 }
 
 FdmaDev upload_fdma(const FdmaTables& t, int slot_len) {

@@ -18,9 +18,13 @@ inline long pitch(long n) { return (n + 15) & ~15L; }
 // factorised seven-diagonal system on the device (hostmath.h PdmaTables, pdma.h)
 struct PdmaDev {
   DBuf l2, ka, imu, al, be, ga, de;
-  int n = 0;
+  DBuf phi1, phi2, fm, psi1, psi2, psi3, psi4, bm;   // the blocked column form (pdma.h PdmaBlkTabs), uploaded by upload_blocks
+  int n = 0, NB = 0;
+  PdmaTables host;                                   // kept for upload_blocks
   void upload(const PdmaTables& t);
+  void upload_blocks();
   PdmaTabs tabs() const { return PdmaTabs{l2.p, ka.p, imu.p, al.p, be.p, ga.p, de.p, n}; }
+  PdmaBlkTabs blk() const { return PdmaBlkTabs{phi1.p, phi2.p, fm.p, psi1.p, psi2.p, psi3.p, psi4.p, bm.p, NB}; }
 };
 
 // device-resident tables of one 1-D basis

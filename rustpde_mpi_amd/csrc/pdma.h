@@ -29,6 +29,20 @@ struct Sten3RowsArgs {
   int row0, nrows;               // rows [row0, row0 + nrows) of the output are produced
 };
 
+// Blocked form of pdma_cols (round 5): the two recurrences are linear with column-independent coefficients, so a block of
+// kPdmaBR rows solves from ZERO inflow and is corrected afterwards with its exact inflow times tabulated homogeneous
+// solutions -- z_j = zp_j + a Phi1_j + b Phi2_j (two inflow values, forward), x_i = xp_i + sum_k c_k Psi_k,i (four, backward).
+// The inflows of all blocks come from a serial pass over the blocks' end states with tabulated block transfer matrices
+// (2 x 2 forward, 4 x 4 backward; one thread per column, NB steps).  Five launches, every one with (blocks x column tiles)
+// workgroups or one thread per column of NB steps: 8320 workgroups at 4097 x 4095 instead of 65 waves.
+constexpr int kPdmaBR = 32;
+struct PdmaBlkTabs {
+  const double *phi1 = nullptr, *phi2 = nullptr;   // n each: forward homogeneous solutions, restarted at every block
+  const double* fm = nullptr;                      // NB x 4: forward transfer (z_last, z_last-1) <- (a, b), row-major 2 x 2
+  const double *psi1 = nullptr, *psi2 = nullptr, *psi3 = nullptr, *psi4 = nullptr;   // n each: backward homogeneous solutions
+  const double* bm = nullptr;                      // NB x 16: backward transfer (x_j0 .. x_j0+3) <- (c1 .. c4), row-major 4 x 4
+  int NB = 0;
+};
 struct PdmaColsArgs {
   const double* in; long ldi;    // n rows (with B2: the first n of the n + 2 orthonormal rows)
   double* out; long ldo;         // n rows
@@ -36,7 +50,11 @@ struct PdmaColsArgs {
   const double *t0, *t1, *t2;    // B2 rows (taps j, j + 2, j + 4), or null: the input is the right-hand side itself
   PdmaTabs f;
   int* nanflag;                  // raised when a NaN is stored (Integrate::exit on the device), may be null
+  PdmaBlkTabs blk{};             // blk.phi1 != null: the blocked form
+  double* ws = nullptr;          // workspace of the blocked form: 12 NB rows of ldw doubles (end states 2 + 4, inflows 2 + 4 per block)
+  long ldw = 0;
 };
+RPDE_HD inline size_t pdma_blk_ws_doubles(int n, long ldw) { return (size_t)12 * ((n + kPdmaBR - 1) / kPdmaBR) * (size_t)ldw; }
 
 struct Sten3LinesArgs {
   const double* in; long ldi; double* out; long ldo;
@@ -122,6 +140,120 @@ RPDE_HD inline bool pdma_column(const PdmaColsArgs& a, int c) {
     }
 #pragma unroll
     for (int q = 0; q < B; ++q) zc[q] = zn[q];
+  }
+  return bad;
+}
+
+// ---- blocked form: block b = rows [b BR, min((b + 1) BR, n)), column c.  Workspace rows (each ldw doubles):
+//   S1 = ws + (2 b + k) ldw            forward end state k = 0: z_last, 1: z_last-1       (NB x 2 rows)
+//   I1 = S1 + 2 NB ldw                 forward inflow of block b: (z_{j0-1}, z_{j0-2})
+//   S2 = I1 + 2 NB ldw                 backward end state k = 0 .. 3: x_{j0 + k}          (NB x 4 rows)
+//   I2 = S2 + 4 NB ldw                 backward inflow of block b: x_{j1 + k}
+RPDE_HD inline double* pdma_ws_s1(const PdmaColsArgs& a) { return a.ws; }
+RPDE_HD inline double* pdma_ws_i1(const PdmaColsArgs& a) { return a.ws + (size_t)2 * a.blk.NB * a.ldw; }
+RPDE_HD inline double* pdma_ws_s2(const PdmaColsArgs& a) { return a.ws + (size_t)4 * a.blk.NB * a.ldw; }
+RPDE_HD inline double* pdma_ws_i2(const PdmaColsArgs& a) { return a.ws + (size_t)8 * a.blk.NB * a.ldw; }
+
+// forward from zero inflow: B2 rows + two-term recurrence; zp -> out, end state -> S1
+RPDE_HD inline void pdma_blk_fwd_local(const PdmaColsArgs& a, int b, int c) {
+  constexpr int BR = kPdmaBR;
+  const int n = a.n, j0 = b * BR;
+  const double* in = a.in + c;
+  double* out = a.out + c;
+  double cur[BR + 4];
+#pragma unroll
+  for (int q = 0; q < BR + 4; ++q) cur[q] = (j0 + q < n) ? in[(long)(j0 + q) * a.ldi] : 0.0;
+  double z1 = 0.0, z2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < BR; ++q) {
+    const int j = j0 + q;
+    if (j < n) {
+      double r = cur[q];
+      if (a.t0) {
+        r = a.t0[j] * cur[q] + a.t1[j] * cur[q + 2];
+        r += a.t2[j] * cur[q + 4];
+      }
+      const double z = (r - a.f.l2[j] * z2 - a.f.ka[j] * z1) * a.f.imu[j];
+      out[(long)j * a.ldo] = z;
+      z2 = z1; z1 = z;
+    }
+  }
+  double* s1 = pdma_ws_s1(a) + (size_t)2 * b * a.ldw + c;
+  s1[0] = z1; s1[a.ldw] = z2;
+}
+// inflows of every block of one column (forward): a serial pass over the end states
+RPDE_HD inline void pdma_blk_fwd_carry(const PdmaColsArgs& a, int c) {
+  double a1 = 0.0, a2 = 0.0;
+  const double* s1 = pdma_ws_s1(a) + c;
+  double* i1 = pdma_ws_i1(a) + c;
+  for (int b = 0; b < a.blk.NB; ++b) {
+    i1[(size_t)(2 * b) * a.ldw] = a1; i1[(size_t)(2 * b + 1) * a.ldw] = a2;
+    const double* m = a.blk.fm + 4 * b;
+    const double e1 = s1[(size_t)(2 * b) * a.ldw], e2 = s1[(size_t)(2 * b + 1) * a.ldw];
+    const double n1 = e1 + m[0] * a1 + m[1] * a2, n2 = e2 + m[2] * a1 + m[3] * a2;
+    a1 = n1; a2 = n2;
+  }
+}
+// exact forward values of the block (in registers), then the backward recurrence from zero inflow; xp -> out, end state -> S2
+RPDE_HD inline void pdma_blk_mid(const PdmaColsArgs& a, int b, int c) {
+  constexpr int BR = kPdmaBR;
+  const int n = a.n, j0 = b * BR;
+  double* out = a.out + c;
+  const double* i1 = pdma_ws_i1(a) + (size_t)2 * b * a.ldw + c;
+  const double a1 = i1[0], a2 = i1[a.ldw];
+  double z[BR];
+#pragma unroll
+  for (int q = 0; q < BR; ++q) {
+    const int j = j0 + q;
+    z[q] = (j < n) ? out[(long)j * a.ldo] + a1 * a.blk.phi1[j] + a2 * a.blk.phi2[j] : 0.0;
+  }
+  double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0;
+#pragma unroll
+  for (int q = BR - 1; q >= 0; --q) {
+    const int i = j0 + q;
+    if (i < n) {
+      const double x = z[q] - a.f.al[i] * x1 - a.f.be[i] * x2 - a.f.ga[i] * x3 - a.f.de[i] * x4;
+      out[(long)i * a.ldo] = x;
+      x4 = x3; x3 = x2; x2 = x1; x1 = x;
+    }
+  }
+  double* s2 = pdma_ws_s2(a) + (size_t)4 * b * a.ldw + c;
+  s2[0] = x1; s2[a.ldw] = x2; s2[2 * a.ldw] = x3; s2[3 * a.ldw] = x4;
+}
+RPDE_HD inline void pdma_blk_bwd_carry(const PdmaColsArgs& a, int c) {
+  double cc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* s2 = pdma_ws_s2(a) + c;
+  double* i2 = pdma_ws_i2(a) + c;
+  for (int b = a.blk.NB - 1; b >= 0; --b) {
+    for (int k = 0; k < 4; ++k) i2[(size_t)(4 * b + k) * a.ldw] = cc[k];
+    const double* m = a.blk.bm + 16 * b;
+    double nn[4];
+    for (int k = 0; k < 4; ++k) {
+      double v = s2[(size_t)(4 * b + k) * a.ldw];
+      for (int q = 0; q < 4; ++q) v += m[4 * k + q] * cc[q];
+      nn[k] = v;
+    }
+    for (int k = 0; k < 4; ++k) cc[k] = nn[k];
+  }
+}
+RPDE_HD inline bool pdma_blk_final(const PdmaColsArgs& a, int b, int c) {
+  constexpr int BR = kPdmaBR;
+  const int n = a.n, j0 = b * BR;
+  double* out = a.out + c;
+  const double* i2 = pdma_ws_i2(a) + (size_t)4 * b * a.ldw + c;
+  const double c1 = i2[0], c2 = i2[a.ldw], c3 = i2[2 * a.ldw], c4 = i2[3 * a.ldw];
+  bool bad = false;
+  double x[BR];
+#pragma unroll
+  for (int q = 0; q < BR; ++q) { const int i = j0 + q; x[q] = (i < n) ? out[(long)i * a.ldo] : 0.0; }
+#pragma unroll
+  for (int q = 0; q < BR; ++q) {
+    const int i = j0 + q;
+    if (i < n) {
+      const double v = x[q] + c1 * a.blk.psi1[i] + c2 * a.blk.psi2[i] + c3 * a.blk.psi3[i] + c4 * a.blk.psi4[i];
+      out[(long)i * a.ldo] = v;
+      bad |= (v != v);
+    }
   }
   return bad;
 }

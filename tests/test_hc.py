@@ -165,6 +165,33 @@ def test_hc_step(emu_lib, periodic, nx, ny, steps, aspect):
     K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, steps, aspect=aspect, check_at=[1, 2, steps], bc="hc")
 
 
+def hc_blocked_ab(lib, periodic, nx, ny, ra, dt, steps, monkeypatch, tol=1e-12):
+    """The blocked PdmaPlus2 column solve (pdma.h: blocks of 32 rows from zero inflow + tabulated homogeneous solutions) against
+    one thread per column over all rows (RPDE_HC_BLOCKED=0): the same step to round-off."""
+    runs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("RPDE_HC_BLOCKED", sw)
+        ctor = R.Navier2D.new_periodic if periodic else R.Navier2D.new_confined
+        nav = ctor(nx, ny, ra, 1.0, dt, 1.0, "hc", library=lib)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(steps)
+        runs.append({k: np.array(getattr(nav, k).vhat) for k in ("velx", "vely", "temp", "pres")})
+        assert nav.exit() is False
+    for k in runs[0]:
+        e = K.rel(runs[0][k], runs[1][k])
+        assert e < tol, (k, e)
+    return runs[0]
+
+
+# my = ny - 2 rows: 33 = 32 + 1, 34 = 32 + 2, 35 = 32 + 3 (short last blocks: the backward inflows shine through the block),
+# 64 (exact), 97 = 3 x 32 + 1, 1023 = 31 x 32 + 31
+@pytest.mark.parametrize("periodic,nx,ny", [(False, 17, 35), (False, 17, 36), (False, 17, 37), (True, 16, 66), (False, 9, 99),
+                                            (False, 17, 1025), (False, 9, 5), (False, 9, 4097)])
+def test_hc_blocked_column_solve_equals_the_serial_one(emu_lib, monkeypatch, periodic, nx, ny):
+    hc_blocked_ab(emu_lib, periodic, nx, ny, 1e5, 0.01, 3, monkeypatch)
+
+
 def test_hc_schedule_and_restrictions(emu_lib):
     nav = R.Navier2D.new_confined(33, 33, 1e5, 1.0, 0.01, 1.0, "hc", library=emu_lib)
     kinds = {t: kind for t, _, _, _, kind in nav.schedule()}
@@ -224,6 +251,13 @@ def test_hc_step_1025_gpu(hip_lib):
     """1025 x 1025 (one-wave whole-line kernels for the velocities, batched column solve over 65 blocks of rows for the
     temperature), Ra = 1e7, dt = 1e-3; shared eigen-decomposition like every large confined comparison."""
     K.run_isolated('check_step_parity(lib, False, 1025, 1025, 1e7, 1e-3, 3, check_at=[1, 3], bc="hc", eig_mode="shared")')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodic,nx,ny,ra,dt", [(False, 17, 35, 1e5, 0.01), (False, 65, 99, 1e5, 0.01), (True, 64, 66, 1e5, 0.01),
+                                                  (False, 257, 1025, 1e7, 1e-3), (False, 129, 4097, 1e8, 2e-4)])
+def test_hc_blocked_column_solve_equals_the_serial_one_gpu(hip_lib, monkeypatch, periodic, nx, ny, ra, dt):
+    hc_blocked_ab(hip_lib, periodic, nx, ny, ra, dt, 3, monkeypatch)
 
 
 @pytest.mark.gpu

@@ -61,6 +61,7 @@ def test_entry_uses_the_oracle_only_in_smoke():
 ENV_SWITCHES = {
     "RPDE_LAPACK_LIB", "RPDE_RCCL_LIB",            # run-time libraries
     "RPDE_GRAPH",                                   # hipGraph replay on / off              (test_gpu_parity.test_graph_*)
+    "RPDE_HC_BLOCKED",                              # "hc": blocked PdmaPlus2 column solve / one thread per column (tests/test_hc.py)
     "RPDE_OVERLAP",                                 # pencil-sharded: transposes of one field on a second stream under the next field's compute (test_sharded.test_overlap_*)
     "RPDE_SYNC_LAUNCHES",                           # diagnostics: every launch named and waited for
     "RPDE_ALLOC_LOG",                               # emulation build only: allocation trace for tools/fault_repro
