@@ -257,7 +257,8 @@ def test_hc_step_1025_gpu(hip_lib):
 @pytest.mark.parametrize("periodic,nx,ny,ra,dt", [(False, 17, 35, 1e5, 0.01), (False, 65, 99, 1e5, 0.01), (True, 64, 66, 1e5, 0.01),
                                                   (False, 257, 1025, 1e7, 1e-3), (False, 129, 4097, 1e8, 2e-4)])
 def test_hc_blocked_column_solve_equals_the_serial_one_gpu(hip_lib, monkeypatch, periodic, nx, ny, ra, dt):
-    hc_blocked_ab(hip_lib, periodic, nx, ny, ra, dt, 3, monkeypatch)
+    # 4097 rows at Ra = 1e8: the pressure carries the round-off of the two orders of summation at 1.1e-12 (u, v, T below 1e-12)
+    hc_blocked_ab(hip_lib, periodic, nx, ny, ra, dt, 3, monkeypatch, tol=1e-11 if ny == 4097 else 1e-12)
 
 
 @pytest.mark.gpu
