@@ -24,6 +24,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- pyt
 cd $R
 python tools/trace_by_tag.py $O/trace $O/schedule.json $O/trace_by_tag.csv 2> $O/trace_by_tag.log
 python tools/profile_step.py > $O/profile_step.txt 2>&1
+python bench.py --no-cpu-baseline --bc hc --steps 30 > $O/bench_hc.json 2> $O/bench_hc.err      # the blocked column solve
+RPDE_HC_BLOCKED=0 python bench.py --no-cpu-baseline --bc hc --steps 30 > $O/bench_hc_serial.json 2> $O/bench_hc_serial.err
 bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>/dev/null
 rm -f $O/*/*.db $O/*/*/*.db
 find $O -name '*kernel_trace.csv' -size +8M -delete
