@@ -255,6 +255,34 @@ int rpde_lnse2d_exit(rpde_lnse2d* h, int* stop);                   /* NaN diverg
 int rpde_lnse2d_div_norm(rpde_lnse2d* h, double* norm);            /* lnse_eq.rs:36-41 */
 int rpde_lnse2d_write(rpde_lnse2d* h, const char* filename);       /* the Field2 snapshot layout (ux uy temp pres tempbc + time + params) */
 int rpde_lnse2d_read(rpde_lnse2d* h, const char* filename);
+/* ---- adjoint-based sensitivity of the final energy (src/navier_stokes_lnse/lnse_adj_grad.rs, lnse_adj_eq.rs) ---- */
+/* n x Navier2DLnse::update_adjoint()                               lnse_adj_grad.rs:71-99 (update_direct == rpde_lnse2d_update, :43-68) */
+int rpde_lnse2d_update_adjoint(rpde_lnse2d* h, int nsteps);
+/* rustpde::integrate(pde, max_time, None)                          src/lib.rs:187-219; timesteps may be null */
+int rpde_lnse2d_integrate(rpde_lnse2d* h, double max_time, long* timesteps);
+/* functions::energy: 0.5 sum(b1 u^2 + b1 v^2 + b2 T^2) of the physical fields (functions.rs:11-58); with a target (three physical
+   nx*ny arrays, or all NULL) of the fields minus the target (lnse_adj_grad.rs:141-155) */
+int rpde_lnse2d_energy(rpde_lnse2d* h, double beta1, double beta2, const double* target_velx, const double* target_vely,
+                       const double* target_temp, size_t len, double* energy);
+/* Navier2DLnse::grad_adjoint(max_time, None, beta1, beta2, target) lnse_adj_grad.rs:105-202: forward loop, energy (-> fun_val),
+   adjoint loop, gradient = -(adjoint fields).  grad_*: physical nx*ny arrays (the `.v` of the returned Field2s; `.vhat` =
+   Space2 forward of them).  filename: where the reference writes "data/grad_adjoint.h5" (groups ux, uy, temp), NULL = no file.
+   The engine is left holding the adjoint fields, like the reference.  timesteps may be NULL. */
+int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double beta1, double beta2, const double* target_velx,
+                             const double* target_vely, const double* target_temp, size_t len, const char* filename, double* fun_val,
+                             double* grad_velx, double* grad_vely, double* grad_temp, long* timesteps);
+/* Navier2DLnse::grad_fd(max_time, None, beta1, beta2)              lnse_fd_grad.rs:31-157: one integration per perturbed grid point,
+   eps = 1e-5 (a test device in the reference too).  points: npoints triples (field 0 velx / 1 vely / 2 temp, i, j), NULL = all */
+int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double beta2, const int* points, long npoints, size_t len,
+                        const char* filename, double* grad_velx, double* grad_vely, double* grad_temp);
+/* functions::l2_norm                                               src/navier_stokes_lnse/functions.rs:30-58 (host arrays) */
+int rpde_l2_norm(size_t len, const double* a1, const double* a2, const double* b1, const double* b2, const double* c1, const double* c2,
+                 double beta1, double beta2, double* out);
+/* opt_routines::steepest_descent_energy_constrained                src/navier_stokes_lnse/opt_routines.rs:16-56 (host arrays; the
+   gradients are projected in place, the new state is written to *_new; alpha > 2 pi is an error like the reference's assert) */
+int rpde_steepest_descent_energy_constrained(size_t len, const double* velx_0, const double* vely_0, const double* temp_0, double* grad_velx,
+                                             double* grad_vely, double* grad_temp, double* velx_new, double* vely_new, double* temp_new,
+                                             double beta1, double beta2, double alpha);
 
 /* ---- operator level: funspace Space2 methods as called by rustpde ---------------------------- */
 /* Space2::new(&base0(n0), &base1(n1)); base1 must be a Chebyshev-family base                     */

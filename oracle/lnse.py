@@ -6,6 +6,9 @@ Follows, in this order:
   constructors      ``src/navier_stokes_lnse/lnse.rs:98-176`` (confined), ``196-253`` (periodic)
   equations         ``src/navier_stokes_lnse/lnse_eq.rs`` (whole file)
   update() / exit() ``lnse.rs:263-288, 305-313``
+  adjoint equations ``lnse_adj_eq.rs:16-94, 217-294``; adjoint step, adjoint gradient ``lnse_adj_grad.rs:43-225``;
+  finite-difference gradient ``lnse_fd_grad.rs:31-157``; energy / l2_norm ``functions.rs:11-58``;
+  steepest descent ``opt_routines.rs:16-56``
 The reference holds no golden output for this step; it is the step of ``Navier2D`` (oracle/navier.py, pinned by the two
 critical Rayleigh numbers) with other convection terms, and the two are tied together by a test: linearised about a mean
 flow M, ``Navier2D`` started from M + eps * q follows M(t) + eps * q_lnse(t) up to O(eps^2)
@@ -171,8 +174,186 @@ class Navier2DLnse:
         self.solve_temp(ux, uy)
         self.time += self.dt
 
+    update_direct = update                       # lnse_adj_grad.rs:43-68 is the same sequence
+
     def exit(self):
         return bool(np.isnan(self.div_norm()))
 
+    def init_random(self, amp, seed):
+        """Seeded stand-in for ``init_random`` (``lnse.rs``: uniform(-amp, amp), order temp, velx, vely)."""
+        rng = np.random.default_rng(seed)
+        for f in (self.temp, self.velx, self.vely):
+            f.v = rng.uniform(-amp, amp, size=f.v.shape)
+            f.forward()
+
+    def set_field_physical(self, name, v):
+        f = getattr(self, name)
+        f.v = np.array(v, dtype=np.float64, copy=True)
+        f.forward()
+
+    # ------------------------------------------------------------------ lnse_adj_eq.rs
+    def _conv_adjoint(self, f, deriv_mean, velx, vely, temp, with_mean_gradients=True):
+        """conv_velx_adjoint / conv_vely_adjoint / conv_temp_adjoint (lnse_adj_eq.rs:16-94):
+        + U d/dx f* + V d/dy f*  - u* d_j U - v* d_j V - T* d_j Tm   (j = the component's direction; the temperature: no
+        mean-gradient terms)."""
+        self.mean.velx.backward()
+        self.mean.vely.backward()
+        um, vm = self.mean.velx.v, self.mean.vely.v
+        conv = self._conv_term(um, f, [1, 0])
+        conv += self._conv_term(vm, f, [0, 1])
+        if with_mean_gradients:
+            conv -= self._conv_term(velx, self.mean.velx, deriv_mean)
+            conv -= self._conv_term(vely, self.mean.vely, deriv_mean)
+            conv -= self._conv_term(temp, self.mean.temp, deriv_mean)
+        self.field.v = conv
+        self.field.forward()
+        vhat = self.field.vhat
+        vhat[vhat.shape[0] * 2 // 3:, :] = 0
+        vhat[:, vhat.shape[1] * 2 // 3:] = 0
+        return vhat.copy()
+
+    def solve_velx_adj(self, velx, vely, temp):   # lnse_adj_eq.rs:217-238
+        self.zero_rhs()
+        self.rhs += self.velx.to_ortho()
+        self.rhs -= self.pres.gradient([1, 0], self.scale) * self.dt
+        self.rhs += self._conv_adjoint(self.velx, [1, 0], velx, vely, temp) * self.dt
+        self.velx.vhat = self.solver_hholtz[0].solve(self.rhs)
+
+    def solve_vely_adj(self, velx, vely, temp):   # lnse_adj_eq.rs:241-262
+        self.zero_rhs()
+        self.rhs += self.vely.to_ortho()
+        self.rhs -= self.pres.gradient([0, 1], self.scale) * self.dt
+        self.rhs += self._conv_adjoint(self.vely, [0, 1], velx, vely, temp) * self.dt
+        self.vely.vhat = self.solver_hholtz[1].solve(self.rhs)
+
+    def solve_temp_adj(self, velx, vely, temp, vely_vhat):   # lnse_adj_eq.rs:269-294
+        self.zero_rhs()
+        self.rhs += self.temp.to_ortho()
+        self.rhs += self._conv_adjoint(self.temp, None, velx, vely, temp, with_mean_gradients=False) * self.dt
+        self.rhs += vely_vhat * self.dt
+        self.temp.vhat = self.solver_hholtz[2].solve(self.rhs)
+
+    def update_adjoint(self):                    # lnse_adj_grad.rs:71-99
+        uyhat = self.vely.to_ortho()
+        self.velx.backward()
+        self.vely.backward()
+        self.temp.backward()
+        velx, vely, temp = self.velx.v.copy(), self.vely.v.copy(), self.temp.v.copy()
+        self.solve_velx_adj(velx, vely, temp)
+        self.solve_vely_adj(velx, vely, temp)
+        div = self.div()
+        self.solve_pres(div)
+        self.correct_velocity(1.0)
+        self.update_pres(div)
+        self.solve_temp_adj(velx, vely, temp, uyhat)
+        self.time += self.dt
+
+    # ------------------------------------------------------------------ lnse_adj_grad.rs / lnse_fd_grad.rs / functions.rs
+    def _exit_grad(self, max_time, timestep, max_timestep=10_000_000):   # lnse_adj_grad.rs:204-225
+        if self.time + self.dt * 1e-4 >= max_time:
+            return True
+        if timestep >= max_timestep:
+            return True
+        return bool(np.isnan(self.div_norm()))
+
+    def energy(self, beta1, beta2):               # functions.rs:11-28
+        self.velx.backward()
+        self.vely.backward()
+        self.temp.backward()
+        return l2_norm(self.velx.v, self.velx.v, self.vely.v, self.vely.v, self.temp.v, self.temp.v, beta1, beta2)
+
+    def grad_adjoint(self, max_time, beta1, beta2, target=None):
+        """lnse_adj_grad.rs:105-202 without the file output: forward loop, energy, the adjoint initial condition
+        beta x (state - target), adjoint loop, gradient = -(the PHYSICAL arrays the state holds at the end -- the
+        `backward()` of the adjoint step runs at the START of a step, so they are the adjoint fields one step before the end,
+        :185-191 as written).  Returns (fun_val, (grad_u, grad_v, grad_t)) as physical arrays."""
+        timestep = 0
+        while True:
+            self.update_direct()
+            timestep += 1
+            if self._exit_grad(max_time, timestep):
+                break
+        self.velx.backward()
+        self.vely.backward()
+        self.temp.backward()
+        if target is None:
+            u, v, t = self.velx.v, self.vely.v, self.temp.v
+        else:
+            u, v, t = self.velx.v - target.velx.v, self.vely.v - target.vely.v, self.temp.v - target.temp.v
+        fun_val = l2_norm(u, u, v, v, t, t, beta1, beta2)
+        if target is not None:
+            self.velx.vhat = self.velx.vhat - self.velx.space.from_ortho(target.velx.vhat)
+            self.vely.vhat = self.vely.vhat - self.vely.space.from_ortho(target.vely.vhat)
+            self.temp.vhat = self.temp.vhat - self.temp.space.from_ortho(target.temp.vhat)
+        self.velx.vhat = self.velx.vhat * beta1
+        self.vely.vhat = self.vely.vhat * beta1
+        self.temp.vhat = self.temp.vhat * beta2
+        self.time = 0.0
+        while True:
+            self.update_adjoint()
+            timestep += 1        # the counter is NOT reset between the loops (:117, :169)
+            if self._exit_grad(max_time, timestep):
+                break
+        fac = -1.0               # MAXIMIZE = false (:16)
+        return fun_val, (fac * self.velx.v, fac * self.vely.v, fac * self.temp.v)
+
+    def _integrate(self, max_time):               # src/lib.rs:187-219 without callbacks
+        timestep = 0
+        while True:
+            self.update()
+            timestep += 1
+            if self.time + self.dt * 1e-4 >= max_time or timestep >= 10_000_000 or self.exit():
+                break
+
+    def grad_fd(self, max_time, beta1, beta2, points=None, eps=1e-5):
+        """lnse_fd_grad.rs:31-157: one integration per perturbed grid point (`points`: an iterable of (field, i, j) to visit
+        instead of every point -- a test device; unvisited entries stay 0)."""
+        base_v = {k: getattr(self, k).v.copy() for k in ("velx", "vely", "temp")}
+        base_h = {k: getattr(self, k).vhat.copy() for k in ("velx", "vely", "temp")}
+
+        def reset():
+            self.time = 0.0
+            for k in base_v:
+                getattr(self, k).v = base_v[k].copy()
+                getattr(self, k).vhat = base_h[k].copy()
+            for f in (self.pres, self.pseu):
+                f.v = f.v * 0.0
+                f.vhat = f.vhat * 0.0
+
+        reset()
+        self._integrate(max_time)
+        e_base = self.energy(beta1, beta2)
+        grads = {k: np.zeros_like(base_v[k]) for k in base_v}
+        if points is None:
+            points = [(k, i, j) for k in ("velx", "vely", "temp") for i in range(base_v[k].shape[0]) for j in range(base_v[k].shape[1])]
+        for k, i, j in points:
+            reset()
+            f = getattr(self, k)
+            f.v[i, j] += eps
+            f.forward()
+            self._integrate(max_time)
+            grads[k][i, j] = 1.0 / eps * (self.energy(beta1, beta2) - e_base)
+        return grads["velx"], grads["vely"], grads["temp"]
+
     def spectral_fields(self, names=("velx", "vely", "temp", "pres", "pseu")):
         return {k: getattr(self, k).vhat.copy() for k in names}
+
+
+def l2_norm(a1, a2, b1, b2, c1, c2, beta1, beta2):
+    """functions.rs:30-58: 0.5 * sum(beta1 a1 a2 + beta1 b1 b2 + beta2 c1 c2) -- a plain sum over the grid points."""
+    return 0.5 * float((beta1 * a1 * a2 + beta1 * b1 * b2 + beta2 * c1 * c2).sum())
+
+
+def steepest_descent_energy_constrained(velx_0, vely_0, temp_0, grad_velx, grad_vely, grad_temp, beta1, beta2, alpha):
+    """opt_routines.rs:16-56: project the gradient perpendicular to the state, rotate the state by alpha towards it at constant
+    energy.  Returns (velx_new, vely_new, temp_new) and the projected gradients (the reference modifies them in place)."""
+    assert alpha <= 2.0 * np.pi, "alpha must be less than 2 pi"
+    n = float(velx_0.size)
+    e0 = l2_norm(velx_0, velx_0, vely_0, vely_0, temp_0, temp_0, beta1, beta2) / n
+    eg = l2_norm(grad_velx, velx_0, grad_vely, vely_0, grad_temp, temp_0, beta1, beta2) / n
+    ee = eg / e0
+    gu, gv, gt = grad_velx - ee * velx_0, grad_vely - ee * vely_0, grad_temp - ee * temp_0
+    eg = l2_norm(gu, gu, gv, gv, gt, gt, beta1, beta2) / n
+    ee2 = np.sqrt(e0 / eg)
+    ca, sa = np.cos(alpha), np.sin(alpha)
+    return (velx_0 * ca + gu * (ee2 * sa), vely_0 * ca + gv * (ee2 * sa), temp_0 * ca + gt * (ee2 * sa)), (gu, gv, gt)

@@ -683,6 +683,99 @@ class Navier2DLnse(Navier2DAdjoint):
     def spectral_fields(self, names=("velx", "vely", "temp", "pres", "pseu")):
         return {k: getattr(self, k).vhat for k in names}
 
+    # ---- adjoint-based sensitivity of the final energy (lnse_adj_grad.rs, lnse_fd_grad.rs) ----
+    def update_direct(self, nsteps: int = 1):
+        """`Navier2DLnse::update_direct` (lnse_adj_grad.rs:43-68): the same sequence as `update`."""
+        self.update(nsteps)
+
+    def update_adjoint(self, nsteps: int = 1):
+        """`Navier2DLnse::update_adjoint` (lnse_adj_grad.rs:71-99)."""
+        self._lib.call("rpde_lnse2d_update_adjoint", self._h, int(nsteps))
+
+    def integrate(self, max_time):
+        n = C.c_long()
+        self._lib.call("rpde_lnse2d_integrate", self._h, float(max_time), C.byref(n))
+        return n.value
+
+    def _target(self, target):
+        if target is None:
+            return [None, None, None]
+        arrs = [as_f64(getattr(target, k).v if hasattr(target, k) else target[i]) for i, k in enumerate(("velx", "vely", "temp"))]
+        for a in arrs:
+            if a.shape != (self.nx, self.ny):
+                raise RpdeError(f"target fields must have shape {(self.nx, self.ny)}")
+        return arrs
+
+    def energy(self, beta1, beta2, target=None):
+        """`functions::energy` (functions.rs:11-28) of the state (minus the target's physical fields, lnse_adj_grad.rs:141-155)."""
+        t = self._target(target)
+        e = C.c_double()
+        self._lib.call("rpde_lnse2d_energy", self._h, float(beta1), float(beta2), *[None if a is None else ptr(a) for a in t],
+                       self.nx * self.ny, C.byref(e))
+        return e.value
+
+    def grad_adjoint(self, max_time, save_intervall, beta1, beta2, target=None, filename="data/grad_adjoint.h5"):
+        """`Navier2DLnse::grad_adjoint` (lnse_adj_grad.rs:105-202) -> (fun_val, (grad_u, grad_v, grad_t)); the gradients are the
+        physical arrays (`.v` of the reference's Field2s).  `target`: an object with `.velx.v / .vely.v / .temp.v` (MeanFields) or
+        three arrays.  `filename`: the reference writes "data/grad_adjoint.h5" unconditionally; None skips the file.
+        `save_intervall` (snapshots "data/flow*.h5" / "data/adjoint*.h5" during the two loops) is not supported: pass None."""
+        if save_intervall is not None:
+            raise RpdeError("grad_adjoint: save_intervall is not supported by the device loop (pass None)")
+        t = self._target(target)
+        n = self.nx * self.ny
+        gu, gv, gt = (np.empty((self.nx, self.ny)) for _ in range(3))
+        fun, steps = C.c_double(), C.c_long()
+        if filename is not None and os.path.dirname(filename):
+            os.makedirs(os.path.dirname(filename), exist_ok=True)
+        self._lib.call("rpde_lnse2d_grad_adjoint", self._h, float(max_time), float(beta1), float(beta2),
+                       *[None if a is None else ptr(a) for a in t], n, None if filename is None else str(filename).encode(),
+                       C.byref(fun), ptr(gu), ptr(gv), ptr(gt), C.byref(steps))
+        return fun.value, (gu, gv, gt)
+
+    def grad_fd(self, max_time, save_intervall, beta1, beta2, points=None, filename="data/grad_fd.h5"):
+        """`Navier2DLnse::grad_fd` (lnse_fd_grad.rs:31-157): one integration per perturbed grid point (3 nx ny integrations --
+        "should only be used for testing").  `points`: iterable of (field, i, j) with field in velx / vely / temp to visit
+        instead of every point (the other entries stay 0)."""
+        if save_intervall is not None:
+            raise RpdeError("grad_fd: save_intervall is not supported by the device loop (pass None)")
+        pts, npts = None, 0
+        if points is not None:
+            code = {"velx": 0, "vely": 1, "temp": 2}
+            arr = np.ascontiguousarray([(code[k] if isinstance(k, str) else int(k), int(i), int(j)) for k, i, j in points],
+                                       dtype=np.intc).reshape(-1, 3)
+            pts, npts = arr.ctypes.data_as(C.POINTER(C.c_int)), arr.shape[0]
+        gu, gv, gt = (np.empty((self.nx, self.ny)) for _ in range(3))
+        if filename is not None and os.path.dirname(filename):
+            os.makedirs(os.path.dirname(filename), exist_ok=True)
+        self._lib.call("rpde_lnse2d_grad_fd", self._h, float(max_time), float(beta1), float(beta2), pts, npts, self.nx * self.ny,
+                       None if filename is None else str(filename).encode(), ptr(gu), ptr(gv), ptr(gt))
+        return gu, gv, gt
+
+
+def l2_norm(a1, a2, b1, b2, c1, c2, beta1, beta2, library=None):
+    """`functions::l2_norm` (src/navier_stokes_lnse/functions.rs:30-58)."""
+    library = library or lib()
+    arrs = [as_f64(a) for a in (a1, a2, b1, b2, c1, c2)]
+    if any(a.shape != arrs[0].shape for a in arrs):
+        raise RpdeError("l2_norm: shapes differ")
+    out = C.c_double()
+    library.call("rpde_l2_norm", arrs[0].size, *[ptr(a) for a in arrs], float(beta1), float(beta2), C.byref(out))
+    return out.value
+
+
+def steepest_descent_energy_constrained(velx_0, vely_0, temp_0, grad_velx, grad_vely, grad_temp, velx_new, vely_new, temp_new,
+                                        beta1, beta2, alpha, library=None):
+    """`opt_routines::steepest_descent_energy_constrained` (opt_routines.rs:16-56): the reference's argument list -- the
+    gradients (C-contiguous float64 arrays) are projected IN PLACE, the rotated state is written into `*_new`."""
+    library = library or lib()
+    ins = [as_f64(a) for a in (velx_0, vely_0, temp_0)]
+    io = [grad_velx, grad_vely, grad_temp, velx_new, vely_new, temp_new]
+    for a in io:
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == ins[0].shape):
+            raise RpdeError("steepest_descent_energy_constrained: gradients and outputs must be C-contiguous float64 arrays of the state's shape")
+    library.call("rpde_steepest_descent_energy_constrained", ins[0].size, *[ptr(a) for a in ins], *[ptr(a) for a in io],
+                 float(beta1), float(beta2), float(alpha))
+
 
 def transpose(a, device=0, library=None):
     library = library or lib()

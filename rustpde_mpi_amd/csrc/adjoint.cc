@@ -507,7 +507,7 @@ void Navier2DAdjointEngine::update(int nsteps) {
 Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc,
                                        bool periodic, const std::string& mean_file)
     : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, dt, {"mean_velx", "mean_vely", "mean_temp"}) {
-  um_.alloc(nx, ny, 1); vm_.alloc(nx, ny, 1);
+  um_.alloc(nx, ny, 1); vm_.alloc(nx, ny, 1); tp_.alloc(nx, ny, 1);
   bool from_file = false;
   if (!mean_file.empty()) {
     if (FILE* f = std::fopen(mean_file.c_str(), "rb")) { std::fclose(f); from_file = true; }
@@ -602,6 +602,240 @@ void Navier2DLnseEngine::update(int nsteps) {
     time_ += dt_;
   }
   dev_sync(st_);
+}
+
+// ================================================================================================
+// adjoint LNSE step and the gradient of the final energy (lnse_adj_eq.rs, lnse_adj_grad.rs, lnse_fd_grad.rs, functions.rs)
+
+// + U d/dx f* + V d/dy f*  - u* d_j U - v* d_j V - T* d_j Tm   (lnse_adj_eq.rs:16-94; the temperature: no mean-gradient terms)
+void Navier2DLnseEngine::conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out) {
+  conv_term(um_, f, 1, 0, 1.0, true);
+  conv_term(vm_, f, 0, 1, 1.0, false);
+  if (mean_gradients) {
+    conv_term(ux_, mean("velx"), d0, d1, -1.0, false);
+    conv_term(uy_, mean("vely"), d0, d1, -1.0, false);
+    conv_term(tp_, mean("temp"), d0, d1, -1.0, false);
+  }
+  conv_finish(out);
+}
+
+void Navier2DLnseEngine::update_adjoint(int nsteps) {
+  F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
+  const double dt = dt_;
+  for (int step = 0; step < nsteps; ++step) {
+    vely.sp->to_ortho(vely.vhat, old_[2], st_);            // adjoint buoyancy: vely.to_ortho() (lnse_adj_grad.rs:73)
+    backward(velx, ux_);
+    backward(vely, uy_);
+    backward(temp, tp_);
+    // solve_velx_adj (lnse_adj_eq.rs:217-238)
+    zero(rhs_);
+    acc_to_ortho(velx, 1.0, rhs_);
+    acc_gradient(pres, 1, 0, -dt, rhs_);
+    conv_adj(velx, 1, 0, true, cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    hh_vel_->solve(rhs_, velx.vhat, st_);
+    // solve_vely_adj (lnse_adj_eq.rs:241-262)
+    zero(rhs_);
+    acc_to_ortho(vely, 1.0, rhs_);
+    acc_gradient(pres, 0, 1, -dt, rhs_);
+    conv_adj(vely, 0, 1, true, cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    hh_vel_->solve(rhs_, vely.vhat, st_);
+    // projection (lnse_adj_grad.rs:87-91)
+    div(div_);
+    solve_pres(div_);
+    correct_velocity(1.0);
+    lincomb(pres.vhat, 1.0, pres.vhat, -nu_, div_);
+    acc_to_ortho(pseu, 1.0 / dt, pres.vhat);
+    // solve_temp_adj (lnse_adj_eq.rs:269-294)
+    zero(rhs_);
+    acc_to_ortho(temp, 1.0, rhs_);
+    conv_adj(temp, 0, 0, false, cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, cv_);
+    lincomb(rhs_, 1.0, rhs_, dt, old_[2]);
+    hh_temp_->solve(rhs_, temp.vhat, st_);
+    time_ += dt_;
+  }
+  dev_sync(st_);
+}
+
+double Navier2DLnseEngine::sumsq(const Arr2& a) {
+  launch_sumsq(a.p(), a.ld, a.rows, a.cols * a.elem, red_.p, st_);
+  dev_sync(st_);
+  double h[2];
+  dev_download(h, red_.p, sizeof(h));
+  return h[1] > 0 ? std::nan("") : h[0];
+}
+
+double Navier2DLnseEngine::energy(double beta1, double beta2, const double* tu, const double* tv, const double* tt) {
+  RPDE_REQUIRE((tu && tv && tt) || (!tu && !tv && !tt), "energy: a target is three arrays (velx, vely, temp) or none");
+  backward(field("velx"), ux_);
+  backward(field("vely"), uy_);
+  backward(field("temp"), tp_);
+  double s[3];
+  Arr2* phys[3] = {&ux_, &uy_, &tp_};
+  const double* tg[3] = {tu, tv, tt};
+  for (int k = 0; k < 3; ++k) {
+    if (tg[k]) {
+      dev_sync(st_);
+      dev_upload2d(ph_.p(), ph_.ld, tg[k], nx_, ny_);
+      lincomb(ta_, 1.0, *phys[k], -1.0, ph_);
+      s[k] = sumsq(ta_);
+    } else {
+      s[k] = sumsq(*phys[k]);
+    }
+  }
+  return 0.5 * (beta1 * s[0] + beta1 * s[1] + beta2 * s[2]);
+}
+
+bool Navier2DLnseEngine::exit_grad(double max_time, long timestep) {
+  if (time_ + dt_ * 1e-4 >= max_time) return true;
+  if (timestep >= 10000000L) return true;
+  if (std::isnan(div_norm())) { std::printf("Divergence is nan\n"); return true; }
+  return false;
+}
+
+long Navier2DLnseEngine::integrate(double max_time) {
+  long timestep = 0;
+  for (;;) {
+    update(1);
+    ++timestep;
+    if (time_ + dt_ * 1e-4 >= max_time) break;
+    if (timestep >= 10000000L) break;
+    if (exit()) break;
+  }
+  return timestep;
+}
+
+void Navier2DLnseEngine::write_gradient(const char* filename, const double* gu, const double* gv, const double* gt) {
+  // Field2::write_unwrap(filename, "ux" | "uy" | "temp") of the gradient fields (lnse_adj_grad.rs:192-200): v, vhat = forward(v)
+  h5::Tree t;
+  Vec x((size_t)nx_), y((size_t)ny_);
+  grid(0, x.data(), x.size());
+  grid(1, y.data(), y.size());
+  const char* const grp[3] = {"ux", "uy", "temp"};
+  const char* const fld[3] = {"velx", "vely", "temp"};
+  const double* g[3] = {gu, gv, gt};
+  for (int k = 0; k < 3; ++k) {
+    const std::string gname = grp[k];
+    F& f = field(fld[k]);
+    t[gname + "/x"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[gname + "/dx"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[gname + "/y"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[gname + "/dy"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[gname + "/v"] = h5::Dataset{{(uint64_t)nx_, (uint64_t)ny_}, Vec(g[k], g[k] + (size_t)nx_ * ny_)};
+    Arr2 vh(f.vhat.rows, f.vhat.cols, ex_);
+    dev_sync(st_);
+    dev_upload2d(ph_.p(), ph_.ld, g[k], nx_, ny_);
+    f.sp->forward(ph_, vh, st_);
+    dev_sync(st_);
+    const int r = vh.rows, c = vh.cols, e = vh.elem;
+    Vec h((size_t)r * c * e);
+    dev_download2d(h.data(), vh.p(), vh.ld, r, (long)c * e);
+    if (e == 1) {
+      t[gname + "/vhat"] = h5::Dataset{{(uint64_t)r, (uint64_t)c}, std::move(h)};
+    } else {
+      h5::Dataset re{{(uint64_t)r, (uint64_t)c}, Vec((size_t)r * c)}, im = re;
+      for (size_t q = 0; q < (size_t)r * c; ++q) { re.data[q] = h[2 * q]; im.data[q] = h[2 * q + 1]; }
+      t[gname + "/vhat_re"] = std::move(re);
+      t[gname + "/vhat_im"] = std::move(im);
+    }
+  }
+  h5::update_file(filename, t);
+}
+
+double Navier2DLnseEngine::grad_adjoint(double max_time, double beta1, double beta2, const double* tu, const double* tv, const double* tt,
+                                        double* gu, double* gv, double* gt, const char* filename, long* timesteps) {
+  RPDE_REQUIRE(gu && gv && gt, "grad_adjoint: null output");
+  RPDE_REQUIRE((tu && tv && tt) || (!tu && !tv && !tt), "grad_adjoint: a target is three arrays (velx, vely, temp) or none");
+  long timestep = 0;
+  for (;;) {                                   // forward loop (:119-136)
+    update_direct(1);
+    ++timestep;
+    if (exit_grad(max_time, timestep)) break;
+  }
+  const double fun_val = energy(beta1, beta2, tu, tv, tt);   // :139-155
+  // initial condition of the adjoint fields (:160-169): (state - from_ortho(target.vhat)) * beta
+  F* fl[3] = {&field("velx"), &field("vely"), &field("temp")};
+  const double* tg[3] = {tu, tv, tt};
+  const double be[3] = {beta1, beta1, beta2};
+  for (int k = 0; k < 3; ++k) {
+    F& f = *fl[k];
+    if (tg[k]) {
+      Arr2 tmp(f.vhat.rows, f.vhat.cols, ex_);
+      dev_sync(st_);
+      dev_upload2d(ph_.p(), ph_.ld, tg[k], nx_, ny_);
+      sp_ortho_->forward(ph_, t1_, st_);       // MeanFields live in the orthonormal space (meanfield.rs:11-18)
+      f.sp->from_ortho(t1_, tmp, st_);
+      lincomb(f.vhat, 1.0, f.vhat, -1.0, tmp);
+      dev_sync(st_);
+    }
+    lincomb(f.vhat, be[k], f.vhat, 0.0, f.vhat);
+  }
+  reset_time();
+  for (;;) {                                   // adjoint loop (:172-187); the step counter keeps running
+    update_adjoint(1);
+    ++timestep;
+    if (exit_grad(max_time, timestep)) break;
+  }
+  // :189-196: the gradient is fac * self.velx.v, the physical arrays of the backward() at the START of the last adjoint step
+  const double fac = -1.0;                     // MAXIMIZE = false (:16)
+  Arr2* phys[3] = {&ux_, &uy_, &tp_};
+  double* out[3] = {gu, gv, gt};
+  dev_sync(st_);
+  for (int k = 0; k < 3; ++k) {
+    dev_download2d(out[k], phys[k]->p(), phys[k]->ld, nx_, ny_);
+    for (size_t q = 0; q < (size_t)nx_ * ny_; ++q) out[k][q] *= fac;
+  }
+  if (filename && *filename) write_gradient(filename, gu, gv, gt);
+  if (timesteps) *timesteps = timestep;
+  return fun_val;
+}
+
+void Navier2DLnseEngine::grad_fd(double max_time, double beta1, double beta2, const int* points, long npoints, double* gu, double* gv,
+                                 double* gt, const char* filename) {
+  RPDE_REQUIRE(gu && gv && gt, "grad_fd: null output");
+  const double eps = 1e-5;                     // lnse_fd_grad.rs:38
+  const char* const fld[3] = {"velx", "vely", "temp"};
+  const size_t np = (size_t)nx_ * ny_;
+  // base state (:41-46): the reference saves v and vhat; the engine keeps spectral fields only, v = backward(vhat)
+  Vec base_v[3];
+  Arr2 base_h[3];
+  for (int k = 0; k < 3; ++k) {
+    F& f = field(fld[k]);
+    base_v[k].resize(np);
+    get_field_physical(fld[k], base_v[k].data(), np);
+    base_h[k].alloc(f.vhat.rows, f.vhat.cols, ex_);
+    lincomb(base_h[k], 1.0, f.vhat, 0.0, f.vhat);
+  }
+  auto reset = [&]() {
+    reset_time();
+    for (int k = 0; k < 3; ++k) { F& f = field(fld[k]); lincomb(f.vhat, 1.0, base_h[k], 0.0, base_h[k]); }
+    zero(field("pres").vhat);
+    zero(field("pseu").vhat);
+  };
+  reset();
+  integrate(max_time);
+  const double e_base = energy(beta1, beta2);
+  double* out[3] = {gu, gv, gt};
+  for (int k = 0; k < 3; ++k) std::fill(out[k], out[k] + np, 0.0);
+  const long total = points ? npoints : (long)(3 * np);
+  for (long q = 0; q < total; ++q) {
+    int k, i, j;
+    if (points) { k = points[3 * q]; i = points[3 * q + 1]; j = points[3 * q + 2]; }
+    else { k = (int)(q / (long)np); i = (int)((q % (long)np) / ny_); j = (int)(q % ny_); }
+    RPDE_REQUIRE(k >= 0 && k < 3 && i >= 0 && i < nx_ && j >= 0 && j < ny_, "grad_fd: point outside the grid");
+    reset();
+    F& f = field(fld[k]);
+    dev_sync(st_);
+    dev_upload2d(ph_.p(), ph_.ld, base_v[k].data(), nx_, ny_);
+    launch_set_element(ph_.p(), (long)i * ph_.ld + j, base_v[k][(size_t)i * ny_ + j] + eps, st_);
+    f.sp->forward(ph_, f.vhat, st_);
+    integrate(max_time);
+    out[k][(size_t)i * ny_ + j] = 1.0 / eps * (energy(beta1, beta2) - e_base);
+  }
+  dev_sync(st_);
+  if (filename && *filename) write_gradient(filename, gu, gv, gt);
 }
 
 }  // namespace rpde

@@ -27,6 +27,8 @@ class GenericFlow2D {
                 double dt_helmholtz, std::initializer_list<const char*> extra_fields);
   virtual ~GenericFlow2D();
   double time() const { return time_; }
+  int nx() const { return nx_; }
+  int ny() const { return ny_; }
   double dt() const { return dt_; }
   void reset_time() { time_ = 0.0; }
   double param(const std::string& key) const;       // ra, pr, nu, ka
@@ -106,7 +108,29 @@ class Navier2DLnseEngine : public GenericFlow2D {
   void set_mean_physical(const std::string& name, const double* host, size_t len);   // "velx" | "vely" | "temp": MeanFields::read's assignment + forward
   void get_mean_physical(const std::string& name, double* host, size_t len);
 
+  // ---- adjoint-based sensitivity of the final energy (third slice of SURVEY 8f-4) ----
+  void update_direct(int nsteps) { update(nsteps); }                  // lnse_adj_grad.rs:43-68: the same sequence as update()
+  void update_adjoint(int nsteps);                                    // lnse_adj_grad.rs:71-99, equations lnse_adj_eq.rs
+  // functions.rs:11-58 `energy`: 0.5 sum(b1 u^2 + b1 v^2 + b2 T^2) over the grid points of the physical fields; target (three
+  // physical arrays of nx*ny doubles, or all null): the fields minus the target (lnse_adj_grad.rs:141-155)
+  double energy(double beta1, double beta2, const double* tu = nullptr, const double* tv = nullptr, const double* tt = nullptr);
+  // lnse_adj_grad.rs:105-202: forward loop to max_time, energy, adjoint initial condition beta (state - target), adjoint loop,
+  // gradient = -(physical adjoint fields as the state holds them: those of the START of the last adjoint step, :185-191).
+  // gu, gv, gt: nx*ny doubles each; filename: the reference's "data/grad_adjoint.h5" (groups ux, uy, temp), or null
+  double grad_adjoint(double max_time, double beta1, double beta2, const double* tu, const double* tv, const double* tt,
+                      double* gu, double* gv, double* gt, const char* filename, long* timesteps);
+  // lnse_fd_grad.rs:31-157: one integration per perturbed grid point (eps = 1e-5).  points: npoints triples (field 0 / 1 / 2, i, j),
+  // or null = every point of velx, vely, temp in the reference's order; entries not visited are 0
+  void grad_fd(double max_time, double beta1, double beta2, const int* points, long npoints, double* gu, double* gv, double* gt,
+               const char* filename);
+  long integrate(double max_time);                                    // src/lib.rs:187-219 without callbacks
+
  private:
+  bool exit_grad(double max_time, long timestep);                     // lnse_adj_grad.rs:204-225
+  void conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out);   // conv_*_adjoint of lnse_adj_eq.rs:16-94
+  double sumsq(const Arr2& a);
+  void write_gradient(const char* filename, const double* gu, const double* gv, const double* gt);
+  Arr2 tp_;                                         // physical temperature of the adjoint step
   void conv_lin(F& mean_f, F& f, Arr2& out);        // conv_velx / vely / temp of lnse_eq.rs:59-110
   F& mean(const std::string& name) { return field("mean_" + name); }
   Arr2 um_, vm_;                                    // physical mean velocities (constant during a run)

@@ -442,6 +442,78 @@ int rpde_lnse2d_read(rpde_lnse2d* h, const char* filename) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(filename, "null pointer"); select_device(h->device); h->e->read(filename); })
 }
 
+int rpde_lnse2d_update_adjoint(rpde_lnse2d* h, int nsteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(nsteps >= 0, "negative step count"); select_device(h->device); h->e->update_adjoint(nsteps); })
+}
+int rpde_lnse2d_integrate(rpde_lnse2d* h, double max_time, long* timesteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); const long n = h->e->integrate(max_time); if (timesteps) *timesteps = n; })
+}
+int rpde_lnse2d_energy(rpde_lnse2d* h, double beta1, double beta2, const double* target_velx, const double* target_vely,
+                       const double* target_temp, size_t len, double* energy) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(energy, "null pointer");
+    RPDE_REQUIRE(!target_velx || len == (size_t)h->e->nx() * h->e->ny(), "energy: target arrays are nx*ny doubles");
+    select_device(h->device);
+    *energy = h->e->energy(beta1, beta2, target_velx, target_vely, target_temp);
+  })
+}
+int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double beta1, double beta2, const double* target_velx,
+                             const double* target_vely, const double* target_temp, size_t len, const char* filename, double* fun_val,
+                             double* grad_velx, double* grad_vely, double* grad_temp, long* timesteps) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(fun_val && grad_velx && grad_vely && grad_temp, "null pointer");
+    RPDE_REQUIRE(len == (size_t)h->e->nx() * h->e->ny(), "grad_adjoint: physical arrays are nx*ny doubles");
+    select_device(h->device);
+    *fun_val = h->e->grad_adjoint(max_time, beta1, beta2, target_velx, target_vely, target_temp, grad_velx, grad_vely, grad_temp, filename, timesteps);
+  })
+}
+int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double beta2, const int* points, long npoints, size_t len,
+                        const char* filename, double* grad_velx, double* grad_vely, double* grad_temp) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(grad_velx && grad_vely && grad_temp, "null pointer");
+    RPDE_REQUIRE(len == (size_t)h->e->nx() * h->e->ny(), "grad_fd: physical arrays are nx*ny doubles");
+    RPDE_REQUIRE(!points || npoints >= 0, "grad_fd: negative point count");
+    select_device(h->device);
+    h->e->grad_fd(max_time, beta1, beta2, points, npoints, grad_velx, grad_vely, grad_temp, filename);
+  })
+}
+// functions.rs:30-58
+int rpde_l2_norm(size_t len, const double* a1, const double* a2, const double* b1, const double* b2, const double* c1, const double* c2,
+                 double beta1, double beta2, double* out) {
+  RPDE_TRY({
+    RPDE_REQUIRE(a1 && a2 && b1 && b2 && c1 && c2 && out, "null pointer");
+    double s = 0.0;
+    for (size_t i = 0; i < len; ++i) s += beta1 * a1[i] * a2[i] + beta1 * b1[i] * b2[i] + beta2 * c1[i] * c2[i];
+    *out = 0.5 * s;
+  })
+}
+// opt_routines.rs:16-56 (host arrays in, host arrays out, like the reference; the gradients are projected in place)
+int rpde_steepest_descent_energy_constrained(size_t len, const double* velx_0, const double* vely_0, const double* temp_0, double* grad_velx,
+                                             double* grad_vely, double* grad_temp, double* velx_new, double* vely_new, double* temp_new,
+                                             double beta1, double beta2, double alpha) {
+  RPDE_TRY({
+    RPDE_REQUIRE(velx_0 && vely_0 && temp_0 && grad_velx && grad_vely && grad_temp && velx_new && vely_new && temp_new, "null pointer");
+    RPDE_REQUIRE(alpha <= 2.0 * M_PI, "alpha must be less than 2 pi");
+    auto l2 = [&](const double* a1, const double* a2, const double* b1, const double* b2, const double* c1, const double* c2) {
+      double s = 0.0;
+      for (size_t i = 0; i < len; ++i) s += beta1 * a1[i] * a2[i] + beta1 * b1[i] * b2[i] + beta2 * c1[i] * c2[i];
+      return 0.5 * s;
+    };
+    const double n = (double)len;
+    const double e0 = l2(velx_0, velx_0, vely_0, vely_0, temp_0, temp_0) / n;
+    double eg = l2(grad_velx, velx_0, grad_vely, vely_0, grad_temp, temp_0) / n;
+    const double ee = eg / e0;
+    for (size_t i = 0; i < len; ++i) { grad_velx[i] -= ee * velx_0[i]; grad_vely[i] -= ee * vely_0[i]; grad_temp[i] -= ee * temp_0[i]; }
+    eg = l2(grad_velx, grad_velx, grad_vely, grad_vely, grad_temp, grad_temp) / n;
+    const double ee2 = std::sqrt(e0 / eg), ca = std::cos(alpha), sa = std::sin(alpha);
+    for (size_t i = 0; i < len; ++i) {
+      velx_new[i] = velx_0[i] * ca + grad_velx[i] * ee2 * sa;
+      vely_new[i] = vely_0[i] * ca + grad_vely[i] * ee2 * sa;
+      temp_new[i] = temp_0[i] * ca + grad_temp[i] * ee2 * sa;
+    }
+  })
+}
+
 int rpde_navier2d_set_velocity(rpde_navier2d* h, double amp, double m, double n) {
   RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->set_velocity(amp, m, n); })
 }

@@ -259,7 +259,7 @@ def test_emu_adjoint_callback_writes_the_flow_file(emu_lib, tmp_path, monkeypatc
 
 
 # ================================================================================================ Navier2DLnse
-def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=True, tol=1e-10, tol_p=1e-8):
+def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=True, tol=1e-10, tol_p=1e-8, adjoint=False):
     """Engine vs oracle after every update, with a non-trivial mean flow (a convection roll) on top of the conduction
     profile: u, v, T to `tol`, pres / pseu to `tol_p` (the Poisson solve's amplified eigenvector round-off)."""
     from oracle import lnse as L
@@ -284,8 +284,12 @@ def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=T
         z.set_temperature(0.1, 1.0, 2.0)
     worst = {}
     for s in range(steps):
-        nav.update(1)
-        ora.update()
+        if adjoint:                          # Navier2DLnse::update_adjoint (lnse_adj_grad.rs:71-99)
+            nav.update_adjoint(1)
+            ora.update_adjoint()
+        else:
+            nav.update(1)
+            ora.update()
         got, want = nav.spectral_fields(), ora.spectral_fields()
         for k in want:
             e = rel(got[k], want[k])
@@ -293,8 +297,77 @@ def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=T
             assert e < (tol_p if k in ("pres", "pseu") else tol), (nx, ny, periodic, s, k, e)
     assert abs(nav.div_norm() - ora.div_norm()) < 1e-8 * max(ora.div_norm(), 1e-12)
     assert nav.exit() == ora.exit() and abs(nav.get_time() - ora.time) < 1e-12
-    print("lnse", nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
+    print("lnse adjoint" if adjoint else "lnse", nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
     return worst
+
+
+def lnse_pair(lib, nx, ny, periodic, ra, pr, dt, seed=0, amp=1e-3, mean_flow=False):
+    from oracle import lnse as L
+    mk_e = R.Navier2DLnse.new_periodic if periodic else R.Navier2DLnse.new_confined
+    mk_o = L.Navier2DLnse.new_periodic if periodic else L.Navier2DLnse.new_confined
+    nav = mk_e(nx, ny, ra, pr, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o(nx, ny, ra, pr, dt, 1.0, "rbc", eig_mode="parity")
+    if mean_flow:
+        x, y = ora.velx.x
+        xs, ys = (x - x[0]) / (x[-1] - x[0]), (y - y[0]) / (y[-1] - y[0])
+        for name, arr in (("velx", 0.3 * np.sin(np.pi * xs)[:, None] * np.cos(np.pi * ys)[None, :]),
+                          ("vely", -0.3 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :]),
+                          ("temp", ora.mean.temp.v + 0.1 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :])):
+            getattr(nav, "mean_" + name).v = arr
+            ora.mean.set_physical(name, arr)
+    ora.init_random(amp, seed)               # the same random physical arrays on both sides
+    for k in ("temp", "velx", "vely"):
+        getattr(nav, k).v = getattr(ora, k).v
+    return nav, ora
+
+
+def check_lnse_gradient(lib, nx, ny, periodic, max_time, ra=3e3, pr=0.1, dt=0.01, with_target=False, fd_points=6, tol=1e-9, tmp_path=None):
+    """grad_adjoint (fun_val and the three gradient fields), energy and grad_fd (a few points) of the engine against the oracle,
+    the parameters of examples/navier_lnse_test_gradient.rs by default."""
+    from oracle import lnse as L
+    nav, ora = lnse_pair(lib, nx, ny, periodic, ra, pr, dt, mean_flow=with_target)
+    target = None
+    if with_target:                          # a target flow (lnse_adj_grad.rs:141-155, 160-166): MeanFields in the orthonormal space
+        target = L.MeanFields(ora.field.space)
+        rng = np.random.default_rng(7)
+        x, y = ora.velx.x
+        ys = (y - y[0]) / (y[-1] - y[0])
+        for name in ("velx", "vely", "temp"):
+            target.set_physical(name, 1e-3 * rng.standard_normal((nx, ny)) * np.sin(np.pi * ys)[None, :])
+            getattr(target, name).backward()
+    base = {k: getattr(ora, k).vhat.copy() for k in ("velx", "vely", "temp")}
+    assert abs(nav.energy(0.5, 0.25) - ora.energy(0.5, 0.25)) < 1e-12 * ora.energy(0.5, 0.25)
+    fn = None if tmp_path is None else str(tmp_path / "data" / "grad_adjoint.h5")
+    fun_e, g_e = nav.grad_adjoint(max_time, None, 0.5, 0.25, target, filename=fn)
+    fun_o, g_o = ora.grad_adjoint(max_time, 0.5, 0.25, target)
+    assert abs(fun_e - fun_o) < tol * abs(fun_o), (fun_e, fun_o)
+    errs = [rel(a, b) for a, b in zip(g_e, g_o)]
+    assert max(errs) < tol, errs
+    assert abs(nav.get_time() - ora.time) < 1e-12
+    for k in ("velx", "vely", "temp"):       # both sides are left holding the adjoint fields
+        assert rel(getattr(nav, k).vhat, getattr(ora, k).vhat) < tol, k
+    if fn is not None:                       # the reference's data/grad_adjoint.h5: groups ux, uy, temp with v and vhat = forward(v)
+        from tests.h5classic import File
+        d = File(fn).datasets
+        for g, arr, f in (("ux", g_e[0], ora.velx), ("uy", g_e[1], ora.vely), ("temp", g_e[2], ora.temp)):
+            assert np.array_equal(d[g + "/v"], arr)
+            want = f.space.forward(arr)
+            got = d[g + "/vhat_re"] + 1j * d[g + "/vhat_im"] if periodic else d[g + "/vhat"]
+            assert rel(got, want) < 1e-11, g
+    # finite differences at a few points: restore the initial state on both sides first
+    rng = np.random.default_rng(3)
+    pts = [(("velx", "vely", "temp")[int(rng.integers(3))], int(rng.integers(nx)), int(rng.integers(1, ny - 1))) for _ in range(fd_points)]
+    for z in (nav, ora):
+        for k in base:
+            getattr(z, k).vhat = base[k]
+    for k in base:
+        getattr(ora, k).backward()           # the reference perturbs the physical arrays the state holds (lnse_fd_grad.rs:41-43)
+    fd_e = nav.grad_fd(max_time, None, 0.5, 0.25, points=pts, filename=None)
+    fd_o = ora.grad_fd(max_time, 0.5, 0.25, points=pts)
+    for a, b, k in zip(fd_e, fd_o, ("velx", "vely", "temp")):
+        # differences of energies of 1e-7 divided by eps = 1e-5: round-off of 1e-16 relative in the energies is 1e-11 / |g|
+        assert np.abs(a - b).max() < 1e-6 * max(np.abs(b).max(), 1e-30) + 1e-12, (k, np.abs(a - b).max(), np.abs(b).max())
+    print("lnse gradient", nx, ny, "periodic" if periodic else "confined", f"fun {fun_o:.6e}", [f"{e:.1e}" for e in errs])
 
 
 def test_oracle_lnse_is_the_linearisation_of_navier2d():
@@ -338,6 +411,65 @@ def test_emu_lnse_step_parity(emu_lib, nx, ny, periodic):
     check_lnse_parity(emu_lib, nx, ny, periodic, steps=4)
 
 
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (16, 13, True)])
+def test_emu_lnse_adjoint_step_parity(emu_lib, nx, ny, periodic):
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=4, adjoint=True)
+
+
+@pytest.mark.parametrize("nx,ny,periodic,with_target", [(16, 13, True, False), (17, 17, False, True)])
+def test_emu_lnse_gradient_parity(emu_lib, tmp_path, nx, ny, periodic, with_target):
+    check_lnse_gradient(emu_lib, nx, ny, periodic, max_time=0.1, with_target=with_target, tmp_path=tmp_path)
+
+
+def test_oracle_lnse_adjoint_gradient_agrees_with_finite_differences():
+    """What pins the restated adjoint equations (oracle/lnse.py <- lnse_adj_eq.rs, lnse_adj_grad.rs): the reference's own
+    validation, examples/navier_lnse_test_gradient.rs -- adjoint gradient against finite differences over every grid point,
+    accepted at |g_fd - g_adj| / |g_adj| <= 0.3.  The full example (horizon 10, 702 integrations of 1000 steps) ran once through
+    tests/golden/make_lnse_gradient_pin.py and its result is committed; here: the committed record is inside the reference's
+    acceptance, and a sub-sampled rerun (horizon 0.5, 40 points) reproduces the agreement."""
+    import json
+    from oracle import lnse as L
+    path = os.path.join(os.path.dirname(__file__), "golden", "lnse_gradient_pin.json")
+    rec = json.load(open(path))
+    assert (rec["nx"], rec["ny"], rec["ra"], rec["pr"], rec["dt"], rec["max_time"]) == (18, 13, 3e3, 0.1, 0.01, 10.0)
+    for k in ("velx", "vely", "temp"):
+        assert rec[k]["rel_diff"] < rec["reference_acceptance"], (k, rec[k])
+    nav = L.Navier2DLnse.new_periodic(18, 13, 3e3, 0.1, 0.01, 1.0, "rbc")
+    nav.init_random(1e-3, 0)
+    base = {k: getattr(nav, k).vhat.copy() for k in ("velx", "vely", "temp")}
+    _, g_adj = nav.grad_adjoint(0.5, 0.5, 0.5)
+    for k in base:
+        getattr(nav, k).vhat = base[k]
+        getattr(nav, k).backward()
+    rng = np.random.default_rng(11)
+    pts = [(k, int(rng.integers(18)), int(rng.integers(2, 11))) for k in ("velx", "vely", "temp") for _ in range(13)]
+    g_fd = nav.grad_fd(0.5, 0.5, 0.5, points=pts)
+    ga = np.array([-dict(zip(("velx", "vely", "temp"), g_adj))[k][i, j] for k, i, j in pts])
+    gf = np.array([dict(zip(("velx", "vely", "temp"), g_fd))[k][i, j] for k, i, j in pts])
+    assert np.linalg.norm(ga - gf) / np.linalg.norm(ga) < 0.3, (ga, gf)
+
+
+def test_emu_l2_norm_and_steepest_descent(emu_lib):
+    """functions::l2_norm and opt_routines::steepest_descent_energy_constrained (host arrays) against the oracle; the rotated
+    state keeps the energy of the old one (the point of the routine) and alpha > 2 pi is refused like the reference's assert."""
+    from oracle import lnse as L
+    rng = np.random.default_rng(2)
+    u0, v0, t0, gu, gv, gt = (rng.standard_normal((18, 13)) for _ in range(6))
+    assert abs(R.l2_norm(u0, gu, v0, gv, t0, gt, 0.5, 0.25, library=emu_lib) - L.l2_norm(u0, gu, v0, gv, t0, gt, 0.5, 0.25)) < 1e-13
+    (un_o, vn_o, tn_o), (gu_o, gv_o, gt_o) = L.steepest_descent_energy_constrained(u0, v0, t0, gu, gv, gt, 0.5, 0.25, 0.3)
+    gu_e, gv_e, gt_e = gu.copy(), gv.copy(), gt.copy()
+    un, vn, tn = (np.empty((18, 13)) for _ in range(3))
+    R.steepest_descent_energy_constrained(u0, v0, t0, gu_e, gv_e, gt_e, un, vn, tn, 0.5, 0.25, 0.3, library=emu_lib)
+    for a, b in ((un, un_o), (vn, vn_o), (tn, tn_o), (gu_e, gu_o), (gv_e, gv_o), (gt_e, gt_o)):
+        assert rel(a, b) < 1e-13
+    e0 = L.l2_norm(u0, u0, v0, v0, t0, t0, 0.5, 0.25)
+    assert abs(L.l2_norm(un, un, vn, vn, tn, tn, 0.5, 0.25) - e0) < 1e-12 * e0
+    with pytest.raises(R.RpdeError, match="2 pi"):
+        R.steepest_descent_energy_constrained(u0, v0, t0, gu_e, gv_e, gt_e, un, vn, tn, 0.5, 0.25, 7.0, library=emu_lib)
+    with pytest.raises(R.RpdeError, match="C-contiguous"):
+        R.steepest_descent_energy_constrained(u0, v0, t0, gu_e.T, gv_e, gt_e, un, vn, tn, 0.5, 0.25, 0.3, library=emu_lib)
+
+
 def test_emu_lnse_mean_from_a_snapshot_and_errors(emu_lib, tmp_path):
     """MeanFields::read_from_confined (meanfield.rs:92-127, 237-259): ux/v, uy/v, temp/v + tempbc/v of a Navier2D snapshot."""
     src = R.Navier2D.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, init_random=None)
@@ -359,6 +491,21 @@ def test_emu_lnse_mean_from_a_snapshot_and_errors(emu_lib, tmp_path):
         R.Navier2DLnse.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "hc", library=emu_lib, mean_file="/nonexistent")
     with pytest.raises(R.RpdeError, match="velx, vely or temp"):
         R.Navier2DLnse._Mean(nav, "pres").v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2)])
+def test_gpu_lnse_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
+    if nx >= 1025:
+        check_lnse_parity(hip_lib, nx, ny, periodic, steps, ra=1e7, dt=1e-3, adjoint=True)
+    else:
+        check_lnse_parity(hip_lib, nx, ny, periodic, steps, adjoint=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,periodic,with_target,max_time", [(16, 13, True, False, 0.2), (33, 33, False, True, 0.1), (64, 33, True, True, 0.1)])
+def test_gpu_lnse_gradient_parity(hip_lib, tmp_path, nx, ny, periodic, with_target, max_time):
+    check_lnse_gradient(hip_lib, nx, ny, periodic, max_time=max_time, with_target=with_target, fd_points=4, tmp_path=tmp_path)
 
 
 @pytest.mark.gpu
