@@ -255,6 +255,20 @@ int rpde_lnse2d_exit(rpde_lnse2d* h, int* stop);                   /* NaN diverg
 int rpde_lnse2d_div_norm(rpde_lnse2d* h, double* norm);            /* lnse_eq.rs:36-41 */
 int rpde_lnse2d_write(rpde_lnse2d* h, const char* filename);       /* the Field2 snapshot layout (ux uy temp pres tempbc + time + params) */
 int rpde_lnse2d_read(rpde_lnse2d* h, const char* filename);
+/* Navier2DNonLin::new_confined / new_periodic                      src/navier_stokes_lnse/nonlin.rs:84-262: the non-linear
+   equations for the deviation from the mean fields (nonlin_eq.rs), same fields, same handle type -- every rpde_lnse2d_* entry
+   serves both solvers, the constructor decides the equations.  rpde_lnse2d_write adds the groups ux_base, uy_base, temp_base
+   (nonlin_io.rs:44-66). */
+int rpde_nonlin2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                  const char* mean_file, int device, rpde_lnse2d** out);
+int rpde_nonlin2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                  const char* mean_file, int device, rpde_lnse2d** out);
+/* n x update_direct(): Navier2DLnse: == update (lnse_adj_grad.rs:43-68); Navier2DNonLin: update + one entry of field_history per
+   step (nonlin_adj_grad.rs:43-81; the history lives in HBM: three spectral arrays per step).  rpde_lnse2d_update_adjoint on a
+   Navier2DNonLin removes the LAST entry per step (:190-193) and fails on an empty history. */
+int rpde_lnse2d_update_direct(rpde_lnse2d* h, int nsteps);
+int rpde_lnse2d_history_len(rpde_lnse2d* h, long* n);
+int rpde_lnse2d_clear_history(rpde_lnse2d* h);
 /* ---- adjoint-based sensitivity of the final energy (src/navier_stokes_lnse/lnse_adj_grad.rs, lnse_adj_eq.rs) ---- */
 /* n x Navier2DLnse::update_adjoint()                               lnse_adj_grad.rs:71-99 (update_direct == rpde_lnse2d_update, :43-68) */
 int rpde_lnse2d_update_adjoint(rpde_lnse2d* h, int nsteps);

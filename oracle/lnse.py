@@ -176,6 +176,9 @@ class Navier2DLnse:
 
     update_direct = update                       # lnse_adj_grad.rs:43-68 is the same sequence
 
+    def reset_time(self):
+        self.time = 0.0
+
     def exit(self):
         return bool(np.isnan(self.div_norm()))
 
@@ -337,6 +340,145 @@ class Navier2DLnse:
 
     def spectral_fields(self, names=("velx", "vely", "temp", "pres", "pseu")):
         return {k: getattr(self, k).vhat.copy() for k in names}
+
+
+class _History:
+    """One entry of ``field_history`` (nonlin_adj_grad.rs:69-77): clones of velx, vely, temp after their ``backward()``."""
+
+    def __init__(self, nav):
+        self.vhat = {k: getattr(nav, k).vhat.copy() for k in ("velx", "vely", "temp")}
+        self.v = {k: getattr(nav, k).v.copy() for k in ("velx", "vely", "temp")}
+
+
+class Navier2DNonLin(Navier2DLnse):
+    """``Navier2DNonLin`` (src/navier_stokes_lnse/nonlin.rs, nonlin_eq.rs, nonlin_adj_eq.rs, nonlin_adj_grad.rs): the full
+    non-linear equations for the deviation from the mean fields -- the LNSE step plus u . grad(u) + U . grad(U), the mean's
+    diffusion and the mean temperature in the buoyancy -- with the history of the forward states that the adjoint loop's
+    convection terms read back."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.field_history = []
+
+    def _conv(self, ux, uy, mean_f, f):          # nonlin_eq.rs:59-134: eight terms
+        self.mean.velx.backward()
+        self.mean.vely.backward()
+        um, vm = self.mean.velx.v, self.mean.vely.v
+        conv = self._conv_term(ux, mean_f, [1, 0])
+        conv += self._conv_term(uy, mean_f, [0, 1])
+        conv += self._conv_term(um, f, [1, 0])
+        conv += self._conv_term(vm, f, [0, 1])
+        conv += self._conv_term(ux, f, [1, 0])
+        conv += self._conv_term(uy, f, [0, 1])
+        conv += self._conv_term(um, mean_f, [1, 0])
+        conv += self._conv_term(vm, mean_f, [0, 1])
+        self.field.v = conv
+        self.field.forward()
+        vhat = self.field.vhat
+        vhat[vhat.shape[0] * 2 // 3:, :] = 0
+        vhat[:, vhat.shape[1] * 2 // 3:] = 0
+        return vhat.copy()
+
+    def _mean_diffusion(self, mean_f, kappa):    # nonlin_eq.rs:204-206, 221-223, 236-238
+        return (mean_f.gradient([2, 0], self.scale) + mean_f.gradient([0, 2], self.scale)) * (self.dt * kappa)
+
+    def solve_velx(self, ux, uy):
+        self.zero_rhs()
+        self.rhs += self.velx.to_ortho()
+        self.rhs -= self.pres.gradient([1, 0], self.scale) * self.dt
+        self.rhs -= self._conv(ux, uy, self.mean.velx, self.velx) * self.dt
+        self.rhs += self._mean_diffusion(self.mean.velx, self.params["nu"])
+        self.velx.vhat = self.solver_hholtz[0].solve(self.rhs)
+
+    def solve_vely(self, ux, uy, buoy):
+        self.zero_rhs()
+        self.rhs += self.vely.to_ortho()
+        self.rhs -= self.pres.gradient([0, 1], self.scale) * self.dt
+        self.rhs += buoy * self.dt
+        self.rhs -= self._conv(ux, uy, self.mean.vely, self.vely) * self.dt
+        self.rhs += self._mean_diffusion(self.mean.vely, self.params["nu"])
+        self.vely.vhat = self.solver_hholtz[1].solve(self.rhs)
+
+    def solve_temp(self, ux, uy):
+        self.zero_rhs()
+        self.rhs += self.temp.to_ortho()
+        self.rhs -= self._conv(ux, uy, self.mean.temp, self.temp) * self.dt
+        self.rhs += self._mean_diffusion(self.mean.temp, self.params["ka"])
+        self.temp.vhat = self.solver_hholtz[2].solve(self.rhs)
+
+    def update(self):                            # nonlin.rs:264-296
+        that = self.temp.to_ortho() + self.mean.temp.to_ortho()
+        self.velx.backward()
+        self.vely.backward()
+        ux, uy = self.velx.v.copy(), self.vely.v.copy()
+        self.solve_velx(ux, uy)
+        self.solve_vely(ux, uy, that)
+        div = self.div()
+        self.solve_pres(div)
+        self.correct_velocity(1.0)
+        self.update_pres(div)
+        self.solve_temp(ux, uy)
+        self.time += self.dt
+
+    def update_direct(self):                     # nonlin_adj_grad.rs:43-81: update() + the history entry
+        self.update()
+        self.velx.backward()
+        self.vely.backward()
+        self.temp.backward()
+        self.field_history.append(_History(self))
+
+    def _conv_adjoint_nl(self, f, deriv, velx, vely, temp, nl, with_gradients=True):   # nonlin_adj_eq.rs:16-118
+        self.mean.velx.backward()
+        self.mean.vely.backward()
+        um, vm = self.mean.velx.v, self.mean.vely.v
+        conv = self._conv_term(um, f, [1, 0])
+        conv += self._conv_term(vm, f, [0, 1])
+        if with_gradients:
+            conv -= self._conv_term(velx, self.mean.velx, deriv)
+            conv -= self._conv_term(vely, self.mean.vely, deriv)
+            conv -= self._conv_term(temp, self.mean.temp, deriv)
+        conv += self._conv_term(nl.v["velx"], f, [1, 0])
+        conv += self._conv_term(nl.v["vely"], f, [0, 1])
+        if with_gradients:
+            for u, k in ((velx, "velx"), (vely, "vely"), (temp, "temp")):
+                fld = getattr(self, k)
+                conv -= u * self.field.space.backward(fld.space.gradient(nl.vhat[k], deriv, self.scale))
+        self.field.v = conv
+        self.field.forward()
+        vhat = self.field.vhat
+        vhat[vhat.shape[0] * 2 // 3:, :] = 0
+        vhat[:, vhat.shape[1] * 2 // 3:] = 0
+        return vhat.copy()
+
+    def update_adjoint(self, field_from_fwd=None):   # nonlin_adj_grad.rs:84-118 (None: the last history entry, like :190-193)
+        nl = self.field_history.pop() if field_from_fwd is None else field_from_fwd
+        uyhat = self.vely.to_ortho()
+        self.velx.backward()
+        self.vely.backward()
+        self.temp.backward()
+        velx, vely, temp = self.velx.v.copy(), self.vely.v.copy(), self.temp.v.copy()
+        # solve_velx_adj / solve_vely_adj (nonlin_adj_eq.rs:127-165)
+        self.zero_rhs()
+        self.rhs += self.velx.to_ortho()
+        self.rhs -= self.pres.gradient([1, 0], self.scale) * self.dt
+        self.rhs += self._conv_adjoint_nl(self.velx, [1, 0], velx, vely, temp, nl) * self.dt
+        self.velx.vhat = self.solver_hholtz[0].solve(self.rhs)
+        self.zero_rhs()
+        self.rhs += self.vely.to_ortho()
+        self.rhs -= self.pres.gradient([0, 1], self.scale) * self.dt
+        self.rhs += self._conv_adjoint_nl(self.vely, [0, 1], velx, vely, temp, nl) * self.dt
+        self.vely.vhat = self.solver_hholtz[1].solve(self.rhs)
+        div = self.div()
+        self.solve_pres(div)
+        self.correct_velocity(1.0)
+        self.update_pres(div)
+        # solve_temp_adj (nonlin_adj_eq.rs:168-188)
+        self.zero_rhs()
+        self.rhs += self.temp.to_ortho()
+        self.rhs += self._conv_adjoint_nl(self.temp, None, velx, vely, temp, nl, with_gradients=False) * self.dt
+        self.rhs += uyhat * self.dt
+        self.temp.vhat = self.solver_hholtz[2].solve(self.rhs)
+        self.time += self.dt
 
 
 def l2_norm(a1, a2, b1, b2, c1, c2, beta1, beta2):

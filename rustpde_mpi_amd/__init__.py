@@ -685,8 +685,9 @@ class Navier2DLnse(Navier2DAdjoint):
 
     # ---- adjoint-based sensitivity of the final energy (lnse_adj_grad.rs, lnse_fd_grad.rs) ----
     def update_direct(self, nsteps: int = 1):
-        """`Navier2DLnse::update_direct` (lnse_adj_grad.rs:43-68): the same sequence as `update`."""
-        self.update(nsteps)
+        """`Navier2DLnse::update_direct` (lnse_adj_grad.rs:43-68): the same sequence as `update`; `Navier2DNonLin`: + one entry
+        of the field history per step (nonlin_adj_grad.rs:43-81)."""
+        self._lib.call("rpde_lnse2d_update_direct", self._h, int(nsteps))
 
     def update_adjoint(self, nsteps: int = 1):
         """`Navier2DLnse::update_adjoint` (lnse_adj_grad.rs:71-99)."""
@@ -750,6 +751,30 @@ class Navier2DLnse(Navier2DAdjoint):
         self._lib.call("rpde_lnse2d_grad_fd", self._h, float(max_time), float(beta1), float(beta2), pts, npts, self.nx * self.ny,
                        None if filename is None else str(filename).encode(), ptr(gu), ptr(gv), ptr(gt))
         return gu, gv, gt
+
+
+class Navier2DNonLin(Navier2DLnse):
+    """Device-resident `Navier2DNonLin` (src/navier_stokes_lnse/nonlin.rs): the non-linear equations for the deviation from the
+    mean fields, with the history of forward states (in HBM) that `update_adjoint` / `grad_adjoint` read back.  Same methods as
+    `Navier2DLnse`; `update_adjoint()` consumes the last history entry (the reference passes it explicitly, taken from
+    `field_history` the same way: nonlin_adj_grad.rs:190-193)."""
+
+    @classmethod
+    def new_confined(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, mean_file=None):
+        return cls._new("rpde_nonlin2d_create_confined", nx, ny, ra, pr, dt, aspect, bc, device, library, False, mean_file)
+
+    @classmethod
+    def new_periodic(cls, nx, ny, ra, pr, dt, aspect, bc, device=0, library=None, mean_file=None):
+        return cls._new("rpde_nonlin2d_create_periodic", nx, ny, ra, pr, dt, aspect, bc, device, library, True, mean_file)
+
+    @property
+    def field_history_len(self):
+        n = C.c_long()
+        self._lib.call("rpde_lnse2d_history_len", self._h, C.byref(n))
+        return n.value
+
+    def clear_field_history(self):
+        self._lib.call("rpde_lnse2d_clear_history", self._h)
 
 
 def l2_norm(a1, a2, b1, b2, c1, c2, beta1, beta2, library=None):

@@ -86,6 +86,13 @@ SIGNATURES = {
     "rpde_lnse2d_div_norm": (C.c_int, [_vp, _dp]),
     "rpde_lnse2d_write": (C.c_int, [_vp, C.c_char_p]),
     "rpde_lnse2d_read": (C.c_int, [_vp, C.c_char_p]),
+    "rpde_nonlin2d_create_confined": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                                C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "rpde_nonlin2d_create_periodic": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                                C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "rpde_lnse2d_update_direct": (C.c_int, [_vp, C.c_int]),
+    "rpde_lnse2d_history_len": (C.c_int, [_vp, C.POINTER(C.c_long)]),
+    "rpde_lnse2d_clear_history": (C.c_int, [_vp]),
     "rpde_lnse2d_update_adjoint": (C.c_int, [_vp, C.c_int]),
     "rpde_lnse2d_integrate": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_long)]),
     "rpde_lnse2d_energy": (C.c_int, [_vp, C.c_double, C.c_double, _dp, _dp, _dp, C.c_size_t, _dp]),

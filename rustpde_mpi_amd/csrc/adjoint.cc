@@ -505,9 +505,10 @@ void Navier2DAdjointEngine::update(int nsteps) {
 // ================================================================================================
 // Navier2DLnse (src/navier_stokes_lnse/lnse.rs, lnse_eq.rs, meanfield.rs)
 Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc,
-                                       bool periodic, const std::string& mean_file)
-    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, dt, {"mean_velx", "mean_vely", "mean_temp"}) {
+                                       bool periodic, const std::string& mean_file, bool nonlinear)
+    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, dt, {"mean_velx", "mean_vely", "mean_temp"}), nonlin_(nonlinear) {
   um_.alloc(nx, ny, 1); vm_.alloc(nx, ny, 1); tp_.alloc(nx, ny, 1);
+  if (nonlin_) { unl_.alloc(nx, ny, 1); vnl_.alloc(nx, ny, 1); }
   bool from_file = false;
   if (!mean_file.empty()) {
     if (FILE* f = std::fopen(mean_file.c_str(), "rb")) { std::fclose(f); from_file = true; }
@@ -555,12 +556,75 @@ void Navier2DLnseEngine::refresh_mean() {
   backward(mean("vely"), vm_);
 }
 
-void Navier2DLnseEngine::conv_lin(F& mean_f, F& f, Arr2& out) {   // lnse_eq.rs:59-110
+void Navier2DLnseEngine::conv_lin(F& mean_f, F& f, Arr2& out) {   // lnse_eq.rs:59-110; nonlin_eq.rs:59-134
   conv_term(ux_, mean_f, 1, 0, 1.0, true);      // ux dM/dx + uy dM/dy
   conv_term(uy_, mean_f, 0, 1, 1.0, false);
   conv_term(um_, f, 1, 0, 1.0, false);          // U df/dx + V df/dy
   conv_term(vm_, f, 0, 1, 1.0, false);
+  if (nonlin_) {
+    conv_term(ux_, f, 1, 0, 1.0, false);        // ux df/dx + uy df/dy
+    conv_term(uy_, f, 0, 1, 1.0, false);
+    conv_term(um_, mean_f, 1, 0, 1.0, false);   // U dM/dx + V dM/dy
+    conv_term(vm_, mean_f, 0, 1, 1.0, false);
+  }
   conv_finish(out);
+}
+
+void Navier2DLnseEngine::mean_diffusion(F& mean_f, double kappa) {
+  acc_gradient(mean_f, 2, 0, dt_ * kappa, rhs_);
+  acc_gradient(mean_f, 0, 2, dt_ * kappa, rhs_);
+}
+
+void Navier2DLnseEngine::update_direct(int nsteps) {
+  if (!nonlin_) { update(nsteps); return; }
+  for (int step = 0; step < nsteps; ++step) {
+    update(1);
+    // nonlin_adj_grad.rs:65-77: clones of velx, vely, temp (after backward()) pushed onto field_history
+    auto h = std::make_unique<Hist>();
+    const char* const names[3] = {"velx", "vely", "temp"};
+    F* dst[3] = {&h->velx, &h->vely, &h->temp};
+    for (int k = 0; k < 3; ++k) {
+      F& f = field(names[k]);
+      dst[k]->sp = f.sp;
+      dst[k]->vhat.alloc(f.vhat.rows, f.vhat.cols, ex_);
+      lincomb(dst[k]->vhat, 1.0, f.vhat, 0.0, f.vhat);
+    }
+    hist_.push_back(std::move(h));
+  }
+  dev_sync(st_);
+}
+
+void Navier2DLnseEngine::write(const std::string& filename) {
+  GenericFlow2D::write(filename);
+  if (!nonlin_) return;
+  h5::Tree t;
+  Vec x((size_t)nx_), y((size_t)ny_);
+  grid(0, x.data(), x.size());
+  grid(1, y.data(), y.size());
+  const char* const grp[3][2] = {{"mean_velx", "ux_base"}, {"mean_vely", "uy_base"}, {"mean_temp", "temp_base"}};
+  for (const auto& fg : grp) {
+    const std::string g = fg[1];
+    t[g + "/x"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/dx"] = h5::Dataset{{(uint64_t)nx_}, x};
+    t[g + "/y"] = h5::Dataset{{(uint64_t)ny_}, y};
+    t[g + "/dy"] = h5::Dataset{{(uint64_t)ny_}, y};
+    h5::Dataset v{{(uint64_t)nx_, (uint64_t)ny_}, Vec((size_t)nx_ * ny_)};
+    get_field_physical(fg[0], v.data.data(), v.data.size());
+    t[g + "/v"] = std::move(v);
+    int r, c, e;
+    spectral_shape(fg[0], &r, &c, &e);
+    Vec vh((size_t)r * c * e);
+    get_field_spectral(fg[0], vh.data(), vh.size());
+    if (e == 1) {
+      t[g + "/vhat"] = h5::Dataset{{(uint64_t)r, (uint64_t)c}, std::move(vh)};
+    } else {
+      h5::Dataset re{{(uint64_t)r, (uint64_t)c}, Vec((size_t)r * c)}, im = re;
+      for (size_t k = 0; k < (size_t)r * c; ++k) { re.data[k] = vh[2 * k]; im.data[k] = vh[2 * k + 1]; }
+      t[g + "/vhat_re"] = std::move(re);
+      t[g + "/vhat_im"] = std::move(im);
+    }
+  }
+  h5::update_file(filename, t);
 }
 
 bool Navier2DLnseEngine::exit() { return std::isnan(div_norm()); }
@@ -570,14 +634,16 @@ void Navier2DLnseEngine::update(int nsteps) {
   const double dt = dt_;
   for (int step = 0; step < nsteps; ++step) {
     temp.sp->to_ortho(temp.vhat, old_[2], st_);            // buoyancy: temp.to_ortho(), no lift (lnse.rs:265)
+    if (nonlin_) lincomb(old_[2], 1.0, old_[2], 1.0, mean("temp").vhat);   // + mean.temp.to_ortho() (nonlin.rs:266)
     backward(velx, ux_);
     backward(vely, uy_);
-    // solve_velx (lnse_eq.rs:179-190)
+    // solve_velx (lnse_eq.rs:179-190; nonlin_eq.rs:193-208)
     zero(rhs_);
     acc_to_ortho(velx, 1.0, rhs_);
     acc_gradient(pres, 1, 0, -dt, rhs_);
     conv_lin(mean("velx"), velx, cv_);
     lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    if (nonlin_) mean_diffusion(mean("velx"), nu_);
     hh_vel_->solve(rhs_, velx.vhat, st_);
     // solve_vely (lnse_eq.rs:193-207)
     zero(rhs_);
@@ -586,6 +652,7 @@ void Navier2DLnseEngine::update(int nsteps) {
     lincomb(rhs_, 1.0, rhs_, dt, old_[2]);
     conv_lin(mean("vely"), vely, cv_);
     lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    if (nonlin_) mean_diffusion(mean("vely"), nu_);
     hh_vel_->solve(rhs_, vely.vhat, st_);
     // projection (lnse.rs:277-281); update_pres (lnse_eq.rs:140-146)
     div(div_);
@@ -598,6 +665,7 @@ void Navier2DLnseEngine::update(int nsteps) {
     acc_to_ortho(temp, 1.0, rhs_);
     conv_lin(mean("temp"), temp, cv_);
     lincomb(rhs_, 1.0, rhs_, -dt, cv_);
+    if (nonlin_) mean_diffusion(mean("temp"), ka_);
     hh_temp_->solve(rhs_, temp.vhat, st_);
     time_ += dt_;
   }
@@ -608,13 +676,23 @@ void Navier2DLnseEngine::update(int nsteps) {
 // adjoint LNSE step and the gradient of the final energy (lnse_adj_eq.rs, lnse_adj_grad.rs, lnse_fd_grad.rs, functions.rs)
 
 // + U d/dx f* + V d/dy f*  - u* d_j U - v* d_j V - T* d_j Tm   (lnse_adj_eq.rs:16-94; the temperature: no mean-gradient terms)
-void Navier2DLnseEngine::conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out) {
+// nl (Navier2DNonLin, nonlin_adj_eq.rs:16-118): the same terms once more with the forward state of this time level in the mean's place
+void Navier2DLnseEngine::conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out, Hist* nl) {
   conv_term(um_, f, 1, 0, 1.0, true);
   conv_term(vm_, f, 0, 1, 1.0, false);
   if (mean_gradients) {
     conv_term(ux_, mean("velx"), d0, d1, -1.0, false);
     conv_term(uy_, mean("vely"), d0, d1, -1.0, false);
     conv_term(tp_, mean("temp"), d0, d1, -1.0, false);
+  }
+  if (nl) {
+    conv_term(unl_, f, 1, 0, 1.0, false);
+    conv_term(vnl_, f, 0, 1, 1.0, false);
+    if (mean_gradients) {
+      conv_term(ux_, nl->velx, d0, d1, -1.0, false);
+      conv_term(uy_, nl->vely, d0, d1, -1.0, false);
+      conv_term(tp_, nl->temp, d0, d1, -1.0, false);
+    }
   }
   conv_finish(out);
 }
@@ -623,6 +701,15 @@ void Navier2DLnseEngine::update_adjoint(int nsteps) {
   F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
   const double dt = dt_;
   for (int step = 0; step < nsteps; ++step) {
+    std::unique_ptr<Hist> nlh;
+    if (nonlin_) {                                         // nonlin_adj_grad.rs:190-193: the last forward state, removed from the history
+      RPDE_REQUIRE(!hist_.empty(), "update_adjoint: the field history is empty (Navier2DNonLin: one update_direct() per adjoint step)");
+      nlh = std::move(hist_.back());
+      hist_.pop_back();
+      backward(nlh->velx, unl_);
+      backward(nlh->vely, vnl_);
+    }
+    Hist* nl = nlh.get();
     vely.sp->to_ortho(vely.vhat, old_[2], st_);            // adjoint buoyancy: vely.to_ortho() (lnse_adj_grad.rs:73)
     backward(velx, ux_);
     backward(vely, uy_);
@@ -631,14 +718,14 @@ void Navier2DLnseEngine::update_adjoint(int nsteps) {
     zero(rhs_);
     acc_to_ortho(velx, 1.0, rhs_);
     acc_gradient(pres, 1, 0, -dt, rhs_);
-    conv_adj(velx, 1, 0, true, cv_);
+    conv_adj(velx, 1, 0, true, cv_, nl);
     lincomb(rhs_, 1.0, rhs_, dt, cv_);
     hh_vel_->solve(rhs_, velx.vhat, st_);
     // solve_vely_adj (lnse_adj_eq.rs:241-262)
     zero(rhs_);
     acc_to_ortho(vely, 1.0, rhs_);
     acc_gradient(pres, 0, 1, -dt, rhs_);
-    conv_adj(vely, 0, 1, true, cv_);
+    conv_adj(vely, 0, 1, true, cv_, nl);
     lincomb(rhs_, 1.0, rhs_, dt, cv_);
     hh_vel_->solve(rhs_, vely.vhat, st_);
     // projection (lnse_adj_grad.rs:87-91)
@@ -650,11 +737,12 @@ void Navier2DLnseEngine::update_adjoint(int nsteps) {
     // solve_temp_adj (lnse_adj_eq.rs:269-294)
     zero(rhs_);
     acc_to_ortho(temp, 1.0, rhs_);
-    conv_adj(temp, 0, 0, false, cv_);
+    conv_adj(temp, 0, 0, false, cv_, nl);
     lincomb(rhs_, 1.0, rhs_, dt, cv_);
     lincomb(rhs_, 1.0, rhs_, dt, old_[2]);
     hh_temp_->solve(rhs_, temp.vhat, st_);
     time_ += dt_;
+    if (nl) dev_sync(st_);                                 // the history entry goes out of scope
   }
   dev_sync(st_);
 }

@@ -101,15 +101,22 @@ class Navier2DLnseEngine : public GenericFlow2D {
  public:
   // mean_file: MeanFields::read_from_confined / _periodic (meanfield.rs:92-127, 194-231) -- "ux/v", "uy/v", "temp/v" (+ "tempbc/v")
   // of a snapshot if the file exists (the reference looks for "mean.h5"), the boundary condition's default mean otherwise
+  // nonlinear: Navier2DNonLin (nonlin.rs, nonlin_eq.rs, nonlin_adj_eq.rs, nonlin_adj_grad.rs) -- the same fields and solvers; the
+  // step keeps u . grad(u) + U . grad(U), the mean's diffusion and the mean temperature in the buoyancy; update_direct() records
+  // the forward states (field_history, in HBM) that the adjoint step's convection terms read back, last in first out
   Navier2DLnseEngine(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc, bool periodic,
-                     const std::string& mean_file);
+                     const std::string& mean_file, bool nonlinear = false);
+  bool nonlinear() const { return nonlin_; }
+  size_t history_len() const { return hist_.size(); }
+  void clear_history() { dev_sync(st_); hist_.clear(); }
+  void write(const std::string& filename);          // nonlin_io.rs:44-66: + the mean fields as ux_base, uy_base, temp_base
   void update(int nsteps);                          // Integrate::update, lnse.rs:263-288
   bool exit();                                      // lnse.rs:305-313: NaN divergence
   void set_mean_physical(const std::string& name, const double* host, size_t len);   // "velx" | "vely" | "temp": MeanFields::read's assignment + forward
   void get_mean_physical(const std::string& name, double* host, size_t len);
 
   // ---- adjoint-based sensitivity of the final energy (third slice of SURVEY 8f-4) ----
-  void update_direct(int nsteps) { update(nsteps); }                  // lnse_adj_grad.rs:43-68: the same sequence as update()
+  void update_direct(int nsteps);                                     // lnse_adj_grad.rs:43-68 = update(); nonlin_adj_grad.rs:43-81: + history
   void update_adjoint(int nsteps);                                    // lnse_adj_grad.rs:71-99, equations lnse_adj_eq.rs
   // functions.rs:11-58 `energy`: 0.5 sum(b1 u^2 + b1 v^2 + b2 T^2) over the grid points of the physical fields; target (three
   // physical arrays of nx*ny doubles, or all null): the fields minus the target (lnse_adj_grad.rs:141-155)
@@ -126,11 +133,16 @@ class Navier2DLnseEngine : public GenericFlow2D {
   long integrate(double max_time);                                    // src/lib.rs:187-219 without callbacks
 
  private:
+  struct Hist { F velx, vely, temp; };              // one forward state: the spectral arrays (the physical ones = backward of them)
   bool exit_grad(double max_time, long timestep);                     // lnse_adj_grad.rs:204-225
-  void conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out);   // conv_*_adjoint of lnse_adj_eq.rs:16-94
+  void conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr2& out, Hist* nl);   // conv_*_adjoint of lnse_adj_eq.rs:16-94 / nonlin_adj_eq.rs:16-118
   double sumsq(const Arr2& a);
   void write_gradient(const char* filename, const double* gu, const double* gv, const double* gt);
   Arr2 tp_;                                         // physical temperature of the adjoint step
+  bool nonlin_ = false;
+  std::vector<std::unique_ptr<Hist>> hist_;
+  Arr2 unl_, vnl_;                                  // physical velocities of the history entry of the current adjoint step
+  void mean_diffusion(F& mean_f, double kappa);     // rhs += dt kappa (dxx + dyy) mean (nonlin_eq.rs:204-206, 221-223, 236-238)
   void conv_lin(F& mean_f, F& f, Arr2& out);        // conv_velx / vely / temp of lnse_eq.rs:59-110
   F& mean(const std::string& name) { return field("mean_" + name); }
   Arr2 um_, vm_;                                    // physical mean velocities (constant during a run)

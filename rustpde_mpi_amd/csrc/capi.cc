@@ -354,13 +354,13 @@ int rpde_adjoint2d_norm_residual(rpde_adjoint2d* h, double* res3) {
 
 // ---- Navier2DLnse (adjoint.h): the same entry points as the adjoint solver over the shared base
 static int create_lnse(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc, const char* mean_file,
-                       int device, bool periodic, rpde_lnse2d** out) {
+                       int device, bool periodic, rpde_lnse2d** out, bool nonlinear = false) {
   RPDE_TRY({
     RPDE_REQUIRE(out && bc, "null pointer");
     select_device(device);
     auto* h = new rpde_lnse2d{nullptr, device};
     try {
-      h->e = new Navier2DLnseEngine(nx, ny, ra, pr, dt, aspect, bc, periodic, mean_file ? mean_file : "mean.h5");
+      h->e = new Navier2DLnseEngine(nx, ny, ra, pr, dt, aspect, bc, periodic, mean_file ? mean_file : "mean.h5", nonlinear);
     } catch (...) {
       delete h;
       throw;
@@ -375,6 +375,23 @@ int rpde_lnse2d_create_confined(int nx, int ny, double ra, double pr, double dt,
 int rpde_lnse2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
                                 const char* mean_file, int device, rpde_lnse2d** out) {
   return create_lnse(nx, ny, ra, pr, dt, aspect, bc, mean_file, device, true, out);
+}
+int rpde_nonlin2d_create_confined(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                  const char* mean_file, int device, rpde_lnse2d** out) {
+  return create_lnse(nx, ny, ra, pr, dt, aspect, bc, mean_file, device, false, out, true);
+}
+int rpde_nonlin2d_create_periodic(int nx, int ny, double ra, double pr, double dt, double aspect, const char* bc,
+                                  const char* mean_file, int device, rpde_lnse2d** out) {
+  return create_lnse(nx, ny, ra, pr, dt, aspect, bc, mean_file, device, true, out, true);
+}
+int rpde_lnse2d_update_direct(rpde_lnse2d* h, int nsteps) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(nsteps >= 0, "negative step count"); select_device(h->device); h->e->update_direct(nsteps); })
+}
+int rpde_lnse2d_history_len(rpde_lnse2d* h, long* n) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(n, "null pointer"); *n = (long)h->e->history_len(); })
+}
+int rpde_lnse2d_clear_history(rpde_lnse2d* h) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); select_device(h->device); h->e->clear_history(); dev_trim(); })
 }
 int rpde_lnse2d_destroy(rpde_lnse2d* h) {
   RPDE_TRY({ if (h) { select_device(h->device); delete h->e; delete h; dev_trim(); } })

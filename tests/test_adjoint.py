@@ -449,6 +449,133 @@ def test_oracle_lnse_adjoint_gradient_agrees_with_finite_differences():
     assert np.linalg.norm(ga - gf) / np.linalg.norm(ga) < 0.3, (ga, gf)
 
 
+# ------------------------------------------------------------------------------------------------ Navier2DNonLin
+def _roll_mean(ora, nav=None, amp=0.3):
+    x, y = ora.velx.x
+    xs, ys = (x - x[0]) / (x[-1] - x[0]), (y - y[0]) / (y[-1] - y[0])
+    for name, arr in (("velx", amp * np.sin(np.pi * xs)[:, None] * np.cos(np.pi * ys)[None, :]),
+                      ("vely", -amp * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :]),
+                      ("temp", ora.mean.temp.v + 0.1 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :])):
+        ora.mean.set_physical(name, arr)
+        if nav is not None:
+            getattr(nav, "mean_" + name).v = arr
+
+
+@pytest.mark.parametrize("periodic,nx,ny", [(False, 17, 17), (True, 16, 17)])
+def test_oracle_nonlin_about_the_conduction_state_is_navier2d(periodic, nx, ny):
+    """What pins the restated non-linear equations (oracle/lnse.py Navier2DNonLin <- nonlin_eq.rs): about the default mean (no flow,
+    the conduction profile) they ARE the equations of Navier2D (oracle/navier.py, pinned by the critical Rayleigh numbers) -- the
+    mean temperature takes the lift's place in the buoyancy and in the convection term, its diffusion is the lift's.  Same initial
+    state, same steps: equal to round-off."""
+    from oracle import lnse as L
+    mk_n = N.Navier2D.new_periodic if periodic else N.Navier2D.new_confined
+    mk_l = L.Navier2DNonLin.new_periodic if periodic else L.Navier2DNonLin.new_confined
+    nav = mk_n(nx, ny, 1e5, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    nl = mk_l(nx, ny, 1e5, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    for z in (nav, nl):
+        z.set_velocity(0.2, 1.0, 1.0)
+        z.set_temperature(0.2, 1.0, 1.0)
+    for _ in range(10):
+        nav.update()
+        nl.update()
+    for k in ("velx", "vely", "temp", "pres"):
+        assert rel(getattr(nl, k).vhat, getattr(nav, k).vhat) < 1e-11, k
+
+
+def test_oracle_nonlin_adjoint_history_terms_are_the_mean_terms():
+    """nonlin_adj_eq.rs:31-48: the adjoint convection terms with the forward state have the form of the terms with the mean.  So the
+    non-linear adjoint step about a mean M with the forward state H equals the LINEAR adjoint step (pinned by the reference's
+    finite-difference example) about the mean M + H."""
+    from oracle import lnse as L
+    n = 17
+    nl = L.Navier2DNonLin.new_confined(n, n, 1e4, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    lin = L.Navier2DLnse.new_confined(n, n, 1e4, 1.0, 0.01, 1.0, "rbc", eig_mode="parity")
+    _roll_mean(nl)
+    nl.set_velocity(0.2, 2.0, 1.0)
+    nl.set_temperature(0.1, 1.0, 2.0)
+    for _ in range(3):
+        nl.update_direct()
+    h = nl.field_history[-1]
+    for name in ("velx", "vely", "temp"):     # mean of the linear solver: M + H (physical arrays; H lies in the composite spaces)
+        lin.mean.set_physical(name, getattr(nl.mean, name).space.backward(getattr(nl.mean, name).vhat) + h.v[name])
+    rng = np.random.default_rng(4)
+    for z in (nl, lin):
+        z.time = 0.0
+    for name in ("velx", "vely", "temp", "pres"):
+        a = rng.standard_normal(getattr(nl, name).vhat.shape)
+        getattr(nl, name).vhat = a.copy()
+        getattr(lin, name).vhat = a.copy()
+    nl.update_adjoint()
+    lin.update_adjoint()
+    for k in ("velx", "vely", "temp", "pres"):
+        assert rel(getattr(nl, k).vhat, getattr(lin, k).vhat) < 1e-11, k
+    assert len(nl.field_history) == 2
+
+
+def check_nonlin_parity(lib, nx, ny, periodic, steps, ra=1e4, dt=0.01, tol=1e-10, tol_p=1e-8, max_time=None, tmp_path=None):
+    """Navier2DNonLin: engine vs oracle through update_direct (with history), update_adjoint (consuming it), and grad_adjoint."""
+    from oracle import lnse as L
+    mk_e = R.Navier2DNonLin.new_periodic if periodic else R.Navier2DNonLin.new_confined
+    mk_o = L.Navier2DNonLin.new_periodic if periodic else L.Navier2DNonLin.new_confined
+    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    _roll_mean(ora, nav)
+    for z in (nav, ora):
+        z.set_velocity(0.2, 2.0, 1.0)
+        z.set_temperature(0.1, 1.0, 2.0)
+    base = {k: getattr(ora, k).vhat.copy() for k in ("velx", "vely", "temp")}
+    worst = {}
+
+    def compare(tag):
+        got, want = nav.spectral_fields(), ora.spectral_fields()
+        for k in want:
+            e = rel(got[k], want[k])
+            worst[k] = max(worst.get(k, 0.0), e)
+            assert e < (tol_p if k in ("pres", "pseu") else tol), (nx, ny, periodic, tag, k, e)
+
+    nav.update(1)                             # Integrate::update: no history entry (nonlin.rs:264-296)
+    ora.update()
+    compare("update")
+    assert nav.field_history_len == 0
+    for s in range(steps):
+        nav.update_direct(1)
+        ora.update_direct()
+        compare(("direct", s))
+    assert nav.field_history_len == steps == len(ora.field_history)
+    for s in range(steps):
+        nav.update_adjoint(1)
+        ora.update_adjoint()
+        compare(("adjoint", s))
+    assert nav.field_history_len == 0
+    with pytest.raises(R.RpdeError, match="history is empty"):
+        nav.update_adjoint(1)
+    if tmp_path is not None:                   # nonlin_io.rs:44-66: the snapshot carries the mean fields
+        fn = str(tmp_path / "nl.h5")
+        nav.write(fn)
+        from tests.h5classic import File
+        d = File(fn).datasets
+        assert rel(d["ux_base/v"], nav.mean_velx.v) < 1e-14 and rel(d["temp_base/v"], nav.mean_temp.v) < 1e-14 and "uy_base/v" in d
+    if max_time is not None:
+        for z in (nav, ora):
+            z.reset_time()
+            for k in base:
+                getattr(z, k).vhat = base[k]
+            for k in ("pres", "pseu"):
+                getattr(z, k).vhat = 0 * getattr(ora, k).vhat
+        fun_e, g_e = nav.grad_adjoint(max_time, None, 0.5, 0.25, filename=None)
+        fun_o, g_o = ora.grad_adjoint(max_time, 0.5, 0.25)
+        assert abs(fun_e - fun_o) < 1e-9 * abs(fun_o)
+        errs = [rel(a, b) for a, b in zip(g_e, g_o)]
+        assert max(errs) < 1e-9, errs
+        assert nav.field_history_len == 0
+    print("nonlin", nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("nx,ny,periodic", [(17, 17, False), (33, 17, False), (16, 17, True)])
+def test_emu_nonlin_parity(emu_lib, tmp_path, nx, ny, periodic):
+    check_nonlin_parity(emu_lib, nx, ny, periodic, steps=3, max_time=0.05, tmp_path=tmp_path)
+
+
 def test_emu_l2_norm_and_steepest_descent(emu_lib):
     """functions::l2_norm and opt_routines::steepest_descent_energy_constrained (host arrays) against the oracle; the rotated
     state keeps the energy of the old one (the point of the routine) and alpha > 2 pi is refused like the reference's assert."""
@@ -500,6 +627,12 @@ def test_gpu_lnse_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
         check_lnse_parity(hip_lib, nx, ny, periodic, steps, ra=1e7, dt=1e-3, adjoint=True)
     else:
         check_lnse_parity(hip_lib, nx, ny, periodic, steps, adjoint=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,periodic,steps,max_time", [(65, 65, False, 4, 0.05), (128, 65, True, 3, 0.05), (513, 257, False, 2, None)])
+def test_gpu_nonlin_parity(hip_lib, tmp_path, nx, ny, periodic, steps, max_time):
+    check_nonlin_parity(hip_lib, nx, ny, periodic, steps, max_time=max_time, tmp_path=tmp_path)
 
 
 @pytest.mark.gpu
