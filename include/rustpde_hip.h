@@ -281,10 +281,17 @@ int rpde_lnse2d_energy(rpde_lnse2d* h, double beta1, double beta2, const double*
 /* Navier2DLnse::grad_adjoint(max_time, None, beta1, beta2, target) lnse_adj_grad.rs:105-202: forward loop, energy (-> fun_val),
    adjoint loop, gradient = -(adjoint fields).  grad_*: physical nx*ny arrays (the `.v` of the returned Field2s; `.vhat` =
    Space2 forward of them).  filename: where the reference writes "data/grad_adjoint.h5" (groups ux, uy, temp), NULL = no file.
-   The engine is left holding the adjoint fields, like the reference.  timesteps may be NULL. */
-int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double beta1, double beta2, const double* target_velx,
+   The engine is left holding the adjoint fields, like the reference.  timesteps may be NULL.  save_intervall > 0: the snapshots
+   "data/flow{time:0>8.2}.h5" / "data/adjoint{time:0>8.2}.h5" and info files of the two loops (:122-130, :176-181), <= 0: None. */
+int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double save_intervall, double beta1, double beta2, const double* target_velx,
                              const double* target_vely, const double* target_temp, size_t len, const char* filename, double* fun_val,
                              double* grad_velx, double* grad_vely, double* grad_temp, long* timesteps);
+/* callback_from_filename(flow_name, info_name, suppress_io, write_flow_intervall)   lnse_io.rs:73-126 / nonlin_io.rs:72-142;
+   write_flow_intervall < 0 = None (OUTPUT_INTERVALL = 1).  rpde_lnse2d_diagnostics: out7 = |div|, Nu, Nuv, Re (Navier2DNonLin::
+   eval_nu / eval_nuvol / eval_re, nonlin_io.rs:145-198; NaN for Navier2DLnse), <u^2>, <v^2>, <T^2> (weighted averages) */
+int rpde_lnse2d_callback_from_filename(rpde_lnse2d* h, const char* flow_name, const char* info_name, int suppress_io,
+                                       double write_flow_intervall);
+int rpde_lnse2d_diagnostics(rpde_lnse2d* h, double* out7);
 /* Navier2DLnse::grad_fd(max_time, None, beta1, beta2)              lnse_fd_grad.rs:31-157: one integration per perturbed grid point,
    eps = 1e-5 (a test device in the reference too).  points: npoints triples (field 0 velx / 1 vely / 2 temp, i, j), NULL = all */
 int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double beta2, const int* points, long npoints, size_t len,

@@ -265,15 +265,41 @@ class Navier2DLnse:
         self.temp.backward()
         return l2_norm(self.velx.v, self.velx.v, self.vely.v, self.vely.v, self.temp.v, self.temp.v, beta1, beta2)
 
-    def grad_adjoint(self, max_time, beta1, beta2, target=None):
+    SUPPRESS_FORWARD_INFO = True                 # lnse_adj_grad.rs:128 passes suppress_io = true, nonlin_adj_grad.rs:137 false
+
+    def _snapshot_refresh(self):
+        """What a snapshot written inside the gradient loops does to the state (lnse_io.rs:73-91, 44-47): on the output interval
+        (OUTPUT_INTERVALL = 1) `write` runs `backward()` on the fields -- the physical arrays grad_adjoint returns."""
+        if (self.time + self.dt / 2.0) % 1.0 < self.dt:
+            for f in (self.velx, self.vely, self.temp, self.pres):
+                f.backward()
+            return True
+        return False
+
+    def averages_of_squares(self):
+        """u2, v2, t2 of the info line (lnse_io.rs:96-101) on the CURRENT state (the reference squares the physical arrays the state
+        holds, which lag one step inside the adjoint loop)."""
+        out = []
+        for f in (self.velx, self.vely, self.temp):
+            self.field.v = f.space.backward(f.vhat) ** 2
+            out.append(self.field.average())
+        return out
+
+    def grad_adjoint(self, max_time, beta1, beta2, target=None, save_intervall=None):
         """lnse_adj_grad.rs:105-202 without the file output: forward loop, energy, the adjoint initial condition
         beta x (state - target), adjoint loop, gradient = -(the PHYSICAL arrays the state holds at the end -- the
         `backward()` of the adjoint step runs at the START of a step, so they are the adjoint fields one step before the end,
         :185-191 as written).  Returns (fun_val, (grad_u, grad_v, grad_t)) as physical arrays."""
         timestep = 0
+        self.snapshots = []
         while True:
             self.update_direct()
             timestep += 1
+            if save_intervall is not None:
+                r = self.time % save_intervall
+                if r < self.dt / 2.0 or r > save_intervall - self.dt / 2.0:
+                    if self._snapshot_refresh():
+                        self.snapshots.append(("flow", self.time))
             if self._exit_grad(max_time, timestep):
                 break
         self.velx.backward()
@@ -295,6 +321,9 @@ class Navier2DLnse:
         while True:
             self.update_adjoint()
             timestep += 1        # the counter is NOT reset between the loops (:117, :169)
+            if save_intervall is not None and (self.time + self.dt / 2.0) % save_intervall < self.dt:
+                if self._snapshot_refresh():
+                    self.snapshots.append(("adjoint", self.time))
             if self._exit_grad(max_time, timestep):
                 break
         fac = -1.0               # MAXIMIZE = false (:16)
@@ -449,6 +478,40 @@ class Navier2DNonLin(Navier2DLnse):
         vhat[vhat.shape[0] * 2 // 3:, :] = 0
         vhat[:, vhat.shape[1] * 2 // 3:] = 0
         return vhat.copy()
+
+    SUPPRESS_FORWARD_INFO = False
+
+    # nonlin_io.rs:145-198 with functions.rs:60-143: the diagnostics of the TOTAL fields (state + mean)
+    def _total(self, name):
+        return getattr(self, name).to_ortho() + getattr(self.mean, name).vhat
+
+    def eval_nu(self):
+        fld = self.field
+        fld.vhat = self._total("temp")
+        fld.vhat = fld.gradient([0, 1], None) * (-2.0 / self.scale[1])
+        fld.backward()
+        x_avg = fld.average_axis(0)
+        return float((x_avg[-1] + x_avg[0]) / 2.0)
+
+    def eval_nuvol(self):
+        fld = self.field
+        fld.vhat = self._total("temp")
+        fld.backward()
+        temp = fld.v.copy()
+        fld.vhat = fld.gradient([0, 1], None) / (self.scale[1] * -1.0)
+        fld.backward()
+        dtdz = fld.v.copy()
+        fld.vhat = self._total("vely")
+        fld.backward()
+        fld.v = (dtdz + fld.v * temp / self.params["ka"]) * 2.0 * self.scale[1]
+        return fld.average()
+
+    def eval_re(self):
+        fld = self.field
+        u = fld.space.backward(self._total("velx"))
+        v = fld.space.backward(self._total("vely"))
+        fld.v = np.sqrt(u ** 2 + v ** 2) * (2.0 * self.scale[1] / self.params["nu"])
+        return fld.average()
 
     def update_adjoint(self, field_from_fwd=None):   # nonlin_adj_grad.rs:84-118 (None: the last history entry, like :190-193)
         nl = self.field_history.pop() if field_from_fwd is None else field_from_fwd

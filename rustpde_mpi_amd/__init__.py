@@ -676,9 +676,21 @@ class Navier2DLnse(Navier2DAdjoint):
         raise RpdeError("Navier2DLnse has no residual (steady_adjoint.rs only)")
 
     def callback(self):
-        os.makedirs("data", exist_ok=True)
-        self.write_unwrap("data/flow{:0>8.2f}.h5".format(self.get_time()))
-        print("time = {:4.2f}      |div| = {:4.2e}".format(self.get_time(), self.div_norm()))
+        """`Integrate::callback` (lnse.rs:298-303 / nonlin.rs:306-310)."""
+        self.callback_from_filename("data/flow{:0>8.2f}.h5".format(self.get_time()), "data/info.txt", False, None)
+
+    def callback_from_filename(self, flow_name, info_name, suppress_io=False, write_flow_intervall=None):
+        """lnse_io.rs:73-126 / nonlin_io.rs:72-142: snapshot on the write interval (None: OUTPUT_INTERVALL = 1), the diagnostics
+        line on stdout and in the info file."""
+        self._lib.call("rpde_lnse2d_callback_from_filename", self._h, str(flow_name).encode(), str(info_name).encode(),
+                       int(bool(suppress_io)), -1.0 if write_flow_intervall is None else float(write_flow_intervall))
+
+    def diagnostics(self):
+        """|div|, Nu, Nuv, Re (Navier2DNonLin: eval_nu / eval_nuvol / eval_re of state + mean, nonlin_io.rs:145-198; NaN for
+        Navier2DLnse), and the weighted averages <u^2>, <v^2>, <T^2> of the info line."""
+        out = np.empty(7)
+        self._lib.call("rpde_lnse2d_diagnostics", self._h, ptr(out))
+        return dict(zip(("div", "nu", "nuvol", "re", "u2", "v2", "t2"), out.tolist()))
 
     def spectral_fields(self, names=("velx", "vely", "temp", "pres", "pseu")):
         return {k: getattr(self, k).vhat for k in names}
@@ -719,16 +731,16 @@ class Navier2DLnse(Navier2DAdjoint):
         """`Navier2DLnse::grad_adjoint` (lnse_adj_grad.rs:105-202) -> (fun_val, (grad_u, grad_v, grad_t)); the gradients are the
         physical arrays (`.v` of the reference's Field2s).  `target`: an object with `.velx.v / .vely.v / .temp.v` (MeanFields) or
         three arrays.  `filename`: the reference writes "data/grad_adjoint.h5" unconditionally; None skips the file.
-        `save_intervall` (snapshots "data/flow*.h5" / "data/adjoint*.h5" during the two loops) is not supported: pass None."""
-        if save_intervall is not None:
-            raise RpdeError("grad_adjoint: save_intervall is not supported by the device loop (pass None)")
+        `save_intervall`: snapshots "data/flow*.h5" / "data/adjoint*.h5" and the info files during the two loops (directory
+        "data" of the working directory, like the reference)."""
         t = self._target(target)
         n = self.nx * self.ny
         gu, gv, gt = (np.empty((self.nx, self.ny)) for _ in range(3))
         fun, steps = C.c_double(), C.c_long()
         if filename is not None and os.path.dirname(filename):
             os.makedirs(os.path.dirname(filename), exist_ok=True)
-        self._lib.call("rpde_lnse2d_grad_adjoint", self._h, float(max_time), float(beta1), float(beta2),
+        self._lib.call("rpde_lnse2d_grad_adjoint", self._h, float(max_time), -1.0 if save_intervall is None else float(save_intervall),
+                       float(beta1), float(beta2),
                        *[None if a is None else ptr(a) for a in t], n, None if filename is None else str(filename).encode(),
                        C.byref(fun), ptr(gu), ptr(gv), ptr(gt), C.byref(steps))
         return fun.value, (gu, gv, gt)
@@ -738,7 +750,7 @@ class Navier2DLnse(Navier2DAdjoint):
         "should only be used for testing").  `points`: iterable of (field, i, j) with field in velx / vely / temp to visit
         instead of every point (the other entries stay 0)."""
         if save_intervall is not None:
-            raise RpdeError("grad_fd: save_intervall is not supported by the device loop (pass None)")
+            raise RpdeError("grad_fd: save_intervall (one snapshot series of the base run, lnse_fd_grad.rs:54) is not supported: pass None")
         pts, npts = None, 0
         if points is not None:
             code = {"velx": 0, "vely": 1, "temp": 2}

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <sys/stat.h>
 
 #include "h5lite.h"
 
@@ -832,14 +833,106 @@ void Navier2DLnseEngine::write_gradient(const char* filename, const double* gu, 
   h5::update_file(filename, t);
 }
 
-double Navier2DLnseEngine::grad_adjoint(double max_time, double beta1, double beta2, const double* tu, const double* tv, const double* tt,
-                                        double* gu, double* gv, double* gt, const char* filename, long* timesteps) {
+void Navier2DLnseEngine::diagnostics(double out[7]) {
+  for (int k = 0; k < 7; ++k) out[k] = std::nan("");
+  out[0] = div_norm();
+  Space2Ops& so = *sp_ortho_;
+  const Vec x0 = base_coords(so.base(0)), y0 = base_coords(so.base(1));
+  Vec wx = base_dx(so.base(0), x0), wy = base_dx(so.base(1), y0);
+  const double lx = std::fabs(x0.back() - x0.front()), ly = std::fabs(y0.back() - y0.front());
+  for (double& w : wx) w /= lx;
+  for (double& w : wy) w /= ly;
+  DBuf dwx, dwy, part((size_t)4 * nx_), out4(4);
+  dwx.upload(wx); dwy.upload(wy);
+  double h[4];
+  // <f^2> (field/average.rs:26-59 of the squared physical field): the volume sum of launch_diag_reduce with T = uy = f
+  const char* const names[3] = {"velx", "vely", "temp"};
+  for (int k = 0; k < 3; ++k) {
+    backward(field(names[k]), ta_);
+    launch_diag_reduce(ta_.p(), ta_.p(), ta_.p(), ta_.p(), ta_.ld, nx_, ny_, dwx.p, dwy.p, 0.0, 0.0, 1.0, 0.0, part.p, out4.p, st_);
+    dev_sync(st_);
+    dev_download(h, out4.p, sizeof(h));
+    out[4 + k] = h[2];
+  }
+  if (!nonlin_) return;
+  // eval_nu / eval_nuvol / eval_re (functions.rs:60-143) on state.to_ortho() + mean.vhat (nonlin_io.rs:145-198)
+  Arr2 tot(so.ortho_rows(), so.ortho_cols(), ex_), g(so.ortho_rows(), so.ortho_cols(), ex_);
+  Arr2 tphys(nx_, ny_, 1), dtdz(nx_, ny_, 1), ux(nx_, ny_, 1), uy(nx_, ny_, 1);
+  auto total = [&](const char* name, Arr2& phys) {
+    F& f = field(name);
+    f.sp->to_ortho(f.vhat, tot, st_);
+    lincomb(tot, 1.0, tot, 1.0, mean(name).vhat);
+    so.backward(tot, phys, st_);
+  };
+  total("velx", ux);
+  total("vely", uy);
+  total("temp", tphys);                        // tot = total temperature
+  so.gradient(tot, 0, 1, 1.0, 1.0, g, st_);    // unscaled d/dy (scale = None)
+  so.backward(g, dtdz, st_);
+  launch_diag_reduce(tphys.p(), dtdz.p(), ux.p(), uy.p(), tphys.ld, nx_, ny_, dwx.p, dwy.p, -2.0 / sy_,
+                     (1.0 / (sy_ * -1.0)) * 2.0 * sy_, (1.0 / ka_) * 2.0 * sy_, 2.0 * sy_ / nu_, part.p, out4.p, st_);
+  dev_sync(st_);
+  dev_download(h, out4.p, sizeof(h));
+  out[1] = (h[1] + h[0]) / 2.0;
+  out[2] = h[2];
+  out[3] = h[3];
+}
+
+void Navier2DLnseEngine::callback_from_filename(const std::string& flow_name, const std::string& info_name, bool suppress_io,
+                                                double write_flow_intervall) {
+  (void)::mkdir("data", 0777);                 // std::fs::create_dir_all("data")
+  const double out_intervall = write_flow_intervall >= 0.0 ? write_flow_intervall : 1.0;   // OUTPUT_INTERVALL (lnse.rs:21)
+  if (std::fmod(time_ + dt_ / 2.0, out_intervall) < dt_) {
+    try {
+      write(flow_name);
+      // write() of the reference refreshes the physical arrays the state holds (lnse_io.rs:44-47) -- the arrays grad_adjoint returns
+      backward(field("velx"), ux_);
+      backward(field("vely"), uy_);
+      backward(field("temp"), tp_);
+    } catch (const std::exception& ex) {
+      std::fprintf(stderr, "Error while writing file \"%s\". Error: %s\n", flow_name.c_str(), ex.what());
+    }
+  }
+  if (suppress_io) return;
+  double d[7];
+  diagnostics(d);
+  char tbuf[64];
+  std::snprintf(tbuf, sizeof tbuf, "%5.3f", time_);
+  FILE* fp = std::fopen(info_name.c_str(), "a");
+  if (nonlin_) {
+    std::printf("time = %s |div| = %s Nu = %s Nuv = %s Re = %s u2 = %s v2 = %s t2 = %s\n", tbuf, rust_exp(d[0], 2).c_str(),
+                rust_exp(d[1], 3).c_str(), rust_exp(d[2], 3).c_str(), rust_exp(d[3], 3).c_str(), rust_exp(d[4], 3).c_str(),
+                rust_exp(d[5], 3).c_str(), rust_exp(d[6], 3).c_str());
+    if (fp) std::fprintf(fp, "%s %s %s %s %s %s %s\n", rust_display(time_).c_str(), rust_display(d[1]).c_str(), rust_display(d[2]).c_str(),
+                         rust_display(d[3]).c_str(), rust_display(d[4]).c_str(), rust_display(d[5]).c_str(), rust_display(d[6]).c_str());
+  } else {
+    std::printf("time = %s      |div| = %s     u2 = %s     v2 = %s    t2 = %s\n", tbuf, rust_exp(d[0], 2).c_str(), rust_exp(d[4], 3).c_str(),
+                rust_exp(d[5], 3).c_str(), rust_exp(d[6], 3).c_str());
+    if (fp) std::fprintf(fp, "%s %s %s %s\n", rust_display(time_).c_str(), rust_display(d[4]).c_str(), rust_display(d[5]).c_str(),
+                         rust_display(d[6]).c_str());
+  }
+  std::fflush(stdout);
+  if (fp) std::fclose(fp);
+  else std::fprintf(stderr, "Couldn't write to file: %s\n", info_name.c_str());
+}
+
+double Navier2DLnseEngine::grad_adjoint(double max_time, double save_intervall, double beta1, double beta2, const double* tu,
+                                        const double* tv, const double* tt, double* gu, double* gv, double* gt, const char* filename,
+                                        long* timesteps) {
   RPDE_REQUIRE(gu && gv && gt, "grad_adjoint: null output");
   RPDE_REQUIRE((tu && tv && tt) || (!tu && !tv && !tt), "grad_adjoint: a target is three arrays (velx, vely, temp) or none");
   long timestep = 0;
+  char fname[64];
   for (;;) {                                   // forward loop (:119-136)
     update_direct(1);
     ++timestep;
+    if (save_intervall > 0.0) {                // :122-130 (Navier2DLnse suppresses the info line here, Navier2DNonLin does not)
+      const double r = std::fmod(time_, save_intervall);
+      if (r < dt_ / 2.0 || r > save_intervall - dt_ / 2.0) {
+        std::snprintf(fname, sizeof fname, "data/flow%08.2f.h5", time_);
+        callback_from_filename(fname, "data/info.txt", !nonlin_, -1.0);
+      }
+    }
     if (exit_grad(max_time, timestep)) break;
   }
   const double fun_val = energy(beta1, beta2, tu, tv, tt);   // :139-155
@@ -864,6 +957,10 @@ double Navier2DLnseEngine::grad_adjoint(double max_time, double beta1, double be
   for (;;) {                                   // adjoint loop (:172-187); the step counter keeps running
     update_adjoint(1);
     ++timestep;
+    if (save_intervall > 0.0 && std::fmod(time_ + dt_ / 2.0, save_intervall) < dt_) {   // :176-181
+      std::snprintf(fname, sizeof fname, "data/adjoint%08.2f.h5", time_);
+      callback_from_filename(fname, "data/info_adjoint.txt", false, -1.0);
+    }
     if (exit_grad(max_time, timestep)) break;
   }
   // :189-196: the gradient is fac * self.velx.v, the physical arrays of the backward() at the START of the last adjoint step

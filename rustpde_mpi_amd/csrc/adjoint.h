@@ -124,8 +124,15 @@ class Navier2DLnseEngine : public GenericFlow2D {
   // lnse_adj_grad.rs:105-202: forward loop to max_time, energy, adjoint initial condition beta (state - target), adjoint loop,
   // gradient = -(physical adjoint fields as the state holds them: those of the START of the last adjoint step, :185-191).
   // gu, gv, gt: nx*ny doubles each; filename: the reference's "data/grad_adjoint.h5" (groups ux, uy, temp), or null
-  double grad_adjoint(double max_time, double beta1, double beta2, const double* tu, const double* tv, const double* tt,
-                      double* gu, double* gv, double* gt, const char* filename, long* timesteps);
+  // save_intervall > 0: the snapshots of the two loops ("data/flow{time:0>8.2}.h5" / "data/adjoint{time:0>8.2}.h5" and the info files,
+  // :122-130, :176-181; directory "data" of the working directory like the reference), <= 0: None
+  double grad_adjoint(double max_time, double save_intervall, double beta1, double beta2, const double* tu, const double* tv,
+                      const double* tt, double* gu, double* gv, double* gt, const char* filename, long* timesteps);
+  // lnse_io.rs:73-126 / nonlin_io.rs:72-142: snapshot on the write interval (< 0: OUTPUT_INTERVALL = 1, lnse.rs:21), then unless
+  // suppressed the line on stdout and in the info file (Navier2DLnse: time u2 v2 t2; Navier2DNonLin: time Nu Nuv Re u2 v2 t2)
+  void callback_from_filename(const std::string& flow_name, const std::string& info_name, bool suppress_io, double write_flow_intervall);
+  // out[7] = |div|, Nu, Nuv, Re (nonlin_io.rs:145-198 on state + mean; NaN for Navier2DLnse, which has none), <u^2>, <v^2>, <T^2>
+  void diagnostics(double out[7]);
   // lnse_fd_grad.rs:31-157: one integration per perturbed grid point (eps = 1e-5).  points: npoints triples (field 0 / 1 / 2, i, j),
   // or null = every point of velx, vely, temp in the reference's order; entries not visited are 0
   void grad_fd(double max_time, double beta1, double beta2, const int* points, long npoints, double* gu, double* gv, double* gt,

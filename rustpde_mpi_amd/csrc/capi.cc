@@ -474,15 +474,25 @@ int rpde_lnse2d_energy(rpde_lnse2d* h, double beta1, double beta2, const double*
     *energy = h->e->energy(beta1, beta2, target_velx, target_vely, target_temp);
   })
 }
-int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double beta1, double beta2, const double* target_velx,
+int rpde_lnse2d_grad_adjoint(rpde_lnse2d* h, double max_time, double save_intervall, double beta1, double beta2, const double* target_velx,
                              const double* target_vely, const double* target_temp, size_t len, const char* filename, double* fun_val,
                              double* grad_velx, double* grad_vely, double* grad_temp, long* timesteps) {
   RPDE_TRY({
     RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(fun_val && grad_velx && grad_vely && grad_temp, "null pointer");
     RPDE_REQUIRE(len == (size_t)h->e->nx() * h->e->ny(), "grad_adjoint: physical arrays are nx*ny doubles");
     select_device(h->device);
-    *fun_val = h->e->grad_adjoint(max_time, beta1, beta2, target_velx, target_vely, target_temp, grad_velx, grad_vely, grad_temp, filename, timesteps);
+    *fun_val = h->e->grad_adjoint(max_time, save_intervall, beta1, beta2, target_velx, target_vely, target_temp, grad_velx, grad_vely, grad_temp, filename, timesteps);
   })
+}
+int rpde_lnse2d_callback_from_filename(rpde_lnse2d* h, const char* flow_name, const char* info_name, int suppress_io,
+                                       double write_flow_intervall) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(flow_name && info_name, "null pointer"); select_device(h->device);
+    h->e->callback_from_filename(flow_name, info_name, suppress_io != 0, write_flow_intervall);
+  })
+}
+int rpde_lnse2d_diagnostics(rpde_lnse2d* h, double* out7) {
+  RPDE_TRY({ RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(out7, "null pointer"); select_device(h->device); h->e->diagnostics(out7); })
 }
 int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double beta2, const int* points, long npoints, size_t len,
                         const char* filename, double* grad_velx, double* grad_vely, double* grad_temp) {

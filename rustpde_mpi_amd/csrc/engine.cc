@@ -1553,7 +1553,7 @@ void Navier2DEngine::read(const std::string& filename) {
   time_ = rd.read("time").data.at(0);
 }
 
-static std::string rust_exp(double v, int prec) {   // Rust's {:.Ne}: d.dd..e[-]x, no padding of the exponent
+std::string rust_exp(double v, int prec) {   // Rust's {:.Ne}: d.dd..e[-]x, no padding of the exponent
   if (std::isnan(v)) return "NaN";
   if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
   char buf[64];
@@ -1563,7 +1563,7 @@ static std::string rust_exp(double v, int prec) {   // Rust's {:.Ne}: d.dd..e[-]
   const int ex = std::atoi(s.c_str() + epos + 1);
   return s.substr(0, epos) + "e" + std::to_string(ex);
 }
-static std::string rust_display(double v) {          // Rust's `{}` for f64: shortest digits that round-trip, NEVER an exponent
+std::string rust_display(double v) {          // Rust's `{}` for f64: shortest digits that round-trip, NEVER an exponent
   if (std::isnan(v)) return "NaN";
   if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
   char buf[400];                                      // 1e-308 in fixed notation needs 326 characters

@@ -32,6 +32,9 @@ Base make_base(BaseKind kind, int n);
 
 Vec base_coords(const Base& b);                 // grid points (unscaled)
 Vec base_dx(const Base& b, const Vec& x);       // src/field.rs:135-163
+// Rust's number formatting for the info lines (defined in engine.cc): {:.Ne} without exponent padding; `{}` of an f64
+std::string rust_exp(double v, int prec);
+std::string rust_display(double v);
 Vec stencil_low(const Base& b);                 // S[k+2,k]  (S[k,k] = 1), length m
 Vec stencil_low1(const Base& b);                // S[k+1,k]: zero for the two-term stencils, length m
 

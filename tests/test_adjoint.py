@@ -8,6 +8,8 @@ the oracle's step beyond its solvers is the property the method is built on: the
 
 Engine (csrc/adjoint.cc, C ABI rpde_adjoint2d_*) against that oracle: emulation build on the CPU, HIP build on the GPU
 (129^2, 257^2, 1025^2, periodic 256 x 129)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -576,6 +578,69 @@ def test_emu_nonlin_parity(emu_lib, tmp_path, nx, ny, periodic):
     check_nonlin_parity(emu_lib, nx, ny, periodic, steps=3, max_time=0.05, tmp_path=tmp_path)
 
 
+def check_lnse_callbacks(lib, tmp_path, monkeypatch, capfd, nonlinear):
+    """Diagnostics against the oracle, the callback's files and lines, and grad_adjoint with `save_intervall`: the snapshots of the
+    two loops appear under data/, and a snapshot at the last adjoint step refreshes the physical arrays the gradient is read from
+    (lnse_io.rs:44-47) -- the oracle mirrors that, so the gradients still agree."""
+    from oracle import lnse as L
+    monkeypatch.chdir(tmp_path)
+    nx, ny, dt = 17, 17, 0.05
+    mk_e = R.Navier2DNonLin if nonlinear else R.Navier2DLnse
+    mk_o = L.Navier2DNonLin if nonlinear else L.Navier2DLnse
+    nav = mk_e.new_confined(nx, ny, 1e4, 1.0, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o.new_confined(nx, ny, 1e4, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    _roll_mean(ora, nav)
+    for z in (nav, ora):
+        z.set_velocity(0.2, 2.0, 1.0)
+        z.set_temperature(0.1, 1.0, 2.0)
+    base = {k: getattr(ora, k).vhat.copy() for k in ("velx", "vely", "temp")}
+    nav.update(2)
+    ora.update(); ora.update()
+    d = nav.diagnostics()
+    u2, v2, t2 = ora.averages_of_squares()
+    for got, want in ((d["u2"], u2), (d["v2"], v2), (d["t2"], t2), (d["div"], ora.div_norm())):
+        assert abs(got - want) < 1e-10 * abs(want), (got, want)
+    if nonlinear:
+        for key, want in (("nu", ora.eval_nu()), ("nuvol", ora.eval_nuvol()), ("re", ora.eval_re())):
+            assert abs(d[key] - want) < 1e-10 * abs(want), (key, d[key], want)
+    else:
+        assert all(np.isnan(d[k]) for k in ("nu", "nuvol", "re"))
+    capfd.readouterr()
+    nav.callback_from_filename("data/x.h5", "data/info.txt", False, 0.1)
+    out = capfd.readouterr().out
+    assert (tmp_path / "data" / "x.h5").exists() and "|div| =" in out and "t2 =" in out and (("Nu =" in out) == nonlinear)
+    cols = open(tmp_path / "data" / "info.txt").read().split()
+    assert len(cols) == (7 if nonlinear else 4) and abs(float(cols[0]) - 0.1) < 1e-12 and abs(float(cols[-1]) - t2) < 1e-10 * t2
+    # grad_adjoint with snapshots: horizon 1.0, save interval 0.5 -> flow files at 0.5 and 1.0 (the output interval is 1: only the
+    # one at 1.0 is written), adjoint file at 1.0 = the last adjoint step
+    for z in (nav, ora):
+        z.reset_time()
+        for k in base:
+            getattr(z, k).vhat = base[k]
+        for k in ("pres", "pseu"):
+            getattr(z, k).vhat = 0 * getattr(ora, k).vhat
+    if nonlinear:
+        nav.clear_field_history()
+        ora.field_history = []
+    fun_e, g_e = nav.grad_adjoint(1.0, 0.5, 0.5, 0.25, filename="data/grad_adjoint.h5")
+    fun_o, g_o = ora.grad_adjoint(1.0, 0.5, 0.25, save_intervall=0.5)
+    assert ora.snapshots == [("flow", pytest.approx(1.0)), ("adjoint", pytest.approx(1.0))]
+    names = sorted(os.listdir(tmp_path / "data"))
+    assert "flow00001.00.h5" in names and "adjoint00001.00.h5" in names and "grad_adjoint.h5" in names and "flow00000.50.h5" not in names
+    assert abs(fun_e - fun_o) < 1e-9 * abs(fun_o)
+    assert max(rel(a, b) for a, b in zip(g_e, g_o)) < 1e-9
+    assert rel(-g_e[0], ora.velx.space.backward(ora.velx.vhat)) < 1e-9     # refreshed: the gradient IS the final adjoint state
+    lines = open(tmp_path / "data" / "info_adjoint.txt").read().strip().splitlines()
+    assert len(lines) == 2                                                  # adjoint loop: times 0.5 and 1.0
+    assert os.path.exists(tmp_path / "data" / "info.txt") == True
+    assert len(open(tmp_path / "data" / "info.txt").read().strip().splitlines()) == (3 if nonlinear else 1)   # LNSE suppresses the forward loop's lines
+
+
+@pytest.mark.parametrize("nonlinear", [False, True])
+def test_emu_lnse_callbacks_and_saved_gradient_loops(emu_lib, tmp_path, monkeypatch, capfd, nonlinear):
+    check_lnse_callbacks(emu_lib, tmp_path, monkeypatch, capfd, nonlinear)
+
+
 def test_emu_l2_norm_and_steepest_descent(emu_lib):
     """functions::l2_norm and opt_routines::steepest_descent_energy_constrained (host arrays) against the oracle; the rotated
     state keeps the energy of the old one (the point of the routine) and alpha > 2 pi is refused like the reference's assert."""
@@ -633,6 +698,12 @@ def test_gpu_lnse_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
 @pytest.mark.parametrize("nx,ny,periodic,steps,max_time", [(65, 65, False, 4, 0.05), (128, 65, True, 3, 0.05), (513, 257, False, 2, None)])
 def test_gpu_nonlin_parity(hip_lib, tmp_path, nx, ny, periodic, steps, max_time):
     check_nonlin_parity(hip_lib, nx, ny, periodic, steps, max_time=max_time, tmp_path=tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nonlinear", [False, True])
+def test_gpu_lnse_callbacks_and_saved_gradient_loops(hip_lib, tmp_path, monkeypatch, capfd, nonlinear):
+    check_lnse_callbacks(hip_lib, tmp_path, monkeypatch, capfd, nonlinear)
 
 
 @pytest.mark.gpu
