@@ -422,7 +422,7 @@ def main():
     ms_t = line_ms + stage_ms(("T1", "T2"))
     ref_bytes = 416.0 * args.nx * args.ny
     pure = [r for r in prof if r["tag"] in ("S1 x: state -> phys-x + d/dx", "S1 x: state -> phys-x", "S2 y: velx, vely -> phys",
-                                            "S2 y: velx -> phys", "S2 y: vely -> phys")]
+                                            "S2 y: velx -> phys", "S2 y: vely -> phys", "S2 y: velx -> phys + vely -> phys")]
     transform_pass = {
         # the headline figure: bytes the transform stages REALLY move (their loads and stores) over their time
         "bytes_moved_S1_S2_S3": moved,

@@ -1029,10 +1029,15 @@ size_t Navier2DEngine::group_end(size_t i) const {
   // compatible consecutive transposes go out together: one launch on one GPU, one all-to-all when sharded
   const Launch& l = step_[i];
   if (line_batch_kind(l) >= 0) {
-    // whole-line kernels of short lines (1025 points: one wave per line): the fields of a stage in one launch
-    static const int mask = [] { const char* e = std::getenv("RPDE_LINE_BATCH"); return e ? std::atoi(e) : 15; }();   // A/B only: bit k = LineBatch kind k
+    // whole-line kernels: the fields of a stage in one launch.  Lines of 1025 points (one wave per line: a launch of one field is
+    // over after one line's latency) since round 3; lines of 4097 points since round 5 (the drain of a field's last workgroups
+    // overlaps the start of the next field's).  RPDE_LINE_BATCH (A/B only): bit k = LineBatch kind k for 1025-point lines,
+    // bit 4 + k for 4097-point lines.
+    constexpr int kLineBatchDefaultMask = 255;
+    static const int mask = [] { const char* e = std::getenv("RPDE_LINE_BATCH"); return e ? std::atoi(e) : kLineBatchDefaultMask; }();
     auto len = [](const Launch& m) { return m.type == Launch::kConvLine ? m.cl.N : m.type == Launch::kRhsLine ? m.rl.N : m.dl.N; };
-    if (!((mask >> line_batch_kind(l)) & 1) || !line_batch_ok(len(l))) return i + 1;
+    const int bit = line_batch_kind(l) + (len(l) == 4096 ? 4 : 0);
+    if (!((mask >> bit) & 1) || !line_batch_ok(len(l))) return i + 1;
     size_t j = i + 1;
     while (j < step_.size() && (int)(j - i) < kLineBatch && step_[j].type == l.type && len(step_[j]) == len(l)) ++j;
     return j;

@@ -693,38 +693,71 @@ static bool s1_pair_on() {
   static const bool on = [] { const char* e = std::getenv("RPDE_S1_PAIR"); return !e || std::atoi(e) != 0; }();
   return on;
 }
-bool line_batch_ok(int N) { return N == 1024; }
-void launch_line_batch(const LineBatch& b, Stream& st) {
-  constexpr int N = 1024;
-  RPDE_REQUIRE(b.n >= 1 && b.n <= kLineBatch, "line batch: 1 .. 3 fields");
-  int nl = 0;
-  for (int i = 0; i < b.n; ++i) {
-    const int li = b.kind == 0 ? b.d0[i].nlines : b.kind == 1 ? b.d0[i].nlines : b.kind == 2 ? b.c[i].nlines : b.r[i].nlines;
-    const int Ni = b.kind <= 1 ? b.d0[i].N : b.kind == 2 ? b.c[i].N : b.r[i].N;
-    RPDE_REQUIRE(Ni == N, "line batch: lines of 1025 points");
-    nl = std::max(nl, li);
-  }
-  if (nl <= 0) return;
+// RPDE_S1_SPLIT=1 (A/B): the two transforms of S1 as two launches of the one-transform kernel -- the line is read twice, but four
+// lines are resident per CU instead of the pair kernel's two
+static bool s1_split_on() {
+  static const bool on = [] { const char* e = std::getenv("RPDE_S1_SPLIT"); return e && std::atoi(e) != 0; }();
+  return on;
+}
+// lines of 4097 points (round 5): the convection term of the full-length core, one field per blockIdx.y like the others
+template <int N>
+__global__ __launch_bounds__(N / 16, 3) void conv_line_batch_kernel(const ConvBatch b) {
+  const ConvLineArgs& c = b.c[blockIdx.y];
+  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= c.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  conv_line<N>(blk, c);
+}
+bool line_batch_ok(int N) { return N == 1024 || N == 4096; }
+// N = 1024: one wave per line, a launch of one field's lines is over after one line's latency.  N = 4096: the
+// chip is full either way; what the common launch saves is the drain of one field's last workgroups before the next field's
+// first ones may start (the fields of a stage are independent: blockIdx.y = field, dispatched in order).
+template <int N>
+static void launch_line_batch_n(const LineBatch& b, int nl, Stream& st) {
   const dim3 grid(8 * ((nl + 7) / 8), b.n), block(N / 16);
   if (b.kind == 0) {
     Dct1Batch k; for (int i = 0; i < b.n; ++i) k.a[i] = b.d0[i];
     hipLaunchKernelGGL(hdct_line_batch_kernel<N>, grid, block, 0, st.s, k);
   } else if (b.kind == 1) {
+    if (s1_split_on()) {   // the A/B form has no batched twin: one field after the other
+      for (int i = 0; i < b.n; ++i) RPDE_REQUIRE(launch_dct_line2(b.d0[i], b.d1[i], st), "line batch: shape");
+      return;
+    }
     Dct2Batch k; for (int i = 0; i < b.n; ++i) { k.a0[i] = b.d0[i]; k.a1[i] = b.d1[i]; }
     bool pair = s1_pair_on();
     for (int i = 0; i < b.n; ++i) pair = pair && hdct_pair_ok(b.d0[i], b.d1[i]);
-    if (pair) hipLaunchKernelGGL(hdct_pair_batch_kernel<N>, grid, dim3(N / 8), 2 * sizeof(double) * hdct_lds_doubles(N), st.s, k);
-    else hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
+    if (pair) {
+      const size_t bytes = 2 * sizeof(double) * hdct_lds_doubles(N);
+      if (bytes > 65536) lds_permission(hdct_pair_batch_kernel<N>, bytes);
+      hipLaunchKernelGGL(hdct_pair_batch_kernel<N>, grid, dim3(N / 8), bytes, st.s, k);
+    } else hipLaunchKernelGGL(hdct_line2_batch_kernel<N>, grid, block, 0, st.s, k);
   } else if (b.kind == 2) {
     ConvBatch k; for (int i = 0; i < b.n; ++i) k.c[i] = b.c[i];
-    // one wave per SIMD (416 VGPRs): budgets of two / three waves spill 159 / 274 registers and measured 0.110 / 0.156 ms
-    // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10)
-    hipLaunchKernelGGL((hconv_line_batch_kernel<N, 1>), grid, block, 0, st.s, k);
+    // N = 1024: one wave per SIMD (416 VGPRs): budgets of two / three waves spill 159 / 274 registers and measured 0.110 / 0.156 ms
+    // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10); N = 4096: the full-length core like conv_line_kernel
+    if constexpr (N == 1024) hipLaunchKernelGGL((hconv_line_batch_kernel<N, 1>), grid, block, 0, st.s, k);
+    else hipLaunchKernelGGL(conv_line_batch_kernel<N>, grid, block, 0, st.s, k);
   } else {
     RhsBatch k; for (int i = 0; i < b.n; ++i) k.r[i] = b.r[i];
     hipLaunchKernelGGL(rhs_line_batch_kernel<N>, grid, block, 0, st.s, k);
   }
   RPDE_HIP(hipGetLastError());
+}
+void launch_line_batch(const LineBatch& b, Stream& st) {
+  RPDE_REQUIRE(b.n >= 1 && b.n <= kLineBatch, "line batch: 1 .. 3 fields");
+  int nl = 0, N = 0;
+  for (int i = 0; i < b.n; ++i) {
+    const int li = b.kind == 0 ? b.d0[i].nlines : b.kind == 1 ? b.d0[i].nlines : b.kind == 2 ? b.c[i].nlines : b.r[i].nlines;
+    const int Ni = b.kind <= 1 ? b.d0[i].N : b.kind == 2 ? b.c[i].N : b.r[i].N;
+    RPDE_REQUIRE(line_batch_ok(Ni) && (i == 0 || Ni == N), "line batch: lines of 1025 or of 4097 points, one length per batch");
+    N = Ni;
+    nl = std::max(nl, li);
+  }
+  if (nl <= 0) return;
+  if (N == 1024) launch_line_batch_n<1024>(b, nl, st);
+  else launch_line_batch_n<4096>(b, nl, st);
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 4) void div_line_kernel(const DivLineArgs a) {
@@ -854,10 +887,7 @@ bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) 
   if (a0.N != a1.N || a0.nlines != a1.nlines || !dct_line_ok(a0) || !dct_line_ok(a1) || (a0.N != 4096 && a0.N != 1024)) return false;
   if (a0.nlines <= 0) return true;
   const dim3 grid(8 * ((a0.nlines + 7) / 8));
-  // RPDE_S1_SPLIT=1 (A/B): the two transforms as two launches of the one-transform kernel -- the line is read twice, but four
-  // lines are resident per CU instead of the pair kernel's two
-  static const bool split = [] { const char* e = std::getenv("RPDE_S1_SPLIT"); return e && std::atoi(e) != 0; }();
-  if (split) return launch_dct_line(a0, st) && launch_dct_line(a1, st);
+  if (s1_split_on()) return launch_dct_line(a0, st) && launch_dct_line(a1, st);
   if (s1_pair_on() && hdct_pair_ok(a0, a1)) {
     const size_t bytes = 2 * sizeof(double) * hdct_lds_doubles(a0.N);
     if (a0.N == 1024) hipLaunchKernelGGL(hdct_pair_kernel<1024>, grid, dim3(128), bytes, st.s, a0, a1);
@@ -1392,7 +1422,7 @@ bool launch_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, Stream& st) 
   }
   return true;
 }
-bool line_batch_ok(int N) { return N == 1024 || N == 256; }
+bool line_batch_ok(int N) { return N == 1024 || N == 256 || N == 4096; }
 void launch_line_batch(const LineBatch& b, Stream& st) {   // the same lines, one field after the other
   for (int i = 0; i < b.n; ++i) {
     bool ok = false;

@@ -211,6 +211,23 @@ def test_whole_line_launches_of_short_lines_go_out_batched(emu_lib):
     assert "S2 y: conv_velx + conv_vely + conv_temp" in tags and len(tags) == 17
 
 
+def test_whole_line_launches_of_4097_point_lines_go_out_batched(emu_lib):
+    """Round 5: lines of 4097 points take the batched form too (bits 4 - 7 of RPDE_LINE_BATCH; kernels.cc launch_line_batch_n<4096>:
+    the full-length convection kernel and the three right-hand sides of S3 behind blockIdx.y) -- the drain of one field's last
+    workgroups overlaps the start of the next field's.  9 x 4097: the pure transforms and the convection terms of S2;
+    4097 x 9: S1 and S3; both against the oracle through the batched launches."""
+    K.check_step_parity(emu_lib, False, 9, 4097, 1e6, 2e-3, 2, check_at=[2])
+    nav, _ = K.make_pair(emu_lib, False, 9, 4097, 1e6, 1.0, 2e-3, 1.0)
+    sched = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert sched["S2 y: velx -> phys + vely -> phys"] == "whole-line transform (2 arrays)"
+    assert sched["S2 y: conv_velx + conv_vely + conv_temp"] == "whole-line convection term (3 arrays)"
+    K.check_step_parity(emu_lib, False, 4097, 9, 1e6, 2e-3, 2, check_at=[2], eig_mode="shared")
+    nav, _ = K.make_pair(emu_lib, False, 4097, 9, 1e6, 1.0, 2e-3, 1.0)
+    sched = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert sched["S1 x: state -> phys-x + d/dx"] == "whole-line transform pair (3 arrays)"
+    assert sched["S3 x: rhs + hholtz-x velx + vely + temp"] == "whole-line rhs + hholtz-x (3 arrays)"
+
+
 def test_confined_step_aspect(emu_lib):
     K.check_step_parity(emu_lib, False, 33, 17, 1e5, 0.01, 5, aspect=2.0)
 

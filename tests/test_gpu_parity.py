@@ -145,23 +145,25 @@ def test_shared_basis_golden(hip_lib, name):
     assert max(res) >= 200 or os.environ.get("RPDE_ALLOW_PARTIAL_GOLDEN"), f"golden ends at step {max(res)}"
 
 
-@pytest.mark.parametrize("switch", ["RPDE_GEMM_PEEL", "RPDE_S1_SPLIT"])
-def test_round5_ab_switches(hip_lib, switch):
+@pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15")])
+def test_round5_ab_switches(hip_lib, switch, value):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
-    and derivative of a state line as two launches instead of the pair kernel): a 4097 x 129 confined run (4096-point x-lines,
-    2048 / 2047-wide parity GEMMs through the 128-tiles) must give bit-identical fields either way.  The switches are read
-    once per process, so each side runs in its own."""
+    and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
+    of the three fields of a stage in one launch at 4097-point lines): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
+    2048 / 2047-wide parity GEMMs through the 128-tiles) and a 129 x 4097 one (4096-point y-lines: S2, the convection terms)
+    must give bit-identical fields either way.  The switches are read once per process, so each side runs in its own."""
     import hashlib
     import os
     import subprocess
     import sys
     code = ("import hashlib, numpy as np, rustpde_mpi_amd as R\n"
-            "nav = R.Navier2D.new_confined(4097, 129, 1e7, 1.0, 1e-3, 1.0, 'rbc', init_random=None)\n"
-            "nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0); nav.update(3)\n"
-            "f = nav.physical_fields()\n"
-            "print('HASH', hashlib.sha256(b''.join(np.ascontiguousarray(f[k]).tobytes() for k in sorted(f))).hexdigest(), float(np.abs(f['pres']).max()))\n")
+            "for nx, ny in ((4097, 129), (129, 4097)):\n"
+            "    nav = R.Navier2D.new_confined(nx, ny, 1e7, 1.0, 1e-3, 1.0, 'rbc', init_random=None)\n"
+            "    nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0); nav.update(3)\n"
+            "    f = nav.physical_fields()\n"
+            "    print('HASH', nx, hashlib.sha256(b''.join(np.ascontiguousarray(f[k]).tobytes() for k in sorted(f))).hexdigest(), float(np.abs(f['pres']).max()))\n")
     out = {}
-    for flag in ("", "1"):
+    for flag in ("", value):
         env = dict(os.environ)
         env.pop(switch, None)
         if flag:
@@ -169,9 +171,10 @@ def test_round5_ab_switches(hip_lib, switch):
         r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(K.GOLDEN)), env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        out[flag] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+        out[flag] = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(out[flag]) == 2, r.stdout[-2000:]
     print(switch, out)
-    assert out[""] == out["1"], out
+    assert out[""] == out[value], out
 
 
 def test_headline_extended_golden_800_steps(hip_lib):
