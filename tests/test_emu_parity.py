@@ -1,6 +1,8 @@
 """CPU-side checks of the kernel sources through their host emulation build (tests/emu/README.md):
 line programs, tables, the fused step schedule -- against the oracle.  The GPU parity tests proper
 are in test_gpu_parity.py and run the same checks on the HIP library."""
+import os
+
 import numpy as np
 import pytest
 
@@ -226,6 +228,30 @@ def test_whole_line_launches_of_4097_point_lines_go_out_batched(emu_lib):
     sched = {t: kind for t, _, _, _, kind in nav.schedule()}
     assert sched["S1 x: state -> phys-x + d/dx"] == "whole-line transform pair (3 arrays)"
     assert sched["S3 x: rhs + hholtz-x velx + vely + temp"] == "whole-line rhs + hholtz-x (3 arrays)"
+
+
+def test_eig_cache(emu_lib, tmp_path, monkeypatch):
+    """RPDE_EIG_CACHE: the second engine of an operator reads the decomposition the first one wrote (one file per pencil,
+    named after its bytes) and steps bit-identically; a truncated file is ignored and replaced."""
+    import glob
+    monkeypatch.setenv("RPDE_EIG_CACHE", str(tmp_path))
+    runs = []
+    for attempt in range(3):
+        nav = R.Navier2D.new_confined(65, 33, 1e5, 1.0, 0.01, 1.0, "rbc", library=emu_lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(3)
+        runs.append(nav.physical_fields())
+        del nav
+        files = glob.glob(str(tmp_path / "eigx_63_*.bin"))
+        assert len(files) == 1, files
+        if attempt == 1:                      # damage the file: the next engine falls back to LAPACK and rewrites it
+            size = os.path.getsize(files[0])
+            with open(files[0], "r+b") as f:
+                f.truncate(size // 2)
+        elif attempt == 2:
+            assert os.path.getsize(files[0]) == size
+    for k in runs[0]:
+        assert np.array_equal(runs[0][k], runs[1][k]) and np.array_equal(runs[0][k], runs[2][k]), k
 
 
 def test_confined_step_aspect(emu_lib):
