@@ -762,11 +762,15 @@ void Navier2DEngine::add_halo(std::initializer_list<double*> arrays, int front, 
 // against the oracle (tests/test_gpu_parity.py: dct_line backward / gradient / forward, conv_line, step parity at 4097).
 // The environment only overrides for A/B measurements, read once per engine: RPDE_WHOLE_LINE=0 turns all of them
 // off, RPDE_DCT_LINE / RPDE_S1_LINE / RPDE_CONV_LINE / RPDE_S3_LINE = 0 | 1 one stage.
-static bool whole_line_on(const char* stage_env) {
+static bool whole_line_on(const char* stage_env, bool dflt = true) {
   if (const char* e = std::getenv(stage_env)) return std::atoi(e) != 0;
   if (const char* e = std::getenv("RPDE_WHOLE_LINE")) return std::atoi(e) != 0;
-  return true;
+  return dflt;
 }
+// the defaults of the stages added last (round 5), one greppable line each: tools/evidence_r05_final2.sh measures both forms of
+// each inside one gpurun call and keeps the faster one as the default before it collects the evidence
+constexpr bool kS6LineDefault = true;   // S6 as prow_line.h
+constexpr bool kS9LineDefault = true;   // S9 as pres_line.h
 #ifdef RPDE_EMU
 static bool whole_line_len(int N) { return N == 256 || N == 1024 || N == 4096; }
 #else
@@ -865,6 +869,43 @@ bool Navier2DEngine::add_div_line(const DivLineArgs& a, const char* tag) {
   l.tag = tag;
   const double n = a.N + 1, m = a.N - 1;
   l.bytes = 8.0 * a.nlines * (2.0 * m + n + m);   // velx row, d/dy vely in; div, g out (row j - 2 is a re-read of a neighbour's row j)
+  step_.push_back(l);
+  return true;
+}
+bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
+  // S6 (y preconditioner + one factorised banded solve per eigen row of the Poisson problem) as one kernel (prow_line.h)
+  PoissonOp& po = *pois_;
+  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !whole_line_len(a.N) || periodic_ || po.rows16.n == 0) return false;
+  if (!prow_tabs_.t0.p) {   // chunk-major copy of the B2 rows for 16 elements per thread
+    const int T = a.N / 16;
+    const Mv3Tables pv = pinv_tables(sp_pseu_->base(1));
+    prow_tabs_.t0.upload(chunk_major16(pv.t0, T, +1)); prow_tabs_.t1.upload(chunk_major16(pv.t1, T, +1));
+    prow_tabs_.t2.upload(chunk_major16(pv.t2, T, +1));
+  }
+  a.t0 = prow_tabs_.t0.p; a.t1 = prow_tabs_.t1.p; a.t2 = prow_tabs_.t2.p;
+  // the factor tables hold the rows [row0, ...): the kernel indexes them with the global row number (like ProgramBuilder::fdma_solve)
+  const FdmaDev& f = po.rows16;
+  const long off = f.row0 * f.tabld;
+  a.q1 = f.q1.p - off; a.p2 = f.p2.p - off; a.q2 = f.q2.p - off; a.r2 = f.r2.p - off;
+  a.tabld = f.tabld;
+  if (!prow_line_ok(a)) return false;
+  Launch l;
+  l.type = Launch::kProwLine;
+  l.prl = a;
+  l.tag = tag;
+  l.bytes = 8.0 * a.nlines * 6.0 * (a.N - 1);   // the line in and out, four factor rows (what the line program of the stage counts)
+  step_.push_back(l);
+  return true;
+}
+bool Navier2DEngine::add_pres_line(const PresLineArgs& a, const char* tag) {
+  // S9 (pressure update and its x-derivative for the next step) as one kernel (pres_line.h)
+  if (!whole_line_on("RPDE_S9_LINE", kS9LineDefault) || !whole_line_len(a.N) || periodic_ || !pres_line_ok(a)) return false;
+  Launch l;
+  l.type = Launch::kPresLine;
+  l.psl = a;
+  l.tag = tag;
+  const double n = a.N + 1, m = a.N - 1;
+  l.bytes = 8.0 * a.nlines * (m + 4.0 * n);   // pseudo-pressure row (row j - 2 is a re-read of a neighbour's row j), div, pres in and out, d/dx pres
   step_.push_back(l);
   return true;
 }
@@ -1134,6 +1175,8 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kRhsLine: RPDE_REQUIRE(launch_rhs_line(l.rl, st_), "internal: rhs line shape"); break;
     case Launch::kCorrLine: RPDE_REQUIRE(launch_corr_line(l.crl, st_), "internal: corr line shape"); break;
     case Launch::kDivLine: RPDE_REQUIRE(launch_div_line(l.dvl, st_), "internal: div line shape"); break;
+    case Launch::kProwLine: RPDE_REQUIRE(launch_prow_line(l.prl, st_), "internal: poisson row shape"); break;
+    case Launch::kPresLine: RPDE_REQUIRE(launch_pres_line(l.psl, st_), "internal: pressure line shape"); break;
     case Launch::kRfftPair: RPDE_REQUIRE(launch_rfft_pair(l.rf, l.rf2, st_), "internal: rfft pair shape"); break;
     case Launch::kFourRhs: RPDE_REQUIRE(launch_four_rhs(l.fr, st_), "internal: fourier rhs shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
@@ -1290,7 +1333,7 @@ std::string Navier2DEngine::describe_step() const {
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x",
-                                        "whole-line transform pair", "whole-line rhs + hholtz-x"};
+                                        "whole-line transform pair", "whole-line rhs + hholtz-x", "whole-line poisson rows", "whole-line pressure update"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -2041,7 +2084,9 @@ void Navier2DEngine::build_confined() {
     T(yx(Y_[2]), X_[0].p, my, mx, true, "T4b");
   }
   // ---- S6: y preconditioner + per-eigenvalue banded solves (line index = eigen index)
-  {
+  ProwLineArgs prw;
+  prw.in = X_[0].p; prw.out = X_[1].p; prw.ld = ldy; prw.nlines = xlines(mx, false); prw.line0 = xb(false); prw.N = ny - 1;
+  if (!add_prow_line(prw, "S6 y: poisson rows")) {
     ProgramBuilder pb = xpb(2, mx);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy), my);   // columns my, my+1 only meet zero table entries
@@ -2096,7 +2141,11 @@ void Navier2DEngine::build_confined() {
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
-  {
+  PresLineArgs psl;
+  psl.ps = yx(Y_[4]); psl.div = yx(DIV_); psl.pres = yx(P_); psl.gx = yx(GX_); psl.ld = ldx; psl.nlines = ylines(ny); psl.line0 = yb_;
+  psl.N = nx - 1; psl.my = my; psl.half = po.half; psl.sdt = 1.0 / dt; psl.nu = nu_; psl.dscale = 1.0 / sx_;
+  psl.lowy = yN.low.p; psl.lowx = xN.low.p; psl.nanflag = flagp();
+  if (!(xN.fft_n == nx - 1 && add_pres_line(psl, "S9 x: pressure update"))) {
     ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xN);
     pb.loadx(0, pb.arr(yx(Y_[4]), ldx), mx, my, yN.low.p, 1.0 / dt, false, po.half);   // parity blocks side by side

@@ -232,10 +232,12 @@ class Navier2DEngine {
   // the step as a list of launches
   struct Launch {
     enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine,
-                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine, kRfftPair, kFourRhs } type;
+                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine, kRfftPair, kFourRhs, kProwLine, kPresLine } type;
     RfftLineArgs rf{}, rf2{};    // kRfftPair (periodic S1: value and x-derivative of a spectral line, rfft_line.h)
     FourRhsArgs fr{};            // kFourRhs  (periodic S3)
     DivLineArgs dvl{};           // kDivLine
+    ProwLineArgs prl{};          // kProwLine
+    PresLineArgs psl{};          // kPresLine
     PdmaLinesArgs pl{};          // kPdmaLines ("hc", pencil-sharded: Helmholtz-y of the temperature on the y-lines of an x-pencil)
     CorrLineArgs crl{};          // kCorrLine
     Sten3RowsArgs s3{};          // kSten3Rows ("hc": temperature composite -> orthonormal along y, pdma.h)
@@ -300,8 +302,11 @@ class Navier2DEngine {
   bool add_rhs_line(RhsLineArgs a, int which, const char* tag);   // S3 as one kernel per field (rhs_line.h)
   bool add_corr_line(CorrLineArgs a, const char* tag);            // S8 as one kernel (corr_line.h)
   bool add_div_line(const DivLineArgs& a, const char* tag);       // S5 as one kernel (div_line.h)
+  bool add_prow_line(ProwLineArgs a, const char* tag);            // S6 as one kernel (prow_line.h)
+  bool add_pres_line(const PresLineArgs& a, const char* tag);     // S9 as one kernel (pres_line.h)
   struct RhsTabs { DBuf t0, t1, t2, q1, p2, q2, r2; };            // chunk-major (16 per thread) tables of rhs_line, per field kind
   RhsTabs rhs_tabs_[2];                                           // 0: velocities (Dirichlet x, nu), 1: temperature (Neumann x, ka)
+  RhsTabs prow_tabs_;                                             // prow_line: B2 rows of the pressure space's y axis (t0, t1, t2 only)
   RhsTabs corr_tabs_[2];                                          // corr_line: 0 the derivative branch (velx), 1 the plain one (vely)
   DBuf corr_w_, corr_h_;                                          // its rank-one term
   void build_confined();

@@ -795,6 +795,42 @@ bool launch_corr_line(const CorrLineArgs& a, Stream& st) {
   RPDE_HIP(hipGetLastError());
   return true;
 }
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void prow_line_kernel(const ProwLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  prow_line<N>(blk, a);
+}
+bool launch_prow_line(const ProwLineArgs& a, Stream& st) {
+  if ((a.N != 4096 && a.N != 1024) || !prow_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
+  if (a.N == 1024) hipLaunchKernelGGL(prow_line_kernel<1024>, grid, block, 0, st.s, a);
+  else hipLaunchKernelGGL(prow_line_kernel<4096>, grid, block, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
+template <int N>
+__global__ __launch_bounds__(N / 16, 4) void pres_line_kernel(const PresLineArgs a) {
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
+  const int chunk = (int)gridDim.x >> 3;
+  const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  if (line >= a.nlines) return;
+  Blk blk{line, 0, N / 16, buf, nullptr, 0};
+  pres_line<N>(blk, a);
+}
+bool launch_pres_line(const PresLineArgs& a, Stream& st) {
+  if ((a.N != 4096 && a.N != 1024) || !pres_line_ok(a)) return false;
+  if (a.nlines <= 0) return true;
+  const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
+  if (a.N == 1024) hipLaunchKernelGGL(pres_line_kernel<1024>, grid, block, 0, st.s, a);
+  else hipLaunchKernelGGL(pres_line_kernel<4096>, grid, block, 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
+  return true;
+}
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   if ((a.N != 4096 && a.N != 1024) || !rhs_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
@@ -1452,6 +1488,28 @@ bool launch_corr_line(const CorrLineArgs& a, Stream&) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
     if (a.N == 4096) corr_line<4096>(blk, a); else if (a.N == 1024) corr_line<1024>(blk, a); else corr_line<256>(blk, a);
+  }
+  return true;
+}
+bool launch_prow_line(const ProwLineArgs& a, Stream&) {
+  if (!prow_line_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) prow_line<4096>(blk, a); else if (a.N == 1024) prow_line<1024>(blk, a); else prow_line<256>(blk, a);
+  }
+  return true;
+}
+bool launch_pres_line(const PresLineArgs& a, Stream&) {
+  if (!pres_line_ok(a)) return false;
+  std::vector<double> lds(hdct_lds_doubles(a.N) + 2);
+  double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
+  for (int line = 0; line < a.nlines; ++line) {
+    std::fill(lds.begin(), lds.end(), std::nan(""));
+    Blk blk{line, 0, a.N / 16, base};
+    if (a.N == 4096) pres_line<4096>(blk, a); else if (a.N == 1024) pres_line<1024>(blk, a); else pres_line<256>(blk, a);
   }
   return true;
 }

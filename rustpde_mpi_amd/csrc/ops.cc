@@ -584,6 +584,15 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
   const int rb = std::max(0, row_begin), re = (row_end < 0 || row_end > m0) ? m0 : row_end;
   const size_t nr = (size_t)std::max(0, re - rb);
   Vec q1(nr * ld, 0.0), p2(nr * ld, 0.0), q2(nr * ld, 0.0), r2(nr * ld, 0.0);
+  // second copy for the whole-line form of the stage (prow_line.h): 16 elements per thread, N = m1 + 1 = 16 T entries per row
+  const int N16 = m1 + 1;
+#ifdef RPDE_EMU
+  const bool want16 = b0.is_cheb() && (N16 == 256 || N16 == 1024 || N16 == 4096);
+#else
+  const bool want16 = b0.is_cheb() && (N16 == 1024 || N16 == 4096);
+#endif
+  const long ld16 = want16 ? N16 : 0;
+  Vec q1w(nr * ld16, 0.0), p2w(nr * ld16, 0.0), q2w(nr * ld16, 0.0), r2w(nr * ld16, 0.0);
   for (int r = rb; r < re; ++r) {
     Bands mtx = bands_axpy(ay, lam[r] + alpha, cy);   // (A_y + (lam_i + alpha) C_y), fdma_tensor.rs:219-221
     fdma_sweep(mtx);
@@ -594,11 +603,26 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
     std::copy(b.begin(), b.end(), p2.begin() + (size_t)(r - rb) * ld);
     std::copy(c.begin(), c.end(), q2.begin() + (size_t)(r - rb) * ld);
     std::copy(d.begin(), d.end(), r2.begin() + (size_t)(r - rb) * ld);
+    if (want16) {
+      const int T16 = N16 / 16;
+      const Vec aw = chunk_major16(t.q1, T16, +1), bw = chunk_major16(t.p2, T16, -1, 1.0),
+                cw = chunk_major16(t.q2, T16, -1), dw = chunk_major16(t.r2, T16, -1);
+      std::copy(aw.begin(), aw.end(), q1w.begin() + (size_t)(r - rb) * ld16);
+      std::copy(bw.begin(), bw.end(), p2w.begin() + (size_t)(r - rb) * ld16);
+      std::copy(cw.begin(), cw.end(), q2w.begin() + (size_t)(r - rb) * ld16);
+      std::copy(dw.begin(), dw.end(), r2w.begin() + (size_t)(r - rb) * ld16);
+    }
   }
   rows.row0 = rb;
   rows.n = m1;
   rows.tabld = ld;
   rows.q1.upload(q1); rows.p2.upload(p2); rows.q2.upload(q2); rows.r2.upload(r2);
+  if (want16 && nr > 0) {
+    rows16.row0 = rb;
+    rows16.n = m1;
+    rows16.tabld = ld16;
+    rows16.q1.upload(q1w); rows16.p2.upload(p2w); rows16.q2.upload(q2w); rows16.r2.upload(r2w);
+  }
 }
 
 void PoissonOp::export_eigenbasis(double* lam_out, double* fwd_out, double* bwd_out) const {

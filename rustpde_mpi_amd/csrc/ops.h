@@ -235,6 +235,10 @@ class PoissonOp {
   Arr2 fwd_e, fwd_o, bwd_e, bwd_o;
   // y direction: per-x-row swept tables, row index = eigen index (confined) or wavenumber (periodic)
   FdmaDev rows;
+  // the same factors a second time, chunk-major for 16 elements per thread (rhs_line.h chunk_major16: ascending q1, descending
+  // p2 / q2 / r2; one row of ny - 1 = 16 T entries per x-row) -- the whole-line form of the stage (prow_line.h, S6 of the
+  // confined step).  Built for real (Chebyshev x) operators whose y-lines have a whole-line length; n = 0: not built.
+  FdmaDev rows16;
 };
 
 // Hholtz<f64, 2> (src/solver/hholtz.rs:29-37, 72-106, 164-187): (I - c0 Dxx - c1 Dyy) vhat = A f by diagonalising x --

@@ -1,0 +1,227 @@
+// S6 of the confined step as one whole-line kernel: per eigen row r of the x operator (a y-line of the XY array behind G1)
+//
+//   g = B2_y f                                          Poisson::solve_par, y preconditioner (src/solver/poisson.rs:222-229,
+//                                                       MatVecFdma rows, src/solver/matvec.rs:207-228)
+//   (A_y + lam_r C_y) p = g                             one four-diagonal system per eigenvalue, swept at setup
+//                                                       (FdmaTensor::solve, src/solver/fdma_tensor.rs:219-233; Fdma::fdma,
+//                                                       src/solver/fdma.rs:101-118: forward and backward substitution)
+//
+// The line program of the stage (engine.cc S6: load, OP_MV3, OP_REC1, OP_REC2, store) runs 512 threads with two LDS slots
+// (two workgroups per CU) and reads the row's four factor tables in its own chunking (10 elements per thread).  Here: 256
+// threads per 4097-point line (64 for 1025), ONE padded line buffer (35 KB: four workgroups per CU), the sweeps as the
+// chunked scans of rhs_line.h / corr_line.h (thread t owns k = 16 t .. 16 t + 15; chunk -> affine map of its inflow, prefix
+// composition across the threads, exact re-run) with the row's factors in a second, 16-element chunk-major copy
+// (PoissonOp::rows16).  Per element the arithmetic is that of the reference's sequential sweeps.  The stage stays bound
+// by its tables: four factor rows per line on top of the line itself (6 x 8 bytes per point).
+#pragma once
+#include "rhs_line.h"
+
+namespace rpde {
+
+struct ProwLineArgs {
+  const double* in = nullptr;     // G1's product: N - 1 coefficients per line (eigen row), XY layout
+  double* out = nullptr;          // the solved rows, same shape
+  long ld = 0;                    // both arrays share the pitch
+  int nlines = 0, line0 = 0;      // local lines, index of the first one in the factor tables
+  int N = 0;
+  const double *t0 = nullptr, *t1 = nullptr, *t2 = nullptr;   // B2 rows of the y axis, chunk-major ascending (rhs_line.h chunk_major16)
+  const double *q1 = nullptr;                                  // per line (pitch tabld): forward substitution, chunk-major ascending
+  const double *p2 = nullptr, *q2 = nullptr, *r2 = nullptr;   // per line: back substitution, chunk-major DESCENDING
+  long tabld = 0;                 // = N doubles: 16 T entries per line
+};
+RPDE_HD inline bool prow_line_ok(const ProwLineArgs& a) {
+  return (a.N == 256 || a.N == 1024 || a.N == 4096) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.q1 && a.p2 && a.q2 && a.r2 &&
+         ((((size_t)a.in) | ((size_t)a.out)) & 15) == 0 && (a.ld & 1) == 0 && a.ld > a.N + 1 && a.tabld == a.N;
+}
+
+template <int N>
+RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
+  using G = HdctGeom<N>;
+  constexpr int T = G::T, W = 6;
+  lds_t buf = (lds_t)blk.lds;
+  lds_t scr = buf + G::SCR;
+  const long off = (long)blk.line * a.ld;
+  const long toff = (long)(blk.line + a.line0) * a.tabld;
+  const int n = N - 1;
+
+  // ---- the line into the padded buffer: f_k at index k + k / 16 + 2, zeros behind it (the taps reach k + 4)
+  RPDE_PHASE(blk, tid) {
+    cgmem2_t src = (cgmem2_t)(a.in + off);
+    dbl2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[tid + u * T];      // the pair m = 2 (tid + u T) <= N - 2: inside the row (ld > N + 1)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { RPDE_PIN(v[u].x); RPDE_PIN(v[u].y); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = 2 * (tid + u * T), q = m + (m >> 4) + 2;
+      buf[q] = v[u].x;
+      buf[q + 1] = (m + 1 < n) ? v[u].y : 0.0;                // f_{N-1} does not exist; m + 1 stays inside the group of 16
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int k = N; k <= N + 4; ++k) buf[k + (k >> 4) + 2] = 0.0;
+    }
+  }
+  RPDE_SYNC(blk);
+
+  // ---- B2 rows + forward substitution, thread t owns k = 16 t .. 16 t + 15 (ascending: the carry flows t - 1 -> t)
+  //   b_k = t0_k f_k + t1_k f_{k+2} + t2_k f_{k+4} (k < N - 1; the last tap only for k < N - 3),  y_k = b_k + q1_k y_{k-2}
+  RPDE_TLS(blk, double, y, 16);
+  RPDE_TLS(blk, double, cm, 2 * W);
+  RPDE_TLS(blk, double, qa, 16);
+  RPDE_PHASE(blk, tid) {
+    const int k0 = 16 * tid;
+    tab_t t0 = (tab_t)a.t0, t1 = (tab_t)a.t1, t2 = (tab_t)a.t2, q1 = (tab_t)(a.q1 + toff);
+    double r[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { const int k = k0 + i; r[i] = buf[k + (k >> 4) + 2]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                           // the band rows of eight elements at a time (registers)
+      double c0[8], c1[8], c2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = t0[j * T + tid]; c1[i] = t1[j * T + tid]; c2[i] = t2[j * T + tid]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { RPDE_PIN(c0[i]); RPDE_PIN(c1[i]); RPDE_PIN(c2[i]); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = 8 * h + i, k = k0 + j;
+        double b = c0[i] * r[j] + c1[i] * r[j + 2];
+        b += (k < n - 2) ? c2[i] * r[j + 4] : 0.0;
+        RPDE_T(y)[j] = (k < n) ? b : 0.0;
+      }
+#ifndef RPDE_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {                     // chunk -> affine map of its inflow (first order)
+      double z = 0.0, m11 = 1.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ei = par + 2 * i;
+        const bool ok = k0 + ei < n;
+        const double q = RPDE_T(qa)[ei];
+        z = ok ? RPDE_T(y)[ei] + q * z : z;
+        m11 = ok ? q * m11 : m11;
+      }
+      double* m = RPDE_T(cm) + par * W;
+      m[0] = m11; m[1] = 0.0; m[2] = 0.0; m[3] = 1.0; m[4] = z; m[5] = 0.0;
+    }
+  }
+#ifdef RPDE_EMU
+  chunk_prefix<1, T>(blk, scr, cm_st);
+#else
+  chunk_prefix<1, T>(blk, scr, cm);
+#endif
+  RPDE_SYNC(blk);                                           // everybody has read the line
+  RPDE_PHASE(blk, tid) {
+    const int k0 = 16 * tid;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      double x1 = RPDE_T(cm)[par * W + 4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ei = par + 2 * i;
+        const bool ok = k0 + ei < n;
+        x1 = ok ? RPDE_T(y)[ei] + RPDE_T(qa)[ei] * x1 : x1;
+        RPDE_T(y)[ei] = x1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int k = k0 + i; buf[k + (k >> 4) + 2] = RPDE_T(y)[i]; }   // y for the descending sweep
+  }
+  RPDE_SYNC(blk);
+
+  // ---- back substitution, descending: thread t owns the chunk of thread T - 1 - t (the carry flows t - 1 -> t again)
+  //   x_k = p2_k y_k + q2_k x_{k+2} + r2_k x_{k+4}
+  RPDE_TLS(blk, double, bb, 16);
+  RPDE_PHASE(blk, tid) {
+    const int k0 = 16 * (T - 1 - tid);
+    tab_t p2 = (tab_t)(a.p2 + toff), q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
+    {
+      double pp[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pp[i] = p2[i * T + tid];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) RPDE_PIN(pp[i]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int k = k0 + i; RPDE_T(bb)[i] = pp[i] * buf[k + (k >> 4) + 2]; }
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      double qq[8], rr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+      double z1 = 0.0, z2 = 0.0, a11 = 1.0, a12 = 0.0, a21 = 0.0, a22 = 1.0;   // state = (most recent value, the one before)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ei = 14 + par - 2 * i;
+        const bool ok = k0 + ei < n;
+        const double q = qq[i], r = rr[i];
+        const double nz = RPDE_T(bb)[ei] + q * z1 + r * z2;
+        const double n1 = q * a11 + r * a21, n2 = q * a12 + r * a22;
+        z2 = ok ? z1 : z2; z1 = ok ? nz : z1;
+        a21 = ok ? a11 : a21; a11 = ok ? n1 : a11;
+        a22 = ok ? a12 : a22; a12 = ok ? n2 : a12;
+      }
+      double* m = RPDE_T(cm) + par * W;
+      m[0] = a11; m[1] = a12; m[2] = a21; m[3] = a22; m[4] = z1; m[5] = z2;
+#ifndef RPDE_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  }
+#ifdef RPDE_EMU
+  chunk_prefix<2, T>(blk, scr, cm_st);
+#else
+  chunk_prefix<2, T>(blk, scr, cm);
+#endif
+  RPDE_SYNC(blk);                                           // everybody has read y
+  RPDE_PHASE(blk, tid) {
+    const int k0 = 16 * (T - 1 - tid);
+    tab_t q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      double qq[8], rr[8];                                  // again (L1 / L2): not kept across the prefix
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+      double x1 = RPDE_T(cm)[par * W + 4], x2 = RPDE_T(cm)[par * W + 5];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ei = 14 + par - 2 * i;
+        const bool ok = k0 + ei < n;
+        const double nx1 = RPDE_T(bb)[ei] + qq[i] * x1 + rr[i] * x2;
+        x2 = ok ? x1 : x2; x1 = ok ? nx1 : x1;
+        RPDE_T(bb)[ei] = x1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int k = k0 + i; buf[k + (k >> 4) + 2] = RPDE_T(bb)[i]; }
+  }
+  RPDE_SYNC(blk);
+
+  // ---- the solution leaves in pairs, coalesced
+  RPDE_PHASE(blk, tid) {
+    gmem2_t dst = (gmem2_t)(a.out + off);
+    gmem_t dst1 = (gmem_t)(a.out + off);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int m = 2 * (tid + u * T);
+      const int p = m + (m >> 4) + 2;
+      const dbl2 v = dbl2{buf[p], buf[p + 1]};
+      if (m + 1 < n) dst[m >> 1] = v;
+      else if (m < n) dst1[m] = v.x;
+    }
+  }
+}
+
+}  // namespace rpde

@@ -146,6 +146,43 @@ def test_confined_step_s5_through_the_whole_line_kernel(emu_lib, monkeypatch, nx
     assert abs(nav.div_norm() - ref.div_norm()) < 1e-9 * max(1.0, ref.div_norm())
 
 
+def test_s6_poisson_rows_as_one_kernel(emu_lib, monkeypatch):
+    """S6 of the confined step -- y preconditioner and one factorised banded solve per eigen row of the Poisson problem -- as
+    the whole-line kernel csrc/prow_line.h (the row's factors in a second, 16-element chunk-major copy: PoissonOp::rows16):
+    against the oracle (257-point y-lines, and 1025: one wave per line) and against the line program of the stage
+    (RPDE_S6_LINE=0: the A/B switch)."""
+    K.check_step_parity(emu_lib, False, 33, 257, 1e6, 2e-3, 3, check_at=[1, 3])
+    K.check_step_parity(emu_lib, False, 17, 1025, 1e6, 2e-3, 2, check_at=[2])
+    nav, ora = K.make_pair(emu_lib, False, 33, 257, 1e6, 1.0, 2e-3, 1.0)
+    assert {t: kind for t, _, _, _, kind in nav.schedule()}["S6 y: poisson rows"] == "whole-line poisson rows"
+    nav.update(3)
+    monkeypatch.setenv("RPDE_S6_LINE", "0")
+    nav0, _ = K.make_pair(emu_lib, False, 33, 257, 1e6, 1.0, 2e-3, 1.0)
+    assert _has_line_program(nav0, "S6 y")
+    nav0.update(3)
+    f1, f0 = nav.physical_fields(), nav0.physical_fields()
+    for k in f0:
+        assert K.rel(f1[k], f0[k]) < 1e-12, (k, K.rel(f1[k], f0[k]))
+
+
+def test_s9_pressure_update_as_one_kernel(emu_lib, monkeypatch):
+    """S9 of the confined step -- pres += to_ortho_x(S_y pseu) / dt - nu div and d/dx pres for the next step -- as the
+    whole-line kernel csrc/pres_line.h: against the oracle (257-point x-lines with few and with many rows, 1025: one wave per
+    line) and against the line program of the stage (RPDE_S9_LINE=0: the A/B switch), incl. the pressure and d/dx p."""
+    K.check_step_parity(emu_lib, False, 257, 17, 1e5, 0.01, 3, check_at=[1, 3])
+    K.check_step_parity(emu_lib, False, 257, 33, 1e5, 0.01, 2, check_at=[2])
+    K.check_step_parity(emu_lib, False, 1025, 17, 1e6, 2e-3, 2, check_at=[2], eig_mode="shared")
+    nav, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    assert {t: kind for t, _, _, _, kind in nav.schedule()}["S9 x: pressure update"] == "whole-line pressure update"
+    nav.update(3)
+    monkeypatch.setenv("RPDE_S9_LINE", "0")
+    nav0, _ = K.make_pair(emu_lib, False, 257, 17, 1e5, 1.0, 0.01, 1.0)
+    assert _has_line_program(nav0, "S9 x")
+    nav0.update(3)
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat) < 1e-12, (k, K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat))
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, monkeypatch, periodic):
     """conv_velx / conv_vely / conv_temp as three transforms per y-line in registers (csrc/dct_line.h conv_line);

@@ -261,12 +261,13 @@ def test_step_through_the_whole_line_kernel(hip_lib):
     K.check_step_parity(hip_lib, True, 16, 4097, 1e6, 1e-3, 3)
 
 
-@pytest.mark.parametrize("stage", ["RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE", "RPDE_WHOLE_LINE"])
+@pytest.mark.parametrize("stage", ["RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S6_LINE", "RPDE_S8_LINE", "RPDE_S9_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE", "RPDE_WHOLE_LINE"])
 def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
     """Each whole-line stage (the default at this length) against the same stage as a line program (<stage>=0): same
     engine, same setup data, three steps.  The oracle comparisons are test_dct_line_backward_4097, test_conv_line_4097
     and the step parity tests; this one pins the A/B switch itself."""
-    n0, n1 = (4097, 65) if stage in ("RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE") else ((65, 4097) if stage != "RPDE_WHOLE_LINE" else (4097, 4097))
+    # (RPDE_S6_LINE: the rows of the Poisson solve are y-lines, one per x eigenvalue)
+    n0, n1 = (4097, 65) if stage in ("RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_S9_LINE") else ((65, 4097) if stage != "RPDE_WHOLE_LINE" else (4097, 4097))
     fields, kinds = {}, {}
     for flag in ("0", "1"):
         monkeypatch.setenv(stage, flag)

@@ -66,7 +66,7 @@ ENV_SWITCHES = {
     "RPDE_SYNC_LAUNCHES",                           # diagnostics: every launch named and waited for
     "RPDE_ALLOC_LOG",                               # emulation build only: allocation trace for tools/fault_repro
     "RPDE_ARENA", "RPDE_ARENA_GUARD",               # device memory from slabs / one hipMalloc per buffer; guard granules (tests/test_arena.py)
-    "RPDE_WHOLE_LINE", "RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S8_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE",
+    "RPDE_WHOLE_LINE", "RPDE_S1_LINE", "RPDE_S3_LINE", "RPDE_S5_LINE", "RPDE_S6_LINE", "RPDE_S8_LINE", "RPDE_S9_LINE", "RPDE_DCT_LINE", "RPDE_CONV_LINE",
                                                     # whole-line kernel / line program per stage (test_whole_line_stage_*, test_emu_parity)
     "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
     "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
@@ -81,7 +81,7 @@ def test_environment_switches_are_the_documented_list():
     for path in _sources(os.path.join(ROOT, "rustpde_mpi_amd"), (".cc", ".h", ".py")):
         src = open(path).read()
         found |= set(re.findall(r'getenv\("(RPDE_[A-Z0-9_]+)"\)', src))
-        found |= set(re.findall(r'whole_line_on\("(RPDE_[A-Z0-9_]+)"\)', src))
+        found |= set(re.findall(r'whole_line_on\("(RPDE_[A-Z0-9_]+)"', src))
         found |= set(re.findall(r'environ(?:\.get)?\(?\[?"(RPDE_[A-Z0-9_]+)"', src))
     assert found == ENV_SWITCHES, (sorted(found - ENV_SWITCHES), sorted(ENV_SWITCHES - found))
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()

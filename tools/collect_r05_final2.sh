@@ -1,0 +1,19 @@
+#!/bin/bash
+# gpurun_out/r05g -> profiles/r05_* (the headline files of the final sources; the first evidence run's headline files move to
+# profiles/r05_first_run/, its files of the other configurations stay)
+O=gpurun_out/r05g; P=profiles
+mkdir -p $P/r05_first_run
+for f in r05_bench.json r05_bench_profiled.json r05_kernel_stats.csv r05_trace_by_tag.csv r05_pmc_traffic.txt r05_sq_counters.txt r05_profile_step.txt r05_schedule.json r05_kernel_resources.txt r05_commit.txt; do
+  [ -f $O/../.moved_$f ] && continue
+  [ -f $P/$f ] && (git mv -f $P/$f $P/r05_first_run/$f 2>/dev/null || mv -f $P/$f $P/r05_first_run/$f)
+done
+git show HEAD:profiles/r05_pmc_traffic.json > $P/r05_first_run/r05_pmc_traffic.json 2>/dev/null
+c=$(cut -c1-7 $O/commit.txt 2>/dev/null)
+cp $O/commit.txt $P/r05_commit.txt
+for f in bench bench_profiled pmc_traffic schedule; do [ -s $O/$f.json ] && cp $O/$f.json $P/r05_$f.json; done
+for f in pmc_traffic sq_counters lds_counters profile_step kernel_resources ab_step laps; do [ -s $O/$f.txt ] && cp $O/$f.txt $P/r05_$f.txt; done
+[ -s $O/pytest_gpu_new.txt ] && cp $O/pytest_gpu_new.txt $P/r05_pytest_gpu_new_${c}.txt
+[ -s $O/trace_by_tag.csv ] && cp $O/trace_by_tag.csv $P/r05_trace_by_tag.csv
+cp $O/trace/*/*kernel_stats.csv $P/r05_kernel_stats.csv 2>/dev/null || cp $O/trace/*kernel_stats.csv $P/r05_kernel_stats.csv 2>/dev/null
+[ -s $O/defaults.txt ] && cp $O/defaults.txt $P/r05_defaults_from_ab.txt
+ls $P | grep r05

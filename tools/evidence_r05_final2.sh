@@ -1,0 +1,58 @@
+#!/bin/bash
+# Round-5 evidence on the FINAL sources in ONE gpurun call (about twenty GPU-minutes were left when this ran): ordered by
+# importance, every step under its own timeout.  The full GPU test suite is NOT part of it (the driver runs it at round end;
+# the suite's last full run of the round is profiles/r05_pytest_gpu_full_214f117.txt, the tests of everything added since ran in
+# calls 4 - 7): here the A/B tests of what this session added, the A/B timings of its switches, then the headline evidence --
+# PMC traffic (the file bench.py reads roofline.traffic from, and whose source hash tests/test_layout.py pins), the bench line,
+# the rocprofv3 kernel trace + stats of the bench command, SQ and LDS counters.
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r05g
+rm -rf $O; mkdir -p $O
+cat $R/.evidence_commit > $O/commit.txt 2>/dev/null
+export EVIDENCE_COMMIT=$(cat $O/commit.txt 2>/dev/null)
+export RPDE_EIG_CACHE=/tmp/rpde_eig; mkdir -p $RPDE_EIG_CACHE      # setup data only (csrc/hostmath.cc); bench.py runs without it below
+T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s" | tee -a $O/laps.txt; }
+# 1. the A/B tests of this session's additions: 4097-point batches, S6 / S9 as whole-line kernels, against the forms they replace
+(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --durations=5 \
+   -k "(round5_ab_switches and LINE_BATCH) or (whole_line_stage_equals_line_program_4097 and (S6 or S9)) or step_parity_1025 or whole_line_kernels_equal_line_programs_1025" 2>&1 \
+   | grep -v "socket.cpp\|amdgpu.ids\|Gloo\] Rank" | tail -40) > $O/pytest_gpu_new.txt
+lap "new A/B tests"
+# 2. A/B timings, hipGraph replay of the bench workload: default, one launch per field, S6 / S9 as line programs, everything of this session off
+(timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 timeout 120 python tools/ab_step.py; RPDE_S6_LINE=0 timeout 120 python tools/ab_step.py;
+ RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py;
+ timeout 120 python tools/ab_step.py) > $O/ab_step.txt 2>$O/ab_step.err
+lap "A/B timings"
+cd /tmp
+# 3. PMC traffic on the final sources (separate passes, as the guide prescribes)
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_fetch.log 2>&1
+timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_write.log 2>&1
+cd $R
+python tools/pmc_traffic.py --fetch $O/fetch --write $O/write --schedule $O/schedule.json --out $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1
+[ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json     # bench.py picks roofline.traffic up from here
+lap "PMC traffic"
+# 4. the bench line (no eig cache: the command the driver runs)
+(unset RPDE_EIG_CACHE; timeout 420 python bench.py > $O/bench.json 2> $O/bench.err)
+lap "bench"
+# 5. rocprofv3 kernel trace + stats of the bench command
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2> $O/bench_profiled.err
+cd $R
+python tools/trace_by_tag.py $O/trace $O/schedule.json $O/trace_by_tag.csv 2> $O/trace_by_tag.log
+lap "rocprofv3 stats"
+# 6. SQ counters per launch (instruction mix), then the LDS counters (what the whole-line kernels' LDS traffic costs)
+cd /tmp
+timeout 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/sq -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_sq.log 2>&1
+timeout 240 rocprofv3 --pmc SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/lds -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_lds.log 2>&1
+cd $R
+python tools/pmc_counters.py $O/sq $O/schedule.json > $O/sq_counters.txt 2>&1
+python tools/pmc_counters.py $O/lds $O/schedule.json > $O/lds_counters.txt 2>&1
+lap "SQ / LDS counters"
+# 7. per-launch HIP-event table, kernel resources
+timeout 200 python tools/profile_step.py > $O/profile_step.txt 2>&1
+bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>/dev/null
+lap "profile_step"
+rm -f $O/*/*.db $O/*/*/*.db
+find $O -name '*kernel_trace.csv' -size +8M -delete
+rm -f $O/fetch/*counter_collection.csv $O/write/*counter_collection.csv $O/sq/*counter_collection.csv $O/lds/*counter_collection.csv $O/*/*/*counter_collection.csv
+tail -12 $O/pytest_gpu_new.txt | cut -c1-200; cat $O/ab_step.txt; tail -c 1800 $O/bench.json; cat $O/trace_by_tag.log; head -32 $O/pmc_traffic.txt; cat $O/laps.txt
