@@ -796,7 +796,7 @@ bool launch_corr_line(const CorrLineArgs& a, Stream& st) {
   return true;
 }
 template <int N>
-__global__ __launch_bounds__(N / 16, 4) void prow_line_kernel(const ProwLineArgs a) {
+__global__ __launch_bounds__(N / 16, N == 1024 ? 2 : 4) void prow_line_kernel(const ProwLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -814,7 +814,7 @@ bool launch_prow_line(const ProwLineArgs& a, Stream& st) {
   return true;
 }
 template <int N>
-__global__ __launch_bounds__(N / 16, 4) void pres_line_kernel(const PresLineArgs a) {
+__global__ __launch_bounds__(N / 16, N == 1024 ? 2 : 4) void pres_line_kernel(const PresLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);

@@ -13,9 +13,10 @@ cat $R/.evidence_commit > $O/commit.txt 2>/dev/null
 export EVIDENCE_COMMIT=$(cat $O/commit.txt 2>/dev/null)
 export RPDE_EIG_CACHE=/tmp/rpde_eig; mkdir -p $RPDE_EIG_CACHE      # setup data only (csrc/hostmath.cc); bench.py runs without it below
 T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s" | tee -a $O/laps.txt; }
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 # 1. the A/B tests of this session's additions: 4097-point batches, S6 / S9 as whole-line kernels, against the forms they replace
-(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --durations=5 \
-   -k "(round5_ab_switches and LINE_BATCH) or (whole_line_stage_equals_line_program_4097 and (S6 or S9)) or step_parity_1025 or whole_line_kernels_equal_line_programs_1025" 2>&1 \
+(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --durations=5 \
+   -k "(round5_ab_switches and LINE_BATCH) or (whole_line_stage_equals_line_program_4097 and (S6 or S9)) or whole_line_kernels_equal_line_programs_1025" 2>&1 \
    | grep -v "socket.cpp\|amdgpu.ids\|Gloo\] Rank" | tail -40) > $O/pytest_gpu_new.txt
 lap "new A/B tests"
 # 2. A/B timings, hipGraph replay of the bench workload: default, one launch per field, S6 / S9 as line programs, everything of this session off
@@ -23,6 +24,39 @@ lap "new A/B tests"
  RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py;
  timeout 120 python tools/ab_step.py) > $O/ab_step.txt 2>$O/ab_step.err
 lap "A/B timings"
+# 2b. keep the faster form of each as the DEFAULT before any evidence is collected: a form that loses by more than 0.3 % against
+# the mean of the two default runs has its default flipped in engine.cc (one greppable line each) and the library rebuilt here,
+# so that the PMC file's source hash, the bench line and the trace all belong to the sources that get committed
+python - "$O" <<'PY' > $O/defaults.txt 2>&1
+import re, subprocess, sys
+O = sys.argv[1]
+rows = {}
+for l in open(O + "/ab_step.txt"):
+    m = re.match(r"AB (.*?)\s+\d+x\d+\s+min ([0-9.]+)\s+median ([0-9.]+)", l)
+    if m: rows.setdefault(m.group(1).strip(), []).append(float(m.group(2)))
+print(rows)
+base = sum(rows["default"]) / len(rows["default"])
+src = open("rustpde_mpi_amd/csrc/engine.cc").read()
+flips = []
+for label, old, new in (("RPDE_LINE_BATCH=15", "constexpr int kLineBatchDefaultMask = 255;", "constexpr int kLineBatchDefaultMask = 15;"),
+                        ("RPDE_S6_LINE=0", "constexpr bool kS6LineDefault = true;", "constexpr bool kS6LineDefault = false;"),
+                        ("RPDE_S9_LINE=0", "constexpr bool kS9LineDefault = true;", "constexpr bool kS9LineDefault = false;")):
+    failed = any(l.startswith("FAILED") and label.split("=")[0].replace("RPDE_", "") in l for l in open(O + "/pytest_gpu_new.txt"))
+    if failed: print(label, "its A/B test FAILED on this box: the new form is switched off")
+    if failed or (label in rows and min(rows[label]) < 0.997 * base):
+        assert old in src
+        src = src.replace(old, new, 1)
+        flips.append(label)
+    print(label, rows.get(label), "vs default", base, "-> FLIP" if label in flips else "-> keep")
+if flips:
+    open("rustpde_mpi_amd/csrc/engine.cc", "w").write(src)
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], capture_output=True, text=True)
+    print("rebuild rc", r.returncode, r.stderr[-500:])
+print("FLIPS", flips)
+PY
+cp rustpde_mpi_amd/csrc/engine.cc $O/engine.cc.final
+(timeout 120 python tools/ab_step.py) >> $O/ab_step.txt 2>>$O/ab_step.err      # the defaults that go into the evidence
+lap "defaults decided"
 cd /tmp
 # 3. PMC traffic on the final sources (separate passes, as the guide prescribes)
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o step -- python $R/tools/pmc_step.py --out $O/schedule.json > $O/pmc_fetch.log 2>&1
@@ -52,6 +86,12 @@ lap "SQ / LDS counters"
 timeout 200 python tools/profile_step.py > $O/profile_step.txt 2>&1
 bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>/dev/null
 lap "profile_step"
+# 8. config 2 (1025^2: S6 / S9 are new kernels there too): A/B timing and its bench line with the parity legs; the "hc" line
+(timeout 60 python tools/ab_step.py 1025 1025 300 5; RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 60 python tools/ab_step.py 1025 1025 300 5) > $O/ab_step_1025.txt 2>&1
+timeout 300 python bench.py --nx 1025 --ny 1025 --ra 1e7 --dt 1e-3 --steps 200 > $O/bench_1025.json 2> $O/bench_1025.err
+lap "config 2"
+timeout 200 python bench.py --no-cpu-baseline --bc hc --steps 30 > $O/bench_hc.json 2> $O/bench_hc.err
+lap "hc"
 rm -f $O/*/*.db $O/*/*/*.db
 find $O -name '*kernel_trace.csv' -size +8M -delete
 rm -f $O/fetch/*counter_collection.csv $O/write/*counter_collection.csv $O/sq/*counter_collection.csv $O/lds/*counter_collection.csv $O/*/*/*counter_collection.csv
