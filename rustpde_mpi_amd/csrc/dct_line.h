@@ -33,9 +33,11 @@ struct DctLineArgs {
   double dscale = 1.0;                    //    (funspace `gradient` along the line, src/field.rs:127-129)
   int fwd = 0;                            // 1: forward transform (funspace `forward` of the orthonormal base, src/field.rs:103-106):
   int cut = 1 << 30;                      //    N + 1 physical values in, coefficients (-1)^k E_k / N (ends halved) out, zero from `cut` on
+  int xpad = 1;                           // 0 (A/B only, RPDE_XPAD=0): the unpadded x-layout of rounds 3 - 4 for the derivative / table stencil too
 };
 
-RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16; }
+RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16 + 16; }   // the padded x-layout ends at N + 3 + (N + 3) / 16; wave totals of the derivative behind it
+template <int N> struct DctGeom { static constexpr int LDS = N + N / 16 + 16; };
 // the 16-byte staging loads need an aligned line start and, for an odd count, one readable element behind the line
 // (N = 1024 runs on the half-length core, hdct_line.h, only)
 RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
@@ -63,6 +65,11 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   tab_t tw2 = (tab_t)a.tw2;
   const int n_in = a.n_in;
   const bool sten = a.sten == 2;
+  // x-layout of the staged line (x[m] at buffer index b = m + 2): padded to b + b / 16 when the line is swept in chunks of 16
+  // per thread (table stencil / derivative) -- see hdct_core (hdct_line.h): unpadded, those chunk accesses are 16-way bank conflicts
+  const bool padx = (a.sten == 1 || a.deriv != 0) && a.xpad != 0;
+  const int padm = padx ? -1 : 0;
+  auto X = [padm](int b) { return b + ((b >> 4) & padm); };
   RPDE_TLS(blk, double, re, 16);
   RPDE_TLS(blk, double, im, 16);
 
@@ -72,20 +79,30 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   // through a buffer descriptor that ends behind the pair holding the last coefficient: a pair outside the line reads zero,
   // no bounds test, no branch, one 32-bit offset per thread (round 5, as hdct_core)
   const RowBuf rb = row_buf(a.in + (long)line * a.ldi, 8L * ((n_in + 1) & ~1));
+  // a Dirichlet line whose DERIVATIVE is wanted gets its stencil c_m = a_m - a_{m-2} here, on the way in, like hdct_core's
+  // lines (the second pair of a thread is its neighbour's first: an L1 hit) -- rounds 2 - 4 sent it through the table-stencil
+  // block below with a table of -1: one more pass of the line through LDS and two more barriers per convection term
+  const bool dsten = a.sten == 2 && a.deriv != 0;
   RPDE_PHASE(blk, tid) {
     constexpr int QP = (N + 4 + 2 * T - 1) / (2 * T);   // pairs per thread: 2 T QP >= N + 4
-    dbl2 v[QP];
+    dbl2 v[QP], o[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
       const int p = tid + q * T;                          // pair p = elements 2 p - 2, 2 p - 1 at byte 16 (p - 1)
       v[q] = row_ld2(rb, 16 * (p - 1), 0);
+      o[q] = dsten ? row_ld2(rb, 16 * (p - 2), 0) : dbl2{0.0, 0.0};
     }
 #pragma unroll
     for (int q = 0; q < QP; ++q) {
       const int p = tid + q * T, k = 2 * p - 2;
-      dbl2 w = v[q];
+      dbl2 w = v[q], u = o[q];
       if (k + 1 >= n_in) w.y = 0.0;
-      if (2 * p + 1 < N + 4) buf2[p] = w;
+      if (k - 1 >= n_in) u.y = 0.0;
+      w.x -= u.x; w.y -= u.y;
+      if (2 * p + 1 < N + 4) {
+        if (padx) { const int xq = X(2 * p); buf[xq] = w.x; buf[xq + 1] = w.y; }   // 2 p is even: the pair stays inside its group of 16
+        else buf2[p] = w;
+      }
     }
   }
   RPDE_SYNC(blk);
@@ -96,14 +113,14 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   bool sten_in_read = sten;
   if (a.sten == 1 || a.deriv) {
     sten_in_read = false;
-    if (a.sten != 0) {
+    if (a.sten == 1 || (a.sten == 2 && staged)) {        // (a staged Dirichlet line has not had its stencil yet)
       tab_t low = (tab_t)a.low;
       RPDE_TLS(blk, double, c, 17);
       RPDE_PHASE(blk, tid) {
         const int k0 = 16 * tid;
         double xs[19], lw[17];
 #pragma unroll
-        for (int i = 0; i < 19; ++i) xs[i] = buf[k0 + i];                       // xs[i] = a_{k0 + i - 2}
+        for (int i = 0; i < 19; ++i) xs[i] = buf[X(k0 + i)];                    // xs[i] = a_{k0 + i - 2}
 #pragma unroll
         for (int i = 0; i < 17; ++i) lw[i] = (a.sten == 2) ? -1.0 : low[max(k0 + i - 2, 0)];
 #pragma unroll
@@ -113,8 +130,8 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
       RPDE_PHASE(blk, tid) {
         const int k0 = 16 * tid;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) buf[k0 + i + 2] = RPDE_T(c)[i];
-        if (tid == T - 1) buf[N + 2] = RPDE_T(c)[16];
+        for (int i = 0; i < 16; ++i) buf[X(k0 + i + 2)] = RPDE_T(c)[i];
+        if (tid == T - 1) buf[X(N + 2)] = RPDE_T(c)[16];
       }
       RPDE_SYNC(blk);
     }
@@ -123,12 +140,12 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
       // owns the chunk lo = 16 (T - 1 - t), so that the carry flows from thread t - 1 to thread t
       RPDE_TLS(blk, double, zz, 16);
       RPDE_TLS(blk, double, vv, 2);
-      lds_t carry = buf + N + 8;
+      lds_t carry = buf + N + N / 16 + 8;      // behind the padded line
       RPDE_PHASE(blk, tid) {
         const int lo = (T - 1 - tid) * 16;
         double bb[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[lo + i + 3];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[X(lo + i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
           double z = 0.0;
@@ -170,9 +187,9 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = lo + i;
-          buf[k + 2] = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+          buf[X(k + 2)] = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
         }
-        if (tid == 0) buf[N + 2] = 0.0;          // d_N = 0
+        if (tid == 0) buf[X(N + 2)] = 0.0;       // d_N = 0
       }
       RPDE_SYNC(blk);
     }
@@ -185,7 +202,9 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int i = tid + t * T;               // m0 = 2 i: x[m0], x[m0+1] = pair i + 1; x[m0-2], x[m0-1] = pair i
-      const dbl2 c = xs2[i + 1], p = xs2[i];
+      dbl2 c, p;
+      if (padx) { const int xq = X(2 * i + 2); c = dbl2{buf[xq], buf[xq + 1]}; p = dbl2{0.0, 0.0}; }   // (padx: the stencil has been applied)
+      else { c = xs2[i + 1]; p = xs2[i]; }
       const double v0 = sten ? c.x - p.x : c.x, v1 = sten ? c.y - p.y : c.y;
       const double f0 = (t == 0 && tid == 0) ? 1.0 : 0.5;      // m = 0: the end of the line
       RPDE_T(re)[t] = a.fwd ? v0 : f0 * v0;
@@ -194,7 +213,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
 #pragma unroll
     for (int t = 8; t < 16; ++t) {
       const int m0 = 2 * N - 2 * (tid + t * T);                // even, 2 <= m0 <= N
-      const double x0 = buf[m0 + 2], x1 = buf[m0 + 1], t0 = buf[m0], t1 = buf[m0 - 1];   // x[m0], x[m0-1], x[m0-2], x[m0-3]
+      const double x0 = buf[X(m0 + 2)], x1 = buf[X(m0 + 1)], t0 = buf[X(m0)], t1 = buf[X(m0 - 1)];   // x[m0], x[m0-1], x[m0-2], x[m0-3]
       const double v0 = sten ? x0 - t0 : x0, v1 = sten ? x1 - t1 : x1;
       const double f0 = (t == 8 && tid == 0) ? 1.0 : 0.5;      // m = N: the other end
       RPDE_T(re)[t] = a.fwd ? v0 : f0 * v0;
@@ -336,6 +355,7 @@ struct ConvLineArgs {
   int nlines, N;
   const double* tw; const double* tw2;
   double dscale; int cut;
+  int xpad = 1;                   // DctLineArgs::xpad of the derivative's transform
 };
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
@@ -360,7 +380,7 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   });
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
-  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
+  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale; a2.xpad = c.xpad;
   dct_line_core<N>(blk, a2, false, [&](int tid, int slot, int k, double v) {
     (void)tid;
     RPDE_T(acc)[slot] += vp[k] * (lift ? v + by[k] : v);

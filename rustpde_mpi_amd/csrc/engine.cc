@@ -767,6 +767,13 @@ static bool whole_line_on(const char* stage_env, bool dflt = true) {
   if (const char* e = std::getenv("RPDE_WHOLE_LINE")) return std::atoi(e) != 0;
   return dflt;
 }
+// RPDE_XPAD=0 (A/B only): the derivative transforms of S1 and of the convection terms with the unpadded x-layout of rounds 3 - 4
+// (16-way LDS bank conflicts in the chunk sweeps, hdct_line.h `padx`); kXpadDefault is flipped by measurement like the others
+constexpr int kXpadDefault = 1;
+static int xpad_on() {
+  if (const char* e = std::getenv("RPDE_XPAD")) return std::atoi(e) != 0 ? 1 : 0;
+  return kXpadDefault;
+}
 // the defaults of the stages added last (round 5), one greppable line each: tools/evidence_r05_final2.sh measures both forms of
 // each inside one gpurun call and keeps the faster one as the default before it collects the evidence
 constexpr bool kS6LineDefault = true;   // S6 as prow_line.h
@@ -784,6 +791,7 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   Launch l;
   l.type = Launch::kDctLine;
   l.dl = a;
+  l.dl.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * ((double)a.n_in + a.N + 1) * a.nlines;
   step_.push_back(l);
@@ -796,6 +804,7 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   Launch l;
   l.type = Launch::kDctLine2;
   l.dl = a0; l.dl2 = a1;
+  l.dl.xpad = l.dl2.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * ((double)a0.n_in + 2.0 * (a0.N + 1)) * a0.nlines;
   step_.push_back(l);
@@ -831,6 +840,7 @@ bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   Launch l;
   l.type = Launch::kConvLine;
   l.cl = c;
+  l.cl.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * (2.0 * c.n_in + (c.bx ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by), out
   step_.push_back(l);

@@ -26,6 +26,7 @@ __device__ __forceinline__ void mfma_f64_vgpr(dbl4& acc, double a, double b) {
   asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+constexpr int kGemmLdsDefault = 1;          // LDS layout of the operand stages (gemm_f64_db_tile LAY), one greppable line: flipped by measurement
 constexpr long kGemmSmallTileBelow = 512;   // fewer 128 x 128 tiles than this (two per CU): use 64 x 64 tiles
 
 // two independent products in one launch (blockIdx.z picks): the even and the odd block of the Poisson
@@ -66,7 +67,14 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 // TM x TM block tile (128 or 64), 4 waves in a 2 x 2 grid, each wave MT x MT MFMA tiles (MT = TM / 32).  The
 // 64-tile serves problems that would not give every CU a 128-tile (small grids; the local products of a
 // pencil-sharded run, 512 x 2048 x 2048 per GPU at 4097^2 on 8 GPUs).
-template <bool NN, int TM, bool OLD = true>
+// LAY: the LDS layout of an operand stage.  0 (rounds 1 - 4): [k/4][row][k%4] -- a fragment (lane l: row l % 16, k l / 16) is
+// one contiguous 512-byte block, but the compiler fetches two fragments per ds_read2st64_b64, which the LDS serves in groups
+// of 16 lanes over 32 banks: the 16 rows of a group are 32 bytes apart, a 4-way bank conflict on every fragment read
+// (SQ_LDS_BANK_CONFLICT: 70 % of the kernel's LDS cycles, profiles/r05_lds_counters.txt).  1 (round 5): [k/4][k%4][row]
+// with 144 doubles per k plane -- the 16 rows of a lane group are 128 contiguous bytes, the next k plane starts 32 banks
+// further (conflict free also as a 32-lane ds_read_b64); the staging stores become 8-byte stores (two lanes of a row hit
+// the same bank: the k/4 planes are 580 doubles apart, which puts them 16 banks apart).
+template <bool NN, int TM, bool OLD = true, int LAY = 0>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
                                                  int tile_m, int tile_n, bool ct = false) {
@@ -76,8 +84,11 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   constexpr int KT = BK / TPR;         // doubles per thread and operand per stage (8 or 4)
   constexpr int VPE = TM / 64;         // NN: k-values per thread and k sub-step (2 or 1)
   static_assert(TM == 128 || TM == 64, "tile sizes 128 and 64");
-  __shared__ __attribute__((aligned(16))) double As[2][KS][TM][4];
-  __shared__ __attribute__((aligned(16))) double Bs[2][KS][TM][4];
+  constexpr int RS = LAY ? TM + 16 : 4;              // LAY 1: doubles per k plane; LAY 0: per row
+  constexpr int SS = LAY ? 4 * RS + 4 : 4 * TM;      // doubles per k/4 block
+  __shared__ __attribute__((aligned(16))) double Asf[2 * KS * SS];
+  __shared__ __attribute__((aligned(16))) double Bsf[2 * KS * SS];
+  auto at = [](int st, int s, int row, int kk) { return LAY ? (st * KS + s) * SS + kk * RS + row : (st * KS + s) * SS + row * 4 + kk; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = tile_m * TM, n0 = tile_n * TM;
@@ -174,30 +185,42 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   auto lstore = [&](int st) {
 #pragma unroll
     for (int h = 0; h < KT / 4; ++h) {
-      dbl2v* d = reinterpret_cast<dbl2v*>(&As[st][(akk >> 2) + h][arow][0]);
-      d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
-      d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
+      if constexpr (LAY) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) Asf[at(st, (akk >> 2) + h, arow, kk)] = ra[4 * h + kk];
+      } else {
+        dbl2v* d = reinterpret_cast<dbl2v*>(&Asf[at(st, (akk >> 2) + h, arow, 0)]);
+        d[0] = dbl2v{ra[4 * h], ra[4 * h + 1]};
+        d[1] = dbl2v{ra[4 * h + 2], ra[4 * h + 3]};
+      }
     }
     if constexpr (!NN) {
 #pragma unroll
       for (int h = 0; h < KT / 4; ++h) {
-        dbl2v* d = reinterpret_cast<dbl2v*>(&Bs[st][(akk >> 2) + h][arow][0]);
-        d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
-        d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
+        if constexpr (LAY) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) Bsf[at(st, (akk >> 2) + h, arow, kk)] = rb[4 * h + kk];
+        } else {
+          dbl2v* d = reinterpret_cast<dbl2v*>(&Bsf[at(st, (akk >> 2) + h, arow, 0)]);
+          d[0] = dbl2v{rb[4 * h], rb[4 * h + 1]};
+          d[1] = dbl2v{rb[4 * h + 2], rb[4 * h + 3]};
+        }
       }
     } else {
 #pragma unroll
       for (int e = 0; e < KS; ++e) {
-        if constexpr (VPE == 2) *reinterpret_cast<dbl2v*>(&Bs[st][e][bn][2 * bkg]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
-        else Bs[st][e][bn][bkg] = rb[e];
+        if constexpr (VPE == 2) {
+          if constexpr (LAY) { Bsf[at(st, e, bn, 2 * bkg)] = rb[2 * e]; Bsf[at(st, e, bn, 2 * bkg + 1)] = rb[2 * e + 1]; }
+          else *reinterpret_cast<dbl2v*>(&Bsf[at(st, e, bn, 2 * bkg)]) = dbl2v{rb[2 * e], rb[2 * e + 1]};
+        } else Bsf[at(st, e, bn, bkg)] = rb[e];
       }
     }
   };
   auto frag = [&](int st, int s, double (&a)[MT], double (&b)[MT]) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = As[st][s][wm * (TM / 2) + i * 16 + l15][l4];
+    for (int i = 0; i < MT; ++i) a[i] = Asf[at(st, s, wm * (TM / 2) + i * 16 + l15, l4)];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) b[j] = Bs[st][s][wn * (TM / 2) + j * 16 + l15][l4];
+    for (int j = 0; j < MT; ++j) b[j] = Bsf[at(st, s, wn * (TM / 2) + j * 16 + l15, l4)];
   };
   auto mma = [&](const double (&a)[MT], const double (&b)[MT]) {
 #pragma unroll
@@ -273,23 +296,30 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
     }
 }
 
-template <bool NN, int TM>
+template <bool NN, int TM, int LAY>
 __global__ __launch_bounds__(256) void gemm_f64_db_kernel(int M, int N, int K,
                                                           const double* __restrict__ A, long lda,
                                                           const double* __restrict__ B, long ldb,
                                                           double* __restrict__ C, long ldc) {
-  gemm_f64_db_tile<NN, TM>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
+  gemm_f64_db_tile<NN, TM, true, LAY>(M, N, K, A, lda, B, ldb, C, ldc, (int)blockIdx.y, (int)blockIdx.x);
+}
+// RPDE_GEMM_LDS=0 | 1 (A/B): the LDS layout of the operand stages (gemm_f64_db_tile LAY); kGemmLdsDefault is set by measurement
+static bool gemm_lay1() {
+  static const bool on = [] { const char* e = std::getenv("RPDE_GEMM_LDS"); return e ? std::atoi(e) != 0 : kGemmLdsDefault != 0; }();
+  return on;
 }
 // DB: 1 = 128-tile, 2 = 64-tile (both two-stage)
 template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
-  constexpr int TM = DB == 2 ? 64 : 128;   // DB 3: the 128-tile with the round-4 loop (the default; DB 1: the peeled loop, A/B)
+  constexpr int TM = (DB == 2 || DB == 5) ? 64 : 128;   // DB 3 / 4: the 128-tile with the round-4 loop, LDS layout 0 / 1 (DB 1: the peeled loop, A/B); DB 2 / 5: the 64-tile
   int tx, ty;
   gemm_tile_of_block(z, tx, ty);
   if (ty * TM >= g.M || tx * TM >= g.N) return;
   if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else if constexpr (DB == 3) gemm_f64_db_tile<NN, 128, true>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+  else if constexpr (DB == 4) gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);   // LDS layout 1
+  else if constexpr (DB == 5) gemm_f64_db_tile<NN, 64, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
 }
 
@@ -308,11 +338,13 @@ static void launch_gemm(int M, int N, int K, const double* A, long lda, const do
   dim3 grid((N + 127) / 128, (M + 127) / 128);
   if ((long)grid.x * grid.y < kGemmSmallTileBelow) {   // too few 128-tiles for the chip
     dim3 g64((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 64>), g64, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
+    if (gemm_lay1()) hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 64, 1>), g64, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
+    else hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 64, 0>), g64, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
     RPDE_HIP(hipGetLastError());
     return;
   }
-  hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
+  if (gemm_lay1()) hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128, 1>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
+  else hipLaunchKernelGGL((gemm_f64_db_kernel<NN, 128, 0>), grid, dim3(256), 0, st.s, M, N, K, A, lda, B, ldb, C, ldc);
   RPDE_HIP(hipGetLastError());
 }
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
@@ -331,10 +363,14 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
   const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc, p0.ct}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.ct};
   const int Mx = std::max(p0.M, p1.M), Nx = std::max(p0.N, p1.N);
   dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, 2);
+  const bool lay1 = gemm_lay1();
   if ((long)grid.x * grid.y * 2 < kGemmSmallTileBelow) {
     dim3 g64((Nx + 63) / 64, (Mx + 63) / 64, 2);
     const GemmSwizzle z = gemm_swizzle((int)g64.x, (int)g64.y);
-    if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
+    if (lay1) {
+      if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 5>), g64, dim3(256), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 5>), g64, dim3(256), 0, st.s, g0, g1, z);
+    } else if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
     else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 2>), g64, dim3(256), 0, st.s, g0, g1, z);
   } else {
     const GemmSwizzle z = gemm_swizzle((int)grid.x, (int)grid.y);
@@ -342,7 +378,10 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     // false>).  Measured in round 5 (profiles/r05_experiments): G1 / G2 1.081 / 1.100 ms with it, 1.071 / 1.092 without -- the
     // 375 instructions around the 64 MFMAs of a stage were never what kept the pipe at 0.81; the round-4 loop stays the default
     static const bool peel = [] { const char* e = std::getenv("RPDE_GEMM_PEEL"); return e && std::atoi(e) != 0; }();
-    if (!peel) {
+    if (!peel && lay1) {
+      if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 4>), grid, dim3(256), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 4>), grid, dim3(256), 0, st.s, g0, g1, z);
+    } else if (!peel) {
       if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 3>), grid, dim3(256), 0, st.s, g0, g1, z);
       else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 3>), grid, dim3(256), 0, st.s, g0, g1, z);
     } else if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 1>), grid, dim3(256), 0, st.s, g0, g1, z);

@@ -45,7 +45,8 @@ struct HdctStoreEmit {
   }
 };
 
-// staged: the input line is already in the buffer (x[m] at buf[m + 2], zeros around it) and a barrier has been passed.
+// staged: the input line is already in the buffer (x[m] at buffer index b = m + 2 -- at b + b / 16 when the transform takes the
+// derivative or a table stencil, see `padx` below --, zeros around it) and a barrier has been passed.
 // fetch(tid) is called once per thread ahead of the last barriers: the caller's chance to put the global loads its emit
 // needs in flight.
 // PAIR: the line runs in one half of a workgroup whose other half runs another transform of the same length
@@ -73,6 +74,15 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   tab_t tw = (tab_t)a.tw;
   tab_t tw2 = (tab_t)a.tw2;
   const int n_in = a.n_in;
+  // x-layout of the staged line: x[m] at buffer index b = m + 2.  A transform that sweeps the line in chunks of 16 per thread
+  // (derivative, table stencil) keeps it at the PADDED index b + b / 16: the chunks of neighbouring lanes are 17 doubles apart
+  // (no bank conflicts).  Unpadded -- the form of rounds 3 and 4 -- the 32 chunk accesses of a derivative are 16-way conflicts:
+  // more than half of the LDS cycles of S1 and of the convection terms (SQ_LDS_BANK_CONFLICT, profiles/r05_lds_counters.txt).
+  // Everything else (the pure transforms, the forward transforms) keeps b: pairs stay 16-byte accesses.  The padded line ends
+  // at N + 3 + (N + 3) / 16 < SCR.
+  const bool padx = (MODE >= 0 ? (MODE & (kHdctDeriv | kHdctSten1)) != 0 : (a.deriv != 0 || a.sten == 1)) && a.xpad != 0;
+  const int padm = padx ? -1 : 0;
+  auto X = [padm](int b) { return b + ((b >> 4) & padm); };
   RPDE_TLS(blk, double, re, 8);
   RPDE_TLS(blk, double, im, 8);
   // the one table entry a thread needs, (cos, sin)(pi tid / N), goes out first: everything else (the twiddles of the
@@ -105,7 +115,10 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
         if (k + 1 >= n_in) c.y = 0.0;
         if (k - 1 >= n_in) o.y = 0.0;
         c.x -= o.x; c.y -= o.y;
-        if (2 * p + 1 < N + 4) buf2[p] = c;
+        if (2 * p + 1 < N + 4) {
+          if (padx) { const int q = X(2 * p); buf[q] = c.x; buf[q + 1] = c.y; }   // 2 p is even: the pair stays inside its group of 16
+          else buf2[p] = c;
+        }
       }
     }
     RPDE_SYNC(blk);
@@ -120,7 +133,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
       const int k0 = 16 * tid;
       double xs[19], lw[17];
 #pragma unroll
-      for (int i = 0; i < 19; ++i) xs[i] = buf[k0 + i];                       // xs[i] = a_{k0 + i - 2}
+      for (int i = 0; i < 19; ++i) xs[i] = buf[X(k0 + i)];                    // xs[i] = a_{k0 + i - 2}
 #pragma unroll
       for (int i = 0; i < 17; ++i) lw[i] = low[max(k0 + i - 2, 0)];
 #pragma unroll
@@ -130,8 +143,8 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     RPDE_PHASE(blk, tid) {
       const int k0 = 16 * tid;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) buf[k0 + i + 2] = RPDE_T(c)[i];
-      if (tid == T - 1) buf[N + 2] = RPDE_T(c)[16];
+      for (int i = 0; i < 16; ++i) buf[X(k0 + i + 2)] = RPDE_T(c)[i];
+      if (tid == T - 1) buf[X(N + 2)] = RPDE_T(c)[16];
     }
     RPDE_SYNC(blk);
   }
@@ -147,7 +160,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
         const int lo = (T - 1 - tid) * 16;
         double bb[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[lo + i + 3];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[X(lo + i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
           double z = 0.0;
@@ -189,9 +202,9 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = lo + i;
-          buf[k + 2] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+          buf[X(k + 2)] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
         }
-        if (tid == 0) buf[N + 2] = 0.0;          // d_N = 0
+        if (tid == 0) buf[X(N + 2)] = 0.0;       // d_N = 0
       }
     }
     RPDE_SYNC(blk);
@@ -209,7 +222,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     double cs[8], sn[8], xa[8], xb[8];
     const double c0 = RPDE_T(cs0)[0], s0 = RPDE_T(cs0)[1];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int j = tid + q * T; xa[q] = buf[j + 2]; xb[q] = buf[N - j + 2]; }
+    for (int q = 0; q < 8; ++q) { const int j = tid + q * T; xa[q] = buf[X(j + 2)]; xb[q] = buf[X(N - j + 2)]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { cs[q] = c0 * kC32[q] - s0 * kS32[q]; sn[q] = s0 * kC32[q] + c0 * kS32[q]; }
     const double f = a_fwd ? 1.0 : ((tid & 1) ? -0.5 : 0.5);
@@ -222,11 +235,11 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
       const double A = fa * xa[q], B = fa * xb[q];
       const double s = A + B, d = A - B;
       const double t2 = 2.0 * sn[q] * d;
-      buf[j + 2] = end ? s : s - t2;
-      if (!end) buf[N - j + 2] = s + t2;
+      buf[X(j + 2)] = end ? s : s - t2;
+      if (!end) buf[X(N - j + 2)] = s + t2;
       e1 += end ? d : 2.0 * cs[q] * d;
     }
-    if (tid == 0) buf[M + 2] = (a_fwd ? 2.0 : 1.0) * buf[M + 2];   // y_M = 2 f_M x_M, M even
+    if (tid == 0) buf[X(M + 2)] = (a_fwd ? 2.0 : 1.0) * buf[X(M + 2)];   // y_M = 2 f_M x_M, M even
     RPDE_T(e1p)[0] = e1;
   }
 #ifndef RPDE_EMU
@@ -243,9 +256,15 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     clds2_t y2 = (clds2_t)buf;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const dbl2 z = y2[tid + t * T + 1];
-      RPDE_T(re)[t] = z.x;
-      RPDE_T(im)[t] = z.y;
+      if (padx) {                                          // the pair (y_{2i}, y_{2i+1}) at b = 2 i + 2: inside one group of 16
+        const int q = X(2 * (tid + t * T) + 2);
+        RPDE_T(re)[t] = buf[q];
+        RPDE_T(im)[t] = buf[q + 1];
+      } else {
+        const dbl2 z = y2[tid + t * T + 1];
+        RPDE_T(re)[t] = z.x;
+        RPDE_T(im)[t] = z.y;
+      }
     }
     SmallDft<8>::run(RPDE_T(re), RPDE_T(im));
   }
@@ -468,7 +487,8 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
   const long LB = (long)hdct_lds_doubles(N);
   {
     Blk all{line, 0, T2, lds};
-    lds2_t bufa = (lds2_t)lds, bufb = (lds2_t)(lds + LB);
+    lds2_t bufa = (lds2_t)lds;
+    lds_t la = (lds_t)lds, lb = (lds_t)(lds + LB);
     const bool dsten = a0.sten == 2;
     const int n_in = a0.n_in;
     const RowBuf rb = row_buf(a0.in + (long)line * a0.ldi, 8L * ((n_in + 1) & ~1));   // as in hdct_core: outside the line reads zero
@@ -488,7 +508,12 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
         if (k + 1 >= n_in) c.y = 0.0;
         if (k - 1 >= n_in) o.y = 0.0;
         c.x -= o.x; c.y -= o.y;
-        if (2 * p + 1 < N + 4) { bufa[p] = c; bufb[p] = c; }
+        if (2 * p + 1 < N + 4) {
+          // the derivative's buffer (and both under a table stencil) in the padded x-layout of hdct_core
+          const int xq = 2 * p + (a1.xpad ? (2 * p) >> 4 : 0);
+          if (a0.sten == 1) { la[xq] = c.x; la[xq + 1] = c.y; } else bufa[p] = c;
+          lb[xq] = c.x; lb[xq + 1] = c.y;
+        }
       }
     }
     RPDE_SYNC(all);
@@ -522,7 +547,7 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
 }
 RPDE_HD inline bool hdct_pair_ok(const DctLineArgs& a0, const DctLineArgs& a1) {
   return a0.in == a1.in && a0.ldi == a1.ldi && a0.n_in == a1.n_in && a0.sten == a1.sten && a0.low == a1.low && a0.N == a1.N &&
-         a0.nlines == a1.nlines && !a0.fwd && !a1.fwd && !a0.deriv && a1.deriv;
+         a0.nlines == a1.nlines && !a0.fwd && !a1.fwd && !a0.deriv && a1.deriv && a0.xpad == a1.xpad;
 }
 
 // One y-line of a convection term on this core (see conv_line in dct_line.h for the mathematics): the physical factors
@@ -549,7 +574,7 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   }
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
-  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
+  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale; a2.xpad = c.xpad;
   {
     cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + off : c.vp + off);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {

@@ -703,7 +703,7 @@ static bool s1_split_on() {
 template <int N>
 __global__ __launch_bounds__(N / 16, 3) void conv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  __shared__ __attribute__((aligned(16))) double buf[DctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;
@@ -866,7 +866,7 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs c) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16];
+  __shared__ __attribute__((aligned(16))) double buf[DctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;

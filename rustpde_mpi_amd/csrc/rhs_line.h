@@ -132,15 +132,18 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   const bool has2 = gline >= 2;
   const double dt = a.dt;
 
-  // ---- forward transform of the convection term; its results leave as -dt c_k into registers (pairs m = 2 (t + u T))
-  RPDE_TLS(blk, double, e, 17);
+  // ---- forward transform of the convection term; its results leave as -dt c_k (pairs m = 2 (t + u T)) straight into the line
+  // buffer at the padded index the assembly below uses -- the same thread owns the same pairs there, and when the transform emits
+  // (behind its last barrier) nobody reads the exchange planes any more.  (Rounds 3 - 4 kept them in 17 registers per thread
+  // across the assembly: 184 registers at a budget of 168, i.e. 18 - 20 spilled ones whose scratch traffic was a quarter of the
+  // stage's HBM bytes -- PMC ratio 1.30, profiles/r05_pmc_traffic.txt.)
   DctLineArgs f{a.conv, a.ld, N + 1, nullptr, 0, a.nlines, N, 0, a.tw, a.tw2, 1.0};
   f.fwd = 1; f.cut = a.cut;
   hdct_core<N>(blk, f, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
-    (void)m;
-    if (u == 8) { RPDE_T(e)[16] = -dt * e0; return; }
-    RPDE_T(e)[2 * u] = -dt * e0;
-    RPDE_T(e)[2 * u + 1] = -dt * e1;
+    (void)tid;
+    const int q = m + (m >> 4) + 2;
+    buf[q] = -dt * e0;
+    if (u != 8) buf[q + 1] = -dt * e1;                      // (u = 8: m = N, the single coefficient of thread 0)
   });
 
   // ---- element-wise assembly in the same layout, then into the buffer at the padded index k + k / 16 (+ 2; the
@@ -200,13 +203,13 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
         // S_x S_y state: rows j, j - 2 at k and k - 2
         const double sx = a0[i].x + cy * c0[i].x, sy = a0[i].y + cy * c0[i].y;
         const double smx = am[i].x + cy * cm[i].x, smy = am[i].y + cy * cm[i].y;
-        double rx = RPDE_T(e)[2 * u] + (sx + lx.x * smx) + gfac * g[i].x;
-        double ry = RPDE_T(e)[2 * u + 1] + (sy + lx.y * smy) + gfac * g[i].y;
+        const int m = 2 * (tid + u * T), q = m + (m >> 4) + 2;
+        double rx = buf[q] + (sx + lx.x * smx) + gfac * g[i].x;
+        double ry = buf[q + 1] + (sy + lx.y * smy) + gfac * g[i].y;
         if (WHICH == 1) {                                   // buoyancy: dt (S_xN S_y T + T_bc)
           rx += dt * ((b0[i].x + cy2 * d0[i].x) + lt[i].x * (bm[i].x + cy2 * dm[i].x) + tb[i].x);
           ry += dt * ((b0[i].y + cy2 * d0[i].y) + lt[i].y * (bm[i].y + cy2 * dm[i].y) + tb[i].y);
         }
-        const int m = 2 * (tid + u * T), q = m + (m >> 4) + 2;
         buf[q] = rx;
         buf[q + 1] = ry;                                    // m + 1 stays inside the group of 16
       }
@@ -217,7 +220,7 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
     if (tid == 0) {                                         // k = N: no own coefficient, the stencil tap of k - 2 only; zeros behind
       const int sn = (N - 2) * 8;
       const double lxn = stab ? row_ld1(lx2, 0, sn) : -1.0;
-      double rn = RPDE_T(e)[16] + lxn * (row_ld1(s0, 0, sn) + cy * row_ld1(s2, 0, sn)) + gfac * row_ld1(g2, 0, N * 8);
+      double rn = buf[N + (N >> 4) + 2] + lxn * (row_ld1(s0, 0, sn) + cy * row_ld1(s2, 0, sn)) + gfac * row_ld1(g2, 0, N * 8);
       if ((WHICH == 1))
         rn += dt * (row_ld1(lx2, 0, sn) * (row_ld1(t0r, 0, sn) + cy2 * row_ld1(t2r, 0, sn)) + row_ld1(b2, 0, N * 8));
       buf[N + (N >> 4) + 2] = rn;

@@ -37,9 +37,10 @@ def test_reference_known_answers(hip_lib):
 
 
 @pytest.mark.parametrize("M,N,K_,transb", [(128, 128, 16, True), (200, 333, 77, True), (257, 129, 255, False),
-                                          (64, 1000, 513, False), (1024, 1025, 1023, True)])
+                                          (64, 1000, 513, False), (1024, 1025, 1023, True),
+                                          (2944, 2945, 130, True), (2945, 2944, 131, False)])   # >= 512 tiles of 128 x 128: the large tile
 def test_mfma_gemm(hip_lib, M, N, K_, transb):
-    """f64 MFMA GEMM (transpose-detecting: asymmetric random operands, ragged edges)."""
+    """f64 MFMA GEMM (transpose-detecting: asymmetric random operands, ragged edges), both block tiles."""
     rng = np.random.default_rng(5)
     a = rng.standard_normal((M, K_))
     b = rng.standard_normal((N, K_) if transb else (K_, N))
@@ -145,11 +146,11 @@ def test_shared_basis_golden(hip_lib, name):
     assert max(res) >= 200 or os.environ.get("RPDE_ALLOW_PARTIAL_GOLDEN"), f"golden ends at step {max(res)}"
 
 
-@pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15")])
+@pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15"), ("RPDE_XPAD", "0"), ("RPDE_GEMM_LDS", "0")])
 def test_round5_ab_switches(hip_lib, switch, value):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
-    of the three fields of a stage in one launch at 4097-point lines): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
+    of the three fields of a stage in one launch at 4097-point lines; RPDE_XPAD=0: the derivative transforms on the unpadded line; RPDE_GEMM_LDS=0: the GEMM's operand stages in the LDS layout of rounds 1 - 4): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
     2048 / 2047-wide parity GEMMs through the 128-tiles) and a 129 x 4097 one (4096-point y-lines: S2, the convection terms)
     must give bit-identical fields either way.  The switches are read once per process, so each side runs in its own."""
     import hashlib

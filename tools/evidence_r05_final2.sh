@@ -16,12 +16,13 @@ T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s" | tee -a $O/laps
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 # 1. the A/B tests of this session's additions: 4097-point batches, S6 / S9 as whole-line kernels, against the forms they replace
 (timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --durations=5 \
-   -k "(round5_ab_switches and LINE_BATCH) or (whole_line_stage_equals_line_program_4097 and (S6 or S9)) or whole_line_kernels_equal_line_programs_1025" 2>&1 \
+   -k "(round5_ab_switches and (LINE_BATCH or XPAD or GEMM_LDS)) or (whole_line_stage_equals_line_program_4097 and (S3 or S6 or S9 or S1 or CONV)) or whole_line_kernels_equal_line_programs_1025 or mfma_gemm or conv_line_4097 or dct_line" 2>&1 \
    | grep -v "socket.cpp\|amdgpu.ids\|Gloo\] Rank" | tail -40) > $O/pytest_gpu_new.txt
 lap "new A/B tests"
 # 2. A/B timings, hipGraph replay of the bench workload: default, one launch per field, S6 / S9 as line programs, everything of this session off
-(timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 timeout 120 python tools/ab_step.py; RPDE_S6_LINE=0 timeout 120 python tools/ab_step.py;
- RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py;
+(timeout 120 python tools/ab_step.py; RPDE_XPAD=0 timeout 120 python tools/ab_step.py; RPDE_GEMM_LDS=0 timeout 120 python tools/ab_step.py;
+ RPDE_LINE_BATCH=15 timeout 120 python tools/ab_step.py; RPDE_S6_LINE=0 timeout 120 python tools/ab_step.py; RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py;
+ RPDE_XPAD=0 RPDE_GEMM_LDS=0 RPDE_LINE_BATCH=15 RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py;
  timeout 120 python tools/ab_step.py) > $O/ab_step.txt 2>$O/ab_step.err
 lap "A/B timings"
 # 2b. keep the faster form of each as the DEFAULT before any evidence is collected: a form that loses by more than 0.3 % against
@@ -36,25 +37,27 @@ for l in open(O + "/ab_step.txt"):
     if m: rows.setdefault(m.group(1).strip(), []).append(float(m.group(2)))
 print(rows)
 base = sum(rows["default"]) / len(rows["default"])
-src = open("rustpde_mpi_amd/csrc/engine.cc").read()
 flips = []
-for label, old, new in (("RPDE_LINE_BATCH=15", "constexpr int kLineBatchDefaultMask = 255;", "constexpr int kLineBatchDefaultMask = 15;"),
-                        ("RPDE_S6_LINE=0", "constexpr bool kS6LineDefault = true;", "constexpr bool kS6LineDefault = false;"),
-                        ("RPDE_S9_LINE=0", "constexpr bool kS9LineDefault = true;", "constexpr bool kS9LineDefault = false;")):
+E, G = "rustpde_mpi_amd/csrc/engine.cc", "rustpde_mpi_amd/csrc/gemm.cc"
+for label, path, old, new in (("RPDE_LINE_BATCH=15", E, "constexpr int kLineBatchDefaultMask = 255;", "constexpr int kLineBatchDefaultMask = 15;"),
+                              ("RPDE_S6_LINE=0", E, "constexpr bool kS6LineDefault = true;", "constexpr bool kS6LineDefault = false;"),
+                              ("RPDE_S9_LINE=0", E, "constexpr bool kS9LineDefault = true;", "constexpr bool kS9LineDefault = false;"),
+                              ("RPDE_XPAD=0", E, "constexpr int kXpadDefault = 1;", "constexpr int kXpadDefault = 0;"),
+                              ("RPDE_GEMM_LDS=0", G, "constexpr int kGemmLdsDefault = 1;", "constexpr int kGemmLdsDefault = 0;")):
     failed = any(l.startswith("FAILED") and label.split("=")[0].replace("RPDE_", "") in l for l in open(O + "/pytest_gpu_new.txt"))
     if failed: print(label, "its A/B test FAILED on this box: the new form is switched off")
     if failed or (label in rows and min(rows[label]) < 0.997 * base):
+        src = open(path).read()
         assert old in src
-        src = src.replace(old, new, 1)
+        open(path, "w").write(src.replace(old, new, 1))
         flips.append(label)
     print(label, rows.get(label), "vs default", base, "-> FLIP" if label in flips else "-> keep")
 if flips:
-    open("rustpde_mpi_amd/csrc/engine.cc", "w").write(src)
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], capture_output=True, text=True)
     print("rebuild rc", r.returncode, r.stderr[-500:])
 print("FLIPS", flips)
 PY
-cp rustpde_mpi_amd/csrc/engine.cc $O/engine.cc.final
+cp rustpde_mpi_amd/csrc/engine.cc $O/engine.cc.final; cp rustpde_mpi_amd/csrc/gemm.cc $O/gemm.cc.final
 (timeout 120 python tools/ab_step.py) >> $O/ab_step.txt 2>>$O/ab_step.err      # the defaults that go into the evidence
 lap "defaults decided"
 cd /tmp

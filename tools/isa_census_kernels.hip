@@ -9,7 +9,7 @@ template <int N, int MODE> __global__ __launch_bounds__(N / 16, 4) void pure_tra
   Blk blk{line, 0, N / 16, buf, nullptr, 0}; hdct_bwd_line<N, MODE>(blk, a);
 }
 template <int N> __global__ __launch_bounds__(N / 16, 3) void conv_term(const ConvLineArgs c) {
-  __shared__ __attribute__((aligned(16))) double buf[N + N / 16]; LINE_OF_BLOCK; if (line >= c.nlines) return;
+  __shared__ __attribute__((aligned(16))) double buf[DctGeom<N>::LDS]; LINE_OF_BLOCK; if (line >= c.nlines) return;
   Blk blk{line, 0, N / 16, buf, nullptr, 0}; conv_line<N>(blk, c);
 }
 template <int N, int WHICH> __global__ __launch_bounds__(N / 16, 3) void rhs_hholtz_x(const RhsLineArgs a) {
