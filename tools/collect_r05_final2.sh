@@ -3,7 +3,7 @@
 # profiles/r05_first_run/, its files of the other configurations stay)
 O=gpurun_out/r05g; P=profiles
 mkdir -p $P/r05_first_run
-for f in r05_bench.json r05_bench_profiled.json r05_kernel_stats.csv r05_trace_by_tag.csv r05_pmc_traffic.txt r05_sq_counters.txt r05_profile_step.txt r05_schedule.json r05_kernel_resources.txt r05_commit.txt; do
+for f in NONE; do   # (the first run was moved once; later calls overwrite the headline files in place)
   [ -f $O/../.moved_$f ] && continue
   [ -f $P/$f ] && (git mv -f $P/$f $P/r05_first_run/$f 2>/dev/null || mv -f $P/$f $P/r05_first_run/$f)
 done
