@@ -33,7 +33,6 @@ struct DctLineArgs {
   double dscale = 1.0;                    //    (funspace `gradient` along the line, src/field.rs:127-129)
   int fwd = 0;                            // 1: forward transform (funspace `forward` of the orthonormal base, src/field.rs:103-106):
   int cut = 1 << 30;                      //    N + 1 physical values in, coefficients (-1)^k E_k / N (ends halved) out, zero from `cut` on
-  int xpad = 1;                           // 0 (A/B only, RPDE_XPAD=0): the unpadded x-layout of rounds 3 - 4 for the derivative / table stencil too
 };
 
 RPDE_HD inline size_t dct_line_lds_doubles(int N) { return (size_t)N + N / 16 + 16; }   // the padded x-layout ends at N + 3 + (N + 3) / 16; wave totals of the derivative behind it
@@ -53,7 +52,8 @@ struct DctStoreEmit {
 };
 
 // staged: the input line is already in the buffer (x[m] at buf[m + 2], zeros around it) and a barrier has been passed
-template <int N, class Emit>
+// PADX: what the caller knows at compile time about the x-layout (1: derivative / table stencil, 0: neither; -1: look at the flags)
+template <int N, class Emit, int PADX = -1>
 RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const Emit& emit) {
   constexpr int T = N / 16;
   static_assert(N == 4096 || N == 256, "N = 16^2 or 16^3");
@@ -67,8 +67,9 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
   const bool sten = a.sten == 2;
   // x-layout of the staged line (x[m] at buffer index b = m + 2): padded to b + b / 16 when the line is swept in chunks of 16
   // per thread (table stencil / derivative) -- see hdct_core (hdct_line.h): unpadded, those chunk accesses are 16-way bank conflicts
-  const bool padx = (a.sten == 1 || a.deriv != 0) && a.xpad != 0;
-  const int padm = padx ? -1 : 0;
+  // (X(r + 16 m) = X(r) + P m, P = 17 or 16: one runtime term per thread and phase, the rest folds into constants)
+  const bool padx = PADX >= 0 ? PADX != 0 : (a.sten == 1 || a.deriv != 0);
+  const int padm = padx ? -1 : 0, P = padx ? 17 : 16;
   auto X = [padm](int b) { return b + ((b >> 4) & padm); };
   RPDE_TLS(blk, double, re, 16);
   RPDE_TLS(blk, double, im, 16);
@@ -100,7 +101,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
       if (k - 1 >= n_in) u.y = 0.0;
       w.x -= u.x; w.y -= u.y;
       if (2 * p + 1 < N + 4) {
-        if (padx) { const int xq = X(2 * p); buf[xq] = w.x; buf[xq + 1] = w.y; }   // 2 p is even: the pair stays inside its group of 16
+        if (padx) { const int xq = X(2 * tid) + P * (q * T / 8); buf[xq] = w.x; buf[xq + 1] = w.y; }   // b = 2 p is even: the pair stays inside its group of 16
         else buf2[p] = w;
       }
     }
@@ -120,7 +121,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
         const int k0 = 16 * tid;
         double xs[19], lw[17];
 #pragma unroll
-        for (int i = 0; i < 19; ++i) xs[i] = buf[X(k0 + i)];                    // xs[i] = a_{k0 + i - 2}
+        for (int i = 0; i < 19; ++i) xs[i] = buf[P * tid + X(i)];               // xs[i] = a_{k0 + i - 2} at b = k0 + i
 #pragma unroll
         for (int i = 0; i < 17; ++i) lw[i] = (a.sten == 2) ? -1.0 : low[max(k0 + i - 2, 0)];
 #pragma unroll
@@ -130,7 +131,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
       RPDE_PHASE(blk, tid) {
         const int k0 = 16 * tid;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) buf[X(k0 + i + 2)] = RPDE_T(c)[i];
+        for (int i = 0; i < 16; ++i) buf[P * tid + X(i + 2)] = RPDE_T(c)[i];
         if (tid == T - 1) buf[X(N + 2)] = RPDE_T(c)[16];
       }
       RPDE_SYNC(blk);
@@ -145,7 +146,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
         const int lo = (T - 1 - tid) * 16;
         double bb[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[X(lo + i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[P * (T - 1 - tid) + X(i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
           double z = 0.0;
@@ -187,7 +188,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = lo + i;
-          buf[X(k + 2)] = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+          buf[P * (T - 1 - tid) + X(i + 2)] = (RPDE_T(zz)[i] + RPDE_T(vv)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
         }
         if (tid == 0) buf[X(N + 2)] = 0.0;       // d_N = 0
       }
@@ -203,7 +204,7 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
     for (int t = 0; t < 8; ++t) {
       const int i = tid + t * T;               // m0 = 2 i: x[m0], x[m0+1] = pair i + 1; x[m0-2], x[m0-1] = pair i
       dbl2 c, p;
-      if (padx) { const int xq = X(2 * i + 2); c = dbl2{buf[xq], buf[xq + 1]}; p = dbl2{0.0, 0.0}; }   // (padx: the stencil has been applied)
+      if (padx) { const int xq = X(2 * tid + 2) + P * (t * T / 8); c = dbl2{buf[xq], buf[xq + 1]}; p = dbl2{0.0, 0.0}; }   // (padx: the stencil has been applied)
       else { c = xs2[i + 1]; p = xs2[i]; }
       const double v0 = sten ? c.x - p.x : c.x, v1 = sten ? c.y - p.y : c.y;
       const double f0 = (t == 0 && tid == 0) ? 1.0 : 0.5;      // m = 0: the end of the line
@@ -213,7 +214,10 @@ RPDE_DEV void dct_line_core(Blk& blk, const DctLineArgs& a, bool staged, const E
 #pragma unroll
     for (int t = 8; t < 16; ++t) {
       const int m0 = 2 * N - 2 * (tid + t * T);                // even, 2 <= m0 <= N
-      const double x0 = buf[X(m0 + 2)], x1 = buf[X(m0 + 1)], t0 = buf[X(m0)], t1 = buf[X(m0 - 1)];   // x[m0], x[m0-1], x[m0-2], x[m0-3]
+      // b = m0 + 2 = (2 N + 2 - 2 tid) - 2 t T: 2 t T is a multiple of 16; the four taps are four runtime terms per thread
+      const int mt = P * (t * T / 8);
+      const double x0 = buf[X(2 * N + 2 - 2 * tid) - mt], x1 = buf[X(2 * N + 1 - 2 * tid) - mt], t0 = buf[X(2 * N - 2 * tid) - mt],
+                   t1 = buf[X(2 * N - 1 - 2 * tid) - mt];      // x[m0], x[m0-1], x[m0-2], x[m0-3]
       const double v0 = sten ? x0 - t0 : x0, v1 = sten ? x1 - t1 : x1;
       const double f0 = (t == 8 && tid == 0) ? 1.0 : 0.5;      // m = N: the other end
       RPDE_T(re)[t] = a.fwd ? v0 : f0 * v0;
@@ -355,7 +359,6 @@ struct ConvLineArgs {
   int nlines, N;
   const double* tw; const double* tw2;
   double dscale; int cut;
-  int xpad = 1;                   // DctLineArgs::xpad of the derivative's transform
 };
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
@@ -374,17 +377,19 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   const bool lift = c.bx != nullptr;
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
-  dct_line_core<N>(blk, a1, false, [&](int tid, int slot, int k, double v) {
+  auto e1 = [&](int tid, int slot, int k, double v) {
     (void)tid;
     RPDE_T(acc)[slot] = up[k] * (lift ? v + bx[k] : v);
-  });
+  };
+  dct_line_core<N, decltype(e1), 0>(blk, a1, false, e1);
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
-  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale; a2.xpad = c.xpad;
-  dct_line_core<N>(blk, a2, false, [&](int tid, int slot, int k, double v) {
+  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
+  auto e2 = [&](int tid, int slot, int k, double v) {
     (void)tid;
     RPDE_T(acc)[slot] += vp[k] * (lift ? v + by[k] : v);
-  });
+  };
+  dct_line_core<N, decltype(e2), 1>(blk, a2, false, e2);
   RPDE_SYNC(blk);
   RPDE_PHASE(blk, tid) {   // the sum as the staged input line of the forward transform
 #pragma unroll
@@ -398,7 +403,7 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   RPDE_SYNC(blk);
   DctLineArgs a3{nullptr, 0, N + 1, nullptr, 0, c.nlines, N, 0, c.tw, c.tw2, 1.0};
   a3.fwd = 1; a3.cut = c.cut;
-  dct_line_core<N>(blk, a3, true, DctStoreEmit{(gmem_t)(c.out + (long)blk.line * c.ldo), 1.0});
+  dct_line_core<N, DctStoreEmit, 0>(blk, a3, true, DctStoreEmit{(gmem_t)(c.out + (long)blk.line * c.ldo), 1.0});
 }
 
 }  // namespace rpde

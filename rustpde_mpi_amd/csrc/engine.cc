@@ -767,17 +767,11 @@ static bool whole_line_on(const char* stage_env, bool dflt = true) {
   if (const char* e = std::getenv("RPDE_WHOLE_LINE")) return std::atoi(e) != 0;
   return dflt;
 }
-// RPDE_XPAD=0 (A/B only): the derivative transforms of S1 and of the convection terms with the unpadded x-layout of rounds 3 - 4
-// (16-way LDS bank conflicts in the chunk sweeps, hdct_line.h `padx`); kXpadDefault is flipped by measurement like the others
-constexpr int kXpadDefault = 1;
-static int xpad_on() {
-  if (const char* e = std::getenv("RPDE_XPAD")) return std::atoi(e) != 0 ? 1 : 0;
-  return kXpadDefault;
-}
 // the defaults of the stages added last (round 5), one greppable line each: tools/evidence_r05_final2.sh measures both forms of
 // each inside one gpurun call and keeps the faster one as the default before it collects the evidence
 constexpr bool kS6LineDefault = true;   // S6 as prow_line.h
 constexpr bool kS9LineDefault = true;   // S9 as pres_line.h
+constexpr int kS6KeepDefault = 1;       // prow_line.h KEEP: a row's back-substitution factors stay in registers (RPDE_S6_KEEP=0: read twice)
 #ifdef RPDE_EMU
 static bool whole_line_len(int N) { return N == 256 || N == 1024 || N == 4096; }
 #else
@@ -791,7 +785,6 @@ bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
   Launch l;
   l.type = Launch::kDctLine;
   l.dl = a;
-  l.dl.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * ((double)a.n_in + a.N + 1) * a.nlines;
   step_.push_back(l);
@@ -804,7 +797,6 @@ bool Navier2DEngine::add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1,
   Launch l;
   l.type = Launch::kDctLine2;
   l.dl = a0; l.dl2 = a1;
-  l.dl.xpad = l.dl2.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * ((double)a0.n_in + 2.0 * (a0.N + 1)) * a0.nlines;
   step_.push_back(l);
@@ -840,7 +832,6 @@ bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   Launch l;
   l.type = Launch::kConvLine;
   l.cl = c;
-  l.cl.xpad = xpad_on();
   l.tag = tag;
   l.bytes = 8.0 * (2.0 * c.n_in + (c.bx ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by), out
   step_.push_back(l);
@@ -898,6 +889,7 @@ bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   const long off = f.row0 * f.tabld;
   a.q1 = f.q1.p - off; a.p2 = f.p2.p - off; a.q2 = f.q2.p - off; a.r2 = f.r2.p - off;
   a.tabld = f.tabld;
+  { const char* e = std::getenv("RPDE_S6_KEEP"); a.keep = e ? (std::atoi(e) != 0) : kS6KeepDefault; }
   if (!prow_line_ok(a)) return false;
   Launch l;
   l.type = Launch::kProwLine;

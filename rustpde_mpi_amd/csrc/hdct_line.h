@@ -80,8 +80,9 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   // more than half of the LDS cycles of S1 and of the convection terms (SQ_LDS_BANK_CONFLICT, profiles/r05_lds_counters.txt).
   // Everything else (the pure transforms, the forward transforms) keeps b: pairs stay 16-byte accesses.  The padded line ends
   // at N + 3 + (N + 3) / 16 < SCR.
-  const bool padx = (MODE >= 0 ? (MODE & (kHdctDeriv | kHdctSten1)) != 0 : (a.deriv != 0 || a.sten == 1)) && a.xpad != 0;
-  const int padm = padx ? -1 : 0;
+  // (X(r + 16 m) = X(r) + P m with P = 17 or 16: one runtime term per thread and phase, everything else folds into constants.)
+  const bool padx = MODE >= 0 ? (MODE & (kHdctDeriv | kHdctSten1)) != 0 : (a.deriv != 0 || a.sten == 1);
+  const int padm = padx ? -1 : 0, P = padx ? 17 : 16;
   auto X = [padm](int b) { return b + ((b >> 4) & padm); };
   RPDE_TLS(blk, double, re, 8);
   RPDE_TLS(blk, double, im, 8);
@@ -116,7 +117,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
         if (k - 1 >= n_in) o.y = 0.0;
         c.x -= o.x; c.y -= o.y;
         if (2 * p + 1 < N + 4) {
-          if (padx) { const int q = X(2 * p); buf[q] = c.x; buf[q + 1] = c.y; }   // 2 p is even: the pair stays inside its group of 16
+          if (padx) { const int xq = X(2 * tid) + P * (q * T / 8); buf[xq] = c.x; buf[xq + 1] = c.y; }   // b = 2 p is even: the pair stays inside its group of 16
           else buf2[p] = c;
         }
       }
@@ -133,7 +134,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
       const int k0 = 16 * tid;
       double xs[19], lw[17];
 #pragma unroll
-      for (int i = 0; i < 19; ++i) xs[i] = buf[X(k0 + i)];                    // xs[i] = a_{k0 + i - 2}
+      for (int i = 0; i < 19; ++i) xs[i] = buf[P * tid + X(i)];               // xs[i] = a_{k0 + i - 2} at b = k0 + i
 #pragma unroll
       for (int i = 0; i < 17; ++i) lw[i] = low[max(k0 + i - 2, 0)];
 #pragma unroll
@@ -143,7 +144,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     RPDE_PHASE(blk, tid) {
       const int k0 = 16 * tid;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) buf[X(k0 + i + 2)] = RPDE_T(c)[i];
+      for (int i = 0; i < 16; ++i) buf[P * tid + X(i + 2)] = RPDE_T(c)[i];
       if (tid == T - 1) buf[X(N + 2)] = RPDE_T(c)[16];
     }
     RPDE_SYNC(blk);
@@ -160,7 +161,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
         const int lo = (T - 1 - tid) * 16;
         double bb[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[X(lo + i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
+        for (int i = 0; i < 16; ++i) bb[i] = 2.0 * (double)(lo + i + 1) * buf[P * (T - 1 - tid) + X(i + 3)];   // 2 (k + 1) c_{k+1}, k + 1 <= N
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
           double z = 0.0;
@@ -202,7 +203,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = lo + i;
-          buf[X(k + 2)] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
+          buf[P * (T - 1 - tid) + X(i + 2)] = (RPDE_T(zz)[i] + RPDE_T(vd)[i & 1]) * ((k == 0) ? 0.5 * a.dscale : a.dscale);
         }
         if (tid == 0) buf[X(N + 2)] = 0.0;       // d_N = 0
       }
@@ -221,8 +222,9 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
                                 0.83146961230254524, 0.92387953251128674, 0.98078528040323043};
     double cs[8], sn[8], xa[8], xb[8];
     const double c0 = RPDE_T(cs0)[0], s0 = RPDE_T(cs0)[1];
+    const int xj = X(tid + 2), xn = X(N + 2 - tid);            // b = j + 2 and N - j + 2 for q = 0; q T is a multiple of 16
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int j = tid + q * T; xa[q] = buf[X(j + 2)]; xb[q] = buf[X(N - j + 2)]; }
+    for (int q = 0; q < 8; ++q) { xa[q] = buf[xj + P * (q * T / 16)]; xb[q] = buf[xn - P * (q * T / 16)]; }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { cs[q] = c0 * kC32[q] - s0 * kS32[q]; sn[q] = s0 * kC32[q] + c0 * kS32[q]; }
     const double f = a_fwd ? 1.0 : ((tid & 1) ? -0.5 : 0.5);
@@ -235,8 +237,8 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
       const double A = fa * xa[q], B = fa * xb[q];
       const double s = A + B, d = A - B;
       const double t2 = 2.0 * sn[q] * d;
-      buf[X(j + 2)] = end ? s : s - t2;
-      if (!end) buf[X(N - j + 2)] = s + t2;
+      buf[xj + P * (q * T / 16)] = end ? s : s - t2;
+      if (!end) buf[xn - P * (q * T / 16)] = s + t2;
       e1 += end ? d : 2.0 * cs[q] * d;
     }
     if (tid == 0) buf[X(M + 2)] = (a_fwd ? 2.0 : 1.0) * buf[X(M + 2)];   // y_M = 2 f_M x_M, M even
@@ -257,7 +259,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (padx) {                                          // the pair (y_{2i}, y_{2i+1}) at b = 2 i + 2: inside one group of 16
-        const int q = X(2 * (tid + t * T) + 2);
+        const int q = X(2 * tid + 2) + P * (t * T / 8);
         RPDE_T(re)[t] = buf[q];
         RPDE_T(im)[t] = buf[q + 1];
       } else {
@@ -510,7 +512,7 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
         c.x -= o.x; c.y -= o.y;
         if (2 * p + 1 < N + 4) {
           // the derivative's buffer (and both under a table stencil) in the padded x-layout of hdct_core
-          const int xq = 2 * p + (a1.xpad ? (2 * p) >> 4 : 0);
+          const int xq = 2 * p + ((2 * p) >> 4);
           if (a0.sten == 1) { la[xq] = c.x; la[xq + 1] = c.y; } else bufa[p] = c;
           lb[xq] = c.x; lb[xq + 1] = c.y;
         }
@@ -547,7 +549,7 @@ RPDE_DEV void hdct_pair_line(int line, double* lds, const DctLineArgs& a0, const
 }
 RPDE_HD inline bool hdct_pair_ok(const DctLineArgs& a0, const DctLineArgs& a1) {
   return a0.in == a1.in && a0.ldi == a1.ldi && a0.n_in == a1.n_in && a0.sten == a1.sten && a0.low == a1.low && a0.N == a1.N &&
-         a0.nlines == a1.nlines && !a0.fwd && !a1.fwd && !a0.deriv && a1.deriv && a0.xpad == a1.xpad;
+         a0.nlines == a1.nlines && !a0.fwd && !a1.fwd && !a0.deriv && a1.deriv;
 }
 
 // One y-line of a convection term on this core (see conv_line in dct_line.h for the mathematics): the physical factors
@@ -574,7 +576,7 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   }
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
-  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale; a2.xpad = c.xpad;
+  a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   {
     cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + off : c.vp + off);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {

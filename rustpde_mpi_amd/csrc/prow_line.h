@@ -28,13 +28,17 @@ struct ProwLineArgs {
   const double *q1 = nullptr;                                  // per line (pitch tabld): forward substitution, chunk-major ascending
   const double *p2 = nullptr, *q2 = nullptr, *r2 = nullptr;   // per line: back substitution, chunk-major DESCENDING
   long tabld = 0;                 // = N doubles: 16 T entries per line
+  int keep = 1;                   // 4097-point lines: the KEEP form of prow_line (three workgroups per CU); 0: the factors read twice at four (RPDE_S6_KEEP, A/B)
 };
 RPDE_HD inline bool prow_line_ok(const ProwLineArgs& a) {
   return (a.N == 256 || a.N == 1024 || a.N == 4096) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.q1 && a.p2 && a.q2 && a.r2 &&
          ((((size_t)a.in) | ((size_t)a.out)) & 15) == 0 && (a.ld & 1) == 0 && a.ld > a.N + 1 && a.tabld == a.N;
 }
 
-template <int N>
+// KEEP: the back-substitution factors q2, r2 of the row stay in registers across the prefix composition (32 doubles; a budget of
+// three waves per SIMD) instead of being read a second time -- they are the row's own (no other line shares them), and between the
+// two reads the L2 has seen 24 MB of other rows: the second read came from HBM (PMC ratio of the stage 1.25)
+template <int N, bool KEEP = false>
 RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   using G = HdctGeom<N>;
   constexpr int T = G::T, W = 6;
@@ -140,6 +144,8 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   // ---- back substitution, descending: thread t owns the chunk of thread T - 1 - t (the carry flows t - 1 -> t again)
   //   x_k = p2_k y_k + q2_k x_{k+2} + r2_k x_{k+4}
   RPDE_TLS(blk, double, bb, 16);
+  RPDE_TLS(blk, double, kq, KEEP ? 16 : 1);
+  RPDE_TLS(blk, double, kr, KEEP ? 16 : 1);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
     tab_t p2 = (tab_t)(a.p2 + toff), q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
@@ -159,6 +165,10 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
       for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+      if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { RPDE_T(kq)[8 * par + i] = qq[i]; RPDE_T(kr)[8 * par + i] = rr[i]; }
+      }
       double z1 = 0.0, z2 = 0.0, a11 = 1.0, a12 = 0.0, a21 = 0.0, a22 = 1.0;   // state = (most recent value, the one before)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -189,11 +199,16 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
     tab_t q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      double qq[8], rr[8];                                  // again (L1 / L2): not kept across the prefix
+      double qq[8], rr[8];
+      if constexpr (KEEP) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+        for (int i = 0; i < 8; ++i) { qq[i] = RPDE_T(kq)[8 * par + i]; rr[i] = RPDE_T(kr)[8 * par + i]; }
+      } else {                                              // again: not kept across the prefix
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+      }
       double x1 = RPDE_T(cm)[par * W + 4], x2 = RPDE_T(cm)[par * W + 5];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

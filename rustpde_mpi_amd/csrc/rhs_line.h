@@ -140,8 +140,8 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   DctLineArgs f{a.conv, a.ld, N + 1, nullptr, 0, a.nlines, N, 0, a.tw, a.tw2, 1.0};
   f.fwd = 1; f.cut = a.cut;
   hdct_core<N>(blk, f, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
-    (void)tid;
-    const int q = m + (m >> 4) + 2;
+    (void)m;                                                // m = 2 (tid + u T); 2 u T is a multiple of 16: one runtime term per thread
+    const int q = (u == 8) ? N + (N >> 4) + 2 : 2 * tid + ((2 * tid) >> 4) + 2 + 17 * (u * T / 8);
     buf[q] = -dt * e0;
     if (u != 8) buf[q + 1] = -dt * e1;                      // (u = 8: m = N, the single coefficient of thread 0)
   });
@@ -203,7 +203,7 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
         // S_x S_y state: rows j, j - 2 at k and k - 2
         const double sx = a0[i].x + cy * c0[i].x, sy = a0[i].y + cy * c0[i].y;
         const double smx = am[i].x + cy * cm[i].x, smy = am[i].y + cy * cm[i].y;
-        const int m = 2 * (tid + u * T), q = m + (m >> 4) + 2;
+        const int q = 2 * tid + ((2 * tid) >> 4) + 2 + 17 * (u * T / 8);   // m = 2 (tid + u T) at m + m / 16 + 2
         double rx = buf[q] + (sx + lx.x * smx) + gfac * g[i].x;
         double ry = buf[q + 1] + (sy + lx.y * smy) + gfac * g[i].y;
         if (WHICH == 1) {                                   // buoyancy: dt (S_xN S_y T + T_bc)

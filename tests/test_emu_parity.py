@@ -146,22 +146,6 @@ def test_confined_step_s5_through_the_whole_line_kernel(emu_lib, monkeypatch, nx
     assert abs(nav.div_norm() - ref.div_norm()) < 1e-9 * max(1.0, ref.div_norm())
 
 
-def test_derivative_transforms_on_the_padded_line_equal_the_unpadded_form(emu_lib, monkeypatch):
-    """Round 5: the derivative transforms (S1's second half, the d/dy transform of a convection term) keep their staged line at the
-    padded index b + b / 16 (no bank conflicts in the chunk sweeps).  RPDE_XPAD=0 keeps the unpadded form: same arithmetic, so
-    bit-identical fields -- 257-point lines in x and y (pair kernel, full-length convection core) and 1025-point y-lines (hconv)."""
-    for nx, ny in ((257, 257), (17, 1025)):
-        runs = {}
-        for flag in ("1", "0"):
-            monkeypatch.setenv("RPDE_XPAD", flag)
-            nav = R.Navier2D.new_confined(nx, ny, 1e6, 1.0, 2e-3, 1.0, "rbc", library=emu_lib, init_random=None)
-            nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
-            nav.update(2)
-            runs[flag] = nav.physical_fields()
-        for k in runs["0"]:
-            assert np.array_equal(runs["0"][k], runs["1"][k]), (nx, ny, k)
-
-
 def test_s6_poisson_rows_as_one_kernel(emu_lib, monkeypatch):
     """S6 of the confined step -- y preconditioner and one factorised banded solve per eigen row of the Poisson problem -- as
     the whole-line kernel csrc/prow_line.h (the row's factors in a second, 16-element chunk-major copy: PoissonOp::rows16):
@@ -179,6 +163,14 @@ def test_s6_poisson_rows_as_one_kernel(emu_lib, monkeypatch):
     f1, f0 = nav.physical_fields(), nav0.physical_fields()
     for k in f0:
         assert K.rel(f1[k], f0[k]) < 1e-12, (k, K.rel(f1[k], f0[k]))
+    # RPDE_S6_KEEP=0: the factors of a row read twice instead of kept in registers -- the same arithmetic
+    monkeypatch.delenv("RPDE_S6_LINE")
+    monkeypatch.setenv("RPDE_S6_KEEP", "0")
+    nav2, _ = K.make_pair(emu_lib, False, 33, 257, 1e6, 1.0, 2e-3, 1.0)
+    nav2.update(3)
+    f2 = nav2.physical_fields()
+    for k in f1:
+        assert np.array_equal(f1[k], f2[k]), k
 
 
 def test_s9_pressure_update_as_one_kernel(emu_lib, monkeypatch):

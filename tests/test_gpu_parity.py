@@ -146,11 +146,11 @@ def test_shared_basis_golden(hip_lib, name):
     assert max(res) >= 200 or os.environ.get("RPDE_ALLOW_PARTIAL_GOLDEN"), f"golden ends at step {max(res)}"
 
 
-@pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15"), ("RPDE_XPAD", "0"), ("RPDE_GEMM_LDS", "0")])
+@pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15"), ("RPDE_GEMM_LDS", "0"), ("RPDE_S6_KEEP", "0")])
 def test_round5_ab_switches(hip_lib, switch, value):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
-    of the three fields of a stage in one launch at 4097-point lines; RPDE_XPAD=0: the derivative transforms on the unpadded line; RPDE_GEMM_LDS=0: the GEMM's operand stages in the LDS layout of rounds 1 - 4): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
+    of the three fields of a stage in one launch at 4097-point lines; RPDE_GEMM_LDS=0: the GEMM's operand stages in the LDS layout of rounds 1 - 4): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
     2048 / 2047-wide parity GEMMs through the 128-tiles) and a 129 x 4097 one (4096-point y-lines: S2, the convection terms)
     must give bit-identical fields either way.  The switches are read once per process, so each side runs in its own."""
     import hashlib

@@ -71,8 +71,8 @@ ENV_SWITCHES = {
     "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
     "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
     "RPDE_S1_SPLIT", "RPDE_GEMM_PEEL",                # A/B of round 5: S1 as two launches, the peeled GEMM loop (test_gpu_parity.test_round5_ab_switches)
+    "RPDE_S6_KEEP",                                 # A/B of round 5: S6 with the back-substitution factors read twice (tests/test_emu_parity.test_s6_*, test_gpu_parity.test_round5_ab_switches)
     "RPDE_GEMM_LDS",                                # A/B of round 5: LDS layout of the GEMM's operand stages (test_gpu_parity.test_round5_ab_switches)
-    "RPDE_XPAD",                                    # A/B of round 5: the unpadded x-layout of the derivative transforms (test_gpu_parity.test_round5_ab_switches, test_emu_parity)
     "RPDE_EIG_CACHE",                               # directory that keeps the x eigen-decomposition between engines of one operator (tests/conftest.py sets it; test_eig_cache)
     "RPDE_COL_PAIR", "RPDE_GEMM_SWIZZLE",           # XCD pairing of the three-kernel correction-y, GEMM tile order (tests/test_gpu_parity)
 }
