@@ -23,5 +23,5 @@ for _ in range(reps):
     nav.update(steps)
     ms.append(nav.last_update_ms() / steps)
 ms.sort()
-label = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("RPDE_") and k not in ("RPDE_EIG_CACHE",)) or "default"
+label = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("RPDE_") and k not in ("RPDE_EIG_CACHE", "RPDE_EVIDENCE_SHORT")) or "default"
 print(f"AB {label:40s} {nx}x{ny}  min {ms[0]:.4f}  median {ms[len(ms) // 2]:.4f} ms/step  ({len(nav.schedule())} launches per step)", flush=True)

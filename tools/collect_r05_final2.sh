@@ -7,7 +7,6 @@ for f in NONE; do   # (the first run was moved once; later calls overwrite the h
   [ -f $O/../.moved_$f ] && continue
   [ -f $P/$f ] && (git mv -f $P/$f $P/r05_first_run/$f 2>/dev/null || mv -f $P/$f $P/r05_first_run/$f)
 done
-git show HEAD:profiles/r05_pmc_traffic.json > $P/r05_first_run/r05_pmc_traffic.json 2>/dev/null
 c=$(cut -c1-7 $O/commit.txt 2>/dev/null)
 cp $O/commit.txt $P/r05_commit.txt
 for f in bench bench_profiled pmc_traffic schedule bench_1025 bench_hc; do [ -s $O/$f.json ] && cp $O/$f.json $P/r05_$f.json; done
