@@ -1,10 +1,10 @@
 """libhdf5-side check of the snapshot files (the consumers are plot/plot2d.py:30-54, which opens the
 files with h5py, and src/io/read_write_hdf5.rs:38-188, which goes through the hdf5 crate = libhdf5).
 
-csrc/h5lite writes and parses the classic HDF5 structures by hand because this image has no libhdf5; the checker of
-the other tests (tests/h5classic.py) is a second reading of the same specification by the same author.  These tests use
-the real library through h5py and SKIP where it is not installed (it is not in the build image): on any box that has
-h5py they (i) open an h5lite snapshot with libhdf5 and compare every dataset, (ii) write the same layout with libhdf5's
+csrc/h5lite writes and parses the classic HDF5 structures by hand; the checker of the other tests (tests/h5classic.py) is a
+second reading of the same specification by the same author.  These tests use the real library through h5py and SKIP where
+it is not installed (it is not in the build image -- tests/test_libhdf5_interop.py runs the same checks through a ctypes
+binding to the image's libhdf5 and does not skip): on any box that has h5py they (i) open an h5lite snapshot with libhdf5 and compare every dataset, (ii) write the same layout with libhdf5's
 defaults and restart an engine from it, (iii) let libhdf5 append to an h5lite file and read the result back through h5lite."""
 import numpy as np
 import pytest
