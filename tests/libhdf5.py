@@ -138,15 +138,16 @@ class File:
         t = self.lib.H5Dget_type(d)
         cls, size = self.lib.H5Tget_class(t), self.lib.H5Tget_size(t)
         self.lib.H5Tclose(t)
-        assert (cls, size) == (1, 8), f"{path}: class {cls} size {size}, expected an 8-byte float"   # H5T_FLOAT = 1
+        assert (cls, size) in ((1, 8), (0, 8)), f"{path}: class {cls} size {size}, expected f64 or a 64-bit integer"   # H5T_FLOAT = 1, H5T_INTEGER = 0
+        mem, dt = (self.f64, np.float64) if cls == 1 else (hid_t.in_dll(self.lib, "H5T_NATIVE_UINT64_g").value, np.uint64)
         s = self.lib.H5Dget_space(d)
         nd = self.lib.H5Sget_simple_extent_ndims(s)
         dims = (hsize_t * max(nd, 1))()
         if nd > 0:
             self.lib.H5Sget_simple_extent_dims(s, dims, None)
         self.lib.H5Sclose(s)
-        a = np.empty(tuple(dims[i] for i in range(nd)), dtype=np.float64)
-        assert self.lib.H5Dread(d, self.f64, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p)) >= 0, path
+        a = np.empty(tuple(dims[i] for i in range(nd)), dtype=dt)
+        assert self.lib.H5Dread(d, mem, H5S_ALL, H5S_ALL, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p)) >= 0, path
         self.lib.H5Dclose(d)
         return a
 

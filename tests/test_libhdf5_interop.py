@@ -128,3 +128,34 @@ def test_h5dump_accepts_a_snapshot(emu_lib, tmp_path):
     assert r.stdout.count("DATASET") == len(R.h5.paths(fn, library=emu_lib))
     r = subprocess.run([h5dump, "-d", "/time", fn], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "H5T_IEEE_F64LE" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_libhdf5_reads_the_other_files_the_engines_write(emu_lib, tmp_path, periodic):
+    """statistics.h5 (statistics.rs:116-161, with its unsigned 64-bit `num_save`), the snapshot of the adjoint-descent solver
+    (steady_adjoint_io.rs) and the gradient file of Navier2DLnse::grad_adjoint: every dataset as libhdf5 sees it equals what the
+    independent pure-Python parser (tests/h5classic.py) and h5lite's own reader see."""
+    from tests.h5classic import File as Classic
+    st, _ = K.check_statistics(emu_lib, periodic, 16 if periodic else 17, 17)
+    files = [str(tmp_path / "statistics.h5")]
+    st.write(files[0])
+    mk = R.Navier2DAdjoint.new_periodic if periodic else R.Navier2DAdjoint.new_confined
+    adj = mk(16 if periodic else 17, 17, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+    adj.set_velocity(0.1, 1.0, 1.0); adj.set_temperature(0.1, 1.0, 1.0)
+    adj.update(2)
+    files.append(str(tmp_path / "adjoint.h5"))
+    adj.write(files[1])
+    mkl = R.Navier2DLnse.new_periodic if periodic else R.Navier2DLnse.new_confined
+    lin = mkl(16 if periodic else 17, 17, 3e3, 0.1, 0.01, 1.0, "rbc", library=emu_lib)
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    files.append(str(tmp_path / "data" / "grad_adjoint.h5"))
+    lin.grad_adjoint(0.05, None, 0.5, 0.5, None, filename=files[2])
+    for fn in files:
+        with H.File(fn, "r") as f:
+            got = f.datasets()
+        ref = Classic(fn).datasets
+        assert sorted(got) == sorted(ref), fn
+        for path, arr in got.items():
+            assert np.array_equal(arr, np.asarray(ref[path]).reshape(arr.shape)), (fn, path)
+    with H.File(files[0], "r") as f:
+        assert f.read("num_save").dtype == np.uint64 and int(f.read("num_save")[0]) == st.num_save
