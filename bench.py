@@ -282,10 +282,11 @@ def main():
         import torch.distributed as dist
         # RPDE_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): all ranks on device 0, gloo transport
         share = os.environ.get("RPDE_BENCH_SHARE_GPU") == "1"
-        if share:
+        if share or args.dry_run_emu:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if share:
+        if not args.dry_run_emu:                 # (the emulation dry run of the harness has no device: gloo, host buffers)
+            torch.cuda.set_device(local_rank)
+        if share or args.dry_run_emu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -327,7 +328,7 @@ def main():
             if int(flag.item()) == 0:
                 nav = None
         if nav is None:
-            comm = TorchComm(device_buffers=True)
+            comm = TorchComm(device_buffers=not args.dry_run_emu)
             nav = make(comm)
             transport = "torch-" + dist.get_backend()
     else:
@@ -338,7 +339,8 @@ def main():
     def barrier():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if not args.dry_run_emu:
+                torch.cuda.synchronize()
             dist.barrier()
 
     nav.update(args.warmup)
