@@ -20,7 +20,7 @@ Base make_base(BaseKind kind, int n) {
   Base b{kind, n, n};
   if (kind == kChebDirichlet || kind == kChebNeumann || kind == kChebDirichletNeumann) b.m = n - 2;
   if (kind == kFourierR2c) {
-    RPDE_REQUIRE(n % 2 == 0, "fourier_r2c needs an even number of points");
+    RPDE_REQUIRE(n >= 2, "fourier_r2c needs at least two points");   // odd lengths: realfft's r2c / c2r take them, so do the Bluestein lines
     b.m = n / 2 + 1;
   }
   RPDE_REQUIRE(n >= 5 || kind == kFourierR2c, "Chebyshev bases need n >= 5");
@@ -123,6 +123,93 @@ Vec rfft_split_twiddles(int nx) {
 Vec dct_direct_costab(int N) {
   Vec t(2 * (size_t)N);
   for (int m = 0; m < 2 * N; ++m) t[m] = (double)cosl(kPiL * (long double)m / (long double)N);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bluestein (chirp-z) tables: a transform of ANY length as a circular convolution of power-of-two length M.
+// The reference's transforms accept every n (rustdct / rustfft under funspace: mixed radix, Rader, Bluestein); its own
+// benches run Chebyshev n = 128, 264, 512, 1024 (benches/benchmark_navier.rs:6-7, benchmark_transform.rs:6), i.e.
+// N = n - 1 = 127, 263 (primes), 511 = 7 * 73, 1023 = 3 * 11 * 31 -- lengths no small-radix plan covers.
+//   2 j k = j^2 + k^2 - (k - j)^2  =>  sum_j x_j w^(2 j k) = w^(k^2) sum_j (x_j w^(j^2)) w^(-(k - j)^2)
+int bluestein_len(int lags) {
+  int m = 2;
+  while (m < lags) m *= 2;
+  return m;
+}
+namespace {
+using CplxL = std::pair<long double, long double>;
+// in-place radix-2 FFT (forward sign) in long double: setup only, M <= 16384
+void fft_long(std::vector<CplxL>& a) {
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t k = 0; k < len / 2; ++k) {
+      const long double ang = -2.0L * kPiL * (long double)k / (long double)len;
+      const long double wr = cosl(ang), wi = sinl(ang);
+      for (size_t i = k; i < n; i += len) {
+        const CplxL u = a[i], v = a[i + len / 2];
+        const long double tr = v.first * wr - v.second * wi, ti = v.first * wi + v.second * wr;
+        a[i] = {u.first + tr, u.second + ti};
+        a[i + len / 2] = {u.first - tr, u.second - ti};
+      }
+    }
+  }
+}
+// (cos, sin)(pi * (m^2 mod period) / den): the argument is reduced in integers, so the chirp is exact to the last bit of
+// cosl / sinl however large m^2 gets
+CplxL chirp(long m, long period, long den) {
+  const long r = (long)(((long long)m * (long long)m) % (long long)period);
+  const long double a = kPiL * (long double)r / (long double)den;
+  return {cosl(a), sinl(a)};
+}
+// FFT_M of the wrapped filter b~[m mod M] = (cos, sgn * sin)(pi m^2 / den), m in [lo, hi], scaled by 1 / M
+void filter_spectrum(Vec& out, size_t off, int M, long lo, long hi, long period, long den, int sgn) {
+  RPDE_REQUIRE(hi - lo + 1 <= M, "bluestein: the convolution length does not hold the lags");
+  std::vector<CplxL> b((size_t)M, CplxL{0.0L, 0.0L});
+  for (long m = lo; m <= hi; ++m) {
+    const CplxL c = chirp(m, period, den);
+    b[(size_t)(((m % M) + M) % M)] = {c.first, sgn * c.second};
+  }
+  fft_long(b);
+  for (int i = 0; i < M; ++i) {
+    out[off + 2 * (size_t)i] = (double)(b[(size_t)i].first / (long double)M);
+    out[off + 2 * (size_t)i + 1] = (double)(b[(size_t)i].second / (long double)M);
+  }
+}
+}  // namespace
+
+// DCT-I of N + 1 points: w = exp(i pi / (2 N)), chirp (cos, sin)(pi j^2 / (2 N)) for j <= N [2 (N + 1) doubles], then the
+// spectrum of the filter w^(-m^2), |m| <= N [2 M doubles]
+Vec bluestein_dct_tables(int N, int M) {
+  RPDE_REQUIRE(N >= 1 && M >= 2 * N + 1, "bluestein_dct_tables: M >= 2 N + 1");
+  Vec t(2 * (size_t)(N + 1) + 2 * (size_t)M);
+  for (int j = 0; j <= N; ++j) {
+    const CplxL c = chirp(j, 4L * N, 2L * N);
+    t[2 * (size_t)j] = (double)c.first;
+    t[2 * (size_t)j + 1] = (double)c.second;
+  }
+  filter_spectrum(t, 2 * (size_t)(N + 1), M, -N, N, 4L * N, 2L * N, -1);
+  return t;
+}
+// real FFT of nx points (K = nx / 2): chirp (cos, sin)(pi j^2 / nx), j < nx [2 nx doubles]; the forward filter
+// exp(+i pi m^2 / nx), -(nx - 1) <= m <= K [2 M]; the backward filter exp(-i pi m^2 / nx), -K <= m <= nx - 1 [2 M]
+Vec bluestein_rfft_tables(int nx, int M) {
+  const int K = nx / 2;
+  RPDE_REQUIRE(nx >= 2 && M >= nx + K, "bluestein_rfft_tables: M >= nx + nx / 2");
+  Vec t(2 * (size_t)nx + 4 * (size_t)M);
+  for (int j = 0; j < nx; ++j) {
+    const CplxL c = chirp(j, 2L * nx, nx);
+    t[2 * (size_t)j] = (double)c.first;
+    t[2 * (size_t)j + 1] = (double)c.second;
+  }
+  filter_spectrum(t, 2 * (size_t)nx, M, -(long)(nx - 1), K, 2L * nx, nx, +1);
+  filter_spectrum(t, 2 * (size_t)nx + 2 * (size_t)M, M, -(long)K, nx - 1, 2L * nx, nx, -1);
   return t;
 }
 

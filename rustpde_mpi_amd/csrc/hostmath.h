@@ -47,6 +47,10 @@ Vec fft_twiddles(int nfft);            // (cos, -sin)(2 pi k / nfft), k < nfft
 Vec dct_split_twiddles(int N);         // (cos, sin)(pi k / N), k <= N
 Vec rfft_split_twiddles(int nx);       // (cos, sin)(2 pi k / nx), k <= nx/2
 Vec dct_direct_costab(int N);          // cos(pi m / N), m < 2N
+// Bluestein (chirp-z) transforms of arbitrary length through a power-of-two FFT of length M (hostmath.cc)
+int bluestein_len(int lags);                    // smallest power of two >= lags
+Vec bluestein_dct_tables(int N, int M);         // chirp (cos, sin)(pi j^2 / (2N)), j <= N | filter spectrum / M  (M >= 2N + 1)
+Vec bluestein_rfft_tables(int nx, int M);       // chirp (cos, sin)(pi j^2 / nx), j < nx | forward | backward filter spectra / M  (M >= nx + nx/2)
 
 // from_ortho as MV3 + ascending REC1 + descending REC1 (tables of length m, padded with zeros)
 struct FromOrthoTables {

@@ -18,6 +18,8 @@ using CfgS = LineCfg<128, 10, 2, 1024, 8>;      // slots up to 1280 doubles
 using CfgM = LineCfg<256, 10, 1024, 2048, 8>;   // slots up to 2560 doubles
 using CfgL = LineCfg<512, 10, 2048, 4096, 8>;   // slots up to 5120 doubles
 using CfgX = LineCfg<1024, 18, 4096, 8192, 8>;  // Fourier lines of 8192 / 16384 reals: one slot of up to 17408 doubles
+using CfgXC = LineCfg<1024, 10, 8192, 8192, 8, true>;   // Chebyshev lines of 2049 .. 4096 points other than 2^k + 1: Bluestein with
+                                                        // M = 8192, two slots of 8704 doubles (153 KB with the scan carries)
 static_assert(CfgS::EPT % 2 == 0 && CfgS::C == CfgS::EPT, "scan chunk must equal EPT");
 
 // ------------------------------------------------------------------------------- transposed tile copy
@@ -1565,7 +1567,7 @@ LineClass line_class_for(int slot_len) {
     case 0: return {CfgS::T, CfgS::C};
     case 1: return {CfgM::T, CfgM::C};
     case 2: return {CfgL::T, CfgL::C};
-    case 3: return {CfgX::T, CfgX::C};
+    case 3: return slot_len <= CfgXC::kMaxSlotLen ? LineClass{CfgXC::T, CfgXC::C} : LineClass{CfgX::T, CfgX::C};   // scan tables: Chebyshev axes only
     default: fail("line too long for one workgroup: slot length " + std::to_string(slot_len));
   }
 }
@@ -1584,24 +1586,29 @@ void launch_line_program(const Program& pg, Stream& st) {
   if (pg.nlines <= 0 || pg.ncomp <= 0) return;
   const int sl = pg.slot_len;
   const int ci = class_index(sl);
-  auto fft_ok = [&](int fmin, int fmax) { return pg.fft_n == 0 || (pg.fft_n >= fmin && pg.fft_n <= fmax); };
+  const int flen = pg.blu_m > 0 ? pg.blu_m : pg.fft_n;   // the FFT length the kernel has to hold (Bluestein: the convolution length)
+  auto fft_ok = [&](int fmin, int fmax) { return flen == 0 || (flen >= fmin && flen <= fmax); };
   if (ci == 0 && fft_ok(CfgS::FMIN, CfgS::FMAX)) launch_cfg<CfgS>(pg, st);
   else if (ci == 1 && fft_ok(CfgM::FMIN, CfgM::FMAX)) launch_cfg<CfgM>(pg, st);
   else if (ci == 2 && fft_ok(CfgL::FMIN, CfgL::FMAX)) launch_cfg<CfgL>(pg, st);
-  else if (ci == 3 && fft_ok(CfgX::FMIN, CfgX::FMAX) && pg.fft_n > 0) {
+  else if (ci == 3) {
+    bool cheb_ops = false;
     for (int i = 0; i < pg.nops; ++i) {
       const int c = pg.ops[i].code;
-      RPDE_REQUIRE(c != OP_DCT && c != OP_REC1 && c != OP_REC2 && c != OP_CDIFF && c != OP_PUSH && c != OP_POPAXPY &&
-                       c != OP_STEN && c != OP_MV3,
-                   "the long-line configuration (nx = 8192, 16384) runs Fourier programs only");
+      cheb_ops |= c == OP_DCT || c == OP_REC1 || c == OP_REC2 || c == OP_CDIFF || c == OP_PUSH || c == OP_POPAXPY || c == OP_STEN || c == OP_MV3;
     }
-    RPDE_REQUIRE(pg.nslots == 1, "the long-line configuration (nx = 8192, 16384) has one LDS slot");
-    launch_cfg<CfgX>(pg, st);
+    if (cheb_ops || pg.nslots > 1) {
+      RPDE_REQUIRE(sl <= CfgXC::kMaxSlotLen && (flen == 0 || flen == CfgXC::FMAX) && (pg.fft_n == 0 || pg.blu_m > 0),
+                   "the 1024-thread Chebyshev configuration runs lines of up to 4096 points with the Bluestein transform only");
+      launch_cfg<CfgXC>(pg, st);
+    } else {
+      RPDE_REQUIRE(fft_ok(CfgX::FMIN, CfgX::FMAX), "no line-kernel configuration for FFT length " + std::to_string(flen) + " at slot length " + std::to_string(sl));
+      launch_cfg<CfgX>(pg, st);
+    }
   }
   else fail("no line-kernel configuration for slot length " + std::to_string(sl) +
-            " / FFT length " + std::to_string(pg.fft_n) +
-            " (supported: Chebyshev n = 2^k + 1 <= 4097, Fourier nx = 2^k <= 16384, or any n <= 500"
-            " through the direct transform)");
+            " / FFT length " + std::to_string(flen) +
+            " (supported: Chebyshev n <= 4097, Fourier nx = 2^k <= 16384 or any nx <= 5461)");
 }
 
 }  // namespace rpde

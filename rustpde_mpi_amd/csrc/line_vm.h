@@ -174,7 +174,9 @@ struct Program {
   int nlines;     // grid.x (local lines of this rank)
   int line0;      // global index of local line 0 (pencil-sharded runs; 0 otherwise)
   int ncomp;      // grid.y
-  int fft_n;      // complex FFT length used by OP_DCT / OP_RFFT (0: direct O(n^2) DCT)
+  int fft_n;      // complex FFT length used by OP_DCT / OP_RFFT (0: no plan of that length: Bluestein, or the direct O(n^2) DCT)
+  int blu_m;      // > 0: lines of this length transform by Bluestein's chirp-z algorithm through two power-of-two FFTs of length
+                  // blu_m (tw = their twiddles, tw2 = the chirp and filter tables of hostmath.cc bluestein_*_tables)
   int tw;         // table index of the FFT twiddles W_N (N complex: cos, -sin)
   int tw2;        // table index of the split twiddles (cos, sin)(pi k / N) resp. (2 pi k / nx)
   int* nanflag;   // device flag raised by guarded stores (OP_STORE with acc = 1); may be null
@@ -186,7 +188,7 @@ struct Program {
 
 // ---------------------------------------------------------------------------------------------
 // kernel configuration (compile time): T threads, EPT elements per thread
-template <int T_, int EPT_, int FMIN_, int FMAX_, int RM_>
+template <int T_, int EPT_, int FMIN_, int FMAX_, int RM_, bool CHEB_ = (T_ <= 512)>
 struct LineCfg {
   static constexpr int T = T_;
   static constexpr int EPT = EPT_;
@@ -197,9 +199,10 @@ struct LineCfg {
   static constexpr int C = (EPT_ + 1) & ~1;           // scan chunk per thread (even)
   static constexpr int G = (T_ + 15) / 16;             // scan groups
   static constexpr int kMaxSlotLen = T_ * EPT_;
-  // T = 1024 (16 waves) is the long-Fourier-line configuration: one 139 KB work area per
-  // workgroup, so no DCT (needs two slots) and no banded scans (a Fourier axis has none)
-  static constexpr bool kCheb = (T_ <= 512);
+  // T = 1024 (16 waves), EPT = 18 is the long-Fourier-line configuration: one 139 KB work area per
+  // workgroup, so no DCT (needs two slots) and no banded scans (a Fourier axis has none); T = 1024, EPT = 10 (CHEB_ = true)
+  // is the configuration of Chebyshev lines of 2049 .. 4096 points other than 2^k + 1 (Bluestein, M = 8192: two slots of 70 KB)
+  static constexpr bool kCheb = CHEB_;
   static constexpr int kCarryLen = 2 * ((T_ + 63) / 64) * 6 + 4;  // doubles: wave totals of a scan
 };
 
@@ -765,6 +768,174 @@ RPDE_DEVN void rfft_backward_lds(Blk& blk, lds_t x, int nx, tab_t tw, tab_t tw2)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Transforms of ARBITRARY length (Bluestein / chirp-z): the reference transforms any n (rustdct / rustfft / realfft under
+// funspace, call sites src/field.rs:103-110; its benches run Chebyshev n = 128, 264, 512, 1024: benches/benchmark_navier.rs:6-7,
+// benchmark_transform.rs:6).  With 2 j k = j^2 + k^2 - (k - j)^2 a length-L transform is a convolution with a chirp:
+//   sum_j x_j w^(2 j k) = w^(k^2) * sum_j (x_j w^(j^2)) w^(-(k - j)^2),
+// evaluated as a circular convolution of power-of-two length M (>= number of distinct lags) with the power-of-two FFT of this
+// file: a = x * chirp (zero padded) -> FFT_M -> times the tabulated spectrum of the filter / M, conjugated -> FFT_M -> conjugate
+// (= inverse FFT) -> times the chirp.  The work area W = M complex numbers at the padded index pidx() starts at the line itself.
+//
+// the two FFTs and the point-wise product in between; on return W holds V with (a (*) b)_k = conj(V_k)
+template <class Cfg>
+RPDE_DEVN void bluestein_convolve(Blk& blk, lds_t x, int M, tab_t tw, tab_t hs) {
+  constexpr int T = Cfg::T, ZP = Cfg::ZPT;
+  lds2_t W = (lds2_t)x;
+  fft_dispatch<Cfg>(blk, x, M, tw);
+  RPDE_PHASE(blk, tid) {
+    double hr[ZP], hi[ZP];   // filter spectrum: all fetched before the first use
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) { const int i = min(tid + q * T, M - 1); hr[q] = hs[2 * i]; hi[q] = hs[2 * i + 1]; }
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) { RPDE_PIN(hr[q]); RPDE_PIN(hi[q]); }
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) {
+      const int i = tid + q * T;
+      if (i < M) {
+        const dbl2 v = W[pidx(i)];
+        W[pidx(i)] = dbl2{v.x * hr[q] - v.y * hi[q], -(v.x * hi[q] + v.y * hr[q])};
+      }
+    }
+  }
+  RPDE_SYNC(blk);
+  fft_dispatch<Cfg>(blk, x, M, tw);
+}
+// stage the chirped input (QA values per thread, element i = tid + q T, i < na) into the zero-padded work area
+template <class Cfg, int QA>
+RPDE_DEV void bluestein_stage(Blk& blk, lds_t x, int na, int M, const double* ar, const double* ai) {
+  constexpr int T = Cfg::T, ZP = Cfg::ZPT;
+  lds2_t W = (lds2_t)x;
+  RPDE_SYNC(blk);   // every thread has read its part of the line
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < ZP; ++q) {
+      const int i = tid + q * T;
+      dbl2 v = dbl2{0.0, 0.0};
+      if (q < QA) { if (i < na) v = dbl2{RPDE_TPK(ar, QA)[q < QA ? q : 0], RPDE_TPK(ai, QA)[q < QA ? q : 0]}; }
+      if (i < M) W[pidx(i)] = v;
+    }
+  }
+  RPDE_SYNC(blk);
+}
+
+// DCT-I of the N + 1 reals of slot x, any N >= 1:  E_k = x_0 + (-1)^k x_N + 2 sum_{0<j<N} x_j cos(pi j k / N) = Re sum_j g_j x_j w^(2 j k),
+// w = exp(i pi / (2 N)); M >= 2 N + 1.  bt = bluestein_dct_tables(N, M); pre / post: scaling tables (may be null) like the direct form
+template <class Cfg>
+RPDE_DEVN void dct1_bluestein(Blk& blk, lds_t x, int N, int M, tab_t pre, tab_t post, tab_t tw, tab_t bt) {
+  constexpr int T = Cfg::T;
+  constexpr int QI = Cfg::ZPT / 2 + 1;   // N + 1 <= M / 2 + 1 inputs and outputs
+  tab_t chirp = bt, hs = bt + 2 * (N + 1);
+  {
+    RPDE_TLS(blk, double, ar, QI);
+    RPDE_TLS(blk, double, ai, QI);
+    RPDE_PHASE(blk, tid) {
+#pragma unroll
+      for (int q = 0; q < QI; ++q) {
+        const int j = tid + q * T;
+        if (j <= N) {
+          double v = x[j];
+          if (pre) v *= pre[j];
+          if (j != 0 && j != N) v *= 2.0;
+          RPDE_T(ar)[q] = v * chirp[2 * j];
+          RPDE_T(ai)[q] = v * chirp[2 * j + 1];
+        }
+      }
+    }
+    bluestein_stage<Cfg, QI>(blk, x, N + 1, M, RPDE_TLS_PTR(ar), RPDE_TLS_PTR(ai));
+  }
+  bluestein_convolve<Cfg>(blk, x, M, tw, hs);
+  RPDE_TLS(blk, double, e, QI);
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+      const int k = tid + q * T;
+      if (k <= N) {
+        const dbl2 v = ((lds2_t)x)[pidx(k)];
+        double ek = chirp[2 * k] * v.x + chirp[2 * k + 1] * v.y;   // Re (w^(k^2) conj V_k)
+        if (post) ek *= post[k];
+        RPDE_T(e)[q] = ek;
+      }
+    }
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < QI; ++q) { const int k = tid + q * T; if (k <= N) x[k] = RPDE_T(e)[q]; }
+  }
+  RPDE_SYNC(blk);
+}
+
+// real FFT of any length nx (K = nx / 2, M >= nx + K); bt = bluestein_rfft_tables(nx, M).
+//   forward: nx reals -> K + 1 interleaved complex, unnormalised:  X_k = sum_j x_j w^(2 j k), w = exp(-i pi / nx)
+//   backward: K + 1 interleaved complex -> nx reals, scaled by 1 / nx:  x_j = Re sum_k g_k X_k u^(2 j k) / nx, u = conj w,
+//             g = 1 for k = 0 and 2 k = nx, else 2 (the imaginary parts of those two are ignored, like realfft's c2r)
+template <class Cfg, bool FWD>
+RPDE_DEVN void rfft_bluestein(Blk& blk, lds_t x, int nx, int M, tab_t tw, tab_t bt) {
+  constexpr int T = Cfg::T, ZP = Cfg::ZPT;
+  constexpr int QK = ZP / 2 + 1;         // K + 1 <= M / 3 + 1 spectral coefficients
+  constexpr int QA = FWD ? ZP : QK, QO = FWD ? QK : ZP;
+  const int K = nx / 2;
+  tab_t chirp = bt, hs = bt + 2 * nx + (FWD ? 0 : 2 * M);
+  {
+    RPDE_TLS(blk, double, ar, QA);
+    RPDE_TLS(blk, double, ai, QA);
+    RPDE_PHASE(blk, tid) {
+#pragma unroll
+      for (int q = 0; q < QA; ++q) {
+        const int j = tid + q * T;
+        if constexpr (FWD) {
+          if (j < nx) {
+            const double v = x[j];
+            RPDE_T(ar)[q] = v * chirp[2 * j];
+            RPDE_T(ai)[q] = -(v * chirp[2 * j + 1]);
+          }
+        } else {
+          if (j <= K) {
+            const bool self = (j == 0) || (2 * j == nx);
+            const double g = self ? 1.0 : 2.0;
+            const double xr = g * x[2 * j], xi = self ? 0.0 : g * x[2 * j + 1];
+            const double c = chirp[2 * j], sn = chirp[2 * j + 1];
+            RPDE_T(ar)[q] = xr * c - xi * sn;
+            RPDE_T(ai)[q] = xr * sn + xi * c;
+          }
+        }
+      }
+    }
+    bluestein_stage<Cfg, QA>(blk, x, FWD ? nx : K + 1, M, RPDE_TLS_PTR(ar), RPDE_TLS_PTR(ai));
+  }
+  bluestein_convolve<Cfg>(blk, x, M, tw, hs);
+  RPDE_TLS(blk, double, yr, QO);
+  RPDE_TLS(blk, double, yi, FWD ? QO : 1);
+  const double sc = 1.0 / (double)nx;
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < QO; ++q) {
+      const int k = tid + q * T;
+      if (k < (FWD ? K + 1 : nx)) {
+        const dbl2 v = ((lds2_t)x)[pidx(k)];
+        const double c = chirp[2 * k], sn = chirp[2 * k + 1];
+        if constexpr (FWD) {   // w^(k^2) conj V_k = (c - i s)(Vr - i Vi)
+          RPDE_T(yr)[q] = c * v.x - sn * v.y;
+          RPDE_T(yi)[q] = -(c * v.y + sn * v.x);
+        } else {               // Re (u^(j^2) conj V_j) / nx
+          RPDE_T(yr)[q] = sc * (c * v.x + sn * v.y);
+        }
+      }
+    }
+  }
+  RPDE_SYNC(blk);
+  RPDE_PHASE(blk, tid) {
+#pragma unroll
+    for (int q = 0; q < QO; ++q) {
+      const int k = tid + q * T;
+      if constexpr (FWD) { if (k <= K) { x[2 * k] = RPDE_T(yr)[q]; x[2 * k + 1] = RPDE_T(yi)[q]; } }
+      else { if (k < nx) x[k] = RPDE_T(yr)[q]; }
+    }
+  }
+  RPDE_SYNC(blk);
+}
+
+// ---------------------------------------------------------------------------------------------
 // chunked scans for stride-2 linear recurrences
 //
 // Coef concept:   double b(int k)  inhomogeneous term (already multiplied by p_k)
@@ -987,9 +1158,9 @@ RPDE_DEVN void scan_recurrence(Blk& blk, lds_t dst, int n, lds_t carry, const Fi
       __syncthreads();
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
-        // prefix over the (at most 8) wave totals: lane l < NW holds total l, a 3-level shuffle
+        // prefix over the (at most 16) wave totals: lane l < NW holds total l, a log2(NW)-level shuffle
         // scan composes them, wave w picks the inclusive prefix of wave w-1
-        static_assert(NW <= 8, "cross-wave scan assumes at most 8 waves");
+        static_assert(NW <= 16, "cross-wave scan: one lane per wave total, log2(NW) shuffle levels");
         clds_t p = carry + (par * NW + (lane < NW ? lane : 0)) * W;
         Affine<ORDER> t = Affine<ORDER>{p[0], p[1], p[2], p[3], p[4], p[5]};
         t = affine_select<ORDER>(lane < NW, t, affine_identity<ORDER>());
@@ -1540,7 +1711,8 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         } else {
           tab_t pre = op.tab >= 0 ? (tab_t)pg.tabs[op.tab] : (tab_t) nullptr;
           tab_t post = op.i0 >= 0 ? (tab_t)pg.tabs[op.i0] : (tab_t) nullptr;
-          dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
+          if (pg.blu_m > 0) dct1_bluestein<Cfg>(blk, d, n - 1, pg.blu_m, pre, post, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+          else dct1_direct<Cfg>(blk, d, n - 1, pre, post, (tab_t)pg.tabs[pg.tw2]);
         }
       } break;
       case OP_MUL: {
@@ -1616,10 +1788,12 @@ RPDE_DEV void run_line_program(Blk& blk, const Program& pg) {
         RPDE_SYNC(blk);
       } break;
       case OP_RFFT_F:
-        rfft_forward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+        if (pg.blu_m > 0) rfft_bluestein<Cfg, true>(blk, d, n, pg.blu_m, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+        else rfft_forward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
         break;
       case OP_RFFT_B:
-        rfft_backward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+        if (pg.blu_m > 0) rfft_bluestein<Cfg, false>(blk, d, n, pg.blu_m, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
+        else rfft_backward_lds<Cfg>(blk, d, n, (tab_t)pg.tabs[pg.tw], (tab_t)pg.tabs[pg.tw2]);
         break;
       case OP_CIK: {
         RPDE_TLS(blk, double, vr, EPT);

@@ -7,20 +7,31 @@ namespace rpde {
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Transform plan of an axis.  Power-of-two lengths (Chebyshev n = 2^k + 1, Fourier nx = 2^k) keep the packed plans the whole-line
+// kernels are built on; EVERY other length runs Bluestein's algorithm through the same power-of-two FFT (line_vm.h) -- the
+// reference accepts any n (funspace over rustdct / rustfft / realfft; benches/benchmark_navier.rs:6-7 runs 128, 264, 512).
+// Limits: the padded work area of M complex numbers must fit the LDS slots of one workgroup -- two slots for a Chebyshev axis
+// (M <= 8192: n <= 4097, like the power-of-two plans), one for a Fourier axis (M <= 8192: nx <= 5461).
 AxisTables::AxisTables(const Base& b) : base(b) {
+  static const bool force_direct = std::getenv("RPDE_DCT_DIRECT") && std::atoi(std::getenv("RPDE_DCT_DIRECT")) != 0;
   if (b.is_cheb()) {
     const int N = b.n - 1;
+    RPDE_REQUIRE(N >= 1, "a Chebyshev axis needs at least two points");
+    slot_len = slot_len_for(b.n);
     if (is_pow2(N) && N >= 2 && N <= 4096) {
       fft_n = N;
       tw.upload(fft_twiddles(N));
       tw2.upload(dct_split_twiddles(N));
-    } else {
-      RPDE_REQUIRE(b.n <= 500, "Chebyshev sizes other than n = 2^k + 1 (<= 4097) are only "
-                               "supported up to n = 500 (direct transform)");
-      fft_n = 0;
+    } else if (force_direct && b.n <= 500) {
       tw2.upload(dct_direct_costab(N));
+    } else {
+      blu_m = bluestein_len(2 * N + 1);
+      RPDE_REQUIRE(blu_m <= 8192, "Chebyshev axis of " + std::to_string(b.n) + " points: at most 4097 "
+                   "(the work area of one line must fit the LDS of a workgroup)");
+      tw.upload(fft_twiddles(blu_m));
+      blu.upload(bluestein_dct_tables(N, blu_m));
+      slot_len = std::max(slot_len, (fft_work_doubles(blu_m) / 2 + 1) & ~1);
     }
-    slot_len = slot_len_for(b.n);
     fwd_post.upload(cheb_fwd_post(b.n));
     bwd_pre.upload(cheb_bwd_pre(b.n));
     Mv3Tables pv = pinv_tables(b);
@@ -39,12 +50,21 @@ AxisTables::AxisTables(const Base& b) : base(b) {
       fo_qdn.upload(chunk_major(f.q_dn, lc, -1));
     }
   } else {
-    RPDE_REQUIRE(is_pow2(b.n) && b.n >= 4 && b.n <= 16384,
-                 "fourier_r2c needs nx = 2^k with 4 <= nx <= 16384");
-    fft_n = b.n / 2;
-    tw.upload(fft_twiddles(fft_n));
-    tw2.upload(rfft_split_twiddles(b.n));
+    RPDE_REQUIRE(b.n >= 2, "fourier_r2c needs nx >= 2");
     slot_len = slot_len_for(b.n + 2);
+    if (is_pow2(b.n) && b.n >= 4) {
+      RPDE_REQUIRE(b.n <= 16384, "fourier_r2c: nx = 2^k up to 16384");
+      fft_n = b.n / 2;
+      tw.upload(fft_twiddles(fft_n));
+      tw2.upload(rfft_split_twiddles(b.n));
+    } else {
+      blu_m = bluestein_len(b.n + b.n / 2);
+      RPDE_REQUIRE(blu_m <= 8192, "fourier_r2c of " + std::to_string(b.n) + " points: lengths other than nx = 2^k are supported "
+                   "up to nx = 5461 (the Bluestein work area of one line must fit the LDS of a workgroup)");
+      tw.upload(fft_twiddles(blu_m));
+      blu.upload(bluestein_rfft_tables(b.n, blu_m));
+      slot_len = std::max(slot_len, fft_work_doubles(blu_m));
+    }
   }
 }
 
@@ -78,12 +98,14 @@ ProgramBuilder::ProgramBuilder(int nslots, int slot_len, int nlines, int ncomp) 
   pg.nlines = nlines;
   pg.ncomp = ncomp;
   pg.tw = pg.tw2 = 0;
+  pg.blu_m = 0;
 }
 void ProgramBuilder::set_fft(const AxisTables& ax) {
   ax_ = &ax;
   pg.fft_n = ax.fft_n;
+  pg.blu_m = ax.blu_m;
   pg.tw = ax.tw.p ? tab(ax.tw.p) : 0;
-  pg.tw2 = tab(ax.tw2.p);
+  pg.tw2 = tab(ax.blu_m > 0 ? ax.blu.p : ax.tw2.p);
 }
 int ProgramBuilder::arr(double* p, long ld, int es, long coff) {
   for (int i = 0; i < narr_; ++i)

@@ -30,7 +30,10 @@ struct PdmaDev {
 // device-resident tables of one 1-D basis
 struct AxisTables {
   Base base{};
-  int fft_n = 0;       // complex FFT length (0: direct O(n^2) DCT)
+  int fft_n = 0;       // complex FFT length of the power-of-two plans (Chebyshev n = 2^k + 1, Fourier nx = 2^k); 0: none
+  int blu_m = 0;       // > 0: every other length -- Bluestein's algorithm through FFTs of this power-of-two length (line_vm.h);
+                       // fft_n = blu_m = 0: the direct O(n^2) DCT (RPDE_DCT_DIRECT=1, n <= 500: a cross-check, not a product path)
+  DBuf blu;            // bluestein_*_tables (chirp, filter spectra); tw = the twiddles of the length-blu_m FFT then
   int slot_len = 0;    // slot length for lines of this axis (doubles)
   DBuf tw, tw2, fwd_post, bwd_pre;             // transforms
   DBuf low;                                     // stencil (composite): S[k+2,k]

@@ -1,21 +1,36 @@
-"""Build tests/emu/librustpde_emu.so (host emulation of the kernel sources; see README.md)."""
+"""Build tests/emu/librustpde_emu.so (host emulation of the kernel sources; see README.md).
+
+One object per source under tests/emu/build/, compiled in parallel and rebuilt when the source or any header is newer."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "..", "rustpde_mpi_amd", "csrc"))
 OUT = os.path.join(HERE, "librustpde_emu.so")
+BDIR = os.path.join(HERE, "build")
 SOURCES = ["kernels.cc", "gemm.cc", "hostmath.cc", "ops.cc", "rccl_transport.cc", "h5lite.cc", "engine.cc", "adjoint.cc", "capi.cc"]
+FLAGS = ["-std=c++17", "-O2", "-DRPDE_EMU", "-fPIC", "-Wno-unknown-pragmas"]
 
 
 def build(force=False):
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cc", ".h"))]
-    deps.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "rustpde_hip.h")))
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) > max(map(os.path.getmtime, deps)):
-        return OUT
-    cmd = ["g++", "-std=c++17", "-O2", "-DRPDE_EMU", "-shared", "-fPIC", "-Wno-unknown-pragmas"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT, "-ldl"]
-    subprocess.check_call(cmd)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "rustpde_hip.h")))
+    hdr_t = max(map(os.path.getmtime, headers))
+    os.makedirs(BDIR, exist_ok=True)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(BDIR, s.replace(".cc", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append(["g++", *FLAGS, "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+    if jobs or not os.path.exists(OUT) or os.path.getmtime(OUT) < max(map(os.path.getmtime, objs)):
+        tmp = OUT + ".tmp%d" % os.getpid()
+        subprocess.check_call(["g++", "-shared", "-fPIC", *objs, "-o", tmp, "-ldl"])
+        os.replace(tmp, OUT)
     return OUT
 
 
