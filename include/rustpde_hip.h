@@ -386,7 +386,10 @@ int rpde_gemm(int M, int N, int K, const double* a, const double* b, int transb,
 
 /* micro-benchmark of one line-program shape (bench/tests only): LOAD + <what> + STORE on `nlines`  *
  * Chebyshev-Dirichlet lines of n points; what in {copy, sten, mv3, cdiff, fromortho, fdma, dct,     *
- * dct2, rfft}; returns the mean device time of one launch in ms (HIP events, `reps` launches)      */
+ * dct2, rfft}; returns the mean device time of one launch in ms (HIP events, `reps` launches).     *
+ * what in {forward2d, backward2d, to_ortho2d, from_ortho2d}: Field2 on cheb_dirichlet(n) x          *
+ * cheb_dirichlet(nlines), the operations the reference's criterion benches time                      *
+ * (benches/benchmark_transform.rs:6-22, benchmark_to_ortho.rs:6-40), arrays resident in HBM          */
 int rpde_microbench(const char* what, int n, int nlines, int reps, int device, double* ms);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", flags=()
     bdir = os.path.join(CSRC, "build" if not variant else f"build_{variant}")
     os.makedirs(bdir, exist_ok=True)
     hdr_t = _newest_header()
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(bdir, src.replace(".cc", ".o"))
@@ -51,6 +51,10 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", flags=()
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t)):
             continue
+        jobs.append((sp, obj))
+
+    def compile_one(job):
+        sp, obj = job
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
                "-Wno-unused-result", *flags, "-c", sp, "-o", obj + ".tmp"]
         # hipcc reads the sources twice (device pass, host pass): an edit in between gives an object whose host and device
@@ -63,7 +67,11 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", flags=()
             if max(os.path.getmtime(sp), _newest_header()) == seen:
                 break
         os.replace(obj + ".tmp", obj)
-        hdr_t = max(hdr_t, seen)
+
+    if jobs:   # the translation units are independent: all of them at once (kernels.cc alone is most of the wall time)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, jobs))
     if (force or not os.path.exists(out)
             or os.path.getmtime(out) < max(os.path.getmtime(o) for o in objs)):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]

@@ -1125,6 +1125,43 @@ int rpde_microbench(const char* what, int n, int nlines, int reps, int device, d
       return 0;
     }
 #endif
+    // the reference's criterion benches of Field2 on cheb_dirichlet(n) x cheb_dirichlet(nlines) (benches/benchmark_transform.rs:
+    // field.forward(); benchmark_to_ortho.rs: field.to_ortho(), field.from_ortho(&array)), arrays resident in HBM
+    if (w == "forward2d" || w == "backward2d" || w == "to_ortho2d" || w == "from_ortho2d") {
+      Space2Ops sp(make_base(kChebDirichlet, n), make_base(kChebDirichlet, nlines));
+      Arr2 phys(n, nlines), spec(n - 2, nlines - 2), ortho(n, nlines);
+      {
+        Vec hbuf((size_t)n * phys.ld);
+        for (size_t i = 0; i < hbuf.size(); ++i) hbuf[i] = std::sin(0.001 * (double)i);
+        phys.buf.upload(hbuf);
+        ortho.buf.upload(hbuf);
+        hbuf.resize((size_t)(n - 2) * spec.ld);
+        spec.buf.upload(hbuf);
+      }
+      auto once = [&]() {
+        if (w == "forward2d") sp.forward(phys, spec, st);
+        else if (w == "backward2d") sp.backward(spec, phys, st);
+        else if (w == "to_ortho2d") sp.to_ortho(spec, ortho, st);
+        else sp.from_ortho(ortho, spec, st);
+      };
+      once();
+      dev_sync(st);
+#ifndef RPDE_EMU
+      hipEvent_t e0, e1;
+      RPDE_HIP(hipEventCreate(&e0)); RPDE_HIP(hipEventCreate(&e1));
+      RPDE_HIP(hipEventRecord(e0, st.s));
+      for (int r = 0; r < reps; ++r) once();
+      RPDE_HIP(hipEventRecord(e1, st.s));
+      RPDE_HIP(hipEventSynchronize(e1));
+      float t = 0.f;
+      RPDE_HIP(hipEventElapsedTime(&t, e0, e1));
+      *ms = t / reps;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#else
+      *ms = 0.0;
+#endif
+      return 0;
+    }
     if (w == "dct_line") {   // whole-line backward transform (hdct_line.h)
       AxisTables ax(make_base(kChebDirichlet, n));
       const long ld = pitch(n + 2);

@@ -62,8 +62,12 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   RPDE_HIP(hipStreamCreate(&st_.s));
 #endif
   if (comm_.size > 1) {
+    // Default: on for the stream-ordered transport only (the engine's own RCCL communicator: an exchange on the second stream
+    // really runs beside the main stream's kernels).  The callback transport is a blocking host call behind a stream sync --
+    // nothing can overlap there, and per-field exchanges would only add four latency-bound collectives per step (13 -> 17).
+    // RPDE_OVERLAP=1 / 0 forces either order with either transport (the A/B tests do).
     const char* e = std::getenv("RPDE_OVERLAP");
-    overlap_ = !e || std::atoi(e) != 0;
+    overlap_ = e ? std::atoi(e) != 0 : comm_.rccl != nullptr;
   }
 #ifndef RPDE_EMU
   if (overlap_) {
@@ -876,7 +880,7 @@ bool Navier2DEngine::add_div_line(const DivLineArgs& a, const char* tag) {
 bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   // S6 (y preconditioner + one factorised banded solve per eigen row of the Poisson problem) as one kernel (prow_line.h)
   PoissonOp& po = *pois_;
-  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !whole_line_len(a.N) || periodic_ || po.rows16.n == 0) return false;
+  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !whole_line_len(a.N) || periodic_ || !po.ensure_rows16()) return false;
   if (!prow_tabs_.t0.p) {   // chunk-major copy of the B2 rows for 16 elements per thread
     const int T = a.N / 16;
     const Mv3Tables pv = pinv_tables(sp_pseu_->base(1));

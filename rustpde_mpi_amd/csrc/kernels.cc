@@ -1073,6 +1073,7 @@ void launch_pdma_cols(const PdmaColsArgs& a, Stream& st) {
   if (a.n <= 0 || a.ncols <= 0) return;
   if (a.blk.phi1) {
     RPDE_REQUIRE(a.ws && a.ldw >= a.ncols && a.blk.NB == (a.n + kPdmaBR - 1) / kPdmaBR, "pdma_cols: workspace / tables of the blocked form");
+    RPDE_REQUIRE(a.in != a.out, "pdma_cols (blocked form): in place is not supported -- a block reads rows its neighbours write");
     const dim3 tiles((a.ncols + 63) / 64), blocks((a.ncols + 63) / 64, a.blk.NB);
     hipLaunchKernelGGL(pdma_cols_blk_kernel<0>, blocks, dim3(64), 0, st.s, a);
     hipLaunchKernelGGL(pdma_cols_blk_kernel<1>, tiles, dim3(64), 0, st.s, a);
@@ -1353,6 +1354,7 @@ void launch_sten3_rows(const Sten3RowsArgs& a, Stream&) {
 void launch_pdma_cols(const PdmaColsArgs& a, Stream&) {
   if (a.blk.phi1) {   // the blocked form, phase by phase like the device
     RPDE_REQUIRE(a.ws && a.ldw >= a.ncols && a.blk.NB == (a.n + kPdmaBR - 1) / kPdmaBR, "pdma_cols: workspace / tables of the blocked form");
+    RPDE_REQUIRE(a.in != a.out, "pdma_cols (blocked form): in place is not supported -- a block reads rows its neighbours write");
     for (int b = 0; b < a.blk.NB; ++b) for (int c = 0; c < a.ncols; ++c) pdma_blk_fwd_local(a, b, c);
     for (int c = 0; c < a.ncols; ++c) pdma_blk_fwd_carry(a, c);
     for (int b = 0; b < a.blk.NB; ++b) for (int c = 0; c < a.ncols; ++c) pdma_blk_mid(a, b, c);

@@ -606,15 +606,6 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
   const int rb = std::max(0, row_begin), re = (row_end < 0 || row_end > m0) ? m0 : row_end;
   const size_t nr = (size_t)std::max(0, re - rb);
   Vec q1(nr * ld, 0.0), p2(nr * ld, 0.0), q2(nr * ld, 0.0), r2(nr * ld, 0.0);
-  // second copy for the whole-line form of the stage (prow_line.h): 16 elements per thread, N = m1 + 1 = 16 T entries per row
-  const int N16 = m1 + 1;
-#ifdef RPDE_EMU
-  const bool want16 = b0.is_cheb() && (N16 == 256 || N16 == 1024 || N16 == 4096);
-#else
-  const bool want16 = b0.is_cheb() && (N16 == 1024 || N16 == 4096);
-#endif
-  const long ld16 = want16 ? N16 : 0;
-  Vec q1w(nr * ld16, 0.0), p2w(nr * ld16, 0.0), q2w(nr * ld16, 0.0), r2w(nr * ld16, 0.0);
   for (int r = rb; r < re; ++r) {
     Bands mtx = bands_axpy(ay, lam[r] + alpha, cy);   // (A_y + (lam_i + alpha) C_y), fdma_tensor.rs:219-221
     fdma_sweep(mtx);
@@ -625,26 +616,50 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
     std::copy(b.begin(), b.end(), p2.begin() + (size_t)(r - rb) * ld);
     std::copy(c.begin(), c.end(), q2.begin() + (size_t)(r - rb) * ld);
     std::copy(d.begin(), d.end(), r2.begin() + (size_t)(r - rb) * ld);
-    if (want16) {
-      const int T16 = N16 / 16;
-      const Vec aw = chunk_major16(t.q1, T16, +1), bw = chunk_major16(t.p2, T16, -1, 1.0),
-                cw = chunk_major16(t.q2, T16, -1), dw = chunk_major16(t.r2, T16, -1);
-      std::copy(aw.begin(), aw.end(), q1w.begin() + (size_t)(r - rb) * ld16);
-      std::copy(bw.begin(), bw.end(), p2w.begin() + (size_t)(r - rb) * ld16);
-      std::copy(cw.begin(), cw.end(), q2w.begin() + (size_t)(r - rb) * ld16);
-      std::copy(dw.begin(), dw.end(), r2w.begin() + (size_t)(r - rb) * ld16);
-    }
   }
   rows.row0 = rb;
   rows.n = m1;
   rows.tabld = ld;
   rows.q1.upload(q1); rows.p2.upload(p2); rows.q2.upload(q2); rows.r2.upload(r2);
-  if (want16 && nr > 0) {
-    rows16.row0 = rb;
-    rows16.n = m1;
-    rows16.tabld = ld16;
-    rows16.q1.upload(q1w); rows16.p2.upload(p2w); rows16.q2.upload(q2w); rows16.r2.upload(r2w);
+  rows_c1_ = c1; rows_alpha_ = alpha; rows_rb_ = rb; rows_re_ = re;
+}
+
+// The same factors a second time, chunk-major for 16 elements per thread: only the whole-line form of S6 reads them
+// (Navier2DEngine::add_prow_line), so only that caller builds them -- 4 x (nx - 2) x 4096 doubles = 0.54 GB at 4097^2 that the
+// tensor Helmholtz operators of the adjoint solver, the generic operator API and RPDE_S6_LINE=0 never carried a use for.
+bool PoissonOp::ensure_rows16() {
+  if (rows16.n > 0) return true;
+  const Base &b0 = sp.base(0), &b1 = sp.base(1);
+  const int m1 = b1.m, N16 = m1 + 1;
+#ifdef RPDE_EMU
+  const bool want16 = b0.is_cheb() && (N16 == 256 || N16 == 1024 || N16 == 4096);
+#else
+  const bool want16 = b0.is_cheb() && (N16 == 1024 || N16 == 4096);
+#endif
+  const int rb = rows_rb_, re = rows_re_;
+  if (!want16 || re <= rb) return false;
+  const Bands ay = bands_axpy(Bands{Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0)}, rows_c1_, hholtz_mat_b(b1));
+  const Bands cy = hholtz_mat_a(b1);
+  const size_t nr = (size_t)(re - rb);
+  const long ld16 = N16;
+  const int T16 = N16 / 16;
+  Vec q1w(nr * ld16, 0.0), p2w(nr * ld16, 0.0), q2w(nr * ld16, 0.0), r2w(nr * ld16, 0.0);
+  for (int r = rb; r < re; ++r) {
+    Bands mtx = bands_axpy(ay, lam[r] + rows_alpha_, cy);
+    fdma_sweep(mtx);
+    FdmaTables t = fdma_tables(mtx);
+    const Vec aw = chunk_major16(t.q1, T16, +1), bw = chunk_major16(t.p2, T16, -1, 1.0),
+              cw = chunk_major16(t.q2, T16, -1), dw = chunk_major16(t.r2, T16, -1);
+    std::copy(aw.begin(), aw.end(), q1w.begin() + (size_t)(r - rb) * ld16);
+    std::copy(bw.begin(), bw.end(), p2w.begin() + (size_t)(r - rb) * ld16);
+    std::copy(cw.begin(), cw.end(), q2w.begin() + (size_t)(r - rb) * ld16);
+    std::copy(dw.begin(), dw.end(), r2w.begin() + (size_t)(r - rb) * ld16);
   }
+  rows16.row0 = rb;
+  rows16.n = m1;
+  rows16.tabld = ld16;
+  rows16.q1.upload(q1w); rows16.p2.upload(p2w); rows16.q2.upload(q2w); rows16.r2.upload(r2w);
+  return true;
 }
 
 void PoissonOp::export_eigenbasis(double* lam_out, double* fwd_out, double* bwd_out) const {

@@ -240,8 +240,12 @@ class PoissonOp {
   FdmaDev rows;
   // the same factors a second time, chunk-major for 16 elements per thread (rhs_line.h chunk_major16: ascending q1, descending
   // p2 / q2 / r2; one row of ny - 1 = 16 T entries per x-row) -- the whole-line form of the stage (prow_line.h, S6 of the
-  // confined step).  Built for real (Chebyshev x) operators whose y-lines have a whole-line length; n = 0: not built.
+  // confined step).  Built ON FIRST USE (ensure_rows16) for real (Chebyshev x) operators whose y-lines have a whole-line length; n = 0: not built.
   FdmaDev rows16;
+  bool ensure_rows16();          // builds them on first use (Navier2DEngine::add_prow_line); false: this operator has no such form
+ private:
+  double rows_c1_ = 0.0, rows_alpha_ = 0.0;
+  int rows_rb_ = 0, rows_re_ = 0;
 };
 
 // Hholtz<f64, 2> (src/solver/hholtz.rs:29-37, 72-106, 164-187): (I - c0 Dxx - c1 Dyy) vhat = A f by diagonalising x --

@@ -1,6 +1,7 @@
 """Build tests/emu/librustpde_emu.so (host emulation of the kernel sources; see README.md).
 
 One object per source under tests/emu/build/, compiled in parallel and rebuilt when the source or any header is newer."""
+import fcntl
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -14,6 +15,14 @@ FLAGS = ["-std=c++17", "-O2", "-DRPDE_EMU", "-fPIC", "-Wno-unknown-pragmas"]
 
 
 def build(force=False):
+    # one builder at a time (pytest-xdist workers, the ranks of a multi-process test): the others wait and find it built
+    os.makedirs(BDIR, exist_ok=True)
+    with open(os.path.join(BDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "rustpde_hip.h")))
     hdr_t = max(map(os.path.getmtime, headers))

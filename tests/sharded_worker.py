@@ -33,7 +33,12 @@ def run(rank, world, port, lib_path, device_build, cases, out_path):
         ab_overlap = len(case) > 8 and case[8] == "overlap_ab"   # the same run with RPDE_OVERLAP=0: fields must be bit-identical
         ctor = "new_periodic" if periodic else "new_confined"
         # the reference's spelling of the sharded constructors: Navier2DMpi::new_confined(&universe, nx, ny, ...)
-        nav = getattr(R.Navier2DMpi, ctor)(comm, nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
+        if ab_overlap:
+            os.environ["RPDE_OVERLAP"] = "1"   # the default of the native RCCL transport, forced here for the callback transport
+        try:
+            nav = getattr(R.Navier2DMpi, ctor)(comm, nx, ny, ra, 1.0, dt, aspect, bc, library=lib)
+        finally:
+            os.environ.pop("RPDE_OVERLAP", None)
         nav.set_velocity(0.2, 1.0, 1.0)
         nav.set_temperature(0.2, 1.0, 1.0)
         nav.update(steps)

@@ -74,6 +74,7 @@ ENV_SWITCHES = {
     "RPDE_S6_KEEP",                                 # A/B of round 5: S6 with the back-substitution factors read twice (tests/test_emu_parity.test_s6_*, test_gpu_parity.test_round5_ab_switches)
     "RPDE_GEMM_LDS",                                # A/B of round 5: LDS layout of the GEMM's operand stages (test_gpu_parity.test_round5_ab_switches)
     "RPDE_EIG_CACHE",                               # directory that keeps the x eigen-decomposition between engines of one operator (tests/conftest.py sets it; test_eig_cache)
+    "RPDE_DCT_DIRECT",                              # cross-check of the Bluestein lines: the O(n^2) cosine sum for n <= 500 (tests/test_general_lengths.py)
     "RPDE_COL_PAIR", "RPDE_GEMM_SWIZZLE",           # XCD pairing of the three-kernel correction-y, GEMM tile order (tests/test_gpu_parity)
 }
 
