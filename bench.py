@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--parity-independent", action="store_true")
     p.add_argument("--no-extended-golden", action="store_true", help="stop the independent-golden comparison at step 200")
     p.add_argument("--no-cpu-single-thread", action="store_true")
+    # the other solvers of SURVEY 8f-4 (not the driver's line): Navier2DAdjoint::update (steady_adjoint.rs:541-608), Navier2DLnse::update /
+    # update_adjoint (lnse.rs:263-288, lnse_adj_grad.rs:71-99), Navier2DNonLin::update (nonlin.rs:264-296)
+    p.add_argument("--solver", default="navier", choices=["navier", "adjoint", "lnse", "lnse_adjoint", "nonlin"])
     return p.parse_args()
 
 
@@ -273,8 +276,90 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+def cpu_baseline_other_solver(args, name, which, step):
+    """The oracle of one of the SURVEY 8f-4 solvers timed on the host cores (bounded sample: 1 warm-up + cpu_steps updates);
+    returns (baseline dict, the oracle instance after those updates -- the checker of the parity leg, its name)."""
+    from oracle import adjoint as OA, lnse as OL
+    ocls = OA.Navier2DAdjoint if args.solver == "adjoint" else getattr(OL, name)
+    ora = getattr(ocls, which)(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", eig_mode="parity")
+    ora.set_velocity(0.2, 1.0, 1.0)
+    ora.set_temperature(0.2, 1.0, 1.0)
+    step(ora, 1, False)
+    t0 = time.perf_counter()
+    step(ora, args.cpu_steps, False)
+    dt = time.perf_counter() - t0
+    base = {"value": args.cpu_steps / dt, "unit": "updates/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{args.cpu_steps} updates of the same case after 1 warm-up update (NumPy/SciPy oracle)"}
+    return base, ora, f"oracle ({ocls.__module__}.{name})"
+
+
+def bench_other_solver(args):
+    """`--solver adjoint | lnse | lnse_adjoint | nonlin`: updates per second of one of the SURVEY 8f-4 solvers on one GPU, with the
+    CPU oracle timed beside it and the parity of a fresh engine against that oracle instance (spectral u, v, T: tol; pressure: 1e-8,
+    tests/test_adjoint.py).  One JSON line in the format of the main bench (no per-launch roofline: these steps are
+    compositions of the generic device operators, profiled as a whole in profiles/)."""
+    import numpy as np
+    import rustpde_mpi_amd as R
+    name = {"adjoint": "Navier2DAdjoint", "lnse": "Navier2DLnse", "lnse_adjoint": "Navier2DLnse", "nonlin": "Navier2DNonLin"}[args.solver]
+    ecls = getattr(R, name)
+    which = "new_periodic" if args.periodic else "new_confined"
+    kw = {} if args.solver == "adjoint" else {"mean_file": "/nonexistent/mean.h5"}
+
+    def make():
+        nav = getattr(ecls, which)(args.nx, args.ny, args.ra, 1.0, args.dt, args.aspect, "rbc", **kw)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        return nav
+
+    def step(z, n, engine):
+        if args.solver == "lnse_adjoint":
+            if engine:
+                z.update_adjoint(n)
+            else:
+                for _ in range(n):
+                    z.update_adjoint()
+        elif engine:
+            z.update(n)
+        else:
+            for _ in range(n):
+                z.update()
+
+    nav = make()
+    step(nav, args.warmup, True)
+    nav.div_norm()                       # drains the stream
+    t0 = time.perf_counter()
+    step(nav, args.steps, True)
+    nav.div_norm()
+    elapsed = time.perf_counter() - t0
+    bad = nav.exit() if args.solver != "adjoint" else (nav.div_norm() != nav.div_norm())
+    del nav
+    out = {"metric": f"updates/sec ({name}{'::update_adjoint' if args.solver == 'lnse_adjoint' else '::update'}, f64)",
+           "value": args.steps / elapsed, "unit": "updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic (set_velocity(0.2,1,1), set_temperature(0.2,1,1); default mean fields)",
+           "config": {"workload": f"{name}::{which} {args.nx}x{args.ny} Ra={args.ra:g} Pr=1 dt={args.dt:g} aspect={args.aspect:g} bc=rbc",
+                      "parallelism": "single GPU"},
+           "roofline": None, "nan": bool(bad)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"], ora, checker = cpu_baseline_other_solver(args, name, which, step)
+        nav = make()
+        step(nav, 1 + args.cpu_steps, True)
+        names = ("velx", "vely", "temp", "pres")
+        got, want = nav.spectral_fields(names), ora.spectral_fields(names)   # spectral coefficients: every solver's oracle has them
+        rel = {k: float(np.linalg.norm(got[k] - want[k]) / max(np.linalg.norm(want[k]), 1e-300)) for k in names}
+        out["parity"] = {"steps": 1 + args.cpu_steps, "rel_l2": rel, "tol": PARITY_TOL, "tol_pres": 1e-8,
+                         "checker": f"{checker}, independent eigen-decompositions",
+                         "ok": all(rel[k] < (1e-8 if k == "pres" else PARITY_TOL) for k in names)}
+    print(json.dumps(out))
+    if "parity" in out and not out["parity"]["ok"]:
+        sys.exit(f"parity vs the oracle: {out['parity']['rel_l2']}")
+
+
 def main():
     args = parse()
+    if args.solver != "navier":
+        bench_other_solver(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -353,14 +353,13 @@ void GenericFlow2D::solve_pres(const Arr2& d) {   // steady_adjoint_eq.rs:226-23
 
 void GenericFlow2D::correct_velocity(double c) {   // steady_adjoint_eq.rs:183-192
   F &ps = field("pseu"), &u = field("velx"), &v = field("vely");
-  Arr2 tmp(u.vhat.rows, u.vhat.cols, ex_);
+  if (cvt_.rows != u.vhat.rows || cvt_.cols != u.vhat.cols) cvt_.alloc(u.vhat.rows, u.vhat.cols, ex_);   // once: no allocation inside the step
   ps.sp->gradient(ps.vhat, 1, 0, sx_, sy_, t0_, st_);
-  u.sp->from_ortho(t0_, tmp, st_);
-  lincomb(u.vhat, 1.0, u.vhat, -c, tmp);
+  u.sp->from_ortho(t0_, cvt_, st_);
+  lincomb(u.vhat, 1.0, u.vhat, -c, cvt_);
   ps.sp->gradient(ps.vhat, 0, 1, sx_, sy_, t0_, st_);
-  v.sp->from_ortho(t0_, tmp, st_);
-  lincomb(v.vhat, 1.0, v.vhat, -c, tmp);
-  dev_sync(st_);          // tmp goes out of scope
+  v.sp->from_ortho(t0_, cvt_, st_);
+  lincomb(v.vhat, 1.0, v.vhat, -c, cvt_);
 }
 
 double GenericFlow2D::norm(const Arr2& a) {   // functions.rs:24-35

@@ -69,7 +69,7 @@ class GenericFlow2D {
   std::unique_ptr<HholtzAdiOp> hh_vel_, hh_temp_;
   std::unique_ptr<PoissonOp> pois_;
   std::map<std::string, F> f_;
-  Arr2 rhs_, div_, t0_, t1_, old_[3], ux_, uy_, ta_, ph_, conv_, cv_, cp_;
+  Arr2 rhs_, div_, t0_, t1_, old_[3], ux_, uy_, ta_, ph_, conv_, cv_, cp_, cvt_;
   DBuf red_;
 };
 

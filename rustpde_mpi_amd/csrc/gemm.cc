@@ -311,16 +311,32 @@ static bool gemm_lay1() {
 // DB: 1 = 128-tile, 2 = 64-tile (both two-stage)
 template <bool NN, int DB>
 __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
-  const GemmArgs& g = blockIdx.z ? g1 : g0;
   constexpr int TM = (DB == 2 || DB == 5) ? 64 : 128;   // DB 3 / 4: the 128-tile with the round-4 loop, LDS layout 0 / 1 (DB 1: the peeled loop, A/B); DB 2 / 5: the 64-tile
   int tx, ty;
   gemm_tile_of_block(z, tx, ty);
+  const GemmArgs& g = blockIdx.z ? g1 : g0;
   if (ty * TM >= g.M || tx * TM >= g.N) return;
   if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else if constexpr (DB == 3) gemm_f64_db_tile<NN, 128, true>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else if constexpr (DB == 4) gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);   // LDS layout 1
   else if constexpr (DB == 5) gemm_f64_db_tile<NN, 64, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
   else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+}
+
+// RPDE_GEMM_PERSIST=1 (A/B, round 6): a workgroup works off its tile of BOTH problems one after the other instead of the two
+// problems being two rounds of workgroups -- no drain / relaunch between the rounds.  A kernel of its own: inside the pair kernel
+// the loop cost 90 more registers (315: one workgroup per CU).
+template <bool NN>
+__global__ __launch_bounds__(256, 2) void gemm_f64_pair_persist_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
+  int tx, ty;
+  gemm_tile_of_block(z, tx, ty);
+#pragma unroll 1
+  for (int zz = 0; zz < 2; ++zz) {
+    const GemmArgs& g = zz ? g1 : g0;
+    if (!(ty * 128 >= g.M || tx * 128 >= g.N))
+      gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+    __syncthreads();
+  }
 }
 
 // the steady-state loop addresses its operands with 32-bit byte offsets from a scalar base (gemm_f64_db_tile)
@@ -378,7 +394,12 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     // false>).  Measured in round 5 (profiles/r05_experiments): G1 / G2 1.081 / 1.100 ms with it, 1.071 / 1.092 without -- the
     // 375 instructions around the 64 MFMAs of a stage were never what kept the pipe at 0.81; the round-4 loop stays the default
     static const bool peel = [] { const char* e = std::getenv("RPDE_GEMM_PEEL"); return e && std::atoi(e) != 0; }();
-    if (!peel && lay1) {
+    static const bool persist = [] { const char* e = std::getenv("RPDE_GEMM_PERSIST"); return e && std::atoi(e) != 0; }();
+    if (!peel && lay1 && persist) {
+      grid.z = 1;
+      if (nn) hipLaunchKernelGGL((gemm_f64_pair_persist_kernel<true>), grid, dim3(256), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair_persist_kernel<false>), grid, dim3(256), 0, st.s, g0, g1, z);
+    } else if (!peel && lay1) {
       if (nn) hipLaunchKernelGGL((gemm_f64_pair_kernel<true, 4>), grid, dim3(256), 0, st.s, g0, g1, z);
       else hipLaunchKernelGGL((gemm_f64_pair_kernel<false, 4>), grid, dim3(256), 0, st.s, g0, g1, z);
     } else if (!peel) {

@@ -369,24 +369,21 @@ void Space2Ops::run_lines3(Kind kind, const AxisTables& ax, const double* in, lo
     case kToOrtho: sten3(in, ldi, out, ldo); return;
     case kFromOrtho: solve(in, ldi, out, ldo, true, ax.fo_pdma); return;
     case kForward: {
-      DBuf t((size_t)nlines * ldt);
-      run_lines(kForwardOrtho, ox, in, ldi, n, t.p, ldt, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
-      solve(t.p, ldt, out, ldo, true, ax.fo_pdma);
-      dev_sync(st);
+      Arr2& t = scr_.get(3, nlines, n, ncomp);
+      run_lines(kForwardOrtho, ox, in, ldi, n, t.p(), ldt, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
+      solve(t.p(), ldt, out, ldo, true, ax.fo_pdma);
       return;
     }
     case kBackward: {
-      DBuf t((size_t)nlines * ldt);
-      sten3(in, ldi, t.p, ldt);
-      run_lines(kBackwardOrtho, ox, t.p, ldt, n, out, ldo, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
-      dev_sync(st);
+      Arr2& t = scr_.get(3, nlines, n, ncomp);
+      sten3(in, ldi, t.p(), ldt);
+      run_lines(kBackwardOrtho, ox, t.p(), ldt, n, out, ldo, n, nlines, ncomp, st, 0, 1.0, nullptr, nullptr);
       return;
     }
     case kDiff: {
-      DBuf t((size_t)nlines * ldt);
-      sten3(in, ldi, t.p, ldt);
-      run_lines(kDiff, ox, t.p, ldt, n, out, ldo, n, nlines, ncomp, st, order, scale, nullptr, nullptr);
-      dev_sync(st);
+      Arr2& t = scr_.get(3, nlines, n, ncomp);
+      sten3(in, ldi, t.p(), ldt);
+      run_lines(kDiff, ox, t.p(), ldt, n, out, ldo, n, nlines, ncomp, st, order, scale, nullptr, nullptr);
       return;
     }
     case kForwardOrtho: case kBackwardOrtho: case kPinvMatvec:
@@ -435,7 +432,8 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
   const bool cplx_to_real = fourier && (kind == kBackwardOrtho || kind == kBackward);
   RPDE_REQUIRE(in.rows == li && out.rows == lo && in.cols == out.cols, "shape mismatch in axis-0 operator");
   const int ncols = in.cols;
-  Arr2 tin(ncols, li, in.elem), tout(ncols, lo, out.elem);
+  scr_.enter(st);
+  Arr2 &tin = scr_.get(0, ncols, li, in.elem), &tout = scr_.get(1, ncols, lo, out.elem);
   launch_transpose(in.p(), in.ld, tin.p(), tin.ld, in.rows, in.cols, in.elem, st);
   if (fourier) {
     // lines are genuinely complex (or real <-> complex): one component, element stride 1
@@ -457,50 +455,49 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
               fd, diag, pd);
   }
   launch_transpose(tout.p(), tout.ld, out.p(), out.ld, tout.rows, tout.cols, out.elem, st);
-  dev_sync(st);  // temporaries are released on return
 }
 
 void Space2Ops::forward(const Arr2& v, Arr2& vhat, Stream& st) {
   RPDE_REQUIRE(v.rows == phys_rows() && v.cols == phys_cols() && v.elem == 1, "forward: bad input shape");
   RPDE_REQUIRE(vhat.rows == spec_rows() && vhat.cols == spec_cols() && vhat.elem == elem(),
                "forward: bad output shape");
-  Arr2 t(phys_rows(), spec_cols(), 1);
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, phys_rows(), spec_cols(), 1);
   apply_axis(kForward, 1, v, t, st);
   apply_axis(kForward, 0, t, vhat, st);
-  dev_sync(st);
 }
 void Space2Ops::backward(const Arr2& vhat, Arr2& v, Stream& st) {
   RPDE_REQUIRE(v.rows == phys_rows() && v.cols == phys_cols() && v.elem == 1, "backward: bad output shape");
   RPDE_REQUIRE(vhat.rows == spec_rows() && vhat.cols == spec_cols() && vhat.elem == elem(),
                "backward: bad input shape");
-  Arr2 t(phys_rows(), spec_cols(), 1);
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, phys_rows(), spec_cols(), 1);
   apply_axis(kBackward, 0, vhat, t, st);
   apply_axis(kBackward, 1, t, v, st);
-  dev_sync(st);
 }
 void Space2Ops::to_ortho(const Arr2& vhat, Arr2& out, Stream& st) {
   RPDE_REQUIRE(out.rows == ortho_rows() && out.cols == ortho_cols() && out.elem == elem(),
                "to_ortho: bad output shape");
-  Arr2 t(ortho_rows(), spec_cols(), elem());
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, ortho_rows(), spec_cols(), elem());
   apply_axis(kToOrtho, 0, vhat, t, st);
   apply_axis(kToOrtho, 1, t, out, st);
-  dev_sync(st);
 }
 void Space2Ops::from_ortho(const Arr2& in, Arr2& vhat, Stream& st) {
   RPDE_REQUIRE(in.rows == ortho_rows() && in.cols == ortho_cols() && in.elem == elem(),
                "from_ortho: bad input shape");
-  Arr2 t(spec_rows(), ortho_cols(), elem());
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, spec_rows(), ortho_cols(), elem());
   apply_axis(kFromOrtho, 0, in, t, st);
   apply_axis(kFromOrtho, 1, t, vhat, st);
-  dev_sync(st);
 }
 void Space2Ops::gradient(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& out, Stream& st) {
   RPDE_REQUIRE(out.rows == ortho_rows() && out.cols == ortho_cols() && out.elem == elem(),
                "gradient: bad output shape");
-  Arr2 t(ortho_rows(), spec_cols(), elem());
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, ortho_rows(), spec_cols(), elem());
   apply_axis(kDiff, 0, vhat, t, st, d0, s0);
   apply_axis(kDiff, 1, t, out, st, d1, s1);
-  dev_sync(st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -546,15 +543,15 @@ void HholtzAdiOp::solve(const Arr2& in, Arr2& out, Stream& st) {
   RPDE_REQUIRE(out.rows == sp.spec_rows() && out.cols == sp.spec_cols() && out.elem == e,
                "HholtzAdi: output must have the composite shape");
   const bool cheb0 = sp.base(0).is_cheb();
-  Arr2 t0(sp.spec_rows(), sp.ortho_cols(), e), t1(sp.spec_rows(), sp.spec_cols(), e),
-      t2(sp.spec_rows(), sp.spec_cols(), e);
+  scr_.enter(st);
+  Arr2 &t0 = scr_.get(0, sp.spec_rows(), sp.ortho_cols(), e), &t1 = scr_.get(1, sp.spec_rows(), sp.spec_cols(), e),
+       &t2 = scr_.get(2, sp.spec_rows(), sp.spec_cols(), e);
   const Arr2* cur = &in;
   if (cheb0) { sp.apply_axis(Space2Ops::kPinvMatvec, 0, in, t0, st); cur = &t0; }
   sp.apply_axis(Space2Ops::kPinvMatvec, 1, *cur, t1, st);
   if (cheb0) sp.apply_axis(Space2Ops::kFdmaSolve, 0, t1, t2, st, 0, 1.0, &fdma[0], nullptr, &pdma[0]);
   else sp.apply_axis(Space2Ops::kDiagSolve, 0, t1, t2, st, 0, 1.0, nullptr, diag0.p);
   sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, out, st, 0, 1.0, &fdma[1], nullptr, &pdma[1]);
-  dev_sync(st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -691,23 +688,22 @@ void PoissonOp::solve(const Arr2& in, Arr2& out, Stream& st) {
                "Poisson: output must have the composite shape");
   const bool cheb0 = sp.base(0).is_cheb();
   const int m0 = sp.spec_rows(), m1 = sp.spec_cols();
-  Arr2 t0(m0, sp.ortho_cols(), e), t1(m0, m1, e), t2(m0, m1, e), t3(m0, m1, e);
+  scr_.enter(st);
+  Arr2 &t0 = scr_.get(0, m0, sp.ortho_cols(), e), &t1 = scr_.get(1, m0, m1, e), &t2 = scr_.get(2, m0, m1, e), &t3 = scr_.get(3, m0, m1, e);
   const Arr2* cur = &in;
   if (cheb0) { sp.apply_axis(Space2Ops::kPinvMatvec, 0, in, t0, st); cur = &t0; }
   sp.apply_axis(Space2Ops::kPinvMatvec, 1, *cur, t1, st);
   if (cheb0) {
     // ghat[k, :] = sum_i fwd[k, i] rhs[i, :]  per parity block (rows of one parity: stride 2 ld)
-    launch_gemm_nn(me, m1, me, fwd_e.p(), fwd_e.ld, t1.p(), 2 * t1.ld, t2.p(), t2.ld, st);
-    launch_gemm_nn(mo, m1, mo, fwd_o.p(), fwd_o.ld, t1.p() + t1.ld, 2 * t1.ld,
-                   t2.p() + (size_t)me * t2.ld, t2.ld, st);
+    // (both parity blocks of a transform in ONE launch, like the step's G1 / G2: twice the tiles to fill the chip with)
+    launch_gemm_pair(true, GemmProblem{me, m1, me, fwd_e.p(), fwd_e.ld, t1.p(), 2 * t1.ld, t2.p(), t2.ld},
+                     GemmProblem{mo, m1, mo, fwd_o.p(), fwd_o.ld, t1.p() + t1.ld, 2 * t1.ld, t2.p() + (size_t)me * t2.ld, t2.ld}, st);
     sp.apply_axis(Space2Ops::kFdmaSolve, 1, t2, t3, st, 0, 1.0, &rows);
-    launch_gemm_nn(me, m1, me, bwd_e.p(), bwd_e.ld, t3.p(), t3.ld, out.p(), 2 * out.ld, st);
-    launch_gemm_nn(mo, m1, mo, bwd_o.p(), bwd_o.ld, t3.p() + (size_t)me * t3.ld, t3.ld,
-                   out.p() + out.ld, 2 * out.ld, st);
+    launch_gemm_pair(true, GemmProblem{me, m1, me, bwd_e.p(), bwd_e.ld, t3.p(), t3.ld, out.p(), 2 * out.ld},
+                     GemmProblem{mo, m1, mo, bwd_o.p(), bwd_o.ld, t3.p() + (size_t)me * t3.ld, t3.ld, out.p() + out.ld, 2 * out.ld}, st);
   } else {
     sp.apply_axis(Space2Ops::kFdmaSolve, 1, t1, out, st, 0, 1.0, &rows);
   }
-  dev_sync(st);
 }
 
 }  // namespace rpde

@@ -143,6 +143,42 @@ struct Arr2 {
   size_t bytes() const { return (size_t)rows * ld * sizeof(double); }
 };
 
+// Work arrays an operator keeps between calls (grow-only): the generic operators allocate nothing and wait for nothing once
+// warm, so a solver composed of them (adjoint.cc: several hundred launches per update) queues its whole step without a host
+// round trip.  All calls of one operator are expected on ONE stream; a call on another stream first waits for the previous one.
+class ScratchPool {
+ public:
+  Arr2& get(int slot, int rows, int cols, int elem) {
+    RPDE_REQUIRE(slot >= 0 && slot < kSlots, "scratch slot");
+    Arr2& a = a_[slot];
+    const long ld = pitch((long)cols * elem);
+    const size_t need = (size_t)rows * ld;
+    if (a.buf.n < need) { wait(); a.buf.alloc(need); }
+    a.rows = rows; a.cols = cols; a.elem = elem; a.ld = ld;
+    return a;
+  }
+  void enter(Stream& st) {
+#ifndef RPDE_EMU
+    if (used_ && last_ != st.s) (void)hipStreamSynchronize(last_);
+    last_ = st.s; used_ = true;
+#else
+    (void)st;
+#endif
+  }
+ private:
+  static constexpr int kSlots = 6;
+  Arr2 a_[kSlots];
+  void wait() {
+#ifndef RPDE_EMU
+    if (used_) (void)hipStreamSynchronize(last_);   // the buffer that is about to be replaced may still be read
+#endif
+  }
+#ifndef RPDE_EMU
+  hipStream_t last_ = nullptr;
+#endif
+  bool used_ = false;
+};
+
 // funspace Space2<B0, B1> on device (canonical layout)
 class Space2Ops {
  public:
@@ -175,6 +211,7 @@ class Space2Ops {
 
  private:
   std::unique_ptr<AxisTables> ax_[2];
+  ScratchPool scr_;   // 0, 1: the transposed copies of an axis-0 operator; 2: between the two axes of a 2-D operator; 3: three-term axis
   void run_lines(Kind kind, const AxisTables& ax, const double* in, long ldi, int len_in,
                  double* out, long ldo, int len_out, int nlines, int ncomp, Stream& st, int order,
                  double scale, const FdmaDev* fd, const double* diag, const PdmaDev* pd = nullptr);
@@ -205,6 +242,8 @@ class HholtzAdiOp {
   PdmaDev pdma[2];      // Chebyshev axes with the three-term stencil: PdmaPlus2 (hholtz_adi.rs:62-64)
   DBuf diag0;           // Fourier axis 0: 1 + c0 k^2
   Space2Ops& sp;
+ private:
+  ScratchPool scr_;
 };
 
 // Setup data supplied by the host: the x eigenvalues of the next PLAIN Poisson solver built on this thread (alpha = 0; the
@@ -244,6 +283,7 @@ class PoissonOp {
   FdmaDev rows16;
   bool ensure_rows16();          // builds them on first use (Navier2DEngine::add_prow_line); false: this operator has no such form
  private:
+  ScratchPool scr_;
   double rows_c1_ = 0.0, rows_alpha_ = 0.0;
   int rows_rb_ = 0, rows_re_ = 0;
 };

@@ -148,6 +148,17 @@ def test_shared_basis_golden(hip_lib, name):
 
 @pytest.mark.parametrize("switch,value", [("RPDE_GEMM_PEEL", "1"), ("RPDE_S1_SPLIT", "1"), ("RPDE_LINE_BATCH", "15"), ("RPDE_GEMM_LDS", "0"), ("RPDE_S6_KEEP", "0")])
 def test_round5_ab_switches(hip_lib, switch, value):
+    _ab_switch_bit_identical(switch, value, "((4097, 129), (129, 4097))")
+
+
+def test_round6_gemm_persist_bit_identical(hip_lib):
+    """RPDE_GEMM_PERSIST=1 (round 6): one workgroup works off its tile of both parity blocks in turn (512 persistent workgroups)
+    instead of two rounds of 512 -- same tiles, same arithmetic; 2049 x 2049 is the smallest square whose parity GEMMs take the
+    128-tiles (16 x 17 x 2 = 544 tiles)."""
+    _ab_switch_bit_identical("RPDE_GEMM_PERSIST", "1", "((2049, 2049),)")
+
+
+def _ab_switch_bit_identical(switch, value, sizes):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
     of the three fields of a stage in one launch at 4097-point lines; RPDE_GEMM_LDS=0: the GEMM's operand stages in the LDS layout of rounds 1 - 4): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
@@ -158,7 +169,7 @@ def test_round5_ab_switches(hip_lib, switch, value):
     import subprocess
     import sys
     code = ("import hashlib, numpy as np, rustpde_mpi_amd as R\n"
-            "for nx, ny in ((4097, 129), (129, 4097)):\n"
+            f"for nx, ny in {sizes}:\n"
             "    nav = R.Navier2D.new_confined(nx, ny, 1e7, 1.0, 1e-3, 1.0, 'rbc', init_random=None)\n"
             "    nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0); nav.update(3)\n"
             "    f = nav.physical_fields()\n"
@@ -173,7 +184,7 @@ def test_round5_ab_switches(hip_lib, switch, value):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[flag] = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
-        assert len(out[flag]) == 2, r.stdout[-2000:]
+        assert len(out[flag]) == sizes.count("(") - 1, r.stdout[-2000:]
     print(switch, out)
     assert out[""] == out[value], out
 
