@@ -110,7 +110,7 @@ GenericFlow2D::GenericFlow2D(int nx, int ny, double ra, double pr, double dt, do
   pois_ = std::make_unique<PoissonOp>(*sp_pseu_, 1.0 / (sx_ * sx_), 1.0 / (sy_ * sy_));
 
   auto mk = [&](const std::string& name, Space2Ops* sp, bool ro = false) {
-    F f{sp, Arr2(sp->spec_rows(), sp->spec_cols(), ex_), ro};
+    F f{sp, Arr2(sp->spec_rows(), sp->spec_cols(), ex_), ro, name == "tempbc" || name.rfind("mean_", 0) == 0};
     f_.emplace(name, std::move(f));
   };
   mk("velx", sp_vel_.get()); mk("vely", sp_vel_.get()); mk("temp", sp_temp_.get());
@@ -179,6 +179,7 @@ void GenericFlow2D::set_field_spectral(const std::string& name, const double* ho
   F& f = field(name);
   RPDE_REQUIRE(!f.read_only, name + " is fixed by the boundary condition");
   RPDE_REQUIRE(len == (size_t)f.vhat.rows * f.vhat.cols * f.vhat.elem, "set_field: wrong length for the spectral shape of " + name);
+  if (f.constant) drop_constant_gradients();
   dev_sync(st_);
   dev_upload2d(f.vhat.p(), f.vhat.ld, host, f.vhat.rows, (long)f.vhat.cols * f.vhat.elem);
 }
@@ -194,6 +195,7 @@ void GenericFlow2D::set_field_physical(const std::string& name, const double* ho
   F& f = field(name);
   RPDE_REQUIRE(!f.read_only, name + " is fixed by the boundary condition");
   RPDE_REQUIRE(len == (size_t)nx_ * ny_, "set_field: physical arrays are nx*ny doubles");
+  if (f.constant) drop_constant_gradients();
   dev_sync(st_);
   dev_upload2d(ph_.p(), ph_.ld, host, nx_, ny_);
   f.sp->forward(ph_, f.vhat, st_);
@@ -319,7 +321,22 @@ void GenericFlow2D::acc_to_ortho(F& f, double s, Arr2& out) {
   lincomb(out, 1.0, out, s, t0_);
 }
 
+void GenericFlow2D::drop_constant_gradients() {
+  if (const_grad_.empty()) return;
+  dev_sync(st_);
+  const_grad_.clear();
+}
+
 void GenericFlow2D::acc_gradient(F& f, int d0, int d1, double s, Arr2& out) {
+  if (f.constant) {
+    auto it = const_grad_.find({&f, 100 + d0, d1});
+    if (it == const_grad_.end()) {
+      it = const_grad_.emplace(std::make_tuple(&f, 100 + d0, d1), Arr2(out.rows, out.cols, out.elem)).first;
+      f.sp->gradient(f.vhat, d0, d1, sx_, sy_, it->second, st_);
+    }
+    lincomb(out, 1.0, out, s, it->second);
+    return;
+  }
   f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
   lincomb(out, 1.0, out, s, t0_);
 }
@@ -327,9 +344,18 @@ void GenericFlow2D::acc_gradient(F& f, int d0, int d1, double s, Arr2& out) {
 void GenericFlow2D::backward(F& f, Arr2& phys) { f.sp->backward(f.vhat, phys, st_); }
 
 void GenericFlow2D::conv_term(const Arr2& u, F& f, int d0, int d1, double s, bool first) {
-  f.sp->gradient(f.vhat, d0, d1, sx_, sy_, t0_, st_);
-  sp_ortho_->backward(t0_, cp_, st_);
-  ew_muladd(conv_.p(), conv_.ld, s, u.p(), u.ld, cp_.p(), cp_.ld, nx_, ny_, !first, st_);
+  const Arr2* g = &cp_;
+  if (f.constant) {   // the lift, the mean fields: the physical gradient is the same in every term and step of a run
+    auto it = const_grad_.find({&f, d0, d1});
+    if (it == const_grad_.end()) {
+      it = const_grad_.emplace(std::make_tuple(&f, d0, d1), Arr2(nx_, ny_, 1)).first;
+      f.sp->gradient_backward(f.vhat, d0, d1, sx_, sy_, it->second, st_);
+    }
+    g = &it->second;
+  } else {
+    f.sp->gradient_backward(f.vhat, d0, d1, sx_, sy_, cp_, st_);   // backward_ortho(gradient(..)): one line program per axis
+  }
+  ew_muladd(conv_.p(), conv_.ld, s, u.p(), u.ld, g->p(), g->ld, nx_, ny_, !first, st_);
 }
 
 void GenericFlow2D::conv_finish(Arr2& out) {

@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "ops.h"
@@ -46,7 +47,11 @@ class GenericFlow2D {
   Stream& stream() { return st_; }
 
  protected:
-  struct F { Space2Ops* sp; Arr2 vhat; bool read_only = false; };
+  struct F { Space2Ops* sp; Arr2 vhat; bool read_only = false;
+             bool constant = false; };   // the lift and the mean fields: their gradients are computed once per run, not once per term and step
+  // gradients of the constant fields (physical: key d0, d1; orthonormal: key 100 + d0, d1), dropped whenever a field is set
+  std::map<std::tuple<const F*, int, int>, Arr2> const_grad_;
+  void drop_constant_gradients();
   F& field(const std::string& name);
   void acc_to_ortho(F& f, double s, Arr2& out);
   void acc_gradient(F& f, int d0, int d1, double s, Arr2& out);

@@ -342,6 +342,12 @@ void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
+  if (f.buf == &PS_ && pseu_in_yx_ && pseu_from_y4_) {
+    // the periodic step with the real-view S6 (build_periodic) leaves the pseudo-pressure in YX layout only
+    launch_transpose(yx(Y_[4]), ldx_, PS_.p, ldy_, my_, kx_, 2, st_);
+    dev_sync(st_);
+    pseu_in_yx_ = false;
+  }
   if (f.buf == &PS_ && pseu_in_yx_) {
     // the confined step leaves the pseudo-pressure in YX layout with the x parity blocks side by side
     // (build_confined, G2): bring it to the canonical array on demand
@@ -880,7 +886,8 @@ bool Navier2DEngine::add_div_line(const DivLineArgs& a, const char* tag) {
 bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   // S6 (y preconditioner + one factorised banded solve per eigen row of the Poisson problem) as one kernel (prow_line.h)
   PoissonOp& po = *pois_;
-  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !whole_line_len(a.N) || periodic_ || !po.ensure_rows16()) return false;
+  // (periodic: the caller hands real lines -- two per wavenumber, tdiv = 2 -- between real-view transposes, one rank only)
+  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !(whole_line_len(a.N) || a.N == 2048) || (periodic_ && a.tdiv != 2) || !po.ensure_rows16()) return false;
   if (!prow_tabs_.t0.p) {   // chunk-major copy of the B2 rows for 16 elements per thread
     const int T = a.N / 16;
     const Mv3Tables pv = pinv_tables(sp_pseu_->base(1));
@@ -900,6 +907,18 @@ bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   l.prl = a;
   l.tag = tag;
   l.bytes = 8.0 * a.nlines * 6.0 * (a.N - 1);   // the line in and out, four factor rows (what the line program of the stage counts)
+  step_.push_back(l);
+  return true;
+}
+bool Navier2DEngine::add_per_rows(const PerRowsArgs& a, const char* tag, double arrays) {
+  // the stages of the periodic step without a transform or a recurrence along x: one thread per complex number (per_rows.h);
+  // RPDE_PER_ROWS=0 keeps the line programs (A/B, tests/test_emu_parity.py)
+  if (!whole_line_on("RPDE_PER_ROWS")) return false;
+  Launch l;
+  l.type = Launch::kPerRows;
+  l.pr = a;
+  l.tag = tag;
+  l.bytes = 16.0 * a.nlines * a.kx * arrays;
   step_.push_back(l);
   return true;
 }
@@ -1183,6 +1202,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
     case Launch::kDivLine: RPDE_REQUIRE(launch_div_line(l.dvl, st_), "internal: div line shape"); break;
     case Launch::kProwLine: RPDE_REQUIRE(launch_prow_line(l.prl, st_), "internal: poisson row shape"); break;
     case Launch::kPresLine: RPDE_REQUIRE(launch_pres_line(l.psl, st_), "internal: pressure line shape"); break;
+    case Launch::kPerRows: launch_per_rows(l.pr, st_); break;
     case Launch::kRfftPair: RPDE_REQUIRE(launch_rfft_pair(l.rf, l.rf2, st_), "internal: rfft pair shape"); break;
     case Launch::kFourRhs: RPDE_REQUIRE(launch_four_rhs(l.fr, st_), "internal: fourier rhs shape"); break;
     case Launch::kSten3Rows: launch_sten3_rows(l.s3, st_); break;
@@ -1194,7 +1214,7 @@ void Navier2DEngine::run_launch(const Launch& l) {
 void Navier2DEngine::update(int nsteps) {
   RPDE_REQUIRE(nsteps >= 0, "update: negative step count");
   if (nsteps > 0) dirty_ = false;
-  if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
+  if (nsteps > 0 && (pseu_half_ > 0 || pseu_from_y4_)) pseu_in_yx_ = true;
 #ifndef RPDE_EMU
   hipEvent_t e0 = ev0_, e1 = ev1_;
   RPDE_HIP(hipEventRecord(e0, st_.s));
@@ -1273,7 +1293,7 @@ void Navier2DEngine::update(int nsteps) {
 
 std::string Navier2DEngine::profile(int nsteps) {
   struct Acc { long n = 0; double ms = 0, bytes = 0, flops = 0; };
-  if (nsteps > 0 && pseu_half_ > 0) pseu_in_yx_ = true;
+  if (nsteps > 0 && (pseu_half_ > 0 || pseu_from_y4_)) pseu_in_yx_ = true;
   std::vector<std::string> order;
   std::map<std::string, Acc> acc;
   for (int s = 0; s < nsteps; ++s) {
@@ -1339,7 +1359,8 @@ std::string Navier2DEngine::describe_step() const {
     static const char* const kKind[] = {"line program", "transpose", "gemm pair", "gemm pair", "set element", "halo", "column scan",
                                         "column scan", "whole-line transform", "whole-line transform pair", "whole-line convection term",
                                         "whole-line rhs + hholtz-x", "row stencil", "column solve", "whole-line correction-x", "line solve", "whole-line div + poisson precond-x",
-                                        "whole-line transform pair", "whole-line rhs + hholtz-x", "whole-line poisson rows", "whole-line pressure update"};
+                                        "whole-line transform pair", "whole-line rhs + hholtz-x", "whole-line poisson rows", "whole-line pressure update",
+                                        "element-wise rows"};
     double bytes = 0.0;
     for (size_t k = i; k < j; ++k) bytes += step_[k].bytes;
     std::string kind = kKind[(int)l.type];
@@ -1363,7 +1384,7 @@ std::string Navier2DEngine::trace_launch(const std::string& tag) {
   for (size_t i = 0; i < step_.size(); ++i)
     if (traceable(step_[i]) && std::string(step_[i].tag).find(tag) != std::string::npos) { which = i; break; }
   RPDE_REQUIRE(which < step_.size(), "trace_launch: no line program with tag containing \"" + tag + "\"");
-  if (pseu_half_ > 0) pseu_in_yx_ = true;
+  if (pseu_half_ > 0 || pseu_from_y4_) pseu_in_yx_ = true;
   std::string out;
 #ifndef RPDE_EMU
   Launch l = step_[which];
@@ -2342,7 +2363,8 @@ void Navier2DEngine::build_periodic() {
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");
   }
   // ---- S5: divergence
-  {
+  if (!add_per_rows(PerRowsArgs{kPerDiv, ylines(ny), yb_, kx, ldx, yx(U_), yx(Y_[0]), yx(DIV_), nullptr, yD.low.p, my, 1.0 / sx_, 0.0, nullptr},
+                    "S5 x: div", 3.0)) {
     ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xF);
     pb.loadx(0, pb.arr(yx(U_), ldx), nc, my, yD.low.p);
@@ -2351,10 +2373,31 @@ void Navier2DEngine::build_periodic() {
     pb.store(0, pb.arr(yx(DIV_), ldx), nc);
     add_line(pb, "S5 x: div");
   }
-  Tc(yx(DIV_), X_[0].p, ny, kx, true, "T5a");
   // ---- S6: Poisson: y preconditioner + one banded solve per wavenumber
   PoissonOp& po = *pois_;
-  {
+  // One rank, y-lines of a whole-line length: the REAL transpose of the interleaved YX array (ny x 2 kx doubles) has the real and
+  // the imaginary part of a wavenumber's row as two consecutive contiguous real lines (2 kx x ny) -- the row solve is the
+  // whole-line kernel of the confined step (prow_line.h, two lines per factor row), and the real transpose back is the YX
+  // pseudo-pressure C7 / S9 read.  No strided complex access anywhere; the canonical array `pseu` is rebuilt from Y_[4] on demand.
+  bool s6_real = false;
+  if (comm_.size == 1 && (ldy & 1) == 0) {
+    ProwLineArgs pl;
+    pl.in = X_[0].p; pl.out = X_[1].p; pl.ld = ldy / 2; pl.nlines = nc; pl.line0 = 0; pl.N = ny - 1; pl.tdiv = 2;
+    const size_t mark = step_.size();
+    add_transpose(yx(DIV_), ldx, X_[0].p, ldy / 2, ny, nc, 1, true, false, "T5a");
+    if (add_prow_line(pl, "S6 y: poisson rows")) {
+      s6_real = true;
+      for (int e = 0; e < 2; ++e) {
+        Launch l; l.type = Launch::kSetElem; l.out = X_[1].p; l.rows = e * (int)(ldy / 2); l.tag = "pseu[0,0]=0"; step_.push_back(l);
+      }
+      add_transpose(X_[1].p, ldy / 2, yx(Y_[4]), ldx, nc, my, 1, false, false, "T5");
+    } else {
+      step_.resize(mark);   // not this shape: the complex transposes and the line program below
+    }
+  }
+  pseu_from_y4_ = s6_real;
+  if (!s6_real) Tc(yx(DIV_), X_[0].p, ny, kx, true, "T5a");
+  if (!s6_real) {
     ProgramBuilder pb = xpb(2, kx, true);   // slot 1: scratch of the banded back-substitution
     pb.set_fft(yN);
     pb.load(0, pb.arr(X_[0].p, ldy, 2, 1), ny);
@@ -2363,18 +2406,19 @@ void Navier2DEngine::build_periodic() {
     pb.store(0, pb.arr(PS_.p, ldy, 2, 1), my);
     add_line(pb, "S6 y: poisson rows");
   }
-  if (xb(true) == 0)
+  if (!s6_real && xb(true) == 0)
     for (int e = 0; e < 2; ++e) {
       Launch l; l.type = Launch::kSetElem; l.out = PS_.p; l.rows = e; l.tag = "pseu[0,0]=0"; step_.push_back(l);
     }
   // ---- C7: y part of the velocity correction as column scans on the YX pseudo-pressure (colscan.h / colscan1.h, as in the
   // confined step: from_ortho_y(to_ortho_y ps) and from_ortho_y(-d/dy to_ortho_y ps); the interleaved re / im columns are
   // independent columns) -- replaces the y-line program S7 and two of its three transposes
-  Tc(PS_.p, yx(Y_[4]), kx, my, false, "T5");
+  if (!s6_real) Tc(PS_.p, yx(Y_[4]), kx, my, false, "T5");
   add_halo({yx(Y_[4])}, 2, 4, "H2 halo pseu");
   add_col_corr(yx(Y_[4]), 0, yx(Y_[2]), yx(Y_[3]), nc, "C7 y: correction-y (column scan)");
   // ---- S8: x part of the velocity correction
-  {
+  if (!add_per_rows(PerRowsArgs{kPerCorr, ylines(my), yb_, kx, ldx, yx(Y_[2]), yx(Y_[3]), yx(U_), yx(V_), nullptr, my, -1.0 / sx_, 0.0, flagp()},
+                    "S8 x: correction-x", 6.0)) {
     ProgramBuilder pb = ypb(1, my);
     pb.set_fft(xF);
     pb.load(0, pb.arr(yx(Y_[2]), ldx), nc);
@@ -2390,7 +2434,8 @@ void Navier2DEngine::build_periodic() {
     add_line(pb, "S8 x: correction-x");
   }
   // ---- S9: pressure update
-  {
+  if (!add_per_rows(PerRowsArgs{kPerPres, ylines(ny), yb_, kx, ldx, yx(Y_[4]), yx(DIV_), yx(P_), nullptr, yN.low.p, my, 1.0 / dt, -nu_, flagp()},
+                    "S9 x: pressure update", 4.0)) {
     ProgramBuilder pb = ypb(1, ny);
     pb.set_fft(xF);
     pb.loadx(0, pb.arr(yx(Y_[4]), ldx), nc, my, yN.low.p, 1.0 / dt);

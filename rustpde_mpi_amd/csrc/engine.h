@@ -232,7 +232,8 @@ class Navier2DEngine {
   // the step as a list of launches
   struct Launch {
     enum Type { kLine, kTranspose, kGemmPairNT, kGemmPairNN, kSetElem, kHalo, kColHholtz, kColDiff, kDctLine, kDctLine2, kConvLine, kRhsLine,
-                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine, kRfftPair, kFourRhs, kProwLine, kPresLine } type;
+                kSten3Rows, kPdmaCols, kCorrLine, kPdmaLines, kDivLine, kRfftPair, kFourRhs, kProwLine, kPresLine, kPerRows } type;
+    PerRowsArgs pr{};            // kPerRows  (periodic S5 / S8 / S9: element-wise along x, per_rows.h)
     RfftLineArgs rf{}, rf2{};    // kRfftPair (periodic S1: value and x-derivative of a spectral line, rfft_line.h)
     FourRhsArgs fr{};            // kFourRhs  (periodic S3)
     DivLineArgs dvl{};           // kDivLine
@@ -293,6 +294,7 @@ class Navier2DEngine {
   DBuf coldot_, colkap_;             // rank-one sums of the column scans
   int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
   bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)
+  bool pseu_from_y4_ = false;   // periodic step with the real-view S6: the canonical pseu is the complex transpose of Y_[4]
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);
   bool add_dct_line2(const DctLineArgs& a0, const DctLineArgs& a1, const char* tag);
@@ -303,6 +305,7 @@ class Navier2DEngine {
   bool add_corr_line(CorrLineArgs a, const char* tag);            // S8 as one kernel (corr_line.h)
   bool add_div_line(const DivLineArgs& a, const char* tag);       // S5 as one kernel (div_line.h)
   bool add_prow_line(ProwLineArgs a, const char* tag);            // S6 as one kernel (prow_line.h)
+  bool add_per_rows(const PerRowsArgs& a, const char* tag, double arrays);   // periodic S5 / S8 / S9 as element-wise kernels (per_rows.h); arrays: array passes of the stage
   bool add_pres_line(const PresLineArgs& a, const char* tag);     // S9 as one kernel (pres_line.h)
   struct RhsTabs { DBuf t0, t1, t2, q1, p2, q2, r2; };            // chunk-major (16 per thread) tables of rhs_line, per field kind
   RhsTabs rhs_tabs_[2];                                           // 0: velocities (Dirichlet x, nu), 1: temperature (Neumann x, ka)

@@ -798,7 +798,7 @@ bool launch_corr_line(const CorrLineArgs& a, Stream& st) {
   return true;
 }
 template <int N, bool KEEP>
-__global__ __launch_bounds__(N / 16, N == 1024 ? 2 : (KEEP ? 3 : 4)) void prow_line_kernel(const ProwLineArgs a) {
+__global__ __launch_bounds__(N / 16, N <= 2048 ? 2 : (KEEP ? 3 : 4)) void prow_line_kernel(const ProwLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -807,10 +807,11 @@ __global__ __launch_bounds__(N / 16, N == 1024 ? 2 : (KEEP ? 3 : 4)) void prow_l
   prow_line<N, KEEP>(blk, a);
 }
 bool launch_prow_line(const ProwLineArgs& a, Stream& st) {
-  if ((a.N != 4096 && a.N != 1024) || !prow_line_ok(a)) return false;
+  if ((a.N != 4096 && a.N != 2048 && a.N != 1024) || !prow_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
   const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
   if (a.N == 1024) hipLaunchKernelGGL((prow_line_kernel<1024, true>), grid, block, 0, st.s, a);   // one wave per line: registers to spare
+  else if (a.N == 2048) hipLaunchKernelGGL((prow_line_kernel<2048, true>), grid, block, 0, st.s, a);   // two waves per line (2049-point y-lines: BASELINE config 5)
   else if (a.keep) hipLaunchKernelGGL((prow_line_kernel<4096, true>), grid, block, 0, st.s, a);
   else hipLaunchKernelGGL((prow_line_kernel<4096, false>), grid, block, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
@@ -833,6 +834,15 @@ bool launch_pres_line(const PresLineArgs& a, Stream& st) {
   else hipLaunchKernelGGL(pres_line_kernel<4096>, grid, block, 0, st.s, a);
   RPDE_HIP(hipGetLastError());
   return true;
+}
+__global__ __launch_bounds__(256) void per_rows_kernel(const PerRowsArgs a) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x), line = (int)blockIdx.y;
+  if (k < a.kx) per_rows_point(a, line, k);
+}
+void launch_per_rows(const PerRowsArgs& a, Stream& st) {
+  if (a.nlines <= 0 || a.kx <= 0) return;
+  hipLaunchKernelGGL(per_rows_kernel, dim3((a.kx + 255) / 256, a.nlines), dim3(256), 0, st.s, a);
+  RPDE_HIP(hipGetLastError());
 }
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   if ((a.N != 4096 && a.N != 1024) || !rhs_line_ok(a)) return false;
@@ -1503,8 +1513,8 @@ bool launch_prow_line(const ProwLineArgs& a, Stream&) {
   for (int line = 0; line < a.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
-    if (a.keep) { if (a.N == 4096) prow_line<4096, true>(blk, a); else if (a.N == 1024) prow_line<1024, true>(blk, a); else prow_line<256, true>(blk, a); }
-    else if (a.N == 4096) prow_line<4096>(blk, a); else if (a.N == 1024) prow_line<1024>(blk, a); else prow_line<256>(blk, a);
+    if (a.keep) { if (a.N == 4096) prow_line<4096, true>(blk, a); else if (a.N == 2048) prow_line<2048, true>(blk, a); else if (a.N == 1024) prow_line<1024, true>(blk, a); else prow_line<256, true>(blk, a); }
+    else if (a.N == 4096) prow_line<4096>(blk, a); else if (a.N == 2048) prow_line<2048>(blk, a); else if (a.N == 1024) prow_line<1024>(blk, a); else prow_line<256>(blk, a);
   }
   return true;
 }
@@ -1518,6 +1528,10 @@ bool launch_pres_line(const PresLineArgs& a, Stream&) {
     if (a.N == 4096) pres_line<4096>(blk, a); else if (a.N == 1024) pres_line<1024>(blk, a); else pres_line<256>(blk, a);
   }
   return true;
+}
+void launch_per_rows(const PerRowsArgs& a, Stream&) {
+  for (int line = 0; line < a.nlines; ++line)
+    for (int k = 0; k < a.kx; ++k) per_rows_point(a, line, k);
 }
 bool launch_rhs_line(const RhsLineArgs& a, Stream&, long long*) {
   if (!rhs_line_ok(a)) return false;

@@ -10,6 +10,7 @@
 #include "div_line.h"
 #include "prow_line.h"
 #include "pres_line.h"
+#include "per_rows.h"
 
 namespace rpde {
 
@@ -116,6 +117,7 @@ bool launch_div_line(const DivLineArgs& a, Stream& st);     // div_line.h: S5 of
 bool launch_corr_line(const CorrLineArgs& a, Stream& st);   // corr_line.h: S8 of the confined step per x-line
 bool launch_prow_line(const ProwLineArgs& a, Stream& st);   // prow_line.h: S6 of the confined step per eigen row
 bool launch_pres_line(const PresLineArgs& a, Stream& st);   // pres_line.h: S9 of the confined step per x-line
+void launch_per_rows(const PerRowsArgs& a, Stream& st);     // per_rows.h: S5 / S8 / S9 of the periodic step, one thread per complex number
 bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace = nullptr);   // rhs_line.h: S3 of the confined step per x-line
 // one y-line of a convection term: two backward transforms, the physical products, the forward transform with the
 // 2/3 rule, all in registers + one exchange buffer (dct_line.h conv_line; three workgroups per CU)

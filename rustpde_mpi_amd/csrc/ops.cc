@@ -342,6 +342,16 @@ void Space2Ops::run_lines(Kind kind, const AxisTables& ax, const double* in, lon
         if (order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order);
       }
       break;
+    case kDiffBackward:
+      if (b.is_cheb()) {
+        pb.to_ortho(0, ax);
+        for (int o = 0; o < order; ++o) pb.cdiff(0, 0, b.n, 1.0 / scale);
+        pb.dct(0, b.n, ax.bwd_pre.p, nullptr);
+      } else {
+        if (order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order);
+        pb.rfft_b(0, b.n);
+      }
+      break;
     case kPinvMatvec: pb.pinv_matvec(0, ax); break;
     case kFdmaSolve: pb.fdma_solve(0, len_in, *fd); break;
     case kDiagSolve: pb.tabdiv(0, 0, len_in, diag, b.is_cheb() ? 0 : 1); break;
@@ -386,6 +396,12 @@ void Space2Ops::run_lines3(Kind kind, const AxisTables& ax, const double* in, lo
       run_lines(kDiff, ox, t.p(), ldt, n, out, ldo, n, nlines, ncomp, st, order, scale, nullptr, nullptr);
       return;
     }
+    case kDiffBackward: {
+      Arr2& t = scr_.get(3, nlines, n, ncomp);
+      sten3(in, ldi, t.p(), ldt);
+      run_lines(kDiffBackward, ox, t.p(), ldt, n, out, ldo, n, nlines, ncomp, st, order, scale, nullptr, nullptr);
+      return;
+    }
     case kForwardOrtho: case kBackwardOrtho: case kPinvMatvec:
       run_lines(kind, ox, in, ldi, len_in, out, ldo, len_out, nlines, ncomp, st, order, scale, nullptr, nullptr);
       return;
@@ -413,6 +429,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
       case kBackwardOrtho: return input ? no : n;
       case kBackward: return input ? m : n;
       case kDiff: return input ? m : no;
+      case kDiffBackward: return input ? m : n;
       case kPinvMatvec: return input ? n : n - 2;
       case kFdmaSolve: case kDiagSolve: return m;
     }
@@ -429,7 +446,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
   // axis 0: transpose, run along the now contiguous axis, transpose back
   const bool fourier = !b.is_cheb();
   const bool real_to_cplx = fourier && (kind == kForwardOrtho || kind == kForward);
-  const bool cplx_to_real = fourier && (kind == kBackwardOrtho || kind == kBackward);
+  const bool cplx_to_real = fourier && (kind == kBackwardOrtho || kind == kBackward || kind == kDiffBackward);
   RPDE_REQUIRE(in.rows == li && out.rows == lo && in.cols == out.cols, "shape mismatch in axis-0 operator");
   const int ncols = in.cols;
   scr_.enter(st);
@@ -442,7 +459,7 @@ void Space2Ops::apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Strea
     const int ai = pb.arr(tin.p(), tin.ld), ao = pb.arr(tout.p(), tout.ld);
     pb.load(0, ai, li * in.elem);
     if (real_to_cplx) pb.rfft_f(0, b.n);
-    else if (cplx_to_real) pb.rfft_b(0, b.n);
+    else if (cplx_to_real) { if (kind == kDiffBackward && order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order); pb.rfft_b(0, b.n); }
     else if (kind == kDiff) { if (order > 0) pb.cik(0, 0, b.m, 1.0 / scale, order); }
     else if (kind == kDiagSolve) pb.tabdiv(0, 0, 2 * b.m, diag, 1);
     else if (kind == kToOrtho || kind == kFromOrtho) {}
@@ -498,6 +515,15 @@ void Space2Ops::gradient(const Arr2& vhat, int d0, int d1, double s0, double s1,
   Arr2& t = scr_.get(2, ortho_rows(), spec_cols(), elem());
   apply_axis(kDiff, 0, vhat, t, st, d0, s0);
   apply_axis(kDiff, 1, t, out, st, d1, s1);
+}
+
+void Space2Ops::gradient_backward(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& phys, Stream& st) {
+  RPDE_REQUIRE(phys.rows == phys_rows() && phys.cols == phys_cols() && phys.elem == 1, "gradient_backward: bad output shape");
+  RPDE_REQUIRE(vhat.rows == spec_rows() && vhat.cols == spec_cols() && vhat.elem == elem(), "gradient_backward: bad input shape");
+  scr_.enter(st);
+  Arr2& t = scr_.get(2, phys_rows(), spec_cols(), 1);
+  apply_axis(kDiffBackward, 0, vhat, t, st, d0, s0);   // axis 0 first: a Fourier axis turns the complex coefficients into real rows
+  apply_axis(kDiffBackward, 1, t, phys, st, d1, s1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -626,12 +652,13 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
 // tensor Helmholtz operators of the adjoint solver, the generic operator API and RPDE_S6_LINE=0 never carried a use for.
 bool PoissonOp::ensure_rows16() {
   if (rows16.n > 0) return true;
-  const Base &b0 = sp.base(0), &b1 = sp.base(1);
+  const Base& b1 = sp.base(1);
   const int m1 = b1.m, N16 = m1 + 1;
+  // (a Fourier x axis too: the rows of the periodic step's S6 are the wavenumbers)
 #ifdef RPDE_EMU
-  const bool want16 = b0.is_cheb() && (N16 == 256 || N16 == 1024 || N16 == 4096);
+  const bool want16 = N16 == 256 || N16 == 1024 || N16 == 2048 || N16 == 4096;
 #else
-  const bool want16 = b0.is_cheb() && (N16 == 1024 || N16 == 4096);
+  const bool want16 = N16 == 1024 || N16 == 2048 || N16 == 4096;
 #endif
   const int rb = rows_rb_, re = rows_re_;
   if (!want16 || re <= rb) return false;

@@ -200,10 +200,15 @@ class Space2Ops {
   void to_ortho(const Arr2& vhat, Arr2& out, Stream& st);
   void from_ortho(const Arr2& in, Arr2& vhat, Stream& st);
   void gradient(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& out, Stream& st);
+  // backward_ortho(gradient(vhat, [d0, d1], [s0, s1])) -- what `conv_term` needs of a field (functions.rs:56-69): the two
+  // factors of an axis are one line program (stencil, derivative recurrence, inverse transform), so the pair costs two
+  // line programs and two transposes instead of four and four
+  void gradient_backward(const Arr2& vhat, int d0, int d1, double s0, double s1, Arr2& phys, Stream& st);
 
   // single-axis building blocks on canonical arrays (axis 0 goes through a transposed copy)
   enum Kind { kToOrtho, kFromOrtho, kForwardOrtho, kBackwardOrtho, kForward, kBackward, kDiff,
-              kPinvMatvec, kFdmaSolve, kDiagSolve };
+              kPinvMatvec, kFdmaSolve, kDiagSolve,
+              kDiffBackward };   // derivative (order, scale) and backward transform of a composite line in one line program
   // kFdmaSolve along a three-term axis takes `pd` (PdmaPlus2) instead of `fd`
   void apply_axis(Kind kind, int axis, const Arr2& in, Arr2& out, Stream& st, int order = 0,
                   double scale = 1.0, const FdmaDev* fd = nullptr, const double* diag = nullptr,

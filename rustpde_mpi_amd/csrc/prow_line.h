@@ -29,9 +29,11 @@ struct ProwLineArgs {
   const double *p2 = nullptr, *q2 = nullptr, *r2 = nullptr;   // per line: back substitution, chunk-major DESCENDING
   long tabld = 0;                 // = N doubles: 16 T entries per line
   int keep = 1;                   // 4097-point lines: the KEEP form of prow_line (three workgroups per CU); 0: the factors read twice at four (RPDE_S6_KEEP, A/B)
+  int tdiv = 1;                   // lines per factor row: 2 in the periodic step, where the real and the imaginary part of a wavenumber's
+                                  // row are two consecutive real lines (engine.cc build_periodic: real-view transposes around S6)
 };
 RPDE_HD inline bool prow_line_ok(const ProwLineArgs& a) {
-  return (a.N == 256 || a.N == 1024 || a.N == 4096) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.q1 && a.p2 && a.q2 && a.r2 &&
+  return (a.N == 256 || a.N == 1024 || a.N == 2048 || a.N == 4096) && (a.tdiv == 1 || a.tdiv == 2) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.q1 && a.p2 && a.q2 && a.r2 &&
          ((((size_t)a.in) | ((size_t)a.out)) & 15) == 0 && (a.ld & 1) == 0 && a.ld > a.N + 1 && a.tabld == a.N;
 }
 
@@ -45,7 +47,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   lds_t buf = (lds_t)blk.lds;
   lds_t scr = buf + G::SCR;
   const long off = (long)blk.line * a.ld;
-  const long toff = (long)(blk.line + a.line0) * a.tabld;
+  const long toff = (long)((blk.line + a.line0) / a.tdiv) * a.tabld;
   const int n = N - 1;
 
   // ---- the line into the padded buffer: f_k at index k + k / 16 + 2, zeros behind it (the taps reach k + 4)

@@ -191,6 +191,39 @@ def test_s9_pressure_update_as_one_kernel(emu_lib, monkeypatch):
         assert K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat) < 1e-12, (k, K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat))
 
 
+def check_periodic_rows_ab(lib, monkeypatch, nx, ny, steps=4, bc="rbc"):
+    """S5 / S8 / S9 of the PERIODIC step as element-wise kernels (csrc/per_rows.h: one thread per complex number, the default)
+    against the same stages as line programs (RPDE_PER_ROWS=0), same engine, same setup data; both meet the oracle."""
+    K.check_step_parity(lib, True, nx, ny, 1e5, 0.01, steps, check_at=[1, steps], bc=bc)
+    nav, _ = K.make_pair(lib, True, nx, ny, 1e5, 1.0, 0.01, 1.0, bc=bc)
+    kinds = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert all(kinds[t] == "element-wise rows" for t in ("S5 x: div", "S8 x: correction-x", "S9 x: pressure update")), kinds
+    nav.update(steps)
+    monkeypatch.setenv("RPDE_PER_ROWS", "0")
+    nav0, _ = K.make_pair(lib, True, nx, ny, 1e5, 1.0, 0.01, 1.0, bc=bc)
+    assert all(_has_line_program(nav0, t) for t in ("S5 x", "S8 x", "S9 x"))
+    nav0.update(steps)
+    monkeypatch.delenv("RPDE_PER_ROWS")
+    assert nav.exit() is False and nav0.exit() is False
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat) < 1e-12, (k, K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat))
+
+
+@pytest.mark.parametrize("nx,ny,bc", [(64, 33, "rbc"), (18, 13, "rbc"), (256, 65, "rbc"), (32, 33, "hc")])
+def test_periodic_elementwise_stages_equal_line_programs(emu_lib, monkeypatch, nx, ny, bc):
+    check_periodic_rows_ab(emu_lib, monkeypatch, nx, ny, bc=bc)
+
+
+def test_periodic_elementwise_stages_raise_the_nan_flag(emu_lib):
+    """The stores of S8 / S9 are the device side of Integrate::exit (navier.rs:482-489): a NaN in the state must raise the flag."""
+    nav, _ = K.make_pair(emu_lib, True, 32, 17, 1e5, 1.0, 0.01, 1.0)
+    v = nav.velx.vhat.copy()
+    v[3, 2] = np.nan
+    nav.velx.vhat = v
+    nav.update(1)
+    assert nav.exit() is True
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 def test_step_with_the_convection_terms_through_the_whole_line_kernel(emu_lib, monkeypatch, periodic):
     """conv_velx / conv_vely / conv_temp as three transforms per y-line in registers (csrc/dct_line.h conv_line);

@@ -295,6 +295,12 @@ def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
         assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (stage, k)
 
 
+@pytest.mark.parametrize("nx,ny,bc", [(64, 33, "rbc"), (18, 13, "rbc"), (4096, 257, "rbc"), (1000, 129, "rbc"), (256, 129, "hc")])
+def test_periodic_elementwise_stages_equal_line_programs(hip_lib, monkeypatch, nx, ny, bc):
+    from tests.test_emu_parity import check_periodic_rows_ab
+    check_periodic_rows_ab(hip_lib, monkeypatch, nx, ny, steps=3, bc=bc)
+
+
 @pytest.mark.parametrize("switch", ["RPDE_WHOLE_LINE", "RPDE_LINE_BATCH", "RPDE_S1_PAIR"])
 def test_whole_line_kernels_equal_line_programs_1025(hip_lib, monkeypatch, switch):
     """1025 x 1025 (BASELINE configs[1]): the whole-line kernels of 1025-point lines (one wave per line, the half-length core,

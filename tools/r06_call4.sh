@@ -3,10 +3,10 @@
 # GPU parity tests, first bench lines (with CPU oracle + parity legs), a rocprofv3 kernel summary of one adjoint update.
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r06d
+O=$R/gpurun_out/${RPDE_CALL_DIR:-r06d}
 rm -rf $O; mkdir -p $O
 export RPDE_EIG_CACHE=/tmp/rpde_eig; mkdir -p $RPDE_EIG_CACHE
-timeout 900 python -m pytest tests/test_adjoint.py -m gpu -q -x 2>&1 | grep -v "mean.h5\|Gloo" | tail -6 > $O/pytest_adjoint.txt; cat $O/pytest_adjoint.txt
+timeout 900 python -m pytest tests/test_adjoint.py tests/test_general_lengths.py -m gpu -q -x -k "adjoint or lnse or nonlin or gradient" 2>&1 | grep -v "mean.h5\|Gloo" | tail -6 > $O/pytest_adjoint.txt; cat $O/pytest_adjoint.txt
 for sv in adjoint lnse lnse_adjoint nonlin; do
   timeout 600 python bench.py --solver $sv --nx 1025 --ny 1025 --ra 1e5 --dt 0.01 --steps 20 --warmup 3 --cpu-steps 2 2> $O/bench_${sv}_1025.err | grep '^{' > $O/bench_${sv}_1025.json
   python -c "import json,sys; d=json.load(open('$O/bench_${sv}_1025.json')); print('$sv', round(d['ms_per_step'],3), 'ms/update; cpu', round(1e3/d['cpu_baseline']['value'],1), 'ms; parity', d['parity']['rel_l2'], d['parity']['ok'])" 2>&1 | tail -1
