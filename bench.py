@@ -570,7 +570,15 @@ def main():
         sent, nx_ = nav.comm_stats()
         out["exchange"] = {"alltoalls_per_step": nx_, "bytes_sent_per_gpu_per_step": sent,
                            "GB/s_per_gpu": sent * args.steps / elapsed / 1e9,
-                           "xgmi_peak_GB/s_per_gpu": 7 * 153.0}
+                           "xgmi_peak_GB/s_per_gpu": 7 * 153.0,
+                           # every exchange of one step as rank 0 saw it in the profile pass (HIP events around pack + all-to-all +
+                           # unpack, serial order): the measured form of DESIGN.md section 6's table; bytes = algorithmic bytes of
+                           # the launch on this rank (an array transpose: its 1 / P share read and written once)
+                           "per_exchange": [{"tag": r["tag"], "per_step": r["launches"] / args.profile_steps,
+                                             "ms": round(r["ms_total"] / r["launches"], 4), "bytes": r["bytes"]}
+                                            for r in prof if r["tag"][0] in "TH" or "summary" in r["tag"]],
+                           "ms_per_step_in_exchanges": round(sum(r["ms_total"] for r in prof if r["tag"][0] in "TH" or "summary" in r["tag"])
+                                                             / args.profile_steps, 4)}
     if world == 1 and not args.no_cpu_baseline:
         eig = None if args.periodic else nav.poisson_eigenbasis()
         del nav   # free the timed engine's HBM before the parity engine is built

@@ -100,11 +100,20 @@ void rccl_comm_destroy(RcclComm* c) {
 void rccl_alltoallv(RcclComm* c, const double* send, const int64_t* sc, double* recv, const int64_t* rc,
                     Stream& st) {
   const Api& a = api();
+  // the block a rank keeps (the diagonal block of the pencil transpose: 1 / P of the array) is a device-to-device copy on the
+  // same stream, not a send to itself through the communicator; the P - 1 others go out as one group, one message per peer
+  size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
+  for (int q = 0; q < c->rank; ++q) { self_so += (size_t)sc[q]; self_ro += (size_t)rc[q]; }
+  RPDE_REQUIRE(sc[c->rank] == rc[c->rank], "alltoallv: a rank sends itself what it receives from itself");
+  if (sc[c->rank] > 0)
+    RPDE_HIP(hipMemcpyAsync(recv + self_ro, send + self_so, (size_t)sc[c->rank] * sizeof(double), hipMemcpyDeviceToDevice, st.s));
+  if (c->size == 1) return;
   check(a.GroupStart(), "ncclGroupStart");
-  size_t so = 0, ro = 0;
   for (int q = 0; q < c->size; ++q) {
-    if (sc[q] > 0) check(a.Send(send + so, (size_t)sc[q], ncclDouble, q, c->comm, st.s), "ncclSend");
-    if (rc[q] > 0) check(a.Recv(recv + ro, (size_t)rc[q], ncclDouble, q, c->comm, st.s), "ncclRecv");
+    if (q != c->rank) {
+      if (sc[q] > 0) check(a.Send(send + so, (size_t)sc[q], ncclDouble, q, c->comm, st.s), "ncclSend");
+      if (rc[q] > 0) check(a.Recv(recv + ro, (size_t)rc[q], ncclDouble, q, c->comm, st.s), "ncclRecv");
+    }
     so += (size_t)sc[q]; ro += (size_t)rc[q];
   }
   check(a.GroupEnd(), "ncclGroupEnd");

@@ -56,4 +56,6 @@ def test_bench_line_contract_two_ranks(emu_lib):
     assert d["scaling"] == "strong" and d["value"] > 0 and d["ms_per_step"] > 0
     assert "pencil-sharded over 2 GPUs" in d["config"]["parallelism"] and "torch-gloo" in d["config"]["parallelism"]
     assert d["exchange"]["alltoalls_per_step"] > 0 and d["exchange"]["bytes_sent_per_gpu_per_step"] > 0
+    per = d["exchange"]["per_exchange"]                # every exchange of a step with its time (the measured form of DESIGN.md 6's table)
+    assert {"T1", "T2", "T4b", "T4c"} <= {r["tag"] for r in per} and all(r["ms"] > 0 for r in per) and d["exchange"]["ms_per_step_in_exchanges"] > 0
     assert "cpu_baseline" not in d                     # rank 0 at N = 1 only
