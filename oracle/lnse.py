@@ -38,6 +38,20 @@ class MeanFields:
         m.temp.forward()
         return m
 
+    @classmethod
+    def new_hc(cls, space):
+        """``new_hc_confined / new_hc_periodic`` (meanfield.rs:52-86, 154-188): no mean flow; per x a parabola in y with its
+        vertex (value 0, slope 0) at the top wall and the value -0.5 cos(2 pi (x - x0) / L) at the bottom wall; forward and
+        backward transformed like the reference does."""
+        m = cls(space)
+        x, y = m.temp.x
+        f_x = -0.5 * np.cos(2.0 * np.pi * (x - x[0]) / (x[-1] - x[0]))
+        a = f_x / (y[0] - y[-1]) ** 2
+        m.temp.v[:, :] = a[:, None] * ((y - y[-1]) ** 2)[None, :]
+        m.temp.forward()
+        m.temp.backward()
+        return m
+
     def set_physical(self, name, v):
         f = getattr(self, name)
         f.v = np.array(v, dtype=np.float64, copy=True)
@@ -46,8 +60,9 @@ class MeanFields:
 
 class Navier2DLnse:
     def __init__(self, nx, ny, ra, pr, dt, aspect, bc, periodic, eig_mode="full"):
-        if bc != "rbc":
-            raise ValueError(f"Boundary condition type {bc!r} not supported by this oracle")
+        if bc not in ("rbc", "hc"):              # lnse.rs:115-119, 202-206 / nonlin.rs:117-121, 208-212
+            raise ValueError(f"Boundary condition type {bc!r} not recognized!")
+        temp_y = B.cheb_dirichlet if bc == "rbc" else B.cheb_dirichlet_neumann
         self.periodic, self.nx, self.ny = periodic, nx, ny
         self.scale = scale = [aspect, 1.0]
         nu = get_nu(ra, pr, scale[1] * 2.0)
@@ -61,17 +76,17 @@ class Navier2DLnse:
             self.vely = Field2(S(bx(nx), B.cheb_dirichlet(ny)))
             self.pres = Field2(S(bx(nx), B.chebyshev(ny)))
             self.pseu = Field2(S(bx(nx), B.cheb_neumann(ny)))
-            self.temp = Field2(S(bx(nx), B.cheb_dirichlet(ny)))
+            self.temp = Field2(S(bx(nx), temp_y(ny)))
         else:
             self.field = Field2(S(B.chebyshev(nx), B.chebyshev(ny)))
             self.velx = Field2(S(B.cheb_dirichlet(nx), B.cheb_dirichlet(ny)))
             self.vely = Field2(S(B.cheb_dirichlet(nx), B.cheb_dirichlet(ny)))
             self.pres = Field2(S(B.chebyshev(nx), B.chebyshev(ny)))
             self.pseu = Field2(S(B.cheb_neumann(nx), B.cheb_neumann(ny)))
-            self.temp = Field2(S(B.cheb_neumann(nx), B.cheb_dirichlet(ny)))
+            self.temp = Field2(S(B.cheb_neumann(nx), temp_y(ny)))
         for f in (self.velx, self.vely, self.temp, self.pres):
             f.scale(scale)
-        self.mean = MeanFields.new_rbc(self.field.space)
+        self.mean = MeanFields.new_rbc(self.field.space) if bc == "rbc" else MeanFields.new_hc(self.field.space)   # meanfield.rs:112-119
         c_nu = [dt * nu / scale[0] ** 2, dt * nu / scale[1] ** 2]
         c_ka = [dt * ka / scale[0] ** 2, dt * ka / scale[1] ** 2]
         self.solver_hholtz = [HholtzAdi(self.velx.space, c_nu), HholtzAdi(self.vely.space, c_nu), HholtzAdi(self.temp.space, c_ka)]

@@ -88,8 +88,7 @@ GenericFlow2D::GenericFlow2D(int nx, int ny, double ra, double pr, double dt, do
                              double dt_helmholtz, std::initializer_list<const char*> extra_fields)
     : nx_(nx), ny_(ny), ex_(periodic ? 2 : 1), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");
-  RPDE_REQUIRE(bc == "rbc", "bc = \"hc\" is not supported by this solver (Navier2DAdjoint: the reference builds its four-diagonal tensor "
-                            "solver Hholtz on the three-term base cheb_dirichlet_neumann, steady_adjoint.rs:312-318, which Fdma cannot hold)");
+  hc_ = bc == "hc";
   RPDE_REQUIRE(nx >= 8 && ny >= 8, "grid too small");
   RPDE_REQUIRE(!periodic || nx % 2 == 0, "fourier_r2c needs an even number of points");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
@@ -102,7 +101,8 @@ GenericFlow2D::GenericFlow2D(int nx, int ny, double ra, double pr, double dt, do
   const BaseKind bx_tmp = periodic ? kFourierR2c : kChebNeumann;
   const BaseKind bx_ort = periodic ? kFourierR2c : kChebyshev;
   sp_vel_ = std::make_unique<Space2Ops>(make_base(bx_vel, nx), make_base(kChebDirichlet, ny));
-  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebDirichlet, ny));
+  // "hc" (lnse.rs:115-119, 202-206; nonlin.rs:117-121, 208-212): Dirichlet at the bottom, Neumann at the top -- the three-term base
+  sp_temp_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(hc_ ? kChebDirichletNeumann : kChebDirichlet, ny));
   sp_ortho_ = std::make_unique<Space2Ops>(make_base(bx_ort, nx), make_base(kChebyshev, ny));
   sp_pseu_ = std::make_unique<Space2Ops>(make_base(bx_tmp, nx), make_base(kChebNeumann, ny));
   hh_vel_ = std::make_unique<HholtzAdiOp>(*sp_vel_, dt_helmholtz * nu_ / (sx_ * sx_), dt_helmholtz * nu_ / (sy_ * sy_));
@@ -134,16 +134,39 @@ GenericFlow2D::GenericFlow2D(int nx, int ny, double ra, double pr, double dt, do
     Vec prof((size_t)nx * ny);
     for (int i = 0; i < nx; ++i)
       for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = m * y[j] + n;
+    if (hc_) prof = hc_profile();   // bc_hc (boundary_conditions.rs:96-134 / 163-202)
     dev_upload2d(ph_.p(), ph_.ld, prof.data(), nx, ny);
     sp_ortho_->forward(ph_, field("tempbc").vhat, st_);
   }
   dev_sync(st_);
 }
 
+// per x a parabola in y with its vertex (value 0, slope 0) at the top wall y[n-1] and the value -0.5 cos(2 pi (x - x0) / L) at the
+// bottom wall y[0]: the lift bc_hc (boundary_conditions.rs:96-134 / 163-202) and the default mean temperature of "hc"
+// (MeanFields::new_hc_confined / _periodic, meanfield.rs:52-86, 154-188)
+Vec GenericFlow2D::hc_profile() const {
+  const Vec x = base_coords(sp_ortho_->base(0)), y = base_coords(sp_ortho_->base(1));
+  const double x0 = x.front(), length = x.back() - x.front(), d = y.front() - y.back();
+  Vec prof((size_t)nx_ * ny_);
+  for (int i = 0; i < nx_; ++i) {
+    const double a = -0.5 * std::cos(2.0 * M_PI * (x[i] - x0) / length) / (d * d);
+    for (int j = 0; j < ny_; ++j) prof[(size_t)i * ny_ + j] = a * (y[j] - y.back()) * (y[j] - y.back());
+  }
+  return prof;
+}
+
+static const std::string& adjoint_bc(const std::string& bc) {
+  // bc = "rbc" ("hc": the reference builds its four-diagonal tensor solver Hholtz on the three-term base cheb_dirichlet_neumann,
+  // steady_adjoint.rs:312-318, which its Fdma cannot hold; refused here by name)
+  RPDE_REQUIRE(bc != "hc", "bc = \"hc\" is not supported by Navier2DAdjoint (the reference builds its four-diagonal tensor solver Hholtz on "
+                           "the three-term base cheb_dirichlet_neumann, steady_adjoint.rs:312-318, which Fdma cannot hold)");
+  return bc;
+}
+
 Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
                                              const std::string& bc, bool periodic)
     // the Helmholtz solvers of the FORWARD step run on DT_NAVIER (steady_adjoint.rs:273-295)
-    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, bc, periodic, kDtNavier, {"velx_adj", "vely_adj", "temp_adj", "pres_adj"}) {
+    : GenericFlow2D(nx, ny, ra, pr, dt, aspect, adjoint_bc(bc), periodic, kDtNavier, {"velx_adj", "vely_adj", "temp_adj", "pres_adj"}) {
   // smoother (1 - weight D2) (steady_adjoint.rs:300-322): velx and vely live in the same space -> one solver serves both
   norm_vel_ = std::make_unique<TensorHholtzOp>(*sp_vel_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
   norm_temp_ = std::make_unique<TensorHholtzOp>(*sp_temp_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
@@ -562,6 +585,7 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
     Vec prof((size_t)nx * ny);
     for (int i = 0; i < nx; ++i)
       for (int j = 0; j < ny; ++j) prof[(size_t)i * ny + j] = -(y[j] - y.front()) / height + 0.5;
+    if (hc_) prof = hc_profile();   // MeanFields::new_hc_confined / _periodic (meanfield.rs:52-86, 154-188)
     set_mean_physical("temp", prof.data(), prof.size());
   }
   refresh_mean();

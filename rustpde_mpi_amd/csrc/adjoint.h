@@ -67,7 +67,8 @@ class GenericFlow2D {
   std::vector<std::string> snapshot_fields_{"velx", "vely", "temp", "pres", "tempbc"};   // write(): group names ux uy temp pres tempbc
 
   int nx_, ny_, ex_;
-  bool periodic_;
+  bool periodic_, hc_ = false;
+  Vec hc_profile() const;
   double ra_, pr_, nu_, ka_, dt_, sx_, sy_, time_ = 0.0;
   Stream st_;
   std::unique_ptr<Space2Ops> sp_vel_, sp_temp_, sp_ortho_, sp_pseu_;
@@ -84,7 +85,7 @@ class Navier2DAdjointEngine : public GenericFlow2D {
   static constexpr double kWeightLaplacian = 1e-1;  // WEIGHT_LAPLACIAN steady_adjoint.rs:62
   static constexpr double kDtNavier = 1e-3;         // DT_NAVIER        steady_adjoint.rs:64
 
-  // Navier2DAdjoint::new_confined / new_periodic (steady_adjoint.rs:215-370, 372-531); bc = "rbc" ("hc": the reference
+  // Navier2DAdjoint::new_confined / new_periodic (steady_adjoint.rs:215-370, 372-531); bc = "rbc" (Navier2DLnse / Navier2DNonLin take "hc" too; here "hc": the reference
   // builds Hholtz -- a four-diagonal FdmaTensor -- on the three-term base cheb_dirichlet_neumann, which its Fdma cannot hold;
   // refused here)
   Navier2DAdjointEngine(int nx, int ny, double ra, double pr, double dt, double aspect, const std::string& bc, bool periodic);

@@ -2129,15 +2129,18 @@ void Navier2DEngine::build_confined() {
     GemmProblem g0{po.me, my, po.me, po.bwd_e.p(), po.bwd_e.ld, X_[1].p, ldy, yx(Y_[4]), ldx};
     GemmProblem g1{po.mo, my, po.mo, po.bwd_o.p(), po.bwd_o.ld, X_[1].p + (size_t)po.me * ldy, ldy, yx(Y_[4]) + po.half, ldx};
     g0.ct = g1.ct = true;
+    g0.zero00 = true;           // pseu[0, 0] = 0 (solve_pres, navier_eq.rs:158-162): x = 0 is in the even block, first row of the YX array
     add_gemm_pair(true, g0, g1, "G2 even + odd");
   } else {
     T(X_[1].p, yx(Y_[2]), mx, my, false, "T4c");
     // pseu[j, i] = sum_k g[j, k] bwd[i, k]; the two parity blocks land side by side in x, like on one GPU
-    add_gemm_pair(false, GemmProblem{myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[4]), ldx},
-                  GemmProblem{myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld, yx(Y_[4]) + po.half, ldx},
-                  "G2 even + odd");
+    GemmProblem g0{myl, po.me, po.me, yx(Y_[2]), ldx, po.bwd_e.p(), po.bwd_e.ld, yx(Y_[4]), ldx};
+    const GemmProblem g1{myl, po.mo, po.mo, yx(Y_[2]) + po.me, ldx, po.bwd_o.p(), po.bwd_o.ld, yx(Y_[4]) + po.half, ldx};
+    const bool both = g0.M > 0 && g0.N > 0 && g1.M > 0 && g1.N > 0;   // (the pair launcher folds the zeroed element in only then)
+    g0.zero00 = yb_ == 0 && both;
+    add_gemm_pair(false, g0, g1, "G2 even + odd");
+    if (yb_ == 0 && !both) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
   }
-  if (yb_ == 0) { Launch l; l.type = Launch::kSetElem; l.out = yx(Y_[4]); l.tag = "pseu[0,0]=0"; step_.push_back(l); }
   // ---- C7: y part of the velocity correction as column scans: from_ortho_y(to_ortho_y ps) and
   // from_ortho_y(-d/dy to_ortho_y ps), columns interleaved on the way out (no S7, no T5)
   add_halo({yx(Y_[4])}, 2, 4, "H2 halo pseu");
@@ -2383,13 +2386,11 @@ void Navier2DEngine::build_periodic() {
   if (comm_.size == 1 && (ldy & 1) == 0) {
     ProwLineArgs pl;
     pl.in = X_[0].p; pl.out = X_[1].p; pl.ld = ldy / 2; pl.nlines = nc; pl.line0 = 0; pl.N = ny - 1; pl.tdiv = 2;
+    pl.zero0 = 1;               // pseu[0, 0] = 0 (navier_eq.rs:158-162) in the store of wavenumber 0's two lines
     const size_t mark = step_.size();
     add_transpose(yx(DIV_), ldx, X_[0].p, ldy / 2, ny, nc, 1, true, false, "T5a");
     if (add_prow_line(pl, "S6 y: poisson rows")) {
       s6_real = true;
-      for (int e = 0; e < 2; ++e) {
-        Launch l; l.type = Launch::kSetElem; l.out = X_[1].p; l.rows = e * (int)(ldy / 2); l.tag = "pseu[0,0]=0"; step_.push_back(l);
-      }
       add_transpose(X_[1].p, ldy / 2, yx(Y_[4]), ldx, nc, my, 1, false, false, "T5");
     } else {
       step_.resize(mark);   // not this shape: the complex transposes and the line program below

@@ -32,7 +32,7 @@ constexpr long kGemmSmallTileBelow = 512;   // fewer 128 x 128 tiles than this (
 // two independent products in one launch (blockIdx.z picks): the even and the odd block of the Poisson
 // eigen-transforms.  512 tiles are exactly one round on 256 CUs with two workgroups each -- prologue, epilogue
 // and the store burst of a round are not hidden; 1024 tiles give every CU a second round to overlap them with
-struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; bool ct; };
+struct GemmArgs { int M, N, K; const double* A; long lda; const double* B; long ldb; double* C; long ldc; bool ct; bool z00; };
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own: in the linear
 // order an XCD works on a few n-tiles of EVERY m-tile, so each of the 8 L2s pulls the whole A operand (measured:
 // 2.4 x the operand bytes).  With rx * ry = 8 rectangular regions of bw x bh tiles, one per XCD, the panels an L2
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 template <bool NN, int TM, bool OLD = true, int LAY = 0>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
-                                                 int tile_m, int tile_n, bool ct = false) {
+                                                 int tile_m, int tile_n, bool ct = false, bool z00 = false) {
   constexpr int BK = 16, KS = 4;
   constexpr int MT = TM / 32;          // MFMA tiles per wave and dimension
   constexpr int TPR = 256 / TM;        // threads per operand row (k contiguous)
@@ -291,7 +291,8 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM / 2) + i * 16 + l4 + 4 * r;
         // ct: C^T -- the four lanes of a column write 32 contiguous bytes of row n, the four registers the 128 bytes
-        if (m < M && n < N) C[ct ? (long)n * ldc + m : (long)m * ldc + n] = acc[i][j][r];
+        // z00: the element (0, 0) leaves as 0 (GemmProblem::zero00 -- pseu[0, 0] = 0 without a launch of its own)
+        if (m < M && n < N) C[ct ? (long)n * ldc + m : (long)m * ldc + n] = (z00 && (m | n) == 0) ? 0.0 : acc[i][j][r];
       }
     }
 }
@@ -316,11 +317,11 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
   gemm_tile_of_block(z, tx, ty);
   const GemmArgs& g = blockIdx.z ? g1 : g0;
   if (ty * TM >= g.M || tx * TM >= g.N) return;
-  if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else if constexpr (DB == 3) gemm_f64_db_tile<NN, 128, true>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else if constexpr (DB == 4) gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);   // LDS layout 1
-  else if constexpr (DB == 5) gemm_f64_db_tile<NN, 64, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
-  else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+  if constexpr (DB == 2) gemm_f64_db_tile<NN, 64>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
+  else if constexpr (DB == 3) gemm_f64_db_tile<NN, 128, true>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
+  else if constexpr (DB == 4) gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);   // LDS layout 1
+  else if constexpr (DB == 5) gemm_f64_db_tile<NN, 64, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
+  else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
 }
 
 // RPDE_GEMM_PERSIST=1 (A/B, round 6): a workgroup works off its tile of BOTH problems one after the other instead of the two
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pair_persist_kernel(const Gem
   for (int zz = 0; zz < 2; ++zz) {
     const GemmArgs& g = zz ? g1 : g0;
     if (!(ty * 128 >= g.M || tx * 128 >= g.N))
-      gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct);
+      gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
     __syncthreads();
   }
 }
@@ -365,7 +366,7 @@ static void launch_gemm(int M, int N, int K, const double* A, long lda, const do
 }
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st) {
   if (p0.M <= 0 || p0.N <= 0 || p1.M <= 0 || p1.N <= 0) {
-    RPDE_REQUIRE(!(p0.ct || p1.ct), "transposed store: both problems must be non-empty");
+    RPDE_REQUIRE(!(p0.ct || p1.ct || p0.zero00 || p1.zero00), "transposed store / zeroed element: both problems must be non-empty");
     for (const GemmProblem* p : {&p0, &p1}) {
       if (nn) launch_gemm<true>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
       else launch_gemm<false>(p->M, p->N, p->K, p->A, p->lda, p->B, p->ldb, p->C, p->ldc, st);
@@ -376,7 +377,7 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     if (nn) gemm_require_32bit<true>(p->M, p->N, p->K, p->lda, p->ldb);
     else gemm_require_32bit<false>(p->M, p->N, p->K, p->lda, p->ldb);
   }
-  const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc, p0.ct}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.ct};
+  const GemmArgs g0{p0.M, p0.N, p0.K, p0.A, p0.lda, p0.B, p0.ldb, p0.C, p0.ldc, p0.ct, p0.zero00}, g1{p1.M, p1.N, p1.K, p1.A, p1.lda, p1.B, p1.ldb, p1.C, p1.ldc, p1.ct, p1.zero00};
   const int Mx = std::max(p0.M, p1.M), Nx = std::max(p0.N, p1.N);
   dim3 grid((Nx + 127) / 128, (Mx + 127) / 128, 2);
   const bool lay1 = gemm_lay1();

@@ -1217,6 +1217,7 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     if (p->ct)
       for (int m = 0; m < p->M; ++m)
         for (int n = 0; n < p->N; ++n) p->C[(long)n * p->ldc + m] = tmp[(size_t)m * p->N + n];
+    if (p->zero00) p->C[0] = 0.0;
   }
 }
 void launch_xchg_pack(const XchgDesc& d, double* send, Stream&) {

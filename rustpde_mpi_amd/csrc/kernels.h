@@ -54,7 +54,9 @@ void launch_gemm_nn(int M, int N, int K, const double* A, long lda, const double
 // two independent products of the same kind (nn: both as launch_gemm_nn, else as launch_gemm_nt) in ONE launch
 struct GemmProblem { int M = 0, N = 0, K = 0; const double* A = nullptr; long lda = 0; const double* B = nullptr; long ldb = 0;
                      double* C = nullptr; long ldc = 0;
-                     bool ct = false; };   // ct: store the product transposed, C[n * ldc + m] (launch_gemm_pair only)
+                     bool ct = false;      // ct: store the product transposed, C[n * ldc + m] (launch_gemm_pair only)
+                     bool zero00 = false; };   // the element (m, n) = (0, 0) of the product is stored as 0: `pseu[0, 0] = 0` (solve_pres,
+                                               // navier_eq.rs:158-162) rides in the store of the GEMM that produces pseu (launch_gemm_pair only)
 void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Stream& st);
 
 // out[r * ldo + c] = in[r * ldi + c], r < rows, c < cols (doubles)

@@ -29,6 +29,8 @@ struct ProwLineArgs {
   const double *p2 = nullptr, *q2 = nullptr, *r2 = nullptr;   // per line: back substitution, chunk-major DESCENDING
   long tabld = 0;                 // = N doubles: 16 T entries per line
   int keep = 1;                   // 4097-point lines: the KEEP form of prow_line (three workgroups per CU); 0: the factors read twice at four (RPDE_S6_KEEP, A/B)
+  int zero0 = 0;                  // 1: element 0 of the lines of factor row 0 leaves as 0 -- `pseu[0, 0] = 0` (solve_pres, navier_eq.rs:158-162)
+                                  // of the periodic step rides in the store (both parts of wavenumber 0)
   int tdiv = 1;                   // lines per factor row: 2 in the periodic step, where the real and the imaginary part of a wavenumber's
                                   // row are two consecutive real lines (engine.cc build_periodic: real-view transposes around S6)
 };
@@ -234,7 +236,8 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
     for (int u = 0; u < 8; ++u) {
       const int m = 2 * (tid + u * T);
       const int p = m + (m >> 4) + 2;
-      const dbl2 v = dbl2{buf[p], buf[p + 1]};
+      dbl2 v = dbl2{buf[p], buf[p + 1]};
+      if (m == 0 && a.zero0 && (blk.line + a.line0) / a.tdiv == 0) v.x = 0.0;
       if (m + 1 < n) dst[m >> 1] = v;
       else if (m < n) dst1[m] = v.x;
     }

@@ -261,15 +261,15 @@ def test_emu_adjoint_callback_writes_the_flow_file(emu_lib, tmp_path, monkeypatc
 
 
 # ================================================================================================ Navier2DLnse
-def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=True, tol=1e-10, tol_p=1e-8, adjoint=False):
+def check_lnse_parity(lib, nx, ny, periodic, steps, ra=1e5, dt=0.01, mean_flow=True, tol=1e-10, tol_p=1e-8, adjoint=False, bc="rbc"):
     """Engine vs oracle after every update, with a non-trivial mean flow (a convection roll) on top of the conduction
     profile: u, v, T to `tol`, pres / pseu to `tol_p` (the Poisson solve's amplified eigenvector round-off)."""
     from oracle import lnse as L
     mk_e = R.Navier2DLnse.new_periodic if periodic else R.Navier2DLnse.new_confined
     mk_o = L.Navier2DLnse.new_periodic if periodic else L.Navier2DLnse.new_confined
-    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
-    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
-    assert rel(nav.mean_temp.v, ora.mean.temp.v) < 1e-13                  # the default mean: conduction profile, no flow
+    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, bc, library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, bc, eig_mode="parity")
+    assert rel(nav.mean_temp.v, ora.mean.temp.v) < 1e-13                  # the default mean: conduction profile ("hc": the parabolas of meanfield.rs:52-86), no flow
     assert np.abs(nav.mean_velx.v).max() == 0.0
     if mean_flow:
         x, y = ora.velx.x
@@ -413,6 +413,18 @@ def test_emu_lnse_step_parity(emu_lib, nx, ny, periodic):
     check_lnse_parity(emu_lib, nx, ny, periodic, steps=4)
 
 
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (24, 25, False)])
+def test_emu_lnse_hc(emu_lib, nx, ny, periodic):
+    """bc = "hc" (lnse.rs:115-119, 202-206; nonlin.rs:117-121, 208-212; MeanFields::new_hc_*, meanfield.rs:52-86, 154-188): the
+    temperature on cheb_dirichlet_neumann along y, the parabolic default mean -- forward and adjoint LNSE step and the non-linear
+    solver against the oracle; Navier2DAdjoint keeps refusing it by name (steady_adjoint.rs:312-318)."""
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=3, bc="hc")
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=3, adjoint=True, mean_flow=False, bc="hc")
+    check_nonlin_parity(emu_lib, nx, ny, periodic, steps=3, bc="hc")
+    with pytest.raises(R.RpdeError, match="not supported by Navier2DAdjoint"):
+        R.Navier2DAdjoint.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "hc", library=emu_lib)
+
+
 @pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (16, 13, True)])
 def test_emu_lnse_adjoint_step_parity(emu_lib, nx, ny, periodic):
     check_lnse_parity(emu_lib, nx, ny, periodic, steps=4, adjoint=True)
@@ -514,13 +526,13 @@ def test_oracle_nonlin_adjoint_history_terms_are_the_mean_terms():
     assert len(nl.field_history) == 2
 
 
-def check_nonlin_parity(lib, nx, ny, periodic, steps, ra=1e4, dt=0.01, tol=1e-10, tol_p=1e-8, max_time=None, tmp_path=None):
+def check_nonlin_parity(lib, nx, ny, periodic, steps, ra=1e4, dt=0.01, tol=1e-10, tol_p=1e-8, max_time=None, tmp_path=None, bc="rbc"):
     """Navier2DNonLin: engine vs oracle through update_direct (with history), update_adjoint (consuming it), and grad_adjoint."""
     from oracle import lnse as L
     mk_e = R.Navier2DNonLin.new_periodic if periodic else R.Navier2DNonLin.new_confined
     mk_o = L.Navier2DNonLin.new_periodic if periodic else L.Navier2DNonLin.new_confined
-    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, "rbc", library=lib, mean_file="/nonexistent/mean.h5")
-    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, "rbc", eig_mode="parity")
+    nav = mk_e(nx, ny, ra, 1.0, dt, 1.0, bc, library=lib, mean_file="/nonexistent/mean.h5")
+    ora = mk_o(nx, ny, ra, 1.0, dt, 1.0, bc, eig_mode="parity")
     _roll_mean(ora, nav)
     for z in (nav, ora):
         z.set_velocity(0.2, 2.0, 1.0)
@@ -679,8 +691,8 @@ def test_emu_lnse_mean_from_a_snapshot_and_errors(emu_lib, tmp_path):
     assert np.isfinite(nav.div_norm()) and not nav.exit()
     with pytest.raises(R.RpdeError, match="shape differs"):
         R.Navier2DLnse.new_confined(33, 17, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, mean_file=fn)
-    with pytest.raises(R.RpdeError, match="not supported"):
-        R.Navier2DLnse.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "hc", library=emu_lib, mean_file="/nonexistent")
+    with pytest.raises(R.RpdeError, match="not recognized"):     # lnse.rs:118 (`"hc"` itself is accepted since round 6: test_emu_lnse_hc)
+        R.Navier2DLnse.new_confined(17, 17, 1e4, 1.0, 0.01, 1.0, "xx", library=emu_lib, mean_file="/nonexistent")
     with pytest.raises(R.RpdeError, match="velx, vely or temp"):
         R.Navier2DLnse._Mean(nav, "pres").v
 
