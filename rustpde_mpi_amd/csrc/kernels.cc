@@ -761,8 +761,16 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
   if (N == 1024) launch_line_batch_n<1024>(b, nl, st);
   else launch_line_batch_n<4096>(b, nl, st);
 }
+// waves per SIMD the register budget of S5 / S8 is set for (4: 128 VGPRs, four lines per CU; 3: 168, three lines) -- compile-time
+// switches for A/B builds (python -m rustpde_mpi_amd.build <variant> -DRPDE_S5_WPC=3), decided by measurement
+#ifndef RPDE_S5_WPC
+#define RPDE_S5_WPC 4
+#endif
+#ifndef RPDE_S8_WPC
+#define RPDE_S8_WPC 4
+#endif
 template <int N>
-__global__ __launch_bounds__(N / 16, 4) void div_line_kernel(const DivLineArgs a) {
+__global__ __launch_bounds__(N / 16, N == 4096 ? RPDE_S5_WPC : 4) void div_line_kernel(const DivLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
@@ -780,7 +788,7 @@ bool launch_div_line(const DivLineArgs& a, Stream& st) {
   return true;
 }
 template <int N>
-__global__ __launch_bounds__(N / 16, 4) void corr_line_kernel(const CorrLineArgs a) {
+__global__ __launch_bounds__(N / 16, N == 4096 ? RPDE_S8_WPC : 4) void corr_line_kernel(const CorrLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);

@@ -75,7 +75,7 @@ def test_emu_bluestein_agrees_with_the_direct_transform():
     evaluation of the same DCT-I: both meet the oracle in a child process that selects it."""
     code = ("from tests.emu.build_emu import build\nfrom rustpde_mpi_amd._capi import Lib\nfrom tests import checks as K\n"
             "lib = Lib(build())\nK.check_space_ops(lib, 'cheb_dirichlet', 10, 'cheb_neumann', 300)\n"
-            "K.check_step_parity(lib, False, 24, 25, 1e5, 0.01, 3)\nprint('DIRECT-OK')\n")
+            "K.check_step_parity(lib, False, 12, 13, 1e5, 0.01, 2)\nprint('DIRECT-OK')\n")
     env = dict(os.environ, RPDE_DCT_DIRECT="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIRECT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
@@ -106,7 +106,7 @@ def _engine_gradient_validation(lib, max_time, npts):
 
 
 def test_emu_engine_passes_the_reference_gradient_validation(emu_lib):
-    assert _engine_gradient_validation(emu_lib, 0.5, 13) < 0.3
+    assert _engine_gradient_validation(emu_lib, 0.3, 6) < 0.3   # (the GPU test runs horizon 1)
 
 
 CASES_SHARDED = [(False, 24, 25, 1e5, 0.01, 3, 1.0), (True, 18, 13, 1e4, 0.01, 4, 1.0), (False, 70, 131, 1e5, 0.01, 3, 1.0, "rbc", "single"),   # against the one-rank engine: same eigenbasis
