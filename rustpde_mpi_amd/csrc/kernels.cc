@@ -761,13 +761,14 @@ void launch_line_batch(const LineBatch& b, Stream& st) {
   if (N == 1024) launch_line_batch_n<1024>(b, nl, st);
   else launch_line_batch_n<4096>(b, nl, st);
 }
-// waves per SIMD the register budget of S5 / S8 is set for (4: 128 VGPRs, four lines per CU; 3: 168, three lines) -- compile-time
-// switches for A/B builds (python -m rustpde_mpi_amd.build <variant> -DRPDE_S5_WPC=3), decided by measurement
+// waves per SIMD the register budget of S5 / S8 is set for (4: 128 VGPRs, four lines per CU, 8 / 7 spilled registers; 3: 168,
+// three lines, no scratch) -- compile-time switches for A/B builds (python -m rustpde_mpi_amd.build <variant> -DRPDE_S5_WPC=4).
+// Measured in one call of round 6 (profiles/r06_experiments/call6_ab_wpc.txt): S5 0.141 -> 0.132 ms, S8 0.268 -> 0.265 ms with 3.
 #ifndef RPDE_S5_WPC
-#define RPDE_S5_WPC 4
+#define RPDE_S5_WPC 3
 #endif
 #ifndef RPDE_S8_WPC
-#define RPDE_S8_WPC 4
+#define RPDE_S8_WPC 3
 #endif
 template <int N>
 __global__ __launch_bounds__(N / 16, N == 4096 ? RPDE_S5_WPC : 4) void div_line_kernel(const DivLineArgs a) {
