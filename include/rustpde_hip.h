@@ -296,6 +296,10 @@ int rpde_lnse2d_diagnostics(rpde_lnse2d* h, double* out7);
    eps = 1e-5 (a test device in the reference too).  points: npoints triples (field 0 velx / 1 vely / 2 temp, i, j), NULL = all */
 int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double beta2, const int* points, long npoints, size_t len,
                         const char* filename, double* grad_velx, double* grad_vely, double* grad_temp);
+/* the same with the reference's `save_intervall: Option<f64>` (lnse_fd_grad.rs:35, 54): > 0 = Some: the BASE run calls
+   Integrate::callback on the interval (data/flow{time:0>8.2}.h5, data/info.txt, lnse.rs:298-302); <= 0 = None */
+int rpde_lnse2d_grad_fd_save(rpde_lnse2d* h, double max_time, double save_intervall, double beta1, double beta2, const int* points,
+                             long npoints, size_t len, const char* filename, double* grad_velx, double* grad_vely, double* grad_temp);
 /* functions::l2_norm                                               src/navier_stokes_lnse/functions.rs:30-58 (host arrays) */
 int rpde_l2_norm(size_t len, const double* a1, const double* a2, const double* b1, const double* b2, const double* c1, const double* c2,
                  double beta1, double beta2, double* out);

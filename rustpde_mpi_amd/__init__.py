@@ -748,9 +748,8 @@ class Navier2DLnse(Navier2DAdjoint):
     def grad_fd(self, max_time, save_intervall, beta1, beta2, points=None, filename="data/grad_fd.h5"):
         """`Navier2DLnse::grad_fd` (lnse_fd_grad.rs:31-157): one integration per perturbed grid point (3 nx ny integrations --
         "should only be used for testing").  `points`: iterable of (field, i, j) with field in velx / vely / temp to visit
-        instead of every point (the other entries stay 0)."""
-        if save_intervall is not None:
-            raise RpdeError("grad_fd: save_intervall (one snapshot series of the base run, lnse_fd_grad.rs:54) is not supported: pass None")
+        instead of every point (the other entries stay 0).  `save_intervall`: None, or the interval on which the BASE run calls
+        `callback()` (data/flow{time:0>8.2}.h5, data/info.txt in the working directory)."""
         pts, npts = None, 0
         if points is not None:
             code = {"velx": 0, "vely": 1, "temp": 2}
@@ -760,7 +759,10 @@ class Navier2DLnse(Navier2DAdjoint):
         gu, gv, gt = (np.empty((self.nx, self.ny)) for _ in range(3))
         if filename is not None and os.path.dirname(filename):
             os.makedirs(os.path.dirname(filename), exist_ok=True)
-        self._lib.call("rpde_lnse2d_grad_fd", self._h, float(max_time), float(beta1), float(beta2), pts, npts, self.nx * self.ny,
+        if save_intervall is not None:      # Some(dt): the base run writes its snapshot series (lnse_fd_grad.rs:54)
+            os.makedirs("data", exist_ok=True)
+        self._lib.call("rpde_lnse2d_grad_fd_save", self._h, float(max_time), -1.0 if save_intervall is None else float(save_intervall),
+                       float(beta1), float(beta2), pts, npts, self.nx * self.ny,
                        None if filename is None else str(filename).encode(), ptr(gu), ptr(gv), ptr(gt))
         return gu, gv, gt
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rpde_lnse2d_callback_from_filename": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_double]),
     "rpde_lnse2d_diagnostics": (C.c_int, [_vp, _dp]),
     "rpde_lnse2d_grad_fd": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, _ip, C.c_long, C.c_size_t, C.c_char_p, _dp, _dp, _dp]),
+    "rpde_lnse2d_grad_fd_save": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, _ip, C.c_long, C.c_size_t, C.c_char_p, _dp, _dp, _dp]),
     "rpde_l2_norm": (C.c_int, [C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp]),
     "rpde_steepest_descent_energy_constrained": (C.c_int, [C.c_size_t, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                                            C.c_double, C.c_double]),

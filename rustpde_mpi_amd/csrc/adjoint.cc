@@ -833,11 +833,19 @@ bool Navier2DLnseEngine::exit_grad(double max_time, long timestep) {
   return false;
 }
 
-long Navier2DLnseEngine::integrate(double max_time) {
+long Navier2DLnseEngine::integrate(double max_time, double save_intervall) {
   long timestep = 0;
+  char fname[64];
   for (;;) {
     update(1);
     ++timestep;
+    if (save_intervall > 0.0) {                // src/lib.rs:196-204: Integrate::callback (lnse.rs:298-302 / nonlin.rs) on the save interval
+      const double r = std::fmod(time_, save_intervall);
+      if (r < dt_ / 2.0 || r > save_intervall - dt_ / 2.0) {
+        std::snprintf(fname, sizeof fname, "data/flow%08.2f.h5", time_);
+        callback_from_filename(fname, "data/info.txt", false, -1.0);
+      }
+    }
     if (time_ + dt_ * 1e-4 >= max_time) break;
     if (timestep >= 10000000L) break;
     if (exit()) break;
@@ -1027,7 +1035,7 @@ double Navier2DLnseEngine::grad_adjoint(double max_time, double save_intervall, 
 }
 
 void Navier2DLnseEngine::grad_fd(double max_time, double beta1, double beta2, const int* points, long npoints, double* gu, double* gv,
-                                 double* gt, const char* filename) {
+                                 double* gt, const char* filename, double save_intervall) {
   RPDE_REQUIRE(gu && gv && gt, "grad_fd: null output");
   const double eps = 1e-5;                     // lnse_fd_grad.rs:38
   const char* const fld[3] = {"velx", "vely", "temp"};
@@ -1049,7 +1057,7 @@ void Navier2DLnseEngine::grad_fd(double max_time, double beta1, double beta2, co
     zero(field("pseu").vhat);
   };
   reset();
-  integrate(max_time);
+  integrate(max_time, save_intervall);         // the base run alone writes its snapshot series (lnse_fd_grad.rs:54)
   const double e_base = energy(beta1, beta2);
   double* out[3] = {gu, gv, gt};
   for (int k = 0; k < 3; ++k) std::fill(out[k], out[k] + np, 0.0);

@@ -141,9 +141,10 @@ class Navier2DLnseEngine : public GenericFlow2D {
   void diagnostics(double out[7]);
   // lnse_fd_grad.rs:31-157: one integration per perturbed grid point (eps = 1e-5).  points: npoints triples (field 0 / 1 / 2, i, j),
   // or null = every point of velx, vely, temp in the reference's order; entries not visited are 0
+  // save_intervall > 0: the base run (and only it, :54) calls Integrate::callback on the interval -- data/flow{time:0>8.2}.h5, data/info.txt
   void grad_fd(double max_time, double beta1, double beta2, const int* points, long npoints, double* gu, double* gv, double* gt,
-               const char* filename);
-  long integrate(double max_time);                                    // src/lib.rs:187-219 without callbacks
+               const char* filename, double save_intervall = 0.0);
+  long integrate(double max_time, double save_intervall = 0.0);       // src/lib.rs:187-219; save_intervall <= 0: None
 
  private:
   struct Hist { F velx, vely, temp; };              // one forward state: the spectral arrays (the physical ones = backward of them)

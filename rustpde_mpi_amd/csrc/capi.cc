@@ -504,6 +504,16 @@ int rpde_lnse2d_grad_fd(rpde_lnse2d* h, double max_time, double beta1, double be
     h->e->grad_fd(max_time, beta1, beta2, points, npoints, grad_velx, grad_vely, grad_temp, filename);
   })
 }
+int rpde_lnse2d_grad_fd_save(rpde_lnse2d* h, double max_time, double save_intervall, double beta1, double beta2, const int* points,
+                             long npoints, size_t len, const char* filename, double* grad_velx, double* grad_vely, double* grad_temp) {
+  RPDE_TRY({
+    RPDE_CHECK_HANDLE(h); RPDE_REQUIRE(grad_velx && grad_vely && grad_temp, "null pointer");
+    RPDE_REQUIRE(len == (size_t)h->e->nx() * h->e->ny(), "grad_fd: physical arrays are nx*ny doubles");
+    RPDE_REQUIRE(!points || npoints >= 0, "grad_fd: negative point count");
+    select_device(h->device);
+    h->e->grad_fd(max_time, beta1, beta2, points, npoints, grad_velx, grad_vely, grad_temp, filename, save_intervall);
+  })
+}
 // functions.rs:30-58
 int rpde_l2_norm(size_t len, const double* a1, const double* a2, const double* b1, const double* b2, const double* c1, const double* c2,
                  double beta1, double beta2, double* out) {

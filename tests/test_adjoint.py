@@ -653,6 +653,31 @@ def test_emu_lnse_callbacks_and_saved_gradient_loops(emu_lib, tmp_path, monkeypa
     check_lnse_callbacks(emu_lib, tmp_path, monkeypatch, capfd, nonlinear)
 
 
+def test_emu_grad_fd_base_run_snapshot_series(emu_lib, tmp_path, monkeypatch):
+    """`grad_fd(max_time, Some(save_intervall), ...)` (lnse_fd_grad.rs:35, 54): the BASE run -- and only it -- calls
+    Integrate::callback on the interval (data/flow{time:0>8.2}.h5 + a line of data/info.txt per save, lnse.rs:298-302); the
+    gradient itself is the one of `None`."""
+    monkeypatch.chdir(tmp_path)
+    nav, ora = lnse_pair(emu_lib, 16, 13, True, 3e3, 0.1, 0.01)
+    base = {k: getattr(nav, k).vhat.copy() for k in ("velx", "vely", "temp")}
+    pts = [("velx", 3, 4), ("temp", 7, 6)]
+    g0 = nav.grad_fd(1.0, None, 0.5, 0.25, points=pts, filename=None)
+    assert not os.path.exists(tmp_path / "data")
+    for k in base:
+        getattr(nav, k).vhat = base[k]
+    g1 = nav.grad_fd(1.0, 0.5, 0.5, 0.25, points=pts, filename=None)
+    names = sorted(os.listdir(tmp_path / "data"))
+    # callbacks at t = 0.5 and 1.0 of ONE run (the perturbed runs write nothing): an info line each, the flow snapshot on the
+    # write interval of callback_from_filename(.., None) = OUTPUT_INTERVALL = 1 (lnse.rs:21, lnse_io.rs:80-90)
+    assert names == ["flow00001.00.h5", "info.txt"], names
+    assert len(open(tmp_path / "data" / "info.txt").read().strip().splitlines()) == 2
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a, b)
+    from tests.h5classic import File
+    d = File(str(tmp_path / "data" / "flow00001.00.h5")).datasets
+    assert abs(float(np.ravel(d["time"])[0]) - 1.0) < 1e-9 and d["ux/v"].shape == (16, 13)
+
+
 def test_emu_l2_norm_and_steepest_descent(emu_lib):
     """functions::l2_norm and opt_routines::steepest_descent_energy_constrained (host arrays) against the oracle; the rotated
     state keeps the energy of the old one (the point of the routine) and alpha > 2 pi is refused like the reference's assert."""
