@@ -171,6 +171,9 @@ Navier2DAdjointEngine::Navier2DAdjointEngine(int nx, int ny, double ra, double p
   norm_vel_ = std::make_unique<TensorHholtzOp>(*sp_vel_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
   norm_temp_ = std::make_unique<TensorHholtzOp>(*sp_temp_, kWeightLaplacian / (sx_ * sx_), kWeightLaplacian / (sy_ * sy_));
   dev_sync(st_);
+  const char* e = std::getenv("RPDE_ADJOINT_FUSED");
+  if (!e || std::atoi(e) != 0)
+    fwd_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, kDtNavier, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false);
 }
 
 GenericFlow2D::~GenericFlow2D() {
@@ -438,6 +441,60 @@ bool Navier2DAdjointEngine::exit() {
   return (r[0] + r[1] + r[2]) / 3.0 < kResTol;
 }
 
+// The forward Navier-Stokes step of Navier2DAdjoint::update as a composition of the generic operators (rounds 5; kept as the A/B
+// form, RPDE_ADJOINT_FUSED=0).  old_[0 .. 2] hold the orthonormal coefficients of the state before the step.
+void Navier2DAdjointEngine::forward_step_generic() {
+  F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
+  F& tempbc = field("tempbc");
+  const double dtn = kDtNavier;
+  backward(velx, ux_);
+  backward(vely, uy_);
+  // solve_velx (steady_adjoint_eq.rs:134-144)
+  lincomb(rhs_, 1.0, old_[0], 0.0, old_[0]);
+  acc_gradient(pres, 1, 0, -dtn, rhs_);
+  conv_term(ux_, velx, 1, 0, 1.0, true);
+  conv_term(uy_, velx, 0, 1, 1.0, false);
+  conv_finish(cv_);
+  lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+  hh_vel_->solve(rhs_, velx.vhat, st_);
+  // solve_vely (steady_adjoint_eq.rs:147-160): buoyancy = temp.to_ortho() * dt, without the lift
+  lincomb(rhs_, 1.0, old_[1], dtn, old_[2]);
+  acc_gradient(pres, 0, 1, -dtn, rhs_);
+  conv_term(ux_, vely, 1, 0, 1.0, true);
+  conv_term(uy_, vely, 0, 1, 1.0, false);
+  conv_finish(cv_);
+  lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+  hh_vel_->solve(rhs_, vely.vhat, st_);
+  // projection (steady_adjoint.rs:563-567)
+  div(div_);
+  solve_pres(div_);
+  correct_velocity(1.0);
+  // update_pres (steady_adjoint_eq.rs:194-201): pres += -nu div + pseu.to_ortho() / dt
+  lincomb(pres.vhat, 1.0, pres.vhat, -nu_, div_);
+  acc_to_ortho(pseu, 1.0 / dtn, pres.vhat);
+  // solve_temp (steady_adjoint_eq.rs:166-180)
+  lincomb(rhs_, 1.0, old_[2], 0.0, old_[2]);
+  acc_gradient(tempbc, 2, 0, dtn * ka_, rhs_);
+  acc_gradient(tempbc, 0, 2, dtn * ka_, rhs_);
+  conv_term(ux_, temp, 1, 0, 1.0, true);
+  conv_term(uy_, temp, 0, 1, 1.0, false);
+  conv_term(ux_, tempbc, 1, 0, 1.0, false);
+  conv_term(uy_, tempbc, 0, 1, 1.0, false);
+  conv_finish(cv_);
+  lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
+  hh_temp_->solve(rhs_, temp.vhat, st_);
+}
+
+// The same step on Navier2DEngine's fused schedule: the state goes in as device arrays (canonical -> the engine's YX layout,
+// d/dx p and d/dy p refreshed), one update(), and u, v, T, p and the pseudo-pressure come back.
+void Navier2DAdjointEngine::forward_step_fused() {
+  dev_sync(st_);                                 // the engine runs on its own stream
+  for (const char* name : {"velx", "vely", "temp", "pres"}) fwd_->set_field_spectral_device(name, field(name).vhat);
+  fwd_->update(1);
+  for (const char* name : {"velx", "vely", "temp", "pres", "pseu"}) fwd_->get_field_spectral_device(name, field(name).vhat);
+  fwd_->sync();
+}
+
 // ------------------------------------------------------------------------------------------------
 void Navier2DAdjointEngine::update(int nsteps) {
   F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
@@ -446,45 +503,10 @@ void Navier2DAdjointEngine::update(int nsteps) {
   const double dtn = kDtNavier, dt = dt_;
   for (int step = 0; step < nsteps; ++step) {
     // ================= forward step for the residual (steady_adjoint.rs:547-585) =================
-    backward(velx, ux_);
-    backward(vely, uy_);
     velx.sp->to_ortho(velx.vhat, old_[0], st_);
     vely.sp->to_ortho(vely.vhat, old_[1], st_);
     temp.sp->to_ortho(temp.vhat, old_[2], st_);
-    // solve_velx (steady_adjoint_eq.rs:134-144)
-    lincomb(rhs_, 1.0, old_[0], 0.0, old_[0]);
-    acc_gradient(pres, 1, 0, -dtn, rhs_);
-    conv_term(ux_, velx, 1, 0, 1.0, true);
-    conv_term(uy_, velx, 0, 1, 1.0, false);
-    conv_finish(cv_);
-    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
-    hh_vel_->solve(rhs_, velx.vhat, st_);
-    // solve_vely (steady_adjoint_eq.rs:147-160): buoyancy = temp.to_ortho() * dt, without the lift
-    lincomb(rhs_, 1.0, old_[1], dtn, old_[2]);
-    acc_gradient(pres, 0, 1, -dtn, rhs_);
-    conv_term(ux_, vely, 1, 0, 1.0, true);
-    conv_term(uy_, vely, 0, 1, 1.0, false);
-    conv_finish(cv_);
-    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
-    hh_vel_->solve(rhs_, vely.vhat, st_);
-    // projection (steady_adjoint.rs:563-567)
-    div(div_);
-    solve_pres(div_);
-    correct_velocity(1.0);
-    // update_pres (steady_adjoint_eq.rs:194-201): pres += -nu div + pseu.to_ortho() / dt
-    lincomb(pres.vhat, 1.0, pres.vhat, -nu_, div_);
-    acc_to_ortho(pseu, 1.0 / dtn, pres.vhat);
-    // solve_temp (steady_adjoint_eq.rs:166-180)
-    lincomb(rhs_, 1.0, old_[2], 0.0, old_[2]);
-    acc_gradient(tempbc, 2, 0, dtn * ka_, rhs_);
-    acc_gradient(tempbc, 0, 2, dtn * ka_, rhs_);
-    conv_term(ux_, temp, 1, 0, 1.0, true);
-    conv_term(uy_, temp, 0, 1, 1.0, false);
-    conv_term(ux_, tempbc, 1, 0, 1.0, false);
-    conv_term(uy_, tempbc, 0, 1, 1.0, false);
-    conv_finish(cv_);
-    lincomb(rhs_, 1.0, rhs_, -dtn, cv_);
-    hh_temp_->solve(rhs_, temp.vhat, st_);
+    if (fwd_) forward_step_fused(); else forward_step_generic();
     // residual (steady_adjoint.rs:572-575) in the norm of solver_norm, sign flipped (577-584)
     velx.sp->to_ortho(velx.vhat, t1_, st_);
     lincomb(t1_, -1.0 / dtn, t1_, 1.0 / dtn, old_[0]);      // -(new - old) / dt

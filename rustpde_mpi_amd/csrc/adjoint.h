@@ -16,6 +16,7 @@
 #include <tuple>
 #include <vector>
 
+#include "engine.h"
 #include "ops.h"
 
 namespace rpde {
@@ -97,6 +98,12 @@ class Navier2DAdjointEngine : public GenericFlow2D {
 
  private:
   std::unique_ptr<TensorHholtzOp> norm_vel_, norm_temp_;
+  // The forward step for the residual (steady_adjoint.rs:547-585) IS Navier2D::update with DT_NAVIER and the buoyancy taken
+  // without the lift: it runs on Navier2DEngine's fused schedule (16 launches) instead of a composition of generic operators;
+  // u, v, T, p go in and u, v, T, p, pseu come back as device arrays (RPDE_ADJOINT_FUSED=0: the generic composition, A/B)
+  std::unique_ptr<Navier2DEngine> fwd_;
+  void forward_step_generic();
+  void forward_step_fused();
 };
 
 // Navier2DLnse (src/navier_stokes_lnse/lnse.rs:24-63, 263-288; equations lnse_eq.rs): the Navier-Stokes equations linearised

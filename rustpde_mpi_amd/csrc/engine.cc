@@ -45,8 +45,8 @@ std::vector<int> Navier2DEngine::split(int n, int parts) {
 }
 
 Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                               const std::string& bc, bool periodic, const CommCb* comm)
-    : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0) {
+                               const std::string& bc, bool periodic, const CommCb* comm, bool buoyancy_lift)
+    : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0), buoyancy_lift_(buoyancy_lift) {
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
@@ -146,6 +146,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   const size_t nyx = (size_t)(nyl_ + 2 + 4) * ldx_;  // two halo rows in front (cross-line y stencil), four behind (column scans)
   const size_t nxy = (size_t)nxl_ * ldy_;
   for (DBuf* b : {&U_, &V_, &T_, &P_, &GY_, &GX_, &TBC_, &TBC2_, &DIV_}) b->alloc(nyx);
+  if (!buoyancy_lift_) TBC0_.alloc(nyx);
   for (auto& b : Y_) b.alloc(nyx);
   if (hc_) TO_.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
@@ -637,6 +638,14 @@ void Navier2DEngine::set_field_spectral(const std::string& name, const double* h
   dev_upload2d(a.p(), a.ld, host, r, (long)c * e);
   canonical_to_state(a, f);
   dev_sync(st_);
+}
+
+void Navier2DEngine::set_field_spectral_device(const std::string& name, const Arr2& canonical) {
+  RPDE_REQUIRE(name != "tempbc", "tempbc is fixed by the boundary condition");
+  canonical_to_state(canonical, field(name));
+}
+void Navier2DEngine::get_field_spectral_device(const std::string& name, Arr2& canonical) {
+  state_to_canonical(field(name), canonical);
 }
 
 void Navier2DEngine::get_field_spectral(const std::string& name, double* host, size_t len) {
@@ -2028,7 +2037,7 @@ void Navier2DEngine::build_confined() {
       r.lowy = yD.low.p; r.lowy2 = yD.low.p; r.stx = which == 2 ? 1 : 2; r.lowx = xN.low.p;
       r.tw = ax.tw.p; r.tw2 = ax.tw2.p;
       if (which == 0) r.grad = yx(GX_);
-      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(TBC_); }
+      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); }
       if (which == 2) r.tbc = yx(TBC2_);
       if (add_rhs_line(r, which, tag)) return;
     }
@@ -2051,7 +2060,7 @@ void Navier2DEngine::build_confined() {
       pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
       pb.pair_last_loads();
       pb.to_ortho_axpby(0, 1.0, 1, dt, xN);
-      pb.load(0, pb.arr(yx(TBC_), ldx), nx, dt, true);
+      pb.load(0, pb.arr(yx(buoyancy_lift_ ? TBC_ : TBC0_), ldx), nx, dt, true);
     }
     pb.pinv_matvec(0, ax);
     pb.fdma_solve(0, mx, hh.fdma[0]);
@@ -2318,7 +2327,7 @@ void Navier2DEngine::build_periodic() {
       if (which == 1) {
         a.gy = yx(GY_);
         a.tsrc = hc ? yx(TO_) : yx(T_); a.tlow = hc ? nullptr : yD.low.p;
-        a.tbc = yx(TBC_); a.ctbc = dt;
+        a.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); a.ctbc = dt;
       }
       if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; }
       a.diag = hh.diag0.p;
@@ -2341,7 +2350,7 @@ void Navier2DEngine::build_periodic() {
       pb.pair_last_loads();                                             // with the state rows
       if (hc) pb.load(0, pb.arr(yx(TO_), ldx), nc, dt, true);
       else pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
-      pb.load(0, pb.arr(yx(TBC_), ldx), nc, dt, true);
+      pb.load(0, pb.arr(yx(buoyancy_lift_ ? TBC_ : TBC0_), ldx), nc, dt, true);
       pb.pair_last_loads();
     } else {
       pb.load(0, pb.arr(yx(TBC2_), ldx), nc, dt * ka_, true);

@@ -32,8 +32,10 @@ struct CommCb {
 
 class Navier2DEngine {
  public:
+  // buoyancy_lift = false: the buoyancy term of solve_vely is temp.to_ortho() alone, without the lift -- the forward step inside
+  // Navier2DAdjoint::update (steady_adjoint_eq.rs:147-160; everything else of that step is Navier2D's, steady_adjoint.rs:547-585)
   Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                 const std::string& bc, bool periodic, const CommCb* comm = nullptr);
+                 const std::string& bc, bool periodic, const CommCb* comm = nullptr, bool buoyancy_lift = true);
   ~Navier2DEngine();
 
   // initial conditions (src/navier_stokes/navier.rs:161-182, functions.rs:85-126)
@@ -49,6 +51,9 @@ class Navier2DEngine {
   void set_field_spectral(const std::string& name, const double* host, size_t len);
   void get_field_spectral(const std::string& name, double* host, size_t len);
   void spectral_shape(const std::string& name, int* rows, int* cols, int* elem);
+  // the same between device arrays in the canonical layout (an engine embedded in another solver, adjoint.cc): no host copy
+  void set_field_spectral_device(const std::string& name, const Arr2& canonical);
+  void get_field_spectral_device(const std::string& name, Arr2& canonical);
 
   void update(int nsteps);           // n x Integrate::update
   double div_norm();                 // ||div||_2 of the current velocity (navier_eq.rs:33-51)
@@ -294,6 +299,8 @@ class Navier2DEngine {
   DBuf coldot_, colkap_;             // rank-one sums of the column scans
   int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
   bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)
+  bool buoyancy_lift_ = true;
+  DBuf TBC0_;                        // buoyancy_lift_ = false: a zero array in the lift's place (buoyancy term only)
   bool pseu_from_y4_ = false;   // periodic step with the real-view S6: the canonical pseu is the complex transpose of Y_[4]
   // whole-line backward transform (dct_line.h) when the shape is covered; otherwise false and the caller adds the line program
   bool add_dct_line(const DctLineArgs& a, const char* tag);

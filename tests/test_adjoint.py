@@ -413,6 +413,29 @@ def test_emu_lnse_step_parity(emu_lib, nx, ny, periodic):
     check_lnse_parity(emu_lib, nx, ny, periodic, steps=4)
 
 
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (65, 257, False)])
+def test_emu_adjoint_fused_forward_step(emu_lib, monkeypatch, nx, ny, periodic):
+    """Round 6: the forward Navier-Stokes step inside Navier2DAdjoint::update (steady_adjoint.rs:547-585 -- Navier2D::update with
+    DT_NAVIER and the buoyancy without the lift) runs on Navier2DEngine's fused schedule.  Against the composition of generic
+    operators it replaces (RPDE_ADJOINT_FUSED=0) after three updates: all nine fields; both forms meet the oracle in
+    check_step_parity of this module (the default form in every other test here)."""
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("RPDE_ADJOINT_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("RPDE_ADJOINT_FUSED", flag)
+        mk = R.Navier2DAdjoint.new_periodic if periodic else R.Navier2DAdjoint.new_confined
+        nav = mk(nx, ny, 1e4, 1.0, 0.005, 1.0, "rbc", library=emu_lib)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(3)
+        return nav.spectral_fields()
+    fused, generic = run(None), run("0")
+    monkeypatch.delenv("RPDE_ADJOINT_FUSED", raising=False)
+    for k in generic:
+        assert rel(fused[k], generic[k]) < (1e-8 if k in ("pres", "pseu", "pres_adj") else 1e-11), (k, rel(fused[k], generic[k]))
+
+
 @pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (24, 25, False)])
 def test_emu_lnse_hc(emu_lib, nx, ny, periodic):
     """bc = "hc" (lnse.rs:115-119, 202-206; nonlin.rs:117-121, 208-212; MeanFields::new_hc_*, meanfield.rs:52-86, 154-188): the

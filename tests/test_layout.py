@@ -70,6 +70,7 @@ ENV_SWITCHES = {
                                                     # whole-line kernel / line program per stage (test_whole_line_stage_*, test_emu_parity)
     "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
     "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
+    "RPDE_ADJOINT_FUSED",                           # Navier2DAdjoint: forward step on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_adjoint_fused_forward_step)
     "RPDE_PER_ROWS",                                # periodic S5 / S8 / S9: element-wise kernels / line programs (test_periodic_elementwise_stages_equal_line_programs)
     "RPDE_GEMM_PERSIST",                            # A/B of round 6: both parity blocks of an eigen-transform by 512 persistent workgroups (test_gpu_parity.test_round6_gemm_persist_bit_identical)
     "RPDE_S1_SPLIT", "RPDE_GEMM_PEEL",                # A/B of round 5: S1 as two launches, the peeled GEMM loop (test_gpu_parity.test_round5_ab_switches)
