@@ -339,7 +339,7 @@ void Navier2DEngine::spectral_shape(const std::string& name, int* rows, int* col
   *elem = f.sp->elem();
 }
 
-void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
+void Navier2DEngine::state_to_canonical(Field& f, Arr2& out, bool wait) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(out.rows == r && out.cols == c && out.elem == e, "internal: canonical shape");
@@ -369,6 +369,12 @@ void Navier2DEngine::state_to_canonical(Field& f, Arr2& out) {
     pseu_in_yx_ = false;
   }
   const bool spec = periodic_;
+  if (comm_.size == 1) {   // one rank holds everything: one launch, no staging copy, no wait (stream-ordered like every launch of the step)
+    if (f.yx) launch_transpose(yx(*f.buf), ldx_, out.p(), out.ld, c, r, e, st_);
+    else launch_copy2d(f.buf->p, ldy_, out.p(), out.ld, r, c * e, st_);
+    if (wait) dev_sync(st_);
+    return;
+  }
   if (f.yx) {   // rows = y index (c of them), row length r * e doubles
     DBuf full((size_t)ny_ * ldx_);
     gather_rows(yx(*f.buf), ldx_, ny_, ypart_, full.p);
@@ -387,7 +393,9 @@ void Navier2DEngine::canonical_to_state(const Arr2& in, Field& f) {
   int r, c, e;
   spectral_shape(f.name, &r, &c, &e);
   RPDE_REQUIRE(in.rows == r && in.cols == c && in.elem == e, "internal: canonical shape");
-  if (f.yx) {
+  if (comm_.size == 1 && f.yx) {   // one rank: straight into the state array
+    launch_transpose(in.p(), in.ld, yx(*f.buf), ldx_, r, c, e, st_);
+  } else if (f.yx) {
     DBuf full((size_t)ny_ * ldx_);
     launch_transpose(in.p(), in.ld, full.p, ldx_, r, c, e, st_);
     scatter_rows_yx(full.p, ldx_, *f.buf, c, r * e);
@@ -645,7 +653,7 @@ void Navier2DEngine::set_field_spectral_device(const std::string& name, const Ar
   canonical_to_state(canonical, field(name));
 }
 void Navier2DEngine::get_field_spectral_device(const std::string& name, Arr2& canonical) {
-  state_to_canonical(field(name), canonical);
+  state_to_canonical(field(name), canonical, /*wait=*/false);   // the caller drains the stream once (sync())
 }
 
 void Navier2DEngine::get_field_spectral(const std::string& name, double* host, size_t len) {

@@ -128,7 +128,7 @@ class Navier2DEngine {
   void construct(int nx, int ny, double ra, double pr, double dt, double aspect, bool periodic);
   void release_device_objects();   // stream, events, graph, communicator: also on a throwing constructor
   Field& field(const std::string& name);
-  void state_to_canonical(Field& f, Arr2& out);
+  void state_to_canonical(Field& f, Arr2& out, bool wait = true);
   void canonical_to_state(const Arr2& in, Field& f);
   void refresh_gy();
 
