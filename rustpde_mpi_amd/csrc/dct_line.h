@@ -40,7 +40,7 @@ template <int N> struct DctGeom { static constexpr int LDS = N + N / 16 + 16; };
 // the 16-byte staging loads need an aligned line start and, for an odd count, one readable element behind the line
 // (N = 1024 runs on the half-length core, hdct_line.h, only)
 RPDE_HD inline bool dct_line_ok(const DctLineArgs& a) {
-  return (a.N == 256 || a.N == 1024 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
+  return (a.N == 256 || a.N == 1024 || a.N == 2048 || a.N == 4096) && a.n_in >= 1 && a.n_in <= a.N + 1 && (((size_t)a.in) & 15) == 0 && (a.ldi & 1) == 0 &&
          ((a.n_in & 1) == 0 || a.n_in < a.ldi) && (a.sten == 0 || a.sten == 2 || (a.sten == 1 && a.low != nullptr));
 }
 

@@ -808,7 +808,7 @@ static bool whole_line_len(int N) { return N == 1024 || N == 4096; }   // 1024: 
 static bool rfft_line_len(int N) { return whole_line_len(N) || N == 8192 || N == 16384; }   // Fourier lines (rfft_line.h)
 
 bool Navier2DEngine::add_dct_line(const DctLineArgs& a, const char* tag) {
-  if (!whole_line_on("RPDE_DCT_LINE") || !whole_line_len(a.N) || !dct_line_ok(a)) return false;
+  if (!whole_line_on("RPDE_DCT_LINE") || !(whole_line_len(a.N) || a.N == 2048) || !dct_line_ok(a)) return false;   // (2049-point lines: this kernel, the convection term and S6 only)
   Launch l;
   l.type = Launch::kDctLine;
   l.dl = a;
@@ -855,7 +855,7 @@ bool Navier2DEngine::add_four_rhs(const FourRhsArgs& a, const char* tag) {
 }
 bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   // a whole convection term per y-line (dct_line.h conv_line: three transforms per line in registers)
-  if (!whole_line_on("RPDE_CONV_LINE") || !whole_line_len(c.N) || !conv_line_ok(c)) return false;
+  if (!whole_line_on("RPDE_CONV_LINE") || !(whole_line_len(c.N) || c.N == 2048) || !conv_line_ok(c)) return false;
   Launch l;
   l.type = Launch::kConvLine;
   l.cl = c;

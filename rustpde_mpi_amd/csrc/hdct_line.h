@@ -66,7 +66,7 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
   const int a_sten = MODE >= 0 ? ((MODE & kHdctSten2) ? 2 : (MODE & kHdctSten1) ? 1 : 0) : a.sten;
   using G = HdctGeom<N>;
   constexpr int T = G::T, M = G::M, PL = G::PL, NW = G::NW;
-  static_assert(N == 4096 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 4, 8 x 8 x 8 or 8 x 8 x 2");
+  static_assert(N == 4096 || N == 2048 || N == 1024 || N == 256, "N / 2 = 8 x 8 x 8 x 4, 8 x 8 x 8 x 2, 8 x 8 x 8 or 8 x 8 x 2");
   static_assert(T % 16 == 0, "padded indices assume T a multiple of 16");
   lds_t buf = (lds_t)blk.lds;
   lds2_t buf2 = (lds2_t)blk.lds;
@@ -340,6 +340,10 @@ RPDE_DEV void hdct_core(Blk& blk, const DctLineArgs& a, bool staged, const Fetch
     pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     exchange(integral_constant<int, 6>{}, integral_constant<int, 8>{});
     pass(integral_constant<int, 9>{}, integral_constant<int, 4>{});
+  } else if constexpr (N == 2048) {   // 2049-point lines (round 6: the y-lines of BASELINE config 5)
+    pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
+    exchange(integral_constant<int, 6>{}, integral_constant<int, 8>{});
+    pass(integral_constant<int, 9>{}, integral_constant<int, 2>{});
   } else if constexpr (N == 1024) {
     pass(integral_constant<int, 6>{}, integral_constant<int, 8>{});
   } else {

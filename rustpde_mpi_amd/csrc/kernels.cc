@@ -874,10 +874,15 @@ bool launch_rhs_line(const RhsLineArgs& a, Stream& st, long long* trace) {
   return true;
 }
 bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
-  if ((a.N != 4096 && a.N != 1024) || !dct_line_ok(a)) return false;
+  if ((a.N != 4096 && a.N != 2048 && a.N != 1024) || !dct_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
   if (a.N == 1024) {   // one wave per line, the half-length core only
     hipLaunchKernelGGL((hdct_line_kernel<1024>), dim3(8 * ((a.nlines + 7) / 8)), dim3(64), 0, st.s, a, nullptr);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
+  if (a.N == 2048) {   // two waves per line (2049-point y-lines)
+    hipLaunchKernelGGL((hdct_line_kernel<2048>), dim3(8 * ((a.nlines + 7) / 8)), dim3(128), 0, st.s, a, nullptr);
     RPDE_HIP(hipGetLastError());
     return true;
   }
@@ -896,8 +901,13 @@ __global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs
   conv_line<N>(blk, c);
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
-  if ((c.N != 4096 && c.N != 1024) || !conv_line_ok(c)) return false;
+  if ((c.N != 4096 && c.N != 2048 && c.N != 1024) || !conv_line_ok(c)) return false;
   if (c.nlines <= 0) return true;
+  if (c.N == 2048) {   // two waves per line on the half-length core, one wave per SIMD (two lines per CU, like the line program, without its phases)
+    hipLaunchKernelGGL((hconv_line_kernel<2048, 1>), dim3(8 * ((c.nlines + 7) / 8)), dim3(128), 0, st.s, c);
+    RPDE_HIP(hipGetLastError());
+    return true;
+  }
   if (c.N == 1024) {   // one wave per line on the half-length core; a 1025^2 grid is four lines per CU: the whole register file per wave
     hipLaunchKernelGGL((hconv_line_kernel<1024, 1>), dim3(8 * ((c.nlines + 7) / 8)), dim3(64), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
@@ -1435,6 +1445,7 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
     if (c.N == 1024) hconv_line<1024>(blk, c);
+    else if (c.N == 2048) hconv_line<2048>(blk, c);
     else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);   // the device's choice of core per length
   }
   return true;
@@ -1564,6 +1575,7 @@ bool launch_dct_line(const DctLineArgs& a, Stream&, long long*) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
     if (a.N == 1024) hdct_bwd_line_by_mode<1024>(blk, a);
+    else if (a.N == 2048) hdct_bwd_line_by_mode<2048>(blk, a);
     else if (a.N == 4096) hdct_bwd_line_by_mode<4096>(blk, a); else hdct_bwd_line_by_mode<256>(blk, a);
   }
   return true;

@@ -36,7 +36,7 @@ def test_reference_known_answers(emu_lib):
     K.check_reference_known_answers(emu_lib)
 
 
-@pytest.mark.parametrize("n", [257, 1025, 4097])
+@pytest.mark.parametrize("n", [257, 1025, 2049, 4097])
 def test_dct_line_backward(emu_lib, n):
     K.check_dct_line_backward(emu_lib, n)
 
@@ -189,6 +189,30 @@ def test_s9_pressure_update_as_one_kernel(emu_lib, monkeypatch):
     nav0.update(3)
     for k in ("velx", "vely", "temp", "pres"):
         assert K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat) < 1e-12, (k, K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat))
+
+
+def check_lines_of_2049_points(lib, monkeypatch, periodic, nx, steps=2):
+    """y-lines of 2049 points (BASELINE config 5's, round 6): the velocity transforms of S2 and the three convection terms on the
+    half-length core with two waves per line (hdct_line.h, N = 2048: passes 8 x 8 x 8 x 2), S6 as the whole-line row solve -- against
+    the oracle and against the line programs of the same stages (RPDE_WHOLE_LINE=0)."""
+    K.check_step_parity(lib, periodic, nx, 2049, 1e6, 1e-3, steps, check_at=[steps])
+    nav, _ = K.make_pair(lib, periodic, nx, 2049, 1e6, 1.0, 1e-3, 1.0)
+    kinds = {t: kind for t, _, _, _, kind in nav.schedule()}
+    assert kinds["S2 y: velx -> phys"] == "whole-line transform" and kinds["S2 y: conv_temp"] == "whole-line convection term"
+    assert kinds["S6 y: poisson rows"] == "whole-line poisson rows"
+    nav.update(steps)
+    monkeypatch.setenv("RPDE_WHOLE_LINE", "0")
+    nav0, _ = K.make_pair(lib, periodic, nx, 2049, 1e6, 1.0, 1e-3, 1.0)
+    assert not any(kind.startswith("whole-line") for _, _, _, _, kind in nav0.schedule())
+    nav0.update(steps)
+    monkeypatch.delenv("RPDE_WHOLE_LINE")
+    for k in ("velx", "vely", "temp", "pres"):
+        assert K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat) < 1e-10, (k, K.rel(getattr(nav, k).vhat, getattr(nav0, k).vhat))
+
+
+@pytest.mark.parametrize("periodic,nx", [(True, 16), (False, 17)])
+def test_step_with_lines_of_2049_points(emu_lib, monkeypatch, periodic, nx):
+    check_lines_of_2049_points(emu_lib, monkeypatch, periodic, nx)
 
 
 def check_periodic_rows_ab(lib, monkeypatch, nx, ny, steps=4, bc="rbc"):

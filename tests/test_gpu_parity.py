@@ -295,6 +295,16 @@ def test_whole_line_stage_equals_line_program_4097(hip_lib, monkeypatch, stage):
         assert K.rel(fields["1"][k], fields["0"][k]) < 1e-11, (stage, k)
 
 
+@pytest.mark.parametrize("periodic,nx", [(True, 256), (False, 129)])
+def test_step_with_lines_of_2049_points(hip_lib, monkeypatch, periodic, nx):
+    from tests.test_emu_parity import check_lines_of_2049_points
+    check_lines_of_2049_points(hip_lib, monkeypatch, periodic, nx, steps=3)
+
+
+def test_dct_line_backward_2049(hip_lib):
+    K.check_dct_line_backward(hip_lib, 2049, nlines=33)
+
+
 @pytest.mark.parametrize("nx,ny,bc", [(64, 33, "rbc"), (18, 13, "rbc"), (4096, 257, "rbc"), (1000, 129, "rbc"), (256, 129, "hc")])
 def test_periodic_elementwise_stages_equal_line_programs(hip_lib, monkeypatch, nx, ny, bc):
     from tests.test_emu_parity import check_periodic_rows_ab
