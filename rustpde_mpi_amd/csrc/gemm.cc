@@ -74,30 +74,36 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 // with 144 doubles per k plane -- the 16 rows of a lane group are 128 contiguous bytes, the next k plane starts 32 banks
 // further (conflict free also as a 32-lane ds_read_b64); the staging stores become 8-byte stores (two lanes of a row hit
 // the same bank: the k/4 planes are 580 doubles apart, which puts them 16 banks apart).
-template <bool NN, int TM, bool OLD = true, int LAY = 0>
+// WAVES: 4 (2 x 2 waves of TM/2 x TM/2) or -- TM = 128 only -- 8 (2 x 4 waves of 64 x 32: half the accumulators per wave, 128 VGPRs,
+// so that the two workgroups of a CU put FOUR waves on a SIMD instead of two; round 6, the pair launcher's default)
+template <bool NN, int TM, bool OLD = true, int LAY = 0, int WAVES = 4>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
                                                  int tile_m, int tile_n, bool ct = false, bool z00 = false) {
   constexpr int BK = 16, KS = 4;
-  constexpr int MT = TM / 32;          // MFMA tiles per wave and dimension
-  constexpr int TPR = 256 / TM;        // threads per operand row (k contiguous)
+  constexpr int NT = 64 * WAVES;       // threads
+  constexpr int WN = WAVES / 2;        // waves along n (2 or 4); two along m
+  constexpr int MT = TM / 32;          // MFMA tiles per wave along m
+  constexpr int MTN = TM / (16 * WN);  // ... along n
+  constexpr int TPR = NT / TM;         // threads per operand row (k contiguous)
   constexpr int KT = BK / TPR;         // doubles per thread and operand per stage (8 or 4)
-  constexpr int VPE = TM / 64;         // NN: k-values per thread and k sub-step (2 or 1)
+  constexpr int VPE = 4 * TM / NT;     // NN: k-values per thread and k sub-step (2 or 1)
   static_assert(TM == 128 || TM == 64, "tile sizes 128 and 64");
+  static_assert(WAVES == 4 || (WAVES == 8 && TM == 128), "4 waves, or 8 waves on the 128-tile");
   constexpr int RS = LAY ? TM + 16 : 4;              // LAY 1: doubles per k plane; LAY 0: per row
   constexpr int SS = LAY ? 4 * RS + 4 : 4 * TM;      // doubles per k/4 block
   __shared__ __attribute__((aligned(16))) double Asf[2 * KS * SS];
   __shared__ __attribute__((aligned(16))) double Bsf[2 * KS * SS];
   auto at = [](int st, int s, int row, int kk) { return LAY ? (st * KS + s) * SS + kk * RS + row : (st * KS + s) * SS + row * 4 + kk; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int m0 = tile_m * TM, n0 = tile_n * TM;
   const int l15 = lane & 15, l4 = lane >> 4;
-  dbl4 acc[MT][MT];
+  dbl4 acc[MT][MTN];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < MTN; ++j) acc[i][j] = dbl4{0.0, 0.0, 0.0, 0.0};
   double ra[KT], rb[KT];
   const int arow = tid / TPR, akk = (tid % TPR) * KT;
   const int bn = tid % TM, bkg = tid / TM;                                   // NN: column n, k group
@@ -216,17 +222,17 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
       }
     }
   };
-  auto frag = [&](int st, int s, double (&a)[MT], double (&b)[MT]) {
+  auto frag = [&](int st, int s, double (&a)[MT], double (&b)[MTN]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) a[i] = Asf[at(st, s, wm * (TM / 2) + i * 16 + l15, l4)];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) b[j] = Bsf[at(st, s, wn * (TM / 2) + j * 16 + l15, l4)];
+    for (int j = 0; j < MTN; ++j) b[j] = Bsf[at(st, s, wn * (TM / WN) + j * 16 + l15, l4)];
   };
-  auto mma = [&](const double (&a)[MT], const double (&b)[MT]) {
+  auto mma = [&](const double (&a)[MT], const double (&b)[MTN]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
+      for (int j = 0; j < MTN; ++j)
         mfma_f64_vgpr(acc[i][j], a[i], b[j]);
   };
 
@@ -238,7 +244,7 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
   // the barrier of a stage sits in front of its LAST group of MFMAs, and the first fragments of the next stage are read
   // behind it: the barrier and the LDS latency of a stage change hide under 16 MFMAs instead of idling the pipe
   {
-    double a0[MT], b0[MT], a1[MT], b1[MT];
+    double a0[MT], b0[MTN], a1[MT], b1[MTN];
     frag(0, 0, a0, b0);
     // steady state: stage t stores the operands of stage t + 1 and loads those of stage t + 2, all three full stages
     if (!OLD && vec16)   // (OLD: the round-4 loop -- every stage through the bounds-tested form below; the default, see launch_gemm_pair)
@@ -285,8 +291,8 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int n = n0 + wn * (TM / 2) + j * 16 + l15;
+    for (int j = 0; j < MTN; ++j) {
+      const int n = n0 + wn * (TM / WN) + j * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM / 2) + i * 16 + l4 + 4 * r;
@@ -322,6 +328,17 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
   else if constexpr (DB == 4) gemm_f64_db_tile<NN, 128, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);   // LDS layout 1
   else if constexpr (DB == 5) gemm_f64_db_tile<NN, 64, true, 1>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
   else gemm_f64_db_tile<NN, 128, false>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
+}
+
+// The 128-tile by eight waves of 64 x 32 (four waves per SIMD with two workgroups per CU): the default of the pair launcher since
+// round 6 (RPDE_GEMM_WAVES=4: the four-wave kernel, A/B)
+template <bool NN>
+__global__ __launch_bounds__(512, 4) void gemm_f64_pair8_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
+  const GemmArgs& g = blockIdx.z ? g1 : g0;
+  int tx, ty;
+  gemm_tile_of_block(z, tx, ty);
+  if (ty * 128 >= g.M || tx * 128 >= g.N) return;
+  gemm_f64_db_tile<NN, 128, true, 1, 8>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
 }
 
 // RPDE_GEMM_PERSIST=1 (A/B, round 6): a workgroup works off its tile of BOTH problems one after the other instead of the two
@@ -396,7 +413,13 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     // 375 instructions around the 64 MFMAs of a stage were never what kept the pipe at 0.81; the round-4 loop stays the default
     static const bool peel = [] { const char* e = std::getenv("RPDE_GEMM_PEEL"); return e && std::atoi(e) != 0; }();
     static const bool persist = [] { const char* e = std::getenv("RPDE_GEMM_PERSIST"); return e && std::atoi(e) != 0; }();
-    if (!peel && lay1 && persist) {
+    // eight waves per 128-tile: the default since round 6 (G1 / G2 1.097 / 1.145 -> 1.045 / 1.083 ms, three alternating runs in one
+    // call, profiles/r06_experiments/call9_ab_gemm_waves.txt; MFMA pipe 92 % -> 96 % busy); RPDE_GEMM_WAVES=4: four waves (A/B)
+    static const bool waves8 = [] { const char* e = std::getenv("RPDE_GEMM_WAVES"); return !e || std::atoi(e) != 4; }();
+    if (!peel && lay1 && waves8 && !persist) {
+      if (nn) hipLaunchKernelGGL((gemm_f64_pair8_kernel<true>), grid, dim3(512), 0, st.s, g0, g1, z);
+      else hipLaunchKernelGGL((gemm_f64_pair8_kernel<false>), grid, dim3(512), 0, st.s, g0, g1, z);
+    } else if (!peel && lay1 && persist) {
       grid.z = 1;
       if (nn) hipLaunchKernelGGL((gemm_f64_pair_persist_kernel<true>), grid, dim3(256), 0, st.s, g0, g1, z);
       else hipLaunchKernelGGL((gemm_f64_pair_persist_kernel<false>), grid, dim3(256), 0, st.s, g0, g1, z);

@@ -158,6 +158,13 @@ def test_round6_gemm_persist_bit_identical(hip_lib):
     _ab_switch_bit_identical("RPDE_GEMM_PERSIST", "1", "((2049, 2049),)")
 
 
+def test_round6_gemm_eight_waves_bit_identical(hip_lib):
+    """Round 6: the 128 x 128 tile of the eigen-transform GEMM runs on eight waves of 64 x 32 (four waves per SIMD) instead of four
+    of 64 x 64 (RPDE_GEMM_WAVES=4: the A/B switch).  Every element of the product accumulates the same MFMAs in the same order:
+    bit-identical fields."""
+    _ab_switch_bit_identical("RPDE_GEMM_WAVES", "4", "((2049, 2049),)")
+
+
 def _ab_switch_bit_identical(switch, value, sizes):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
