@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 // the same bank: the k/4 planes are 580 doubles apart, which puts them 16 banks apart).
 // WAVES: 4 (2 x 2 waves of TM/2 x TM/2) or -- TM = 128 only -- 8 (2 x 4 waves of 64 x 32: half the accumulators per wave, 128 VGPRs,
 // so that the two workgroups of a CU put FOUR waves on a SIMD instead of two; round 6, the pair launcher's default)
-template <bool NN, int TM, bool OLD = true, int LAY = 0, int WAVES = 4>
+// CTS (round 6, the transposed store of G2): the product is accumulated TRANSPOSED -- the MFMA takes the B fragment as its first and
+// the A fragment as its second operand, so a lane holds C(m = lane % 16, n = lane / 16 + 4 r) and the 16 lanes of a register write
+// 128 contiguous bytes of row n of C^T, like the plain store does for C (the runtime `ct` store of the untransposed accumulators
+// writes 32-byte pieces: four times the write requests).  Every element accumulates the same products in the same order (a b = b a).
+template <bool NN, int TM, bool OLD = true, int LAY = 0, int WAVES = 4, bool CTS = false>
 __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb, double* __restrict__ C, long ldc,
                                                  int tile_m, int tile_n, bool ct = false, bool z00 = false) {
@@ -232,8 +236,10 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < MTN; ++j)
-        mfma_f64_vgpr(acc[i][j], a[i], b[j]);
+      for (int j = 0; j < MTN; ++j) {
+        if constexpr (CTS) mfma_f64_vgpr(acc[i][j], b[j], a[i]);
+        else mfma_f64_vgpr(acc[i][j], a[i], b[j]);
+      }
   };
 
   gload(0);
@@ -288,6 +294,20 @@ __device__ __forceinline__ void gemm_f64_db_tile(int M, int N, int K, const doub
     }
   }
   mfma_drain();
+  if constexpr (CTS) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < MTN; ++j) {
+        const int m = m0 + wm * (TM / 2) + i * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * (TM / WN) + j * 16 + l4 + 4 * r;
+          if (m < M && n < N) C[(long)n * ldc + m] = (z00 && (m | n) == 0) ? 0.0 : acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -332,13 +352,13 @@ __global__ __launch_bounds__(256) void gemm_f64_pair_kernel(const GemmArgs g0, c
 
 // The 128-tile by eight waves of 64 x 32 (four waves per SIMD with two workgroups per CU): the default of the pair launcher since
 // round 6 (RPDE_GEMM_WAVES=4: the four-wave kernel, A/B)
-template <bool NN>
+template <bool NN, bool CTS = false>
 __global__ __launch_bounds__(512, 4) void gemm_f64_pair8_kernel(const GemmArgs g0, const GemmArgs g1, const GemmSwizzle z) {
   const GemmArgs& g = blockIdx.z ? g1 : g0;
   int tx, ty;
   gemm_tile_of_block(z, tx, ty);
   if (ty * 128 >= g.M || tx * 128 >= g.N) return;
-  gemm_f64_db_tile<NN, 128, true, 1, 8>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
+  gemm_f64_db_tile<NN, 128, true, 1, 8, CTS>(g.M, g.N, g.K, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, ty, tx, g.ct, g.z00);
 }
 
 // RPDE_GEMM_PERSIST=1 (A/B, round 6): a workgroup works off its tile of BOTH problems one after the other instead of the two
@@ -416,8 +436,13 @@ void launch_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, Str
     // eight waves per 128-tile: the default since round 6 (G1 / G2 1.097 / 1.145 -> 1.045 / 1.083 ms, three alternating runs in one
     // call, profiles/r06_experiments/call9_ab_gemm_waves.txt; MFMA pipe 92 % -> 96 % busy); RPDE_GEMM_WAVES=4: four waves (A/B)
     static const bool waves8 = [] { const char* e = std::getenv("RPDE_GEMM_WAVES"); return !e || std::atoi(e) != 4; }();
+    // both products stored transposed (G2): accumulate them transposed (gemm_f64_db_tile CTS); RPDE_GEMM_CTSWAP=0: the 32-byte store (A/B)
+    static const bool ctswap = [] { const char* e = std::getenv("RPDE_GEMM_CTSWAP"); return !e || std::atoi(e) != 0; }();
     if (!peel && lay1 && waves8 && !persist) {
-      if (nn) hipLaunchKernelGGL((gemm_f64_pair8_kernel<true>), grid, dim3(512), 0, st.s, g0, g1, z);
+      if (ctswap && p0.ct && p1.ct) {
+        if (nn) hipLaunchKernelGGL((gemm_f64_pair8_kernel<true, true>), grid, dim3(512), 0, st.s, g0, g1, z);
+        else hipLaunchKernelGGL((gemm_f64_pair8_kernel<false, true>), grid, dim3(512), 0, st.s, g0, g1, z);
+      } else if (nn) hipLaunchKernelGGL((gemm_f64_pair8_kernel<true>), grid, dim3(512), 0, st.s, g0, g1, z);
       else hipLaunchKernelGGL((gemm_f64_pair8_kernel<false>), grid, dim3(512), 0, st.s, g0, g1, z);
     } else if (!peel && lay1 && persist) {
       grid.z = 1;

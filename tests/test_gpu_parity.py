@@ -165,6 +165,13 @@ def test_round6_gemm_eight_waves_bit_identical(hip_lib):
     _ab_switch_bit_identical("RPDE_GEMM_WAVES", "4", "((2049, 2049),)")
 
 
+def test_round6_gemm_transposed_accumulation_bit_identical(hip_lib):
+    """Round 6: G2 (the product that is stored transposed) accumulates C^T -- the MFMA takes the B fragment first -- so that its
+    stores are 128-byte runs like those of an untransposed product (RPDE_GEMM_CTSWAP=0: the 32-byte transposed store of the
+    untransposed accumulators).  a b = b a exactly and the k order is the same: bit-identical fields."""
+    _ab_switch_bit_identical("RPDE_GEMM_CTSWAP", "0", "((2049, 2049),)")
+
+
 def _ab_switch_bit_identical(switch, value, sizes):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
