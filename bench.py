@@ -524,6 +524,10 @@ def main():
                                   "frac_of_hbm_peak": moved_t / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_t > 0 else None},
         # for comparison only: the reference op sequence has 13 two-dimensional transforms = 416 nx ny bytes
         # (SURVEY.md 8d); this engine executes 11 of them (the lift's gradients are constants)
+        # SURVEY.md 8d's unit (one 2-D transform = 32 nx ny bytes) times the 11 transforms this engine executes per step
+        "executed_transforms": 11,
+        "executed_transforms_bytes": 352.0 * args.nx * args.ny,
+        "executed_transforms_frac": 352.0 * args.nx * args.ny / (line_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if line_ms > 0 else None,
         "reference_sequence_bytes": ref_bytes,
         "reference_sequence_equiv_frac": ref_bytes / (line_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if line_ms > 0 else None,
         "pure_1d_transform_kernels": [
@@ -536,6 +540,11 @@ def main():
     # `transform_pass_ref_equiv_frac` prices the same time with the reference sequence's 13 transforms
     roof["transform_pass_frac"] = transform_pass["frac_of_hbm_peak"]
     roof["transform_pass_ref_equiv_frac"] = transform_pass["reference_sequence_equiv_frac"]
+    # round 6: the stages no longer read what is redundant in the time-independent lift arrays (RPDE_LIFT_STRUCT; 0.54 GB per step
+    # at 4097^2 with "rbc"): `transform_pass_frac` counts the bytes still moved and reads LOWER for a pass that got faster -- the
+    # time of the pass and SURVEY 8d's own unit (11 executed transforms x 32 nx ny bytes) are reported beside it
+    roof["transform_pass_ms"] = line_ms
+    roof["transform_pass_executed_transforms_frac"] = transform_pass["executed_transforms_frac"]
     out = {
         "metric": "timesteps/sec (2D RBC, f64)",
         "value": args.steps / elapsed,

@@ -359,7 +359,11 @@ struct ConvLineArgs {
   int nlines, N;
   const double* tw; const double* tw2;
   double dscale; int cut;
+  long ldl = -1;                  // pitch of bx / by (-1: ld).  0: every line reads line 0 -- a lift that does not depend on x ("rbc":
+                                  // linear in y) has the same gradient on every y-line, and two of a convection term's six input arrays
+                                  // then come out of the L2 instead of HBM (Navier2DEngine::analyse_lift)
 };
+RPDE_HD inline long conv_lift_pitch(const ConvLineArgs& c) { return c.ldl >= 0 ? c.ldl : c.ld; }
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   const DctLineArgs a{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, c.N, 2, c.tw, c.tw2, 1.0};
   DctLineArgs b = a;
@@ -373,7 +377,8 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   lds_t buf = (lds_t)blk.lds;
   const long off = (long)blk.line * c.ld;
   cgmem_t up = (cgmem_t)(c.up + off), vp = (cgmem_t)(c.vp + off);
-  cgmem_t bx = (cgmem_t)(c.bx ? c.bx + off : nullptr), by = (cgmem_t)(c.by ? c.by + off : nullptr);
+  const long offl = (long)blk.line * conv_lift_pitch(c);
+  cgmem_t bx = (cgmem_t)(c.bx ? c.bx + offl : nullptr), by = (cgmem_t)(c.by ? c.by + offl : nullptr);
   const bool lift = c.bx != nullptr;
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};

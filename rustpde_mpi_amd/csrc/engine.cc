@@ -288,6 +288,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
     scatter_rows_xy(ph.p(), ph.ld, BY_, nx, ny, false);
     dev_sync(st_);
   }
+  analyse_lift();
   if (periodic) build_periodic(); else build_confined();
   if (overlap_) overlap_ = apply_overlap_order();
   if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos + column-scan summaries
@@ -556,6 +557,48 @@ void Navier2DEngine::after_exchange(unsigned wait_mask) {
 #else
   (void)wait_mask;    // the emulation runs the launches in program order on the host: an exchange has landed when it returns
 #endif
+}
+
+void Navier2DEngine::analyse_lift() {
+  // The lift and what the step reads of it never change: look at the arrays ONCE.  Nothing is assumed from the name of the boundary
+  // condition -- "hc" (a lift that varies along x) finds no structure and keeps whole arrays.
+  lift_ldl_ = -1; tbc_cols_ = tbc2_cols_ = -1;
+  std::vector<double> h;
+  const int rows = ylines(ny_), ncol = periodic_ ? 2 * kx_ : nx_;
+  if (periodic_ && nx_ % 2 == 0 && rows > 0) {
+    // the imaginary part of the Nyquist mode of a real line is zero; the forward transform of the setup leaves round-off there
+    // (1e-18 of mode 0).  The lift is setup data: its rows are stored with that entry exactly zero, whatever the switch below says
+    for (DBuf* b : {&TBC_, &TBC2_}) {
+      h.resize((size_t)rows * ncol);
+      dev_download2d(h.data(), yx(*b), ldx_, rows, ncol);
+      for (int j = 0; j < rows; ++j) h[(size_t)j * ncol + ncol - 1] = 0.0;
+      dev_upload2d(yx(*b), ldx_, h.data(), rows, ncol);
+    }
+  }
+  if (const char* e = std::getenv("RPDE_LIFT_STRUCT")) if (std::atoi(e) == 0) return;   // A/B only
+  const int nlx = xlines(nx_, false);
+  auto lines_equal = [&](const DBuf& b) {   // all local y-lines of an XY array carry the values of local line 0
+    if (nlx <= 0) return false;
+    h.resize((size_t)nlx * ny_);
+    dev_download2d(h.data(), b.p, ldy_, nlx, ny_);
+    for (int i = 1; i < nlx; ++i)
+      for (int j = 0; j < ny_; ++j)
+        if (h[(size_t)i * ny_ + j] != h[j]) return false;
+    return true;
+  };
+  if (lines_equal(BX_) && lines_equal(BY_)) lift_ldl_ = 0;
+  auto nz_cols = [&](DBuf& b) {   // 1 + the last column of the local rows of a YX array that holds a non-zero
+    if (rows <= 0) return 0;
+    h.resize((size_t)rows * ncol);
+    dev_download2d(h.data(), yx(b), ldx_, rows, ncol);
+    int last = -1;
+    for (int j = 0; j < rows; ++j)
+      for (int k = ncol - 1; k > last; --k)
+        if (h[(size_t)j * ncol + k] != 0.0) { last = k; break; }
+    return last + 1;
+  };
+  tbc_cols_ = buoyancy_lift_ ? nz_cols(TBC_) : 0;
+  tbc2_cols_ = nz_cols(TBC2_);
 }
 
 void Navier2DEngine::halo_rows(double* const* arr, int n, int front, int tail) {
@@ -849,7 +892,8 @@ bool Navier2DEngine::add_four_rhs(const FourRhsArgs& a, const char* tag) {
   l.fr = a;
   l.tag = tag;
   const double nc = a.f.N + 2;   // doubles of a spectral line
-  l.bytes = 8.0 * ((double)a.f.N + nc * (a.which == 1 ? 7.0 : (a.which == 0 ? 4.0 : 4.0))) * a.f.nlines;   // conv line; state rows j, j-2 (+ p | gy, temp rows j, j-2, tbc | tbc2); out
+  const double tb = (a.tbc_cols >= 0 && a.which != 0) ? std::min<double>(a.tbc_cols, nc) : nc;   // what is read of a tbc row
+  l.bytes = 8.0 * ((double)a.f.N + nc * (a.which == 1 ? 6.0 : 3.0) + tb) * a.f.nlines;   // conv line; state rows j, j-2 (+ p | gy, temp rows j, j-2, tbc | tbc2); out
   step_.push_back(l);
   return true;
 }
@@ -860,7 +904,7 @@ bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   l.type = Launch::kConvLine;
   l.cl = c;
   l.tag = tag;
-  l.bytes = 8.0 * (2.0 * c.n_in + (c.bx ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by), out
+  l.bytes = 8.0 * (2.0 * c.n_in + ((c.bx && conv_lift_pitch(c) != 0) ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by -- unless every line reads line 0), out
   step_.push_back(l);
   return true;
 }
@@ -884,7 +928,8 @@ bool Navier2DEngine::add_rhs_line(RhsLineArgs a, int which, const char* tag) {
   l.tag = tag;
   // conv + state + solution, plus d/dx p | T, d/dy p, T_bc | lap(T_bc)  (rows j - 2 are re-reads of a neighbour's row j)
   const double n = a.N + 1, m = a.N - 1;
-  l.bytes = 8.0 * a.nlines * (n + 2.0 * m + (which == 0 ? n : which == 1 ? m + 2.0 * n : n));
+  const double tb = (a.tbc_cols >= 0 && a.tbc_cols <= a.N / 8) ? a.tbc_cols : n;   // what is read of a tbc row (rhs_line.h)
+  l.bytes = 8.0 * a.nlines * (n + 2.0 * m + (which == 0 ? n : which == 1 ? m + n + tb : tb));
   step_.push_back(l);
   return true;
 }
@@ -2000,14 +2045,15 @@ void Navier2DEngine::build_confined() {
     // ("hc" temperature) ny orthonormal coefficients, no stencil
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash, so two workgroups share a CU
-    const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
-                          xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                    xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    if (bx) cl.ldl = lift_ldl_;
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(ys);
       pb.load(0, pb.arr(c.fx, ldy), nin);        // d/dx f (x-derivative taken in S1)
       pb.dct_fused(0, ys, true, ys.bwd_pre.p, nullptr);
-      if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
+      if (c.bx) pb.load(0, pb.arr(c.bx, conv_lift_pitch(c)), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.up, ldy), ny);
       pb.load(1, pb.arr(c.f0, ldy), nin);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
       pb.pair_last_loads();
@@ -2015,7 +2061,7 @@ void Navier2DEngine::build_confined() {
       pb.to_ortho_from(0, 1, ys);
       pb.cdiff(0, 0, ny, 1.0 / sy_);
       pb.dct(0, ny, ys.bwd_pre.p, nullptr);
-      if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
+      if (c.by) pb.load(0, pb.arr(c.by, conv_lift_pitch(c)), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.vp, ldy), ny);
       if (c.by) pb.pair_last_loads();
       pb.unstash_axpy(0, 1.0, 1.0, ny);
@@ -2045,8 +2091,8 @@ void Navier2DEngine::build_confined() {
       r.lowy = yD.low.p; r.lowy2 = yD.low.p; r.stx = which == 2 ? 1 : 2; r.lowx = xN.low.p;
       r.tw = ax.tw.p; r.tw2 = ax.tw2.p;
       if (which == 0) r.grad = yx(GX_);
-      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); }
-      if (which == 2) r.tbc = yx(TBC2_);
+      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); r.tbc_cols = tbc_cols_; }
+      if (which == 2) { r.tbc = yx(TBC2_); r.tbc_cols = tbc2_cols_; }
       if (add_rhs_line(r, which, tag)) return;
     }
     ProgramBuilder pb = ypb(2, my);
@@ -2291,14 +2337,15 @@ void Navier2DEngine::build_periodic() {
   auto conv = [&](DBuf& fx, DBuf& f0, DBuf* bx, DBuf* by, DBuf& out, const char* tag, AxisTables& ys, int nin) {
     // out = DCT_y[ u * (d/dx f + bx) + v * (d/dy f + by) ]; DCT pair = slots 0,1; the first product
     // waits in the register stash
-    const ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
-                          xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
+                    xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
+    if (bx) cl.ldl = lift_ldl_;
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(ys);
       pb.load(0, pb.arr(c.fx, ldy), nin);        // d/dx f (x-derivative taken in S1)
       pb.dct_fused(0, ys, true, ys.bwd_pre.p, nullptr);
-      if (c.bx) pb.load(0, pb.arr(c.bx, ldy), ny, 1.0, true);
+      if (c.bx) pb.load(0, pb.arr(c.bx, conv_lift_pitch(c)), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.up, ldy), ny);
       pb.load(1, pb.arr(c.f0, ldy), nin);        // d/dy f: slot 1 (the DCT's scratch) is free; fetched together with u
       pb.pair_last_loads();
@@ -2306,7 +2353,7 @@ void Navier2DEngine::build_periodic() {
       pb.to_ortho_from(0, 1, ys);
       pb.cdiff(0, 0, ny, 1.0 / sy_);
       pb.dct(0, ny, ys.bwd_pre.p, nullptr);
-      if (c.by) pb.load(0, pb.arr(c.by, ldy), ny, 1.0, true);
+      if (c.by) pb.load(0, pb.arr(c.by, conv_lift_pitch(c)), ny, 1.0, true);
       pb.loadmul(0, pb.arr(c.vp, ldy), ny);
       if (c.by) pb.pair_last_loads();
       pb.unstash_axpy(0, 1.0, 1.0, ny);
@@ -2335,9 +2382,9 @@ void Navier2DEngine::build_periodic() {
       if (which == 1) {
         a.gy = yx(GY_);
         a.tsrc = hc ? yx(TO_) : yx(T_); a.tlow = hc ? nullptr : yD.low.p;
-        a.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); a.ctbc = dt;
+        a.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); a.ctbc = dt; a.tbc_cols = tbc_cols_;
       }
-      if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; }
+      if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; a.tbc_cols = tbc2_cols_; }
       a.diag = hh.diag0.p;
       if (xF.fft_n * 2 == nx && add_four_rhs(a, tag)) return;
     }

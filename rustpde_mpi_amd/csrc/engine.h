@@ -299,6 +299,12 @@ class Navier2DEngine {
   DBuf coldot_, colkap_;             // rank-one sums of the column scans
   int pseu_half_ = 0;                // > 0: the step leaves pseu in YX layout, parity blocks `pseu_half_` columns apart
   bool pseu_in_yx_ = false;          // the canonical array PS_ is out of date (state_to_canonical refreshes it)
+  // structure of the time-independent lift arrays, found once at setup (analyse_lift; RPDE_LIFT_STRUCT=0: not used, A/B): a lift that
+  // does not depend on x -- "rbc": linear in y -- has identical y-lines of its physical gradients (BX_ / BY_: pitch 0, every line reads
+  // line 0 out of the L2) and one x-coefficient per row of its spectral arrays (TBC_: column 0; its Laplacian TBC2_: nothing)
+  long lift_ldl_ = -1;               // pitch the convection term reads BX_ / BY_ with (-1: ldy_)
+  int tbc_cols_ = -1, tbc2_cols_ = -1;   // leading coefficients of a row of TBC_ (TBC0_) / TBC2_ that can be non-zero (-1: not analysed)
+  void analyse_lift();
   bool buoyancy_lift_ = true;
   DBuf TBC0_;                        // buoyancy_lift_ = false: a zero array in the lift's place (buoyancy term only)
   bool pseu_from_y4_ = false;   // periodic step with the real-view S6: the canonical pseu is the complex transpose of Y_[4]

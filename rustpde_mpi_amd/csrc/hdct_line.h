@@ -563,12 +563,12 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   constexpr int T = N / 16;
   lds_t buf = (lds_t)blk.lds;
   lds2_t buf2 = (lds2_t)blk.lds;
-  const long off = (long)blk.line * c.ld;
+  const long off = (long)blk.line * c.ld, offl = (long)blk.line * conv_lift_pitch(c);
   const bool lift = c.bx != nullptr;
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   {
-    cgmem_t up = (cgmem_t)(c.up + off), bx = (cgmem_t)(lift ? c.bx + off : c.up + off);
+    cgmem_t up = (cgmem_t)(c.up + off), bx = (cgmem_t)(lift ? c.bx + offl : c.up + off);
     hdct_core<N>(blk, a1, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (u == 8) { RPDE_T(acc)[16] = up[m] * (lift ? e0 + bx[m] : e0); return; }
       const dbl2 f = ((cgmem2_t)up)[m >> 1];
@@ -582,7 +582,7 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   DctLineArgs a2 = a1;
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   {
-    cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + off : c.vp + off);
+    cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + offl : c.vp + off);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (u == 8) { RPDE_T(acc)[16] += vp[m] * (lift ? e0 + by[m] : e0); return; }
       const dbl2 f = ((cgmem2_t)vp)[m >> 1];

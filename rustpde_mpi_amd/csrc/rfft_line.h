@@ -291,6 +291,8 @@ struct FourRhsArgs {
   const double* tsrc; const double* tlow;   // which 1
   const double* tbc; double ctbc;  // which 1: TBC with ctbc = dt; which 2: TBC2 with ctbc = dt * ka
   const double* diag;              // [N / 2 + 1]
+  int tbc_cols = -1;               // >= 0: only the first tbc_cols doubles of a tbc row can be non-zero (a lift that does not depend on
+                                   // x: mode 0 only, its Laplacian possibly nothing): the other modes are not read (Navier2DEngine::analyse_lift)
 };
 RPDE_HD inline bool four_rhs_ok(const FourRhsArgs& a) {
   return rfft_line_ok(a.f) && (a.ld & 1) == 0 && (((size_t)a.state | (size_t)a.p | (size_t)a.gy | (size_t)a.tsrc | (size_t)a.tbc) & 15) == 0;
@@ -312,6 +314,7 @@ RPDE_DEV void four_rhs_line(Blk& blk, const FourRhsArgs& a) {
   tab_t dg = (tab_t)a.diag;
   gmem2_t dst = (gmem2_t)(a.f.out + (long)line * a.f.ldo);
   const int which = a.which;
+  const int tm = (a.tbc_cols >= 0) ? (a.tbc_cols + 1) / 2 : (1 << 30);   // modes of the tbc row that are read
   rfft_fwd_core<N>(blk, a.f, [&](int, int, int k, double yr, double yi) {
     double vr = (k < a.cut) ? -a.dt * yr : 0.0, vi = (k < a.cut) ? -a.dt * yi : 0.0;
     if (has0) { const dbl2 s = st0[k]; vr += s.x; vi += s.y; }
@@ -321,12 +324,12 @@ RPDE_DEV void four_rhs_line(Blk& blk, const FourRhsArgs& a) {
       const double g = a.pk * (double)k;
       vr -= g * q.y; vi += g * q.x;
     } else if (which == 1) {
-      const dbl2 g = gy[k], b = tb[k];
+      const dbl2 g = gy[k], b = (k < tm) ? tb[k] : dbl2{0.0, 0.0};
       vr += -a.dt * g.x + a.ctbc * b.x; vi += -a.dt * g.y + a.ctbc * b.y;
       if (has0) { const dbl2 s = ts0[k]; vr += a.dt * s.x; vi += a.dt * s.y; }
       if (t2 != 0.0) { const dbl2 s = ts2[k]; vr += a.dt * t2 * s.x; vi += a.dt * t2 * s.y; }
     } else {
-      const dbl2 b = tb[k];
+      const dbl2 b = (k < tm) ? tb[k] : dbl2{0.0, 0.0};
       vr += a.ctbc * b.x; vi += a.ctbc * b.y;
     }
     const double d = dg[k];

@@ -30,6 +30,9 @@ struct RhsLineArgs {
   const double* st2 = nullptr;          // vely: the temperature state (buoyancy)
   const double* grad = nullptr;         // velx: d/dx p, vely: d/dy p (orthonormal rows); temp: unused
   const double* tbc = nullptr;          // vely: T_bc rows; temp: lap(T_bc) rows
+  int tbc_cols = -1;                    // >= 0: only the first tbc_cols coefficients of a tbc row can be non-zero (a lift that does not
+                                        // depend on x has one x-coefficient per row, its Laplacian may vanish altogether): the rest of
+                                        // the row is not read (Navier2DEngine::analyse_lift); -1: whole rows
   double* out = nullptr;                // composite coefficients after the x solve (N - 1 per line)
   long ld = 0;                          // all arrays share the pitch
   int nlines = 0, line0 = 0;            // local lines, global index of the first one
@@ -161,7 +164,14 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   const long rowb = (long)(N + 2) * 8;                      // bytes of a row that may be touched (pairs up to N, N + 1)
   const RowBuf s0 = row_buf(a.st + off, rowb), s2 = row_buf(a.st + off2, rowb);
   const RowBuf t0r = row_buf(((WHICH == 1) ? a.st2 : a.st) + off, rowb), t2r = row_buf(((WHICH == 1) ? a.st2 : a.st) + off2, rowb);
-  const RowBuf g2 = row_buf(((WHICH == 2) ? a.tbc : a.grad) + off, rowb), b2 = row_buf(((WHICH == 1) ? a.tbc : a.conv) + off, rowb);
+  // the tbc row when only its first tcols <= 2 T coefficients can be non-zero: they lie in block u = 0 of the pairs (m = 2 (t + u T)),
+  // so the other blocks are not loaded at all and the descriptor of the row ends behind them (block 0 has no uniform offset: the
+  // range check of the per-thread offset is exact); a longer non-zero part reads whole rows
+  const bool tpart = a.tbc_cols >= 0 && a.tbc_cols <= 2 * T;
+  const int tcols = tpart ? a.tbc_cols : N + 2;
+  const long tbcb = tpart ? 8L * ((tcols + 1) & ~1) : rowb;
+  const int tub = tpart ? (tcols > 0 ? 1 : 0) : 8;
+  const RowBuf g2 = row_buf(((WHICH == 2) ? a.tbc : a.grad) + off, (WHICH == 2) ? tbcb : rowb), b2 = row_buf(((WHICH == 1) ? a.tbc : a.conv) + off, (WHICH == 1) ? tbcb : rowb);
   const RowBuf lx2 = row_buf((stab || (WHICH == 1)) ? a.lowx : a.tw2, rowb);
   const double gfac = (WHICH == 2) ? dt * a.ka : -dt;      // factor of the row g2: d/dx p, d/dy p (- dt) or lap(T_bc) (dt ka)
   RPDE_PHASE(blk, tid) {
@@ -179,11 +189,11 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
         // part that steps back and thread 0 reads zero (in front of the line)
         const int wm = (u == 0) ? vm : v, som = (u == 0) ? 0 : so - 16;
         a0[i] = row_ld2(s0, v, so); am[i] = row_ld2(s0, wm, som); c0[i] = row_ld2(s2, v, so); cm[i] = row_ld2(s2, wm, som);
-        g[i] = row_ld2(g2, v, so);
+        g[i] = ((WHICH != 2) || u < tub) ? row_ld2(g2, v, so) : dbl2{0.0, 0.0};
         lt[i] = (stab || (WHICH == 1)) ? row_ld2(lx2, wm, som) : dbl2{0.0, 0.0};
         if (WHICH == 1) {
           b0[i] = row_ld2(t0r, v, so); bm[i] = row_ld2(t0r, wm, som); d0[i] = row_ld2(t2r, v, so); dm[i] = row_ld2(t2r, wm, som);
-          tb[i] = row_ld2(b2, v, so);
+          tb[i] = (u < tub) ? row_ld2(b2, v, so) : dbl2{0.0, 0.0};
         }
       }
 #pragma unroll
@@ -220,9 +230,9 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
     if (tid == 0) {                                         // k = N: no own coefficient, the stencil tap of k - 2 only; zeros behind
       const int sn = (N - 2) * 8;
       const double lxn = stab ? row_ld1(lx2, 0, sn) : -1.0;
-      double rn = buf[N + (N >> 4) + 2] + lxn * (row_ld1(s0, 0, sn) + cy * row_ld1(s2, 0, sn)) + gfac * row_ld1(g2, 0, N * 8);
+      double rn = buf[N + (N >> 4) + 2] + lxn * (row_ld1(s0, 0, sn) + cy * row_ld1(s2, 0, sn)) + gfac * (((WHICH != 2) || tcols > N) ? row_ld1(g2, 0, N * 8) : 0.0);
       if ((WHICH == 1))
-        rn += dt * (row_ld1(lx2, 0, sn) * (row_ld1(t0r, 0, sn) + cy2 * row_ld1(t2r, 0, sn)) + row_ld1(b2, 0, N * 8));
+        rn += dt * (row_ld1(lx2, 0, sn) * (row_ld1(t0r, 0, sn) + cy2 * row_ld1(t2r, 0, sn)) + ((tcols > N) ? row_ld1(b2, 0, N * 8) : 0.0));
       buf[N + (N >> 4) + 2] = rn;
 #pragma unroll
       for (int k = N + 1; k <= N + 4; ++k) buf[k + (k >> 4) + 2] = 0.0;

@@ -487,3 +487,32 @@ def test_column_scans_several_blocks(emu_lib, periodic, nx, ny):
     """The Helmholtz-y solve and the y-derivatives as column scans (colscan.h) with more than one block of
     64 rows: block carries, partial last block (127 = 64 + 63 rows, 255 = 3 x 64 + 63)."""
     K.check_step_parity(emu_lib, periodic, nx, ny, 1e5, 0.01, 4, check_at=[1, 4])
+
+
+@pytest.mark.parametrize("periodic,nx,ny,bc,structured", [(False, 257, 65, "rbc", True), (False, 65, 257, "rbc", True),
+                                                            (True, 256, 65, "rbc", True), (False, 257, 65, "hc", False)])
+def test_lift_structure_is_found_and_changes_no_bit(emu_lib, monkeypatch, periodic, nx, ny, bc, structured):
+    """Round 6: the engine looks ONCE at the time-independent arrays of the boundary-condition lift (its physical gradients in the
+    temperature's convection term, its spectral rows and its Laplacian in the right-hand sides of vely / temp) and reads only what
+    is not redundant -- for "rbc" (a lift that does not depend on x) one y-line of the gradients for all lines and one leading
+    coefficient per spectral row, nothing of the vanishing Laplacian; "hc" (a lift that varies along x) finds nothing to skip.
+    RPDE_LIFT_STRUCT=0 reads whole arrays: the fields must agree bit for bit, and the schedule's byte count shows what was found."""
+    ctor = R.Navier2D.new_periodic if periodic else R.Navier2D.new_confined
+    out = {}
+    for flag in ("1", "0"):
+        if flag == "0":
+            monkeypatch.setenv("RPDE_LIFT_STRUCT", "0")
+        else:
+            monkeypatch.delenv("RPDE_LIFT_STRUCT", raising=False)
+        nav = ctor(nx, ny, 1e5, 1.0, 0.01, 1.0, bc, library=emu_lib, init_random=None)
+        nav.set_velocity(0.2, 1.0, 1.0)
+        nav.set_temperature(0.2, 1.0, 1.0)
+        nav.update(4)
+        out[flag] = (nav.physical_fields(), sum(row[1] for row in nav.schedule()))
+    monkeypatch.delenv("RPDE_LIFT_STRUCT", raising=False)
+    for k in out["1"][0]:
+        assert np.array_equal(out["1"][0][k], out["0"][0][k]), k
+    if structured:
+        assert out["1"][1] < out["0"][1], (out["1"][1], out["0"][1])
+    else:
+        assert out["1"][1] == out["0"][1]

@@ -172,6 +172,14 @@ def test_round6_gemm_transposed_accumulation_bit_identical(hip_lib):
     _ab_switch_bit_identical("RPDE_GEMM_CTSWAP", "0", "((2049, 2049),)")
 
 
+def test_round6_lift_structure_bit_identical(hip_lib):
+    """Round 6: what the step reads of the time-independent lift arrays (Navier2DEngine::analyse_lift: one y-line of the lift's
+    physical gradients for all lines, the leading non-zero coefficients of its spectral rows) against whole arrays
+    (RPDE_LIFT_STRUCT=0) -- the same values reach the same operations: bit-identical fields.  4097 x 129 / 129 x 4097: the
+    4096-point forms of S3 and of the convection term; 1025 x 1025: the one-wave-per-line forms."""
+    _ab_switch_bit_identical("RPDE_LIFT_STRUCT", "0", "((4097, 129), (129, 4097), (1025, 1025))")
+
+
 def _ab_switch_bit_identical(switch, value, sizes):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
