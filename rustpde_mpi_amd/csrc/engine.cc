@@ -949,7 +949,12 @@ bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   // S6 (y preconditioner + one factorised banded solve per eigen row of the Poisson problem) as one kernel (prow_line.h)
   PoissonOp& po = *pois_;
   // (periodic: the caller hands real lines -- two per wavenumber, tdiv = 2 -- between real-view transposes, one rank only)
-  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !(whole_line_len(a.N) || a.N == 2048) || (periodic_ && a.tdiv != 2) || !po.ensure_rows16()) return false;
+  if (!whole_line_on("RPDE_S6_LINE", kS6LineDefault) || !(whole_line_len(a.N) || a.N == 2048) || (periodic_ && a.tdiv != 2)) return false;
+  // RPDE_S6_DERIVE=1 (A/B, round 6): one factor row per line, the other three derived from it in the kernel (prow_line.h DERIVE).
+  // Measured: S6 0.180 -> 0.158 ms at half the bytes -- the kernel turns latency-bound (3 lines per CU; at 4 it spills 91 registers) --
+  // and the step does not move (5.54 / 5.55 ms); the four tables stay the default, bit for bit the reference's sweeps
+  { const char* e = std::getenv("RPDE_S6_DERIVE"); a.derive = (e && std::atoi(e) != 0) ? 1 : 0; }
+  if (!po.ensure_rows16(a.derive != 0)) return false;
   if (!prow_tabs_.t0.p) {   // chunk-major copy of the B2 rows for 16 elements per thread
     const int T = a.N / 16;
     const Mv3Tables pv = pinv_tables(sp_pseu_->base(1));
@@ -960,7 +965,11 @@ bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   // the factor tables hold the rows [row0, ...): the kernel indexes them with the global row number (like ProgramBuilder::fdma_solve)
   const FdmaDev& f = po.rows16;
   const long off = f.row0 * f.tabld;
-  a.q1 = f.q1.p - off; a.p2 = f.p2.p - off; a.q2 = f.q2.p - off; a.r2 = f.r2.p - off;
+  a.p2 = f.p2.p - off;
+  if (a.derive) {
+    const PoissonOp::Rows16Derived& d = po.rows16d;
+    a.mu = d.mu.p - f.row0; a.aLa = d.aLa.p; a.aLd = d.aLd.p; a.aU1d = d.aU1d.p; a.aU2d = d.aU2d.p; a.aU2sd = d.aU2sd.p; a.b1d = d.b1d.p;
+  } else { a.q1 = f.q1.p - off; a.q2 = f.q2.p - off; a.r2 = f.r2.p - off; }
   a.tabld = f.tabld;
   { const char* e = std::getenv("RPDE_S6_KEEP"); a.keep = e ? (std::atoi(e) != 0) : kS6KeepDefault; }
   if (!prow_line_ok(a)) return false;
@@ -968,7 +977,7 @@ bool Navier2DEngine::add_prow_line(ProwLineArgs a, const char* tag) {
   l.type = Launch::kProwLine;
   l.prl = a;
   l.tag = tag;
-  l.bytes = 8.0 * a.nlines * 6.0 * (a.N - 1);   // the line in and out, four factor rows (what the line program of the stage counts)
+  l.bytes = 8.0 * a.nlines * (a.derive ? 3.0 : 6.0) * (a.N - 1);   // the line in and out, four factor rows (what the line program of the stage counts) -- or one
   step_.push_back(l);
   return true;
 }

@@ -806,20 +806,24 @@ bool launch_corr_line(const CorrLineArgs& a, Stream& st) {
   RPDE_HIP(hipGetLastError());
   return true;
 }
-template <int N, bool KEEP>
+template <int N, bool KEEP, bool DER = false>
 __global__ __launch_bounds__(N / 16, N <= 2048 ? 2 : (KEEP ? 3 : 4)) void prow_line_kernel(const ProwLineArgs a) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= a.nlines) return;
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  prow_line<N, KEEP>(blk, a);
+  prow_line<N, KEEP, DER>(blk, a);
 }
 bool launch_prow_line(const ProwLineArgs& a, Stream& st) {
   if ((a.N != 4096 && a.N != 2048 && a.N != 1024) || !prow_line_ok(a)) return false;
   if (a.nlines <= 0) return true;
   const dim3 grid(8 * ((a.nlines + 7) / 8)), block(a.N / 16);
-  if (a.N == 1024) hipLaunchKernelGGL((prow_line_kernel<1024, true>), grid, block, 0, st.s, a);   // one wave per line: registers to spare
+  if (a.derive) {   // one factor row per line, the others derived from it (prow_line.h DERIVE)
+    if (a.N == 1024) hipLaunchKernelGGL((prow_line_kernel<1024, true, true>), grid, block, 0, st.s, a);
+    else if (a.N == 2048) hipLaunchKernelGGL((prow_line_kernel<2048, true, true>), grid, block, 0, st.s, a);
+    else hipLaunchKernelGGL((prow_line_kernel<4096, true, true>), grid, block, 0, st.s, a);
+  } else if (a.N == 1024) hipLaunchKernelGGL((prow_line_kernel<1024, true>), grid, block, 0, st.s, a);   // one wave per line: registers to spare
   else if (a.N == 2048) hipLaunchKernelGGL((prow_line_kernel<2048, true>), grid, block, 0, st.s, a);   // two waves per line (2049-point y-lines: BASELINE config 5)
   else if (a.keep) hipLaunchKernelGGL((prow_line_kernel<4096, true>), grid, block, 0, st.s, a);
   else hipLaunchKernelGGL((prow_line_kernel<4096, false>), grid, block, 0, st.s, a);
@@ -1534,7 +1538,8 @@ bool launch_prow_line(const ProwLineArgs& a, Stream&) {
   for (int line = 0; line < a.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, a.N / 16, base};
-    if (a.keep) { if (a.N == 4096) prow_line<4096, true>(blk, a); else if (a.N == 2048) prow_line<2048, true>(blk, a); else if (a.N == 1024) prow_line<1024, true>(blk, a); else prow_line<256, true>(blk, a); }
+    if (a.derive) { if (a.N == 4096) prow_line<4096, true, true>(blk, a); else if (a.N == 2048) prow_line<2048, true, true>(blk, a); else if (a.N == 1024) prow_line<1024, true, true>(blk, a); else prow_line<256, true, true>(blk, a); }
+    else if (a.keep) { if (a.N == 4096) prow_line<4096, true>(blk, a); else if (a.N == 2048) prow_line<2048, true>(blk, a); else if (a.N == 1024) prow_line<1024, true>(blk, a); else prow_line<256, true>(blk, a); }
     else if (a.N == 4096) prow_line<4096>(blk, a); else if (a.N == 2048) prow_line<2048>(blk, a); else if (a.N == 1024) prow_line<1024>(blk, a); else prow_line<256>(blk, a);
   }
   return true;

@@ -650,8 +650,7 @@ PoissonOp::PoissonOp(Space2Ops& s, double c0, double c1, int row_begin, int row_
 // The same factors a second time, chunk-major for 16 elements per thread: only the whole-line form of S6 reads them
 // (Navier2DEngine::add_prow_line), so only that caller builds them -- 4 x (nx - 2) x 4096 doubles = 0.54 GB at 4097^2 that the
 // tensor Helmholtz operators of the adjoint solver, the generic operator API and RPDE_S6_LINE=0 never carried a use for.
-bool PoissonOp::ensure_rows16() {
-  if (rows16.n > 0) return true;
+bool PoissonOp::ensure_rows16(bool derive) {
   const Base& b1 = sp.base(1);
   const int m1 = b1.m, N16 = m1 + 1;
   // (a Fourier x axis too: the rows of the periodic step's S6 are the wavenumbers)
@@ -662,27 +661,50 @@ bool PoissonOp::ensure_rows16() {
 #endif
   const int rb = rows_rb_, re = rows_re_;
   if (!want16 || re <= rb) return false;
+  const bool need_p2 = rows16.n == 0, need_full = !derive && !rows16_full_, need_der = derive && !rows16d.built;
+  if (!need_p2 && !need_full && !need_der) return true;
   const Bands ay = bands_axpy(Bands{Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0), Vec(m1, 0.0)}, rows_c1_, hholtz_mat_b(b1));
   const Bands cy = hholtz_mat_a(b1);
   const size_t nr = (size_t)(re - rb);
   const long ld16 = N16;
   const int T16 = N16 / 16;
-  Vec q1w(nr * ld16, 0.0), p2w(nr * ld16, 0.0), q2w(nr * ld16, 0.0), r2w(nr * ld16, 0.0);
-  for (int r = rb; r < re; ++r) {
-    Bands mtx = bands_axpy(ay, lam[r] + rows_alpha_, cy);
-    fdma_sweep(mtx);
-    FdmaTables t = fdma_tables(mtx);
-    const Vec aw = chunk_major16(t.q1, T16, +1), bw = chunk_major16(t.p2, T16, -1, 1.0),
-              cw = chunk_major16(t.q2, T16, -1), dw = chunk_major16(t.r2, T16, -1);
-    std::copy(aw.begin(), aw.end(), q1w.begin() + (size_t)(r - rb) * ld16);
-    std::copy(bw.begin(), bw.end(), p2w.begin() + (size_t)(r - rb) * ld16);
-    std::copy(cw.begin(), cw.end(), q2w.begin() + (size_t)(r - rb) * ld16);
-    std::copy(dw.begin(), dw.end(), r2w.begin() + (size_t)(r - rb) * ld16);
+  if (need_p2 || need_full) {
+    Vec q1w, q2w, r2w, p2w;
+    if (need_p2) p2w.assign(nr * ld16, 0.0);
+    if (need_full) { q1w.assign(nr * ld16, 0.0); q2w.assign(nr * ld16, 0.0); r2w.assign(nr * ld16, 0.0); }
+    for (int r = rb; r < re; ++r) {
+      Bands mtx = bands_axpy(ay, lam[r] + rows_alpha_, cy);
+      fdma_sweep(mtx);
+      FdmaTables t = fdma_tables(mtx);
+      if (need_p2) { const Vec bw = chunk_major16(t.p2, T16, -1, 1.0); std::copy(bw.begin(), bw.end(), p2w.begin() + (size_t)(r - rb) * ld16); }
+      if (need_full) {
+        const Vec aw = chunk_major16(t.q1, T16, +1), cw = chunk_major16(t.q2, T16, -1), dw = chunk_major16(t.r2, T16, -1);
+        std::copy(aw.begin(), aw.end(), q1w.begin() + (size_t)(r - rb) * ld16);
+        std::copy(cw.begin(), cw.end(), q2w.begin() + (size_t)(r - rb) * ld16);
+        std::copy(dw.begin(), dw.end(), r2w.begin() + (size_t)(r - rb) * ld16);
+      }
+    }
+    rows16.row0 = rb;
+    rows16.n = m1;
+    rows16.tabld = ld16;
+    if (need_p2) rows16.p2.upload(p2w);
+    if (need_full) { rows16.q1.upload(q1w); rows16.q2.upload(q2w); rows16.r2.upload(r2w); rows16_full_ = true; }
   }
-  rows16.row0 = rb;
-  rows16.n = m1;
-  rows16.tabld = ld16;
-  rows16.q1.upload(q1w); rows16.p2.upload(p2w); rows16.q2.upload(q2w); rows16.r2.upload(r2w);
+  if (need_der) {
+    // the row's matrix is ay + mu cy with ay = c1 (peye . S): nothing below the diagonal, nothing two above (prow_line.h DERIVE)
+    for (int k = 0; k < m1; ++k) RPDE_REQUIRE(ay.low[k] == 0.0 && ay.up2[k] == 0.0, "Poisson rows: the band structure the derived factors assume");
+    Vec mu(nr), sh(m1, 0.0);
+    for (int r = rb; r < re; ++r) mu[r - rb] = lam[r] + rows_alpha_;
+    for (int k = 2; k < m1; ++k) sh[k] = cy.up2[k - 2];
+    rows16d.mu.upload(mu);
+    rows16d.aLa.upload(chunk_major16(cy.low, T16, +1));
+    rows16d.aLd.upload(chunk_major16(cy.low, T16, -1));
+    rows16d.aU1d.upload(chunk_major16(cy.up1, T16, -1));
+    rows16d.aU2d.upload(chunk_major16(cy.up2, T16, -1));
+    rows16d.aU2sd.upload(chunk_major16(sh, T16, -1));
+    rows16d.b1d.upload(chunk_major16(ay.up1, T16, -1));
+    rows16d.built = true;
+  }
   return true;
 }
 

@@ -286,11 +286,15 @@ class PoissonOp {
   // p2 / q2 / r2; one row of ny - 1 = 16 T entries per x-row) -- the whole-line form of the stage (prow_line.h, S6 of the
   // confined step).  Built ON FIRST USE (ensure_rows16) for real (Chebyshev x) operators whose y-lines have a whole-line length; n = 0: not built.
   FdmaDev rows16;
-  bool ensure_rows16();          // builds them on first use (Navier2DEngine::add_prow_line); false: this operator has no such form
+  // `derive` (prow_line.h DERIVE): only p2 is tabulated per row; q1 / q2 / r2 follow in the kernel from p2, mu = lam_r + alpha and
+  // the one-dimensional bands of the row's matrix c1 B + mu A below (a quarter of the table memory: 0.13 GB instead of 0.54 at 4097^2)
+  struct Rows16Derived { DBuf mu, aLa, aLd, aU1d, aU2d, aU2sd, b1d; bool built = false; } rows16d;
+  bool ensure_rows16(bool derive = false);   // builds them on first use (Navier2DEngine::add_prow_line); false: this operator has no such form
  private:
   ScratchPool scr_;
   double rows_c1_ = 0.0, rows_alpha_ = 0.0;
   int rows_rb_ = 0, rows_re_ = 0;
+  bool rows16_full_ = false;     // q1 / q2 / r2 of rows16 are built too
 };
 
 // Hholtz<f64, 2> (src/solver/hholtz.rs:29-37, 72-106, 164-187): (I - c0 Dxx - c1 Dyy) vhat = A f by diagonalising x --

@@ -13,6 +13,15 @@
 // composition across the threads, exact re-run) with the row's factors in a second, 16-element chunk-major copy
 // (PoissonOp::rows16).  Per element the arithmetic is that of the reference's sequential sweeps.  The stage stays bound
 // by its tables: four factor rows per line on top of the line itself (6 x 8 bytes per point).
+//
+// DERIVE (round 6): of the four factor rows only p2 = 1 / d (d: the swept diagonal) needs the sequential sweep of the setup.  The
+// row's matrix is  c1 B + mu A  (B = peye . S: low = 0, up1 = 1, up2 = 0; A = pinv . S; mu = lam_r + alpha) and the sweep leaves
+//   l_k = low_k / d_{k-2},   up1_k <- up1_k - l_k up2_{k-2},   up2_k unchanged               (Fdma sweep, src/solver/fdma.rs:73-82)
+// so   q1_k = -l_k = -(mu aL_k) p2_{k-2},   r2_k = -(mu aU2_k) p2_k,   q2_k = -((c1 [k+2<n] + mu aU1_k) - l_k (mu aU2_{k-2})) p2_k
+// follow from p2, mu and four one-dimensional tables of A and B that every line shares (L2).  The kernel reads ONE factor row per
+// line instead of four (3 x 8 bytes per point instead of 6) and spends nine multiply-adds per point on the others; products with
+// the rounded reciprocal p2 stand where the setup divides by d: the factors differ from the tabulated ones in their last bit, the
+// solution by what that is worth (tests/test_emu_parity.py test_s6_derived_factors; RPDE_S6_DERIVE=0: the four tables).
 #pragma once
 #include "rhs_line.h"
 
@@ -31,26 +40,60 @@ struct ProwLineArgs {
   int keep = 1;                   // 4097-point lines: the KEEP form of prow_line (three workgroups per CU); 0: the factors read twice at four (RPDE_S6_KEEP, A/B)
   int zero0 = 0;                  // 1: element 0 of the lines of factor row 0 leaves as 0 -- `pseu[0, 0] = 0` (solve_pres, navier_eq.rs:158-162)
                                   // of the periodic step rides in the store (both parts of wavenumber 0)
+  // DERIVE form (see the head of the file): q1 / q2 / r2 may be null; p2 as above, plus
+  int derive = 0;
+  const double* mu = nullptr;     // [factor rows] lam_r + alpha, indexed like the factor tables (global row)
+  const double* aLa = nullptr;    // A.low, chunk-major ASCENDING (the forward pass)
+  const double *aLd = nullptr, *aU1d = nullptr, *aU2d = nullptr, *aU2sd = nullptr, *b1d = nullptr;   // chunk-major DESCENDING: A.low, A.up1, A.up2,
+                                  // A.up2 shifted (entry k = A.up2_{k-2}), c1 B.up1
   int tdiv = 1;                   // lines per factor row: 2 in the periodic step, where the real and the imaginary part of a wavenumber's
                                   // row are two consecutive real lines (engine.cc build_periodic: real-view transposes around S6)
 };
 RPDE_HD inline bool prow_line_ok(const ProwLineArgs& a) {
-  return (a.N == 256 || a.N == 1024 || a.N == 2048 || a.N == 4096) && (a.tdiv == 1 || a.tdiv == 2) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.q1 && a.p2 && a.q2 && a.r2 &&
+  const bool tabs = a.derive ? (a.mu && a.aLa && a.aLd && a.aU1d && a.aU2d && a.aU2sd && a.b1d) : (a.q1 && a.q2 && a.r2);
+  return (a.N == 256 || a.N == 1024 || a.N == 2048 || a.N == 4096) && (a.tdiv == 1 || a.tdiv == 2) && a.in && a.out && a.t0 && a.t1 && a.t2 && a.p2 && tabs &&
          ((((size_t)a.in) | ((size_t)a.out)) & 15) == 0 && (a.ld & 1) == 0 && a.ld > a.N + 1 && a.tabld == a.N;
+}
+
+// DERIVE: q2 / r2 of the eight entries ei = 14 + par - 2 i of a thread's descending chunk from pp[j] = p2_{k0 - 2 + j}
+template <int T>
+RPDE_DEV void prow_derive(const ProwLineArgs& a, double mu, int tid, int par, const double (&pp)[18], double (&qq)[8], double (&rr)[8]) {
+  tab_t aL = (tab_t)a.aLd, aU1 = (tab_t)a.aU1d, aU2 = (tab_t)a.aU2d, aU2s = (tab_t)a.aU2sd, b1 = (tab_t)a.b1d;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                             // four elements at a time: the band tables come out of the L2 / L1, a short wait
+    double tl[4], t1[4], t2[4], ts[4], tb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ei = 14 + par - 2 * (4 * h + j);
+      tl[j] = aL[ei * T + tid]; t1[j] = aU1[ei * T + tid]; t2[j] = aU2[ei * T + tid]; ts[j] = aU2s[ei * T + tid]; tb[j] = b1[ei * T + tid];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { RPDE_PIN(tl[j]); RPDE_PIN(t1[j]); RPDE_PIN(t2[j]); RPDE_PIN(ts[j]); RPDE_PIN(tb[j]); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * h + j, ei = 14 + par - 2 * i;
+      const double l = (mu * tl[j]) * pp[ei];               // p2_{k-2}
+      const double u1 = (tb[j] + mu * t1[j]) - l * (mu * ts[j]);
+      qq[i] = -(u1 * pp[ei + 2]);
+      rr[i] = -((mu * t2[j]) * pp[ei + 2]);
+    }
+  }
 }
 
 // KEEP: the back-substitution factors q2, r2 of the row stay in registers across the prefix composition (32 doubles; a budget of
 // three waves per SIMD) instead of being read a second time -- they are the row's own (no other line shares them), and between the
 // two reads the L2 has seen 24 MB of other rows: the second read came from HBM (PMC ratio of the stage 1.25)
-template <int N, bool KEEP = false>
+template <int N, bool KEEP = false, bool DER = false>
 RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   using G = HdctGeom<N>;
   constexpr int T = G::T, W = 6;
+  static_assert(!DER || KEEP, "the derived factors are computed once and kept");
   lds_t buf = (lds_t)blk.lds;
   lds_t scr = buf + G::SCR;
   const long off = (long)blk.line * a.ld;
   const long toff = (long)((blk.line + a.line0) / a.tdiv) * a.tabld;
   const int n = N - 1;
+  const double mu = DER ? ((tab_t)a.mu)[(blk.line + a.line0) / a.tdiv] : 0.0;
 
   // ---- the line into the padded buffer: f_k at index k + k / 16 + 2, zeros behind it (the taps reach k + 4)
   RPDE_PHASE(blk, tid) {
@@ -80,14 +123,32 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_TLS(blk, double, qa, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * tid;
-    tab_t t0 = (tab_t)a.t0, t1 = (tab_t)a.t1, t2 = (tab_t)a.t2, q1 = (tab_t)(a.q1 + toff);
+    tab_t t0 = (tab_t)a.t0, t1 = (tab_t)a.t1, t2 = (tab_t)a.t2;
     double r[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) { const int k = k0 + i; r[i] = buf[k + (k >> 4) + 2]; }
+    if constexpr (DER) {
+      // q1_k = -(mu aL_k) p2_{k-2}: the ascending chunk t of the row sits in column T - 1 - t of the descending table; the two
+      // entries in front of it are the last two of the chunk before (aL_0 = aL_1 = 0: the first thread needs none)
+      tab_t p2 = (tab_t)(a.p2 + toff), aL = (tab_t)a.aLa;
+      const int col = T - 1 - tid, colp = (tid > 0) ? col + 1 : col;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+      for (int h = 0; h < 2; ++h) {
+        double pm[8], al[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
+        for (int j = 0; j < 8; ++j) { const int i = 8 * h + j; pm[j] = (i < 2) ? p2[(14 + i) * T + colp] : p2[(i - 2) * T + col]; al[j] = aL[i * T + tid]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { RPDE_PIN(pm[j]); RPDE_PIN(al[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) RPDE_T(qa)[8 * h + j] = -((mu * al[j]) * pm[j]);
+      }
+    } else {
+      tab_t q1 = (tab_t)(a.q1 + toff);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                           // the band rows of eight elements at a time (registers)
       double c0[8], c1[8], c2[8];
@@ -152,23 +213,32 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_TLS(blk, double, kr, KEEP ? 16 : 1);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t p2 = (tab_t)(a.p2 + toff), q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
+    tab_t p2 = (tab_t)(a.p2 + toff), q2 = (tab_t)(DER ? a.p2 : a.q2 + toff), r2 = (tab_t)(DER ? a.p2 : a.r2 + toff);   // (DER: unused)
+    double pp[18];                                          // DER: pp[i + 2] = p2_{k0 + i}, pp[0], pp[1] = the two entries below the chunk
     {
-      double pp[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pp[i] = p2[i * T + tid];
+      for (int i = 0; i < 16; ++i) pp[i + 2] = p2[i * T + tid];
+      if constexpr (DER) {
+        const int cp = (tid + 1 < T) ? tid + 1 : tid;       // the chunk below (k0 = 0 needs none: aL_0 = aL_1 = 0)
+        pp[0] = p2[14 * T + cp]; pp[1] = p2[15 * T + cp];
+        RPDE_PIN(pp[0]); RPDE_PIN(pp[1]);
+      }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) RPDE_PIN(pp[i]);
+      for (int i = 0; i < 16; ++i) RPDE_PIN(pp[i + 2]);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const int k = k0 + i; RPDE_T(bb)[i] = pp[i] * buf[k + (k >> 4) + 2]; }
+      for (int i = 0; i < 16; ++i) { const int k = k0 + i; RPDE_T(bb)[i] = pp[i + 2] * buf[k + (k >> 4) + 2]; }
     }
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];
+      if constexpr (DER) {
+        prow_derive<T>(a, mu, tid, par, pp, qq, rr);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+        for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
+      }
       if constexpr (KEEP) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { RPDE_T(kq)[8 * par + i] = qq[i]; RPDE_T(kr)[8 * par + i] = rr[i]; }
@@ -200,7 +270,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_SYNC(blk);                                           // everybody has read y
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t q2 = (tab_t)(a.q2 + toff), r2 = (tab_t)(a.r2 + toff);
+    tab_t q2 = (tab_t)(DER ? a.p2 : a.q2 + toff), r2 = (tab_t)(DER ? a.p2 : a.r2 + toff);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];

@@ -410,15 +410,16 @@ def check_extended_golden(lib, n=4097):
     return rows, first
 
 
-def check_ab_switch(lib, switch, nx, ny, steps, tol=1e-11):
-    """The confined step with an A/B switch of the engine on (default) and off (<switch>=0): same engine, same setup data."""
+def check_ab_switch(lib, switch, nx, ny, steps, tol=1e-11, off_value="0"):
+    """The confined step with an A/B switch of the engine on (default) and off (<switch>=0, or `off_value` for a switch whose
+    default is off): same engine, same setup data."""
     import rustpde_mpi_amd as R
     fields, kinds = {}, {}
     for flag in ("1", "0"):
         if flag == "1":
             os.environ.pop(switch, None)
         else:
-            os.environ[switch] = "0"
+            os.environ[switch] = off_value
         nav = R.Navier2D.new_confined(nx, ny, 1e7, 1.0, 1e-3, 1.0, "rbc", library=lib, init_random=None)
         nav.set_velocity(0.2, 1.0, 1.0); nav.set_temperature(0.2, 1.0, 1.0)
         nav.update(steps)

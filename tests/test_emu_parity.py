@@ -171,6 +171,16 @@ def test_s6_poisson_rows_as_one_kernel(emu_lib, monkeypatch):
     f2 = nav2.physical_fields()
     for k in f1:
         assert np.array_equal(f1[k], f2[k]), k
+    # RPDE_S6_DERIVE=1 (round 6, A/B): p2 alone is read per eigen row, q1 / q2 / r2 are derived from it in the kernel -- the
+    # factors agree with the tabulated ones to their last bit but one, the fields to round-off; half the bytes of the stage
+    monkeypatch.delenv("RPDE_S6_KEEP")
+    monkeypatch.setenv("RPDE_S6_DERIVE", "1")
+    nav3, _ = K.make_pair(emu_lib, False, 33, 257, 1e6, 1.0, 2e-3, 1.0)
+    assert 2 * {t: b for t, b, _, _, _ in nav3.schedule()}["S6 y: poisson rows"] == {t: b for t, b, _, _, _ in nav.schedule()}["S6 y: poisson rows"]
+    nav3.update(3)
+    f3 = nav3.physical_fields()
+    for k in f1:
+        assert K.rel(f1[k], f3[k]) < 1e-13, (k, K.rel(f1[k], f3[k]))
 
 
 def test_s9_pressure_update_as_one_kernel(emu_lib, monkeypatch):

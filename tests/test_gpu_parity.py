@@ -151,6 +151,14 @@ def test_round5_ab_switches(hip_lib, switch, value):
     _ab_switch_bit_identical(switch, value, "((4097, 129), (129, 4097))")
 
 
+@pytest.mark.parametrize("nx,ny,steps", [(129, 4097, 4), (1025, 1025, 10), (65, 2049, 4)])
+def test_round6_s6_derived_factors(hip_lib, nx, ny, steps):
+    """Round 6, an A/B that did not become the default: with RPDE_S6_DERIVE=1 S6 reads ONE factor row per eigen row (p2) and
+    derives q1 / q2 / r2 from it (csrc/prow_line.h DERIVE) instead of reading four.  Products with the rounded reciprocal stand
+    where the setup divides: the factors differ in their last bit, the fields by round-off -- 4096-, 1024- and 2048-point y-lines."""
+    K.check_ab_switch(hip_lib, "RPDE_S6_DERIVE", nx, ny, steps, tol=1e-12, off_value="1")
+
+
 def test_round6_gemm_persist_bit_identical(hip_lib):
     """RPDE_GEMM_PERSIST=1 (round 6): one workgroup works off its tile of both parity blocks in turn (512 persistent workgroups)
     instead of two rounds of 512 -- same tiles, same arithmetic; 2049 x 2049 is the smallest square whose parity GEMMs take the
@@ -180,7 +188,7 @@ def test_round6_lift_structure_bit_identical(hip_lib):
     _ab_switch_bit_identical("RPDE_LIFT_STRUCT", "0", "((4097, 129), (129, 4097), (1025, 1025))")
 
 
-def _ab_switch_bit_identical(switch, value, sizes):
+def _ab_switch_bit_identical(switch, value, sizes, extra=None):
     """The A/B switches of round 5 select another FORM of the same arithmetic (the peeled steady-state loop of the GEMM; value
     and derivative of a state line as two launches instead of the pair kernel; RPDE_LINE_BATCH=15: one launch per field instead
     of the three fields of a stage in one launch at 4097-point lines; RPDE_GEMM_LDS=0: the GEMM's operand stages in the LDS layout of rounds 1 - 4): a 4097 x 129 confined run (4096-point x-lines: S1, S3;
@@ -200,6 +208,7 @@ def _ab_switch_bit_identical(switch, value, sizes):
     for flag in ("", value):
         env = dict(os.environ)
         env.pop(switch, None)
+        env.update(extra or {})
         if flag:
             env[switch] = flag
         r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(K.GOLDEN)), env=env,

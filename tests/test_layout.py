@@ -73,6 +73,7 @@ ENV_SWITCHES = {
     "RPDE_ADJOINT_FUSED",                           # Navier2DAdjoint: forward step on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_adjoint_fused_forward_step)
     "RPDE_PER_ROWS",                                # periodic S5 / S8 / S9: element-wise kernels / line programs (test_periodic_elementwise_stages_equal_line_programs)
     "RPDE_GEMM_WAVES",                              # A/B of round 6: the GEMM's 128-tile by eight waves (test_gpu_parity.test_round6_gemm_eight_waves_bit_identical)
+    "RPDE_S6_DERIVE",                               # A/B of round 6 (=1; not the default): S6 reads one factor row per line and derives the other three (test_emu_parity.test_s6_poisson_rows_as_one_kernel, test_gpu_parity.test_round6_s6_derived_factors)
     "RPDE_LIFT_STRUCT",                             # A/B of round 6: the step reads whole lift arrays / what analyse_lift found non-redundant in them (tests/test_emu_parity.test_lift_structure_*, test_gpu_parity.test_round6_lift_structure_bit_identical)
     "RPDE_GEMM_CTSWAP",                             # A/B of round 6: G2 accumulated transposed (128-byte stores) / the 32-byte transposed store (test_gpu_parity.test_round6_gemm_transposed_accumulation_bit_identical)
     "RPDE_GEMM_PERSIST",                            # A/B of round 6: both parity blocks of an eigen-transform by 512 persistent workgroups (test_gpu_parity.test_round6_gemm_persist_bit_identical)
