@@ -14,8 +14,9 @@ export RPDE_EIG_CACHE=/tmp/rpde_eig; mkdir -p $RPDE_EIG_CACHE      # setup data 
 T0=$(date +%s); lap() { echo "== $1: $(( $(date +%s) - T0 )) s" | tee -a $O/laps.txt; }
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 # 1. A/B timings through the hipGraph replay of the bench workload (one process per side; the default twice)
-(timeout 120 python tools/ab_step.py; RPDE_GEMM_PERSIST=1 timeout 120 python tools/ab_step.py; RPDE_S6_KEEP=0 timeout 120 python tools/ab_step.py;
- RPDE_LINE_BATCH=15 timeout 120 python tools/ab_step.py; RPDE_S6_LINE=0 RPDE_S9_LINE=0 timeout 120 python tools/ab_step.py; timeout 120 python tools/ab_step.py) > $O/ab_step.txt 2>$O/ab_step.err
+(timeout 120 python tools/ab_step.py; RPDE_GEMM_CTSWAP=0 timeout 120 python tools/ab_step.py; RPDE_LIFT_STRUCT=0 timeout 120 python tools/ab_step.py;
+ RPDE_S6_DERIVE=1 timeout 120 python tools/ab_step.py; RPDE_GEMM_WAVES=4 timeout 120 python tools/ab_step.py; RPDE_LINE_BATCH=15 timeout 120 python tools/ab_step.py;
+ timeout 120 python tools/ab_step.py) > $O/ab_step.txt 2>$O/ab_step.err
 lap "A/B timings"
 cd /tmp
 # 2. PMC traffic (separate passes, as the guide prescribes)
