@@ -57,13 +57,13 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
   // ---- the input line into the padded buffer, shifted: r_k = in_{k - SH} at index k + k / 16 + 2, zeros around it
   RPDE_TLS(blk, double, kp, 1);
   RPDE_PHASE(blk, tid) {
-    cgmem2_t src = (cgmem2_t)(a.in[BR] + off);
-    cgmem2_t wt = (cgmem2_t)a.w;
+    // (rows and tables through buffer descriptors: one 32-bit offset per thread, the block u in a scalar register -- line_vm.h)
+    const RowBuf src = row_buf(a.in[BR] + off, 8L * N), wt = row_buf((BR == 0) ? a.w : a.in[BR] + off, 8L * N);
     dbl2 v[8], ww[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      v[u] = src[tid + u * T];                              // the pair m = 2 (tid + u T) <= N - 2: inside the row (ld > N + 1)
-      if (BR == 0) ww[u] = wt[tid + u * T];
+      v[u] = row_ld2(src, 16 * tid, 16 * u * T);            // the pair m = 2 (tid + u T) <= N - 2: inside the row (ld > N + 1)
+      if (BR == 0) ww[u] = row_ld2(wt, 16 * tid, 16 * u * T);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) { RPDE_PIN(v[u].x); RPDE_PIN(v[u].y); if (BR == 0) { RPDE_PIN(ww[u].x); RPDE_PIN(ww[u].y); } }
@@ -100,19 +100,19 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
   RPDE_TLS(blk, double, qa, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * tid;
-    tab_t t0 = (tab_t)tb.t0, t1 = (tab_t)tb.t1, t2 = (tab_t)tb.t2, q1 = (tab_t)tb.q1;
+    const ChunkTab t0 = chunk_tab(tb.t0, T), t1 = chunk_tab(tb.t1, T), t2 = chunk_tab((BR == 1) ? tb.t2 : tb.t1, T), q1 = chunk_tab(tb.q1, T);
     double r[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) { const int k = k0 + i; r[i] = buf[k + (k >> 4) + 2]; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = chunk_ld(q1, tid, i, T);
 #pragma unroll
     for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                           // the taps of eight elements at a time (registers)
       double c0[8], c1[8], c2[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = t0[j * T + tid]; c1[i] = t1[j * T + tid]; c2[i] = (BR == 1) ? t2[j * T + tid] : 0.0; }
+      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = chunk_ld(t0, tid, j, T); c1[i] = chunk_ld(t1, tid, j, T); c2[i] = (BR == 1) ? chunk_ld(t2, tid, j, T) : 0.0; }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(c0[i]); RPDE_PIN(c1[i]); if (BR == 1) RPDE_PIN(c2[i]); }
 #pragma unroll
@@ -169,11 +169,11 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
   RPDE_TLS(blk, double, bb, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t p2 = (tab_t)tb.p2, q2 = (tab_t)tb.q2, r2 = (tab_t)tb.r2;
+    const ChunkTab p2 = chunk_tab(tb.p2, T), q2 = chunk_tab(tb.q2, T), r2 = chunk_tab(tb.r2, T);
     {
       double pp[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pp[i] = p2[i * T + tid];
+      for (int i = 0; i < 16; ++i) pp[i] = chunk_ld(p2, tid, i, T);
 #pragma unroll
       for (int i = 0; i < 16; ++i) RPDE_PIN(pp[i]);
 #pragma unroll
@@ -183,7 +183,7 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       double z1 = 0.0, z2 = 0.0, a11 = 1.0, a12 = 0.0, a21 = 0.0, a22 = 1.0;   // state = (most recent value, the one before)
@@ -213,12 +213,12 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
   RPDE_SYNC(blk);                                           // everybody has read y
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t q2 = (tab_t)tb.q2, r2 = (tab_t)tb.r2;
+    const ChunkTab q2 = chunk_tab(tb.q2, T), r2 = chunk_tab(tb.r2, T);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];                                  // again (L1 / L2): not kept across the prefix
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       double x1 = RPDE_T(cm)[par * W + 4], x2 = RPDE_T(cm)[par * W + 5];
@@ -247,14 +247,12 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
 #endif
   }
   RPDE_PHASE(blk, tid) {
-    gmem2_t dst = (gmem2_t)(a.out[BR] + off);
-    gmem_t dst1 = (gmem_t)(a.out[BR] + off);
-    cgmem2_t ht = (cgmem2_t)a.h;
+    const RowBuf dst = row_buf(a.out[BR] + off, 8L * N), ht = row_buf((BR == 0) ? a.h : a.out[BR] + off, 8L * N);
     dbl2 o[8], hh[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      o[u] = dst[tid + u * T];
-      if (BR == 0) hh[u] = ht[tid + u * T];
+      o[u] = row_ld2(dst, 16 * tid, 16 * u * T);
+      if (BR == 0) hh[u] = row_ld2(ht, 16 * tid, 16 * u * T);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) { RPDE_PIN(o[u].x); RPDE_PIN(o[u].y); if (BR == 0) { RPDE_PIN(hh[u].x); RPDE_PIN(hh[u].y); } }
@@ -266,8 +264,8 @@ RPDE_DEV void corr_line_branch(Blk& blk, const CorrLineArgs& a) {
       dbl2 v = dbl2{buf[p], buf[p + 1]};                    // m + 1 stays inside the group of 16
       if (BR == 0) { v.x += kappa * hh[u].x; v.y += kappa * hh[u].y; }
       v.x += o[u].x; v.y += o[u].y;
-      if (m + 1 < n) { dst[m >> 1] = v; bad |= (v.x != v.x) | (v.y != v.y); }
-      else if (m < n) { dst1[m] = v.x; bad |= (v.x != v.x); }
+      if (m + 1 < n) { row_st2(dst, 16 * tid, 16 * u * T, v); bad |= (v.x != v.x) | (v.y != v.y); }
+      else if (m < n) { row_st1(dst, 16 * tid, 16 * u * T, v.x); bad |= (v.x != v.x); }
     }
     if (bad && a.nanflag) *a.nanflag = 1;
   }

@@ -380,19 +380,29 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   const long offl = (long)blk.line * conv_lift_pitch(c);
   cgmem_t bx = (cgmem_t)(c.bx ? c.bx + offl : nullptr), by = (cgmem_t)(c.by ? c.by + offl : nullptr);
   const bool lift = c.bx != nullptr;
+  // the physical factors of a thread's 17 points through buffer descriptors (line_vm.h RowBuf): slot 2 t is k = tid + t T, slot
+  // 2 t + 1 is N - k = (T - tid) + (15 - t) T -- one per-thread offset each (8 tid, 8 (T - tid)) and the block t in a scalar
+  // register, where flat loads spent a 64-bit vector add per point and array (an eighth of the kernel's vector instructions)
+  const long rowb = 8L * (N + 1);
+  const RowBuf rup = row_buf(c.up + off, rowb), rvp = row_buf(c.vp + off, rowb);
+  const RowBuf rbx = row_buf(lift ? c.bx + offl : c.up + off, rowb), rby = row_buf(lift ? c.by + offl : c.vp + off, rowb);
+  auto pick = [&](const RowBuf& r, cgmem_t flat, int tid, int slot, int k) {
+    if (slot == 16) return flat[k];                          // k = N / 2, thread 0 only
+    return (slot & 1) ? row_ld1(r, 8 * (T - tid), 8 * (15 - (slot >> 1)) * T) : row_ld1(r, 8 * tid, 8 * (slot >> 1) * T);
+  };
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   auto e1 = [&](int tid, int slot, int k, double v) {
-    (void)tid;
-    RPDE_T(acc)[slot] = up[k] * (lift ? v + bx[k] : v);
+    const double u = pick(rup, up, tid, slot, k);
+    RPDE_T(acc)[slot] = u * (lift ? v + pick(rbx, bx, tid, slot, k) : v);
   };
   dct_line_core<N, decltype(e1), 0>(blk, a1, false, e1);
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   auto e2 = [&](int tid, int slot, int k, double v) {
-    (void)tid;
-    RPDE_T(acc)[slot] += vp[k] * (lift ? v + by[k] : v);
+    const double w = pick(rvp, vp, tid, slot, k);
+    RPDE_T(acc)[slot] += w * (lift ? v + pick(rby, by, tid, slot, k) : v);
   };
   dct_line_core<N, decltype(e2), 1>(blk, a2, false, e2);
   RPDE_SYNC(blk);

@@ -567,13 +567,16 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   const bool lift = c.bx != nullptr;
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
+  // (the pairs m = 2 (tid + u T) of the physical factors through buffer descriptors: line_vm.h RowBuf, as conv_line)
+  const long rowb = 8L * (N + 2);
   {
     cgmem_t up = (cgmem_t)(c.up + off), bx = (cgmem_t)(lift ? c.bx + offl : c.up + off);
+    const RowBuf rup = row_buf(c.up + off, rowb), rbx = row_buf(lift ? c.bx + offl : c.up + off, rowb);
     hdct_core<N>(blk, a1, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (u == 8) { RPDE_T(acc)[16] = up[m] * (lift ? e0 + bx[m] : e0); return; }
-      const dbl2 f = ((cgmem2_t)up)[m >> 1];
+      const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T);
       dbl2 g = dbl2{0.0, 0.0};
-      if (lift) g = ((cgmem2_t)bx)[m >> 1];
+      if (lift) g = row_ld2(rbx, 16 * tid, 16 * u * T);
       RPDE_T(acc)[2 * u] = f.x * (e0 + g.x);
       RPDE_T(acc)[2 * u + 1] = f.y * (e1 + g.y);
     });
@@ -583,11 +586,12 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   {
     cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + offl : c.vp + off);
+    const RowBuf rvp = row_buf(c.vp + off, rowb), rby = row_buf(lift ? c.by + offl : c.vp + off, rowb);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (u == 8) { RPDE_T(acc)[16] += vp[m] * (lift ? e0 + by[m] : e0); return; }
-      const dbl2 f = ((cgmem2_t)vp)[m >> 1];
+      const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T);
       dbl2 g = dbl2{0.0, 0.0};
-      if (lift) g = ((cgmem2_t)by)[m >> 1];
+      if (lift) g = row_ld2(rby, 16 * tid, 16 * u * T);
       RPDE_T(acc)[2 * u] += f.x * (e0 + g.x);
       RPDE_T(acc)[2 * u + 1] += f.y * (e1 + g.y);
     });

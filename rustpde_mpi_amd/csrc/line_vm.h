@@ -116,6 +116,19 @@ __device__ __forceinline__ void row_st1(const RowBuf& r, int voff, int soff, dou
 }
 #endif
 
+// A chunk-major table (16 T doubles, entry i of thread t at [i * T + t]; rhs_line.h chunk_major16) read through a buffer descriptor:
+// ONE per-thread byte offset (8 t) serves all sixteen entries of all tables of a phase, the entry is a uniform offset in a scalar
+// register.  A flat load spends a 64-bit vector add per entry beyond the 4 KB an immediate offset reaches (round 6: a fifth of the
+// vector instructions of the banded whole-line kernels was this address arithmetic).
+struct ChunkTab { RowBuf rb; };
+#ifdef RPDE_EMU
+inline ChunkTab chunk_tab(const double* p, int T) { return ChunkTab{row_buf(p, 8L * 16 * T)}; }
+inline double chunk_ld(const ChunkTab& t, int tid, int i, int T) { return row_ld1(t.rb, 8 * tid, 8 * i * T); }
+#else
+__device__ __forceinline__ ChunkTab chunk_tab(const double* p, int T) { return ChunkTab{row_buf(p, 8L * 16 * T)}; }
+__device__ __forceinline__ double chunk_ld(const ChunkTab& t, int tid, int i, int T) { return row_ld1(t.rb, 8 * tid, 8 * i * T); }
+#endif
+
 enum OpCode : int {
   OP_END = 0,
   OP_LOAD,     // d[k] = (acc ? d[k] : 0) + s0 * A[line][map(k)]   k < n (zero tail if !acc); acc = 2: d[k] *= s0 * A; i0 = 1: parity map;

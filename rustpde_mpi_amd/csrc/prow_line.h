@@ -97,10 +97,10 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
 
   // ---- the line into the padded buffer: f_k at index k + k / 16 + 2, zeros behind it (the taps reach k + 4)
   RPDE_PHASE(blk, tid) {
-    cgmem2_t src = (cgmem2_t)(a.in + off);
+    const RowBuf src = row_buf(a.in + off, 8L * N);
     dbl2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[tid + u * T];      // the pair m = 2 (tid + u T) <= N - 2: inside the row (ld > N + 1)
+    for (int u = 0; u < 8; ++u) v[u] = row_ld2(src, 16 * tid, 16 * u * T);      // the pair m = 2 (tid + u T) <= N - 2: inside the row (ld > N + 1)
 #pragma unroll
     for (int u = 0; u < 8; ++u) { RPDE_PIN(v[u].x); RPDE_PIN(v[u].y); }
 #pragma unroll
@@ -123,7 +123,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_TLS(blk, double, qa, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * tid;
-    tab_t t0 = (tab_t)a.t0, t1 = (tab_t)a.t1, t2 = (tab_t)a.t2;
+    const ChunkTab t0 = chunk_tab(a.t0, T), t1 = chunk_tab(a.t1, T), t2 = chunk_tab(a.t2, T);
     double r[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) { const int k = k0 + i; r[i] = buf[k + (k >> 4) + 2]; }
@@ -143,9 +143,9 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
         for (int j = 0; j < 8; ++j) RPDE_T(qa)[8 * h + j] = -((mu * al[j]) * pm[j]);
       }
     } else {
-      tab_t q1 = (tab_t)(a.q1 + toff);
+      const ChunkTab q1 = chunk_tab(a.q1 + toff, T);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+      for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = chunk_ld(q1, tid, i, T);
 #pragma unroll
       for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
     }
@@ -153,7 +153,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
     for (int h = 0; h < 2; ++h) {                           // the band rows of eight elements at a time (registers)
       double c0[8], c1[8], c2[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = t0[j * T + tid]; c1[i] = t1[j * T + tid]; c2[i] = t2[j * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = chunk_ld(t0, tid, j, T); c1[i] = chunk_ld(t1, tid, j, T); c2[i] = chunk_ld(t2, tid, j, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(c0[i]); RPDE_PIN(c1[i]); RPDE_PIN(c2[i]); }
 #pragma unroll
@@ -213,14 +213,14 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_TLS(blk, double, kr, KEEP ? 16 : 1);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t p2 = (tab_t)(a.p2 + toff), q2 = (tab_t)(DER ? a.p2 : a.q2 + toff), r2 = (tab_t)(DER ? a.p2 : a.r2 + toff);   // (DER: unused)
+    const ChunkTab p2 = chunk_tab(a.p2 + toff, T), q2 = chunk_tab(DER ? a.p2 : a.q2 + toff, T), r2 = chunk_tab(DER ? a.p2 : a.r2 + toff, T);   // (DER: q2 / r2 unused)
     double pp[18];                                          // DER: pp[i + 2] = p2_{k0 + i}, pp[0], pp[1] = the two entries below the chunk
     {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pp[i + 2] = p2[i * T + tid];
+      for (int i = 0; i < 16; ++i) pp[i + 2] = chunk_ld(p2, tid, i, T);
       if constexpr (DER) {
         const int cp = (tid + 1 < T) ? tid + 1 : tid;       // the chunk below (k0 = 0 needs none: aL_0 = aL_1 = 0)
-        pp[0] = p2[14 * T + cp]; pp[1] = p2[15 * T + cp];
+        pp[0] = chunk_ld(p2, cp, 14, T); pp[1] = chunk_ld(p2, cp, 15, T);
         RPDE_PIN(pp[0]); RPDE_PIN(pp[1]);
       }
 #pragma unroll
@@ -235,7 +235,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
         prow_derive<T>(a, mu, tid, par, pp, qq, rr);
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       }
@@ -270,7 +270,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
   RPDE_SYNC(blk);                                           // everybody has read y
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t q2 = (tab_t)(DER ? a.p2 : a.q2 + toff), r2 = (tab_t)(DER ? a.p2 : a.r2 + toff);
+    const ChunkTab q2 = chunk_tab(DER ? a.p2 : a.q2 + toff, T), r2 = chunk_tab(DER ? a.p2 : a.r2 + toff, T);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];
@@ -279,7 +279,7 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
         for (int i = 0; i < 8; ++i) { qq[i] = RPDE_T(kq)[8 * par + i]; rr[i] = RPDE_T(kr)[8 * par + i]; }
       } else {                                              // again: not kept across the prefix
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+        for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       }
@@ -300,16 +300,15 @@ RPDE_DEV void prow_line(Blk& blk, const ProwLineArgs& a) {
 
   // ---- the solution leaves in pairs, coalesced
   RPDE_PHASE(blk, tid) {
-    gmem2_t dst = (gmem2_t)(a.out + off);
-    gmem_t dst1 = (gmem_t)(a.out + off);
+    const RowBuf dst = row_buf(a.out + off, 8L * N);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int m = 2 * (tid + u * T);
       const int p = m + (m >> 4) + 2;
       dbl2 v = dbl2{buf[p], buf[p + 1]};
       if (m == 0 && a.zero0 && (blk.line + a.line0) / a.tdiv == 0) v.x = 0.0;
-      if (m + 1 < n) dst[m >> 1] = v;
-      else if (m < n) dst1[m] = v.x;
+      if (m + 1 < n) row_st2(dst, 16 * tid, 16 * u * T, v);
+      else if (m < n) row_st1(dst, 16 * tid, 16 * u * T, v.x);
     }
   }
 }

@@ -248,19 +248,19 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   RPDE_TLS(blk, double, qa, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * tid;
-    tab_t t0 = (tab_t)a.t0, t1 = (tab_t)a.t1, t2 = (tab_t)a.t2, q1 = (tab_t)a.q1;
+    const ChunkTab t0 = chunk_tab(a.t0, T), t1 = chunk_tab(a.t1, T), t2 = chunk_tab(a.t2, T), q1 = chunk_tab(a.q1, T);
     double r[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) { const int k = k0 + i; r[i] = buf[k + (k >> 4) + 2]; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = q1[i * T + tid];
+    for (int i = 0; i < 16; ++i) RPDE_T(qa)[i] = chunk_ld(q1, tid, i, T);
 #pragma unroll
     for (int i = 0; i < 16; ++i) RPDE_PIN(RPDE_T(qa)[i]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                           // the band rows of eight elements at a time (registers)
       double c0[8], c1[8], c2[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = t0[j * T + tid]; c1[i] = t1[j * T + tid]; c2[i] = t2[j * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int j = 8 * h + i; c0[i] = chunk_ld(t0, tid, j, T); c1[i] = chunk_ld(t1, tid, j, T); c2[i] = chunk_ld(t2, tid, j, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(c0[i]); RPDE_PIN(c1[i]); RPDE_PIN(c2[i]); }
 #pragma unroll
@@ -318,11 +318,11 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   RPDE_TLS(blk, double, bb, 16);
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t p2 = (tab_t)a.p2, q2 = (tab_t)a.q2, r2 = (tab_t)a.r2;
+    const ChunkTab p2 = chunk_tab(a.p2, T), q2 = chunk_tab(a.q2, T), r2 = chunk_tab(a.r2, T);
     {
       double pp[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pp[i] = p2[i * T + tid];
+      for (int i = 0; i < 16; ++i) pp[i] = chunk_ld(p2, tid, i, T);
 #pragma unroll
       for (int i = 0; i < 16; ++i) RPDE_PIN(pp[i]);
 #pragma unroll
@@ -332,7 +332,7 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       double z1 = 0.0, z2 = 0.0, a11 = 1.0, a12 = 0.0, a21 = 0.0, a22 = 1.0;   // state = (most recent value, the one before)
@@ -362,12 +362,12 @@ RPDE_DEV void rhs_line(Blk& blk, const RhsLineArgs& a) {
   RPDE_SYNC(blk);                                           // everybody has read y
   RPDE_PHASE(blk, tid) {
     const int k0 = 16 * (T - 1 - tid);
-    tab_t q2 = (tab_t)a.q2, r2 = (tab_t)a.r2;
+    const ChunkTab q2 = chunk_tab(a.q2, T), r2 = chunk_tab(a.r2, T);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       double qq[8], rr[8];                                  // again (L1 / L2): not kept across the prefix
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = q2[ei * T + tid]; rr[i] = r2[ei * T + tid]; }
+      for (int i = 0; i < 8; ++i) { const int ei = 14 + par - 2 * i; qq[i] = chunk_ld(q2, tid, ei, T); rr[i] = chunk_ld(r2, tid, ei, T); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { RPDE_PIN(qq[i]); RPDE_PIN(rr[i]); }
       double x1 = RPDE_T(cm)[par * W + 4], x2 = RPDE_T(cm)[par * W + 5];
