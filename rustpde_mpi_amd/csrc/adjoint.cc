@@ -348,6 +348,7 @@ void GenericFlow2D::acc_to_ortho(F& f, double s, Arr2& out) {
 }
 
 void GenericFlow2D::drop_constant_gradients() {
+  ++const_gen_;
   if (const_grad_.empty()) return;
   dev_sync(st_);
   const_grad_.clear();
@@ -612,6 +613,14 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
   }
   refresh_mean();
   dev_sync(st_);
+  const char* e = std::getenv("RPDE_LNSE_FUSED");
+  if (!nonlin_ && !hc_ && (!e || std::atoi(e) != 0)) {
+    try {
+      fwd_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/true);
+    } catch (const std::exception&) {
+      fwd_.reset();   // a shape the fused schedule does not cover: the generic composition
+    }
+  }
 }
 
 void Navier2DLnseEngine::set_mean_physical(const std::string& name, const double* host, size_t len) {
@@ -701,7 +710,33 @@ void Navier2DLnseEngine::write(const std::string& filename) {
 
 bool Navier2DLnseEngine::exit() { return std::isnan(div_norm()); }
 
+// update() on Navier2DEngine's schedule (adjoint.h fwd_): the mean velocities and the six physical mean gradients once per change of a
+// mean field, the state per call
+void Navier2DLnseEngine::update_fused(int nsteps) {
+  if (fwd_mean_gen_ != const_gen_) {
+    refresh_mean();
+    fwd_->set_lnse_mean_device(0, um_);
+    fwd_->set_lnse_mean_device(1, vm_);
+    const char* const names[3] = {"velx", "vely", "temp"};
+    for (int f = 0; f < 3; ++f)
+      for (int d = 0; d < 2; ++d) {
+        F& m = mean(names[f]);
+        m.sp->gradient_backward(m.vhat, d == 0 ? 1 : 0, d == 0 ? 0 : 1, sx_, sy_, cp_, st_);
+        dev_sync(st_);
+        fwd_->set_lnse_mean_device(2 + 2 * f + d, cp_);
+      }
+    fwd_mean_gen_ = const_gen_;
+  }
+  dev_sync(st_);
+  for (const char* name : {"velx", "vely", "temp", "pres"}) fwd_->set_field_spectral_device(name, field(name).vhat);
+  fwd_->update(nsteps);
+  for (const char* name : {"velx", "vely", "temp", "pres", "pseu"}) fwd_->get_field_spectral_device(name, field(name).vhat);
+  fwd_->sync();
+  time_ += nsteps * dt_;
+}
+
 void Navier2DLnseEngine::update(int nsteps) {
+  if (fwd_ && nsteps > 0) { update_fused(nsteps); return; }
   F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
   const double dt = dt_;
   for (int step = 0; step < nsteps; ++step) {

@@ -52,6 +52,7 @@ class GenericFlow2D {
              bool constant = false; };   // the lift and the mean fields: their gradients are computed once per run, not once per term and step
   // gradients of the constant fields (physical: key d0, d1; orthonormal: key 100 + d0, d1), dropped whenever a field is set
   std::map<std::tuple<const F*, int, int>, Arr2> const_grad_;
+  unsigned long const_gen_ = 1;          // counts the changes of the constant fields (drop_constant_gradients)
   void drop_constant_gradients();
   F& field(const std::string& name);
   void acc_to_ortho(F& f, double s, Arr2& out);
@@ -168,6 +169,12 @@ class Navier2DLnseEngine : public GenericFlow2D {
   F& mean(const std::string& name) { return field("mean_" + name); }
   Arr2 um_, vm_;                                    // physical mean velocities (constant during a run)
   void refresh_mean();
+  // update() of the LINEAR solver, bc = "rbc", on Navier2DEngine's fused schedule (16 launches; engine.h `lnse`) where the whole-line
+  // convection kernel covers the y-lines; RPDE_LNSE_FUSED=0 or any other shape: the composition of generic operators below.  The
+  // state goes in and comes back as device arrays per update(n) call, the mean arrays whenever a mean field was set.
+  std::unique_ptr<Navier2DEngine> fwd_;
+  unsigned long fwd_mean_gen_ = 0;                  // const_gen_ of the mean arrays fwd_ holds
+  void update_fused(int nsteps);
 };
 
 }  // namespace rpde

@@ -362,6 +362,9 @@ struct ConvLineArgs {
   long ldl = -1;                  // pitch of bx / by (-1: ld).  0: every line reads line 0 -- a lift that does not depend on x ("rbc":
                                   // linear in y) has the same gradient on every y-line, and two of a convection term's six input arrays
                                   // then come out of the L2 instead of HBM (Navier2DEngine::analyse_lift)
+  // The linearised convection term of Navier2DLnse (lnse_eq.rs:59-110): um, vm = the physical mean velocities (pitch ld), bx, by = the
+  // physical gradient of the mean field the term belongs to; out = DCT_y[ um d/dx f + vm d/dy f + up bx + vp by ] (conv_line<N, true>).
+  const double* um = nullptr; const double* vm = nullptr;
 };
 RPDE_HD inline long conv_lift_pitch(const ConvLineArgs& c) { return c.ldl >= 0 ? c.ldl : c.ld; }
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
@@ -371,12 +374,13 @@ RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   return dct_line_ok(a) && dct_line_ok(b);   // N = 16^k: three transforms on the full-length core; N = 1024: hconv_line (hdct_line.h), one wave per line
 }
 
-template <int N>
+template <int N, bool MEAN = false>
 RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   constexpr int T = N / 16;
   lds_t buf = (lds_t)blk.lds;
   const long off = (long)blk.line * c.ld;
   cgmem_t up = (cgmem_t)(c.up + off), vp = (cgmem_t)(c.vp + off);
+  cgmem_t um = (cgmem_t)((MEAN ? c.um : c.up) + off), vm = (cgmem_t)((MEAN ? c.vm : c.vp) + off);
   const long offl = (long)blk.line * conv_lift_pitch(c);
   cgmem_t bx = (cgmem_t)(c.bx ? c.bx + offl : nullptr), by = (cgmem_t)(c.by ? c.by + offl : nullptr);
   const bool lift = c.bx != nullptr;
@@ -386,23 +390,37 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   const long rowb = 8L * (N + 1);
   const RowBuf rup = row_buf(c.up + off, rowb), rvp = row_buf(c.vp + off, rowb);
   const RowBuf rbx = row_buf(lift ? c.bx + offl : c.up + off, rowb), rby = row_buf(lift ? c.by + offl : c.vp + off, rowb);
+  const RowBuf rum = row_buf((MEAN ? c.um : c.up) + off, rowb), rvm = row_buf((MEAN ? c.vm : c.vp) + off, rowb);
   auto pick = [&](const RowBuf& r, cgmem_t flat, int tid, int slot, int k) {
     if (slot == 16) return flat[k];                          // k = N / 2, thread 0 only
     return (slot & 1) ? row_ld1(r, 8 * (T - tid), 8 * (15 - (slot >> 1)) * T) : row_ld1(r, 8 * tid, 8 * (slot >> 1) * T);
   };
   RPDE_TLS(blk, double, acc, 17);
+  // The factor loads of an emit sit behind a RUN-TIME condition that always holds (`on`; MEAN: `lift`): with unconditional loads the
+  // compiler lifts the factor streams of all 17 slots above the transform's last passes -- 167 registers for the classic term (u
+  // unconditional, the lift behind `lift`), 174 spilled with `lift` known at compile time, 114 - 258 spilled for the linearised term;
+  // behind the condition the loads stay where the emit is: 136 registers, none spilled, for both (round 6).
+  // Measured (profiles/r06_experiments/call18_*): on THIS core at 4097-point lines the guarded form is slower at three workgroups per CU
+  // (0.72 against 0.65 ms: the early loads were its latency hiding) and equal at four (128 registers, 8 spilled) -- the classic term keeps
+  // its unconditional loads here (RPDE_CONV4096_GUARD: the A/B build); on the half-length core (hconv_line: 400 -> 154 registers, three
+  // waves per SIMD instead of one) the guard is the default and took 28 % off the term.
+#ifdef RPDE_CONV4096_GUARD
+  const bool on = c.up != nullptr;
+#else
+  const bool on = true;
+#endif
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   auto e1 = [&](int tid, int slot, int k, double v) {
-    const double u = pick(rup, up, tid, slot, k);
-    RPDE_T(acc)[slot] = u * (lift ? v + pick(rbx, bx, tid, slot, k) : v);
+    if constexpr (MEAN) RPDE_T(acc)[slot] = lift ? pick(rum, um, tid, slot, k) * v + pick(rup, up, tid, slot, k) * pick(rbx, bx, tid, slot, k) : v;
+    else RPDE_T(acc)[slot] = on ? pick(rup, up, tid, slot, k) * (lift ? v + pick(rbx, bx, tid, slot, k) : v) : v;
   };
   dct_line_core<N, decltype(e1), 0>(blk, a1, false, e1);
   RPDE_SYNC(blk);
   DctLineArgs a2 = a1;
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   auto e2 = [&](int tid, int slot, int k, double v) {
-    const double w = pick(rvp, vp, tid, slot, k);
-    RPDE_T(acc)[slot] += w * (lift ? v + pick(rby, by, tid, slot, k) : v);
+    if constexpr (MEAN) RPDE_T(acc)[slot] += lift ? pick(rvm, vm, tid, slot, k) * v + pick(rvp, vp, tid, slot, k) * pick(rby, by, tid, slot, k) : v;
+    else RPDE_T(acc)[slot] += on ? pick(rvp, vp, tid, slot, k) * (lift ? v + pick(rby, by, tid, slot, k) : v) : v;
   };
   dct_line_core<N, decltype(e2), 1>(blk, a2, false, e2);
   RPDE_SYNC(blk);

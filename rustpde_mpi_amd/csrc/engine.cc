@@ -45,8 +45,8 @@ std::vector<int> Navier2DEngine::split(int n, int parts) {
 }
 
 Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                               const std::string& bc, bool periodic, const CommCb* comm, bool buoyancy_lift)
-    : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0), buoyancy_lift_(buoyancy_lift) {
+                               const std::string& bc, bool periodic, const CommCb* comm, bool buoyancy_lift, bool lnse)
+    : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0), buoyancy_lift_(buoyancy_lift && !lnse), lnse_(lnse) {
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
   RPDE_REQUIRE(comm_.size >= 1 && comm_.rank >= 0 && comm_.rank < comm_.size, "bad rank / size");
@@ -55,6 +55,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
                "sharded engine needs an all-to-all transport");
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");   // navier.rs:251 / 372
   hc_ = bc == "hc";
+  RPDE_REQUIRE(!lnse_ || (comm_.size == 1 && !hc_), "the Navier2DLnse step on the fused schedule: one rank, bc = \"rbc\"");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   // everything that can throw comes after this block; the members below are released by
@@ -151,6 +152,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   if (hc_) TO_.alloc(nyx);
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
+  if (lnse_) for (auto& b : LM_) b.alloc(nxy);
   red_.alloc(2);
   nanflag_.alloc(2);
   {   // column scans (colscan.h): block carries, tables of this rank's rows, summaries that travel between the ranks
@@ -241,7 +243,8 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   mk("tempbc", sp_ortho_.get(), &TBC_, true, true);   // the lift: read-only (snapshots)
 
   // ---- boundary-condition lift (boundary_conditions.rs:18-36 / 143-161) and its constants
-  {
+  // (Navier2DLnse has none: TBC_, TBC2_, BX_, BY_ stay the zero arrays they were allocated as)
+  if (!lnse_) {
     Space2Ops& so = *sp_ortho_;
     const Vec y = base_coords(so.base(1));
     const double x1 = y.front(), x2 = y.back(), y1 = 0.5, y2 = -0.5;
@@ -557,6 +560,13 @@ void Navier2DEngine::after_exchange(unsigned wait_mask) {
 #else
   (void)wait_mask;    // the emulation runs the launches in program order on the host: an exchange has landed when it returns
 #endif
+}
+
+void Navier2DEngine::set_lnse_mean_device(int which, const Arr2& phys) {
+  RPDE_REQUIRE(lnse_ && which >= 0 && which < 8, "set_lnse_mean_device: an engine built for Navier2DLnse, array 0 .. 7");
+  RPDE_REQUIRE(phys.rows == nx_ && phys.cols == ny_ && phys.elem == 1, "set_lnse_mean_device: a physical (nx x ny) array");
+  dev_sync(st_);                                           // (a replayed graph reads these arrays)
+  scatter_rows_xy(phys.p(), phys.ld, LM_[which], nx_, ny_, false);
 }
 
 void Navier2DEngine::analyse_lift() {
@@ -904,7 +914,7 @@ bool Navier2DEngine::add_conv_line(const ConvLineArgs& c, const char* tag) {
   l.type = Launch::kConvLine;
   l.cl = c;
   l.tag = tag;
-  l.bytes = 8.0 * (2.0 * c.n_in + ((c.bx && conv_lift_pitch(c) != 0) ? 5.0 : 3.0) * (c.N + 1)) * c.nlines;   // fx, f0; u, v (, bx, by -- unless every line reads line 0), out
+  l.bytes = 8.0 * (2.0 * c.n_in + ((c.bx && conv_lift_pitch(c) != 0) ? 5.0 : 3.0) * (c.N + 1) + (c.um ? 2.0 * (c.N + 1) : 0.0)) * c.nlines;   // fx, f0; u, v (, bx, by -- unless every line reads line 0), out
   step_.push_back(l);
   return true;
 }
@@ -2057,6 +2067,13 @@ void Navier2DEngine::build_confined() {
     ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                     xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
     if (bx) cl.ldl = lift_ldl_;
+    if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
+      const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
+      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1;
+      RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
+                   "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
+      return;
+    }
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(ys);
@@ -2349,6 +2366,13 @@ void Navier2DEngine::build_periodic() {
     ConvLineArgs cl{fx.p, f0.p, UP_.p, VP_.p, bx ? bx->p : nullptr, by ? by->p : nullptr, ldy, my, out.p, ldy,
                     xlines(nx, false), ny - 1, yD.tw.p, yD.tw2.p, 1.0 / sy_, cut_y};
     if (bx) cl.ldl = lift_ldl_;
+    if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
+      const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
+      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1;
+      RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
+                   "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
+      return;
+    }
     // the line-program form
     auto program = [&](ProgramBuilder& pb, const ConvLineArgs& c) {
       pb.set_fft(ys);

@@ -558,13 +558,18 @@ RPDE_HD inline bool hdct_pair_ok(const DctLineArgs& a0, const DctLineArgs& a1) {
 
 // One y-line of a convection term on this core (see conv_line in dct_line.h for the mathematics): the physical factors
 // u, v (, bx, by) of a thread's 17 points are fetched while the transform that needs them is still in its last passes.
-template <int N>
+template <int N, bool MEAN = false>
 RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   constexpr int T = N / 16;
   lds_t buf = (lds_t)blk.lds;
   lds2_t buf2 = (lds2_t)blk.lds;
   const long off = (long)blk.line * c.ld, offl = (long)blk.line * conv_lift_pitch(c);
   const bool lift = c.bx != nullptr;
+#ifdef RPDE_CONV_GUARD_OFF
+  const bool on = true;                // (A/B build: the form of rounds 4 - 6, 400 - 470 registers)
+#else
+  const bool on = c.up != nullptr;     // always true: see conv_line (dct_line.h) -- the factor loads behind a run-time condition: 154 registers
+#endif
   RPDE_TLS(blk, double, acc, 17);
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   // (the pairs m = 2 (tid + u T) of the physical factors through buffer descriptors: line_vm.h RowBuf, as conv_line)
@@ -572,7 +577,17 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   {
     cgmem_t up = (cgmem_t)(c.up + off), bx = (cgmem_t)(lift ? c.bx + offl : c.up + off);
     const RowBuf rup = row_buf(c.up + off, rowb), rbx = row_buf(lift ? c.bx + offl : c.up + off, rowb);
+    cgmem_t um = (cgmem_t)((MEAN ? c.um : c.up) + off);
+    const RowBuf rum = row_buf((MEAN ? c.um : c.up) + off, rowb);
     hdct_core<N>(blk, a1, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
+      if (!on) { if (u == 8) RPDE_T(acc)[16] = e0; else { RPDE_T(acc)[2 * u] = e0; RPDE_T(acc)[2 * u + 1] = e1; } return; }
+      if constexpr (MEAN) {   // um d/dx f + up bx (lnse_eq.rs:59-110)
+        if (u == 8) { RPDE_T(acc)[16] = um[m] * e0 + up[m] * bx[m]; return; }
+        const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T), g = row_ld2(rbx, 16 * tid, 16 * u * T), h = row_ld2(rum, 16 * tid, 16 * u * T);
+        RPDE_T(acc)[2 * u] = h.x * e0 + f.x * g.x;
+        RPDE_T(acc)[2 * u + 1] = h.y * e1 + f.y * g.y;
+        return;
+      }
       if (u == 8) { RPDE_T(acc)[16] = up[m] * (lift ? e0 + bx[m] : e0); return; }
       const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T);
       dbl2 g = dbl2{0.0, 0.0};
@@ -587,7 +602,17 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   {
     cgmem_t vp = (cgmem_t)(c.vp + off), by = (cgmem_t)(lift ? c.by + offl : c.vp + off);
     const RowBuf rvp = row_buf(c.vp + off, rowb), rby = row_buf(lift ? c.by + offl : c.vp + off, rowb);
+    cgmem_t vm = (cgmem_t)((MEAN ? c.vm : c.vp) + off);
+    const RowBuf rvm = row_buf((MEAN ? c.vm : c.vp) + off, rowb);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
+      if (!on) { if (u == 8) RPDE_T(acc)[16] += e0; else { RPDE_T(acc)[2 * u] += e0; RPDE_T(acc)[2 * u + 1] += e1; } return; }
+      if constexpr (MEAN) {   // + vm d/dy f + vp by
+        if (u == 8) { RPDE_T(acc)[16] += vm[m] * e0 + vp[m] * by[m]; return; }
+        const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T), g = row_ld2(rby, 16 * tid, 16 * u * T), h = row_ld2(rvm, 16 * tid, 16 * u * T);
+        RPDE_T(acc)[2 * u] += h.x * e0 + f.x * g.x;
+        RPDE_T(acc)[2 * u + 1] += h.y * e1 + f.y * g.y;
+        return;
+      }
       if (u == 8) { RPDE_T(acc)[16] += vp[m] * (lift ? e0 + by[m] : e0); return; }
       const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T);
       dbl2 g = dbl2{0.0, 0.0};

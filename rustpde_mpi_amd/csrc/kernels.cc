@@ -621,14 +621,17 @@ static void lds_permission(K kernel, size_t bytes) {
     have[dev & 31].store(bytes, std::memory_order_release);
   }
 }
-template <int N, int WPC>
+#ifndef RPDE_HCONV_WPC
+#define RPDE_HCONV_WPC 1               // waves per SIMD of the convection term on the half-length core (1025- / 2049-point lines; A/B builds: 2, 3)
+#endif
+template <int N, int WPC, bool MEAN = false>   // MEAN: the linearised term of Navier2DLnse (ConvLineArgs::um, vm)
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  hconv_line<N>(blk, c);
+  hconv_line<N, MEAN>(blk, c);
 }
 template <int N, int WHICH, bool TRACE = false, int WPC = 3>
 __global__ __launch_bounds__(N / 16, WPC) void rhs_line_kernel(const RhsLineArgs a, long long* trace) {
@@ -676,11 +679,11 @@ __global__ __launch_bounds__(N / 8, 4) void hdct_pair_batch_kernel(const Dct2Bat
   if (line >= a0.nlines) return;
   hdct_pair_line<N>(line, rpde_lds, a0, a1);
 }
-template <int N, int WPC>
+template <int N, int WPC, bool MEAN = false>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
   RPDE_BATCH_LINE(c.nlines);
-  hconv_line<N>(blk, c);
+  hconv_line<N, MEAN>(blk, c);
 }
 template <int N>
 __global__ __launch_bounds__(N / 16, 3) void rhs_line_batch_kernel(const RhsBatch b) {
@@ -702,15 +705,26 @@ static bool s1_split_on() {
   return on;
 }
 // lines of 4097 points (round 5): the convection term of the full-length core, one field per blockIdx.y like the others
-template <int N>
-__global__ __launch_bounds__(N / 16, 3) void conv_line_batch_kernel(const ConvBatch b) {
+#ifndef RPDE_CONV_WPC
+#define RPDE_CONV_WPC 3                // workgroups per CU of the 4097-point convection term (A/B builds: 4 = 128 registers, 8 spilled)
+#endif
+template <int N, bool MEAN = false>
+__global__ __launch_bounds__(N / 16, RPDE_CONV_WPC) void conv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
+#ifdef RPDE_CONV4096_HALF              // (A/B build: the 4097-point term on the half-length core -- 155 registers with the guarded loads)
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
+#else
   __shared__ __attribute__((aligned(16))) double buf[DctGeom<N>::LDS];
+#endif
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  conv_line<N>(blk, c);
+#ifdef RPDE_CONV4096_HALF
+  hconv_line<N, MEAN>(blk, c);
+#else
+  conv_line<N, MEAN>(blk, c);
+#endif
 }
 bool line_batch_ok(int N) { return N == 1024 || N == 4096; }
 // N = 1024: one wave per line, a launch of one field's lines is over after one line's latency.  N = 4096: the
@@ -739,8 +753,15 @@ static void launch_line_batch_n(const LineBatch& b, int nl, Stream& st) {
     ConvBatch k; for (int i = 0; i < b.n; ++i) k.c[i] = b.c[i];
     // N = 1024: one wave per SIMD (416 VGPRs): budgets of two / three waves spill 159 / 274 registers and measured 0.110 / 0.156 ms
     // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10); N = 4096: the full-length core like conv_line_kernel
-    if constexpr (N == 1024) hipLaunchKernelGGL((hconv_line_batch_kernel<N, 1>), grid, block, 0, st.s, k);
-    else hipLaunchKernelGGL(conv_line_batch_kernel<N>, grid, block, 0, st.s, k);
+    bool mean = b.c[0].um != nullptr;
+    for (int i = 0; i < b.n; ++i) RPDE_REQUIRE((b.c[i].um != nullptr) == mean && (!mean || (b.c[i].vm && b.c[i].bx && b.c[i].by)), "line batch: convection terms of one kind");
+    if constexpr (N == 1024) {
+      if (mean) hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC, true>), grid, block, 0, st.s, k);
+      else hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC>), grid, block, 0, st.s, k);
+    } else {
+      if (mean) hipLaunchKernelGGL((conv_line_batch_kernel<N, true>), grid, block, 0, st.s, k);
+      else hipLaunchKernelGGL(conv_line_batch_kernel<N>, grid, block, 0, st.s, k);
+    }
   } else {
     RhsBatch k; for (int i = 0; i < b.n; ++i) k.r[i] = b.r[i];
     hipLaunchKernelGGL(rhs_line_batch_kernel<N>, grid, block, 0, st.s, k);
@@ -895,30 +916,44 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
   RPDE_HIP(hipGetLastError());
   return true;
 }
-template <int N>
-__global__ __launch_bounds__(N / 16, 3) void conv_line_kernel(const ConvLineArgs c) {
+template <int N, bool MEAN = false>
+__global__ __launch_bounds__(N / 16, RPDE_CONV_WPC) void conv_line_kernel(const ConvLineArgs c) {
+#ifdef RPDE_CONV4096_HALF              // (A/B build: the 4097-point term on the half-length core -- 155 registers with the guarded loads)
+  __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
+#else
   __shared__ __attribute__((aligned(16))) double buf[DctGeom<N>::LDS];
+#endif
   const int chunk = (int)gridDim.x >> 3;
   const int line = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
   if (line >= c.nlines) return;
   Blk blk{line, 0, N / 16, buf, nullptr, 0};
-  conv_line<N>(blk, c);
+#ifdef RPDE_CONV4096_HALF
+  hconv_line<N, MEAN>(blk, c);
+#else
+  conv_line<N, MEAN>(blk, c);
+#endif
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   if ((c.N != 4096 && c.N != 2048 && c.N != 1024) || !conv_line_ok(c)) return false;
+  const bool mean = c.um != nullptr;   // the linearised term (Navier2DLnse): needs all four factor arrays
+  if (mean && !(c.vm && c.bx && c.by)) return false;
   if (c.nlines <= 0) return true;
+  const dim3 grid(8 * ((c.nlines + 7) / 8));
   if (c.N == 2048) {   // two waves per line on the half-length core, one wave per SIMD (two lines per CU, like the line program, without its phases)
-    hipLaunchKernelGGL((hconv_line_kernel<2048, 1>), dim3(8 * ((c.nlines + 7) / 8)), dim3(128), 0, st.s, c);
+    if (mean) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, true>), grid, dim3(128), 0, st.s, c);
+    else hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC>), grid, dim3(128), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   if (c.N == 1024) {   // one wave per line on the half-length core; a 1025^2 grid is four lines per CU: the whole register file per wave
-    hipLaunchKernelGGL((hconv_line_kernel<1024, 1>), dim3(8 * ((c.nlines + 7) / 8)), dim3(64), 0, st.s, c);
+    if (mean) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, true>), grid, dim3(64), 0, st.s, c);
+    else hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC>), grid, dim3(64), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   // 4097-point lines: the full-length core (168 VGPRs, three workgroups per CU); on the half-length core the term spills
-  hipLaunchKernelGGL(conv_line_kernel<4096>, dim3(8 * ((c.nlines + 7) / 8)), dim3(256), 0, st.s, c);
+  if (mean) hipLaunchKernelGGL((conv_line_kernel<4096, true>), grid, dim3(256), 0, st.s, c);
+  else hipLaunchKernelGGL(conv_line_kernel<4096>, grid, dim3(256), 0, st.s, c);
   RPDE_HIP(hipGetLastError());
   return true;
 }
@@ -1443,14 +1478,29 @@ void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream&) {
 }
 bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   if (!conv_line_ok(c)) return false;
+  if (c.um && !(c.vm && c.bx && c.by)) return false;
   std::vector<double> lds(hdct_lds_doubles(c.N) + 2);
   double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
   for (int line = 0; line < c.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
+    if (c.um) {   // the linearised term (Navier2DLnse)
+      if (c.N == 1024) hconv_line<1024, true>(blk, c);
+      else if (c.N == 2048) hconv_line<2048, true>(blk, c);
+#ifdef RPDE_CONV4096_HALF
+      else if (c.N == 4096) hconv_line<4096, true>(blk, c); else conv_line<256, true>(blk, c);
+#else
+      else if (c.N == 4096) conv_line<4096, true>(blk, c); else conv_line<256, true>(blk, c);
+#endif
+      continue;
+    }
     if (c.N == 1024) hconv_line<1024>(blk, c);
     else if (c.N == 2048) hconv_line<2048>(blk, c);
+#ifdef RPDE_CONV4096_HALF
+    else if (c.N == 4096) hconv_line<4096>(blk, c); else conv_line<256>(blk, c);
+#else
     else if (c.N == 4096) conv_line<4096>(blk, c); else conv_line<256>(blk, c);   // the device's choice of core per length
+#endif
   }
   return true;
 }

@@ -413,6 +413,35 @@ def test_emu_lnse_step_parity(emu_lib, nx, ny, periodic):
     check_lnse_parity(emu_lib, nx, ny, periodic, steps=4)
 
 
+@pytest.mark.parametrize("nx,ny,periodic", [(33, 257, False), (32, 257, True)])
+def test_emu_lnse_step_on_the_fused_schedule(emu_lib, monkeypatch, nx, ny, periodic):
+    """Round 6: Navier2DLnse::update (lnse.rs:263-288) on Navier2DEngine's fused schedule -- no lift, the convection terms linearised
+    about the mean fields inside the whole-line convection kernel (conv_line<N, true>: U d/dx f + V d/dy f + u d/dx M + v d/dy M,
+    lnse_eq.rs:59-110), used where that kernel covers the y-lines (here: 257 points, emulation only).  Against the oracle after
+    every update with a convection roll as mean flow, and against the composition of generic operators it replaces
+    (RPDE_LNSE_FUSED=0): equal to round-off but not bit-identical -- the two forms really are different code."""
+    monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=3)
+
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("RPDE_LNSE_FUSED", flag)
+        nav, _ = lnse_pair(emu_lib, nx, ny, periodic, 1e5, 1.0, 0.01, mean_flow=True)
+        nav.update(2)
+        nav.update(1)                          # a second hand-over of the state
+        return nav.spectral_fields()
+    fused, generic = run(None), run("0")
+    monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+    differs = False
+    for k in generic:
+        e = rel(fused[k], generic[k])
+        assert e < (1e-8 if k in ("pres", "pseu") else 1e-11), (k, e)
+        differs = differs or e > 0.0
+    assert differs, "RPDE_LNSE_FUSED made no difference: the fused schedule did not run"
+
+
 @pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (65, 257, False)])
 def test_emu_adjoint_fused_forward_step(emu_lib, monkeypatch, nx, ny, periodic):
     """Round 6: the forward Navier-Stokes step inside Navier2DAdjoint::update (steady_adjoint.rs:547-585 -- Navier2D::update with
@@ -773,7 +802,8 @@ def test_gpu_lnse_gradient_parity(hip_lib, tmp_path, nx, ny, periodic, with_targ
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2)])
+@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2), (256, 1025, True, 3),
+                                                  (129, 2049, False, 2), (65, 4097, False, 2)])
 def test_gpu_lnse_step_parity(hip_lib, nx, ny, periodic, steps):
     if nx >= 1025:
         check_lnse_parity(hip_lib, nx, ny, periodic, steps, ra=1e7, dt=1e-3)
