@@ -93,6 +93,9 @@ void Navier2DEngine::release_device_objects() {
   if (xprod_) { (void)hipEventDestroy(xprod_); xprod_ = nullptr; }
   for (auto& ev : xdone_) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   rccl_comm_destroy(comm_.rccl); comm_.rccl = nullptr;
+  if (stf_.s) { (void)hipStreamSynchronize(stf_.s); (void)hipStreamDestroy(stf_.s); stf_.s = nullptr; }
+  if (evfork_) { (void)hipEventDestroy(evfork_); evfork_ = nullptr; }
+  if (evjoin_) { (void)hipEventDestroy(evjoin_); evjoin_ = nullptr; }
   if (ev0_) { (void)hipEventDestroy(ev0_); ev0_ = nullptr; }
   if (ev1_) { (void)hipEventDestroy(ev1_); ev1_ = nullptr; }
   if (hflag_) { (void)hipHostFree(hflag_); hflag_ = nullptr; }
@@ -293,6 +296,31 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   }
   analyse_lift();
   if (periodic) build_periodic(); else build_confined();
+#ifndef RPDE_EMU
+  {   // RPDE_FORK=1: the two chains behind the second eigen-transform on two streams (engine.h)
+    const char* e = std::getenv("RPDE_FORK");
+    if (comm_.size == 1 && e && std::atoi(e) != 0) {
+      int c7 = -1, s9 = -1;
+      for (size_t i = 0; i < step_.size(); ++i) {
+        const std::string t(step_[i].tag);
+        if (t.rfind("C7 ", 0) == 0 && c7 < 0) c7 = (int)i;
+        if (t.rfind("S9 ", 0) == 0 && s9 < 0) s9 = (int)i;
+      }
+      bool tail = c7 >= 0 && s9 > c7;
+      for (size_t i = (size_t)std::max(c7, 0); tail && i < step_.size(); ++i) {
+        const std::string t(step_[i].tag);
+        const bool first = t.rfind("C7 ", 0) == 0 || t.rfind("S8 ", 0) == 0, second = t.rfind("S9 ", 0) == 0 || t.rfind("C10 ", 0) == 0;
+        tail = ((int)i < s9) ? first : second;
+      }
+      if (tail) {
+        RPDE_HIP(hipStreamCreate(&stf_.s));
+        RPDE_HIP(hipEventCreateWithFlags(&evfork_, hipEventDisableTiming));
+        RPDE_HIP(hipEventCreateWithFlags(&evjoin_, hipEventDisableTiming));
+        fork_main_ = c7; fork_side_ = s9;
+      }
+    }
+  }
+#endif
   if (overlap_) overlap_ = apply_overlap_order();
   if (comm_.size > 1) {   // exchanges per step = batches of compatible consecutive transposes + halos + column-scan summaries
     xchg_count_ = 0;
@@ -1315,7 +1343,7 @@ void Navier2DEngine::update(int nsteps) {
       if (hipStreamBeginCapture(st_.s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         bool ok = true;
         try {   // a throw between Begin and EndCapture must not leave the stream in capture mode
-          for (size_t i = 0; i < step_.size();) i = run_from(i);
+          run_step();
         } catch (...) {
           ok = false;
         }
@@ -1336,6 +1364,9 @@ void Navier2DEngine::update(int nsteps) {
   }
 #endif
   for (int s = 0; s < nsteps; ++s) {
+#ifndef RPDE_EMU
+    if (timed_tag_.empty() && fork_side_ >= 0) { run_step(); time_ += dt_; continue; }
+#endif
     for (size_t i = 0; i < step_.size();) {
       const Launch& l = step_[i];
 #ifndef RPDE_EMU
@@ -1370,6 +1401,30 @@ void Navier2DEngine::update(int nsteps) {
 #else
   last_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 #endif
+}
+
+void Navier2DEngine::run_step() {
+#ifndef RPDE_EMU
+  if (fork_side_ >= 0) {
+    for (size_t i = 0; i < step_.size();) {
+      if ((int)i == fork_main_) {            // both chains start behind everything issued so far
+        RPDE_HIP(hipEventRecord(evfork_, st_.s));
+        RPDE_HIP(hipStreamWaitEvent(stf_.s, evfork_, 0));
+      }
+      if ((int)i >= fork_side_) {            // the second chain: the same launch code on the other stream
+        std::swap(st_.s, stf_.s);
+        try { i = run_from(i); } catch (...) { std::swap(st_.s, stf_.s); throw; }
+        std::swap(st_.s, stf_.s);
+      } else {
+        i = run_from(i);
+      }
+    }
+    RPDE_HIP(hipEventRecord(evjoin_, stf_.s));
+    RPDE_HIP(hipStreamWaitEvent(st_.s, evjoin_, 0));
+    return;
+  }
+#endif
+  for (size_t i = 0; i < step_.size();) i = run_from(i);
 }
 
 std::string Navier2DEngine::profile(int nsteps) {

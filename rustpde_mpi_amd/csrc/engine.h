@@ -288,7 +288,16 @@ class Navier2DEngine {
   hipGraphExec_t graph_exec_ = nullptr;   // the whole step captured once (single GPU): replay removes
   bool graph_tried_ = false;              // the per-launch host cost that dominates small grids
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;   // brackets of update(), created once
+  // The last four launches of a step are two independent chains behind the second eigen-transform: { C7 correction-y -> S8 correction-x }
+  // writes the velocities from the pseudo-pressure, { S9 pressure update -> C10 d/dy pres } the pressure and its gradients.  With
+  // RPDE_FORK the second chain runs on a stream of its own between two events (two parallel branches of the captured graph): on small
+  // grids, where a launch does not fill the chip, the chains overlap (engine.cc run_step).
+  Stream stf_;
+  hipEvent_t evfork_ = nullptr, evjoin_ = nullptr;
+  int fork_side_ = -1;                    // index of the first launch of the second chain (S9), -1: no fork
+  int fork_main_ = -1;                    // index of the first launch of the first chain (C7)
 #endif
+  void run_step();                        // one pass over step_ (forked where fork_side_ >= 0)
   bool use_graph_ = true;
   void add_line(const ProgramBuilder& pb, const char* tag);
   void add_gemm_pair(bool nn, const GemmProblem& p0, const GemmProblem& p1, const char* tag);

@@ -442,6 +442,34 @@ def test_emu_lnse_step_on_the_fused_schedule(emu_lib, monkeypatch, nx, ny, perio
     assert differs, "RPDE_LNSE_FUSED made no difference: the fused schedule did not run"
 
 
+def test_emu_lnse_fused_schedule_follows_a_changed_mean(emu_lib, monkeypatch):
+    """The fused schedule keeps the mean velocities and the mean gradients as device arrays of its own (set_lnse_mean_device): a mean
+    field set BETWEEN two updates must reach them (GenericFlow2D::const_gen_).  Fused against generic with the mean flow switched on
+    after the first update; and the state set from outside between updates (set_field) is what the next fused update starts from."""
+    nx, ny = 17, 257
+
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("RPDE_LNSE_FUSED", flag)
+        nav, ora = lnse_pair(emu_lib, nx, ny, False, 1e5, 1.0, 0.01, mean_flow=False)
+        nav.update(1)
+        x, y = ora.velx.x
+        xs, ys = (x - x[0]) / (x[-1] - x[0]), (y - y[0]) / (y[-1] - y[0])
+        nav.mean_velx.v = 0.3 * np.sin(np.pi * xs)[:, None] * np.cos(np.pi * ys)[None, :]
+        nav.mean_vely.v = -0.3 * np.cos(np.pi * xs)[:, None] * np.sin(np.pi * ys)[None, :]
+        nav.update(1)
+        nav.temp.v = 2.0 * nav.temp.v            # the state changed from outside
+        nav.update(1)
+        return nav.spectral_fields()
+    fused, generic = run(None), run("0")
+    monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+    for k in generic:
+        e = rel(fused[k], generic[k])
+        assert e < (1e-8 if k in ("pres", "pseu") else 1e-11), (k, e)
+
+
 @pytest.mark.parametrize("nx,ny,periodic", [(33, 33, False), (32, 33, True), (65, 257, False)])
 def test_emu_adjoint_fused_forward_step(emu_lib, monkeypatch, nx, ny, periodic):
     """Round 6: the forward Navier-Stokes step inside Navier2DAdjoint::update (steady_adjoint.rs:547-585 -- Navier2D::update with

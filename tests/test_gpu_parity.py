@@ -180,6 +180,15 @@ def test_round6_gemm_transposed_accumulation_bit_identical(hip_lib):
     _ab_switch_bit_identical("RPDE_GEMM_CTSWAP", "0", "((2049, 2049),)")
 
 
+@pytest.mark.parametrize("extra", [None, {"RPDE_GRAPH": "0"}])
+def test_round6_forked_tail_bit_identical(hip_lib, extra):
+    """RPDE_FORK=1 (round 6): behind the second eigen-transform the step is two independent chains -- { C7 correction-y, S8
+    correction-x } and { S9 pressure update, C10 d/dy pres } -- and the second one runs on a stream of its own between two events
+    (two parallel branches of the captured graph; RPDE_GRAPH=0: plain launches on two streams).  The same kernels on the same
+    data: bit-identical fields, on grids where the chains really overlap (launches that do not fill the chip) and at 2049 x 2049."""
+    _ab_switch_bit_identical("RPDE_FORK", "1", "((257, 257), (1025, 1025), (2049, 2049))", extra=extra)
+
+
 def test_round6_lift_structure_bit_identical(hip_lib):
     """Round 6: what the step reads of the time-independent lift arrays (Navier2DEngine::analyse_lift: one y-line of the lift's
     physical gradients for all lines, the leading non-zero coefficients of its spectral rows) against whole arrays

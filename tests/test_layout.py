@@ -71,6 +71,7 @@ ENV_SWITCHES = {
     "RPDE_S1_PAIR", "RPDE_LINE_BATCH",              # S1 pair form, batched launches of 1025-point lines (test_whole_line_kernels_equal_line_programs_1025)
     "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
     "RPDE_ADJOINT_FUSED",                           # Navier2DAdjoint: forward step on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_adjoint_fused_forward_step)
+    "RPDE_FORK",                                    # the two independent chains behind G2 on two streams / graph branches (test_gpu_parity.test_round6_forked_tail_bit_identical)
     "RPDE_LNSE_FUSED",                              # Navier2DLnse::update on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_lnse_step_on_the_fused_schedule)
     "RPDE_PER_ROWS",                                # periodic S5 / S8 / S9: element-wise kernels / line programs (test_periodic_elementwise_stages_equal_line_programs)
     "RPDE_GEMM_WAVES",                              # A/B of round 6: the GEMM's 128-tile by eight waves (test_gpu_parity.test_round6_gemm_eight_waves_bit_identical)
