@@ -614,9 +614,9 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
   refresh_mean();
   dev_sync(st_);
   const char* e = std::getenv("RPDE_LNSE_FUSED");
-  if (!nonlin_ && !hc_ && (!e || std::atoi(e) != 0)) {
+  if (!hc_ && (!e || std::atoi(e) != 0)) {
     try {
-      fwd_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/true);
+      fwd_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/nonlin_ ? 2 : 1);
     } catch (const std::exception&) {
       fwd_.reset();   // a shape the fused schedule does not cover: the generic composition
     }
@@ -725,6 +725,22 @@ void Navier2DLnseEngine::update_fused(int nsteps) {
         dev_sync(st_);
         fwd_->set_lnse_mean_device(2 + 2 * f + d, cp_);
       }
+    if (nonlin_) {
+      // what the mean fields add to the right-hand sides of Navier2DNonLin (nonlin_eq.rs:193-240, nonlin.rs:266): dt nu lap(U);
+      // dt nu lap(V) + dt mean.temp.to_ortho() (the buoyancy of the mean temperature); dt ka lap(T).  The Helmholtz solves are linear:
+      // H^-1 of these constant rows is added behind the solves of the fused step (engine.h, fields nl_velx / nl_vely / nl_temp)
+      const char* const dst[3] = {"nl_velx", "nl_vely", "nl_temp"};
+      for (int f = 0; f < 3; ++f) {
+        F& st = field(names[f]);
+        zero(rhs_);
+        mean_diffusion(mean(names[f]), f == 2 ? ka_ : nu_);
+        if (f == 1) lincomb(rhs_, 1.0, rhs_, dt_, mean("temp").vhat);
+        Arr2 c(st.vhat.rows, st.vhat.cols, st.vhat.elem);
+        (f == 2 ? *hh_temp_ : *hh_vel_).solve(rhs_, c, st_);
+        dev_sync(st_);
+        fwd_->set_field_spectral_device(dst[f], c);
+      }
+    }
     fwd_mean_gen_ = const_gen_;
   }
   dev_sync(st_);

@@ -365,6 +365,9 @@ struct ConvLineArgs {
   // The linearised convection term of Navier2DLnse (lnse_eq.rs:59-110): um, vm = the physical mean velocities (pitch ld), bx, by = the
   // physical gradient of the mean field the term belongs to; out = DCT_y[ um d/dx f + vm d/dy f + up bx + vp by ] (conv_line<N, true>).
   const double* um = nullptr; const double* vm = nullptr;
+  // nonlin != 0 (Navier2DNonLin, nonlin_eq.rs:59-134): (um + up) (d/dx f + bx) + (vm + vp) (d/dy f + by) -- the classic term with the
+  // mean velocities added to the perturbation's (conv_line<N, 2>)
+  int nonlin = 0;
 };
 RPDE_HD inline long conv_lift_pitch(const ConvLineArgs& c) { return c.ldl >= 0 ? c.ldl : c.ld; }
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
@@ -374,7 +377,7 @@ RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
   return dct_line_ok(a) && dct_line_ok(b);   // N = 16^k: three transforms on the full-length core; N = 1024: hconv_line (hdct_line.h), one wave per line
 }
 
-template <int N, bool MEAN = false>
+template <int N, int MEAN = 0>   // 0: Navier2D, 1: Navier2DLnse (linearised), 2: Navier2DNonLin
 RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   constexpr int T = N / 16;
   lds_t buf = (lds_t)blk.lds;
@@ -411,7 +414,8 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
 #endif
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   auto e1 = [&](int tid, int slot, int k, double v) {
-    if constexpr (MEAN) RPDE_T(acc)[slot] = lift ? pick(rum, um, tid, slot, k) * v + pick(rup, up, tid, slot, k) * pick(rbx, bx, tid, slot, k) : v;
+    if constexpr (MEAN == 2) RPDE_T(acc)[slot] = lift ? (pick(rum, um, tid, slot, k) + pick(rup, up, tid, slot, k)) * (v + pick(rbx, bx, tid, slot, k)) : v;
+    else if constexpr (MEAN == 1) RPDE_T(acc)[slot] = lift ? pick(rum, um, tid, slot, k) * v + pick(rup, up, tid, slot, k) * pick(rbx, bx, tid, slot, k) : v;
     else RPDE_T(acc)[slot] = on ? pick(rup, up, tid, slot, k) * (lift ? v + pick(rbx, bx, tid, slot, k) : v) : v;
   };
   dct_line_core<N, decltype(e1), 0>(blk, a1, false, e1);
@@ -419,7 +423,8 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   DctLineArgs a2 = a1;
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   auto e2 = [&](int tid, int slot, int k, double v) {
-    if constexpr (MEAN) RPDE_T(acc)[slot] += lift ? pick(rvm, vm, tid, slot, k) * v + pick(rvp, vp, tid, slot, k) * pick(rby, by, tid, slot, k) : v;
+    if constexpr (MEAN == 2) RPDE_T(acc)[slot] += lift ? (pick(rvm, vm, tid, slot, k) + pick(rvp, vp, tid, slot, k)) * (v + pick(rby, by, tid, slot, k)) : v;
+    else if constexpr (MEAN == 1) RPDE_T(acc)[slot] += lift ? pick(rvm, vm, tid, slot, k) * v + pick(rvp, vp, tid, slot, k) * pick(rby, by, tid, slot, k) : v;
     else RPDE_T(acc)[slot] += on ? pick(rvp, vp, tid, slot, k) * (lift ? v + pick(rby, by, tid, slot, k) : v) : v;
   };
   dct_line_core<N, decltype(e2), 1>(blk, a2, false, e2);

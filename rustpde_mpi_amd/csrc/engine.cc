@@ -45,7 +45,7 @@ std::vector<int> Navier2DEngine::split(int n, int parts) {
 }
 
 Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                               const std::string& bc, bool periodic, const CommCb* comm, bool buoyancy_lift, bool lnse)
+                               const std::string& bc, bool periodic, const CommCb* comm, bool buoyancy_lift, int lnse)
     : nx_(nx), ny_(ny), periodic_(periodic), ra_(ra), pr_(pr), dt_(dt), sx_(aspect), sy_(1.0), buoyancy_lift_(buoyancy_lift && !lnse), lnse_(lnse) {
   if (comm) comm_ = *comm;
   if (const char* e = std::getenv("RPDE_GRAPH")) use_graph_ = std::atoi(e) != 0;
@@ -156,6 +156,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   for (auto& b : X_) b.alloc(nxy);
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   if (lnse_) for (auto& b : LM_) b.alloc(nxy);
+  if (lnse_ == 2) for (auto& b : NLC_) b.alloc(nyx);
   red_.alloc(2);
   nanflag_.alloc(2);
   {   // column scans (colscan.h): block carries, tables of this rank's rows, summaries that travel between the ranks
@@ -244,6 +245,11 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   mk("pres", sp_ortho_.get(), &P_, true, true);
   mk("pseu", sp_pseu_.get(), &PS_, false, false);
   mk("tempbc", sp_ortho_.get(), &TBC_, true, true);   // the lift: read-only (snapshots)
+  if (lnse_ == 2) {
+    mk("nl_velx", sp_vel_.get(), &NLC_[0], true, false);
+    mk("nl_vely", sp_vel_.get(), &NLC_[1], true, false);
+    mk("nl_temp", sp_temp_.get(), &NLC_[2], true, false);
+  }
 
   // ---- boundary-condition lift (boundary_conditions.rs:18-36 / 143-161) and its constants
   // (Navier2DLnse has none: TBC_, TBC2_, BX_, BY_ stay the zero arrays they were allocated as)
@@ -2124,7 +2130,7 @@ void Navier2DEngine::build_confined() {
     if (bx) cl.ldl = lift_ldl_;
     if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
       const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
-      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1;
+      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1; cl.nonlin = lnse_ == 2;
       RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
                    "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
       return;
@@ -2212,6 +2218,15 @@ void Navier2DEngine::build_confined() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, mx, "C4 y: hholtz-y (column scan)");
+    if (lnse_ == 2) {   // + H^-1 (what the mean fields add to the right-hand sides): one line program over the three states
+      ProgramBuilder pb = ypb(1, my);
+      for (int k = 0; k < 3; ++k) {
+        pb.load(0, pb.arr(cout[k], ldx), mx);
+        pb.load(0, pb.arr(yx(NLC_[k]), ldx), mx, 1.0, true);
+        pb.store(0, pb.arr(cout[k], ldx), mx);
+      }
+      add_line(pb, "C4 x: + mean terms");
+    }
     if (hc) { if (P == 1) add_hc_hholtz(yx(Y_[5]), yx(T_), mx); else add_hc_hholtz_sharded(yx(Y_[5]), yx(T_), mx, 1, false); }
     // d/dy vely for the divergence (rows ny, composite x); the halo of velx serves the cross-line stencil of S5
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
@@ -2423,7 +2438,7 @@ void Navier2DEngine::build_periodic() {
     if (bx) cl.ldl = lift_ldl_;
     if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
       const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
-      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1;
+      cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1; cl.nonlin = lnse_ == 2;
       RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
                    "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
       return;
@@ -2513,6 +2528,15 @@ void Navier2DEngine::build_periodic() {
     const double* cin[3] = {yx(Y_[3]), yx(Y_[4]), yx(Y_[5])};
     double* cout[3] = {yx(U_), yx(V_), yx(T_)};
     add_col_hholtz(cin, cout, nc, "C4 y: hholtz-y (column scan)");
+    if (lnse_ == 2) {   // + H^-1 (what the mean fields add to the right-hand sides), as in the confined step
+      ProgramBuilder pb = ypb(1, my);
+      for (int k = 0; k < 3; ++k) {
+        pb.load(0, pb.arr(cout[k], ldx), nc);
+        pb.load(0, pb.arr(yx(NLC_[k]), ldx), nc, 1.0, true);
+        pb.store(0, pb.arr(cout[k], ldx), nc);
+      }
+      add_line(pb, "C4 x: + mean terms");
+    }
     if (hc) { if (comm_.size == 1) add_hc_hholtz(yx(Y_[5]), yx(T_), nc); else add_hc_hholtz_sharded(yx(Y_[5]), yx(T_), kx, 2, true); }
     add_halo({yx(U_), yx(V_)}, 2, 4, "H1 halo velx, vely");
     add_col_diff(yx(V_), yx(Y_[0]), my, yD.low.p, nc, 1.0 / sy_, "C4 y: d/dy vely (column scan)");

@@ -35,7 +35,7 @@ class Navier2DEngine {
   // buoyancy_lift = false: the buoyancy term of solve_vely is temp.to_ortho() alone, without the lift -- the forward step inside
   // Navier2DAdjoint::update (steady_adjoint_eq.rs:147-160; everything else of that step is Navier2D's, steady_adjoint.rs:547-585)
   Navier2DEngine(int nx, int ny, double ra, double pr, double dt, double aspect,
-                 const std::string& bc, bool periodic, const CommCb* comm = nullptr, bool buoyancy_lift = true, bool lnse = false);
+                 const std::string& bc, bool periodic, const CommCb* comm = nullptr, bool buoyancy_lift = true, int lnse = 0);
   // lnse = true: the step of Navier2DLnse (lnse.rs:263-288, lnse_eq.rs) on this schedule -- no lift anywhere (the temperature is the
   // deviation from the mean), and the convection terms linearised about mean fields: U d/dx f + V d/dy f + u d/dx M + v d/dy M
   // (lnse_eq.rs:59-110) with the physical mean velocities and the physical gradients of the three mean fields as time-independent
@@ -44,6 +44,10 @@ class Navier2DEngine {
   // which: 0 U, 1 V (physical mean velocities); 2 + 2 f + d: d/dx (d = 0) or d/dy (d = 1) of mean field f (0 velx, 1 vely, 2 temp),
   // physical; `phys` = (nx x ny) canonical
   void set_lnse_mean_device(int which, const Arr2& phys);
+  // lnse = 2: the step of Navier2DNonLin (nonlin.rs:264-296, nonlin_eq.rs) -- the convection terms (U + u) . grad(M + f) (the classic kernel
+  // with the mean velocities added to u, v and the mean gradients in the lift's place, for all three fields), and what the mean fields
+  // add to the right-hand sides (their diffusion, the mean temperature in the buoyancy) as three time-independent composite arrays
+  // H^-1 c added behind the Helmholtz solves (the solve is linear): fields "nl_velx", "nl_vely", "nl_temp" (set_field_spectral_device).
   ~Navier2DEngine();
 
   // initial conditions (src/navier_stokes/navier.rs:161-182, functions.rs:85-126)
@@ -323,7 +327,8 @@ class Navier2DEngine {
   int tbc_cols_ = -1, tbc2_cols_ = -1;   // leading coefficients of a row of TBC_ (TBC0_) / TBC2_ that can be non-zero (-1: not analysed)
   void analyse_lift();
   bool buoyancy_lift_ = true;
-  bool lnse_ = false;
+  int lnse_ = 0;                      // 1: Navier2DLnse, 2: Navier2DNonLin
+  DBuf NLC_[3];                      // lnse_ == 2: H^-1 of the constant right-hand sides of velx, vely, temp (state layout)
   DBuf LM_[8];                       // lnse_: U, V, then d/dx, d/dy of the mean velx, vely, temp -- physical, XY layout (pitch ldy_)
   DBuf TBC0_;                        // buoyancy_lift_ = false: a zero array in the lift's place (buoyancy term only)
   bool pseu_from_y4_ = false;   // periodic step with the real-view S6: the canonical pseu is the complex transpose of Y_[4]

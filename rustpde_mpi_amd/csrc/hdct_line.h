@@ -558,7 +558,7 @@ RPDE_HD inline bool hdct_pair_ok(const DctLineArgs& a0, const DctLineArgs& a1) {
 
 // One y-line of a convection term on this core (see conv_line in dct_line.h for the mathematics): the physical factors
 // u, v (, bx, by) of a thread's 17 points are fetched while the transform that needs them is still in its last passes.
-template <int N, bool MEAN = false>
+template <int N, int MEAN = 0>
 RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
   constexpr int T = N / 16;
   lds_t buf = (lds_t)blk.lds;
@@ -581,7 +581,14 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
     const RowBuf rum = row_buf((MEAN ? c.um : c.up) + off, rowb);
     hdct_core<N>(blk, a1, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (!on) { if (u == 8) RPDE_T(acc)[16] = e0; else { RPDE_T(acc)[2 * u] = e0; RPDE_T(acc)[2 * u + 1] = e1; } return; }
-      if constexpr (MEAN) {   // um d/dx f + up bx (lnse_eq.rs:59-110)
+      if constexpr (MEAN == 2) {   // (um + up) (d/dx f + bx) (nonlin_eq.rs:59-134)
+        if (u == 8) { RPDE_T(acc)[16] = (um[m] + up[m]) * (e0 + bx[m]); return; }
+        const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T), g = row_ld2(rbx, 16 * tid, 16 * u * T), h = row_ld2(rum, 16 * tid, 16 * u * T);
+        RPDE_T(acc)[2 * u] = (h.x + f.x) * (e0 + g.x);
+        RPDE_T(acc)[2 * u + 1] = (h.y + f.y) * (e1 + g.y);
+        return;
+      }
+      if constexpr (MEAN == 1) {   // um d/dx f + up bx (lnse_eq.rs:59-110)
         if (u == 8) { RPDE_T(acc)[16] = um[m] * e0 + up[m] * bx[m]; return; }
         const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T), g = row_ld2(rbx, 16 * tid, 16 * u * T), h = row_ld2(rum, 16 * tid, 16 * u * T);
         RPDE_T(acc)[2 * u] = h.x * e0 + f.x * g.x;
@@ -606,7 +613,14 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
     const RowBuf rvm = row_buf((MEAN ? c.vm : c.vp) + off, rowb);
     hdct_core<N>(blk, a2, false, HdctNoFetch{}, [&](int tid, int u, int m, double e0, double e1) {
       if (!on) { if (u == 8) RPDE_T(acc)[16] += e0; else { RPDE_T(acc)[2 * u] += e0; RPDE_T(acc)[2 * u + 1] += e1; } return; }
-      if constexpr (MEAN) {   // + vm d/dy f + vp by
+      if constexpr (MEAN == 2) {   // + (vm + vp) (d/dy f + by)
+        if (u == 8) { RPDE_T(acc)[16] += (vm[m] + vp[m]) * (e0 + by[m]); return; }
+        const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T), g = row_ld2(rby, 16 * tid, 16 * u * T), h = row_ld2(rvm, 16 * tid, 16 * u * T);
+        RPDE_T(acc)[2 * u] += (h.x + f.x) * (e0 + g.x);
+        RPDE_T(acc)[2 * u + 1] += (h.y + f.y) * (e1 + g.y);
+        return;
+      }
+      if constexpr (MEAN == 1) {   // + vm d/dy f + vp by
         if (u == 8) { RPDE_T(acc)[16] += vm[m] * e0 + vp[m] * by[m]; return; }
         const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T), g = row_ld2(rby, 16 * tid, 16 * u * T), h = row_ld2(rvm, 16 * tid, 16 * u * T);
         RPDE_T(acc)[2 * u] += h.x * e0 + f.x * g.x;

@@ -624,7 +624,7 @@ static void lds_permission(K kernel, size_t bytes) {
 #ifndef RPDE_HCONV_WPC
 #define RPDE_HCONV_WPC 1               // waves per SIMD of the convection term on the half-length core (1025- / 2049-point lines; A/B builds: 2, 3)
 #endif
-template <int N, int WPC, bool MEAN = false>   // MEAN: the linearised term of Navier2DLnse (ConvLineArgs::um, vm)
+template <int N, int WPC, int MEAN = 0>   // MEAN: the linearised term of Navier2DLnse (ConvLineArgs::um, vm)
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_kernel(const ConvLineArgs c) {
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
   const int chunk = (int)gridDim.x >> 3;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(N / 8, 4) void hdct_pair_batch_kernel(const Dct2Bat
   if (line >= a0.nlines) return;
   hdct_pair_line<N>(line, rpde_lds, a0, a1);
 }
-template <int N, int WPC, bool MEAN = false>
+template <int N, int WPC, int MEAN = 0>
 __global__ __launch_bounds__(N / 16, WPC) void hconv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
   RPDE_BATCH_LINE(c.nlines);
@@ -708,7 +708,7 @@ static bool s1_split_on() {
 #ifndef RPDE_CONV_WPC
 #define RPDE_CONV_WPC 3                // workgroups per CU of the 4097-point convection term (A/B builds: 4 = 128 registers, 8 spilled)
 #endif
-template <int N, bool MEAN = false>
+template <int N, int MEAN = 0>
 __global__ __launch_bounds__(N / 16, RPDE_CONV_WPC) void conv_line_batch_kernel(const ConvBatch b) {
   const ConvLineArgs& c = b.c[blockIdx.y];
 #ifdef RPDE_CONV4096_HALF              // (A/B build: the 4097-point term on the half-length core -- 155 registers with the guarded loads)
@@ -755,11 +755,15 @@ static void launch_line_batch_n(const LineBatch& b, int nl, Stream& st) {
     // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10); N = 4096: the full-length core like conv_line_kernel
     bool mean = b.c[0].um != nullptr;
     for (int i = 0; i < b.n; ++i) RPDE_REQUIRE((b.c[i].um != nullptr) == mean && (!mean || (b.c[i].vm && b.c[i].bx && b.c[i].by)), "line batch: convection terms of one kind");
+    const bool nl = mean && b.c[0].nonlin != 0;
+    for (int i = 0; i < b.n; ++i) RPDE_REQUIRE(!mean || (b.c[i].nonlin != 0) == nl, "line batch: convection terms of one kind");
     if constexpr (N == 1024) {
-      if (mean) hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC, true>), grid, block, 0, st.s, k);
+      if (nl) hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC, 2>), grid, block, 0, st.s, k);
+      else if (mean) hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC, 1>), grid, block, 0, st.s, k);
       else hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC>), grid, block, 0, st.s, k);
     } else {
-      if (mean) hipLaunchKernelGGL((conv_line_batch_kernel<N, true>), grid, block, 0, st.s, k);
+      if (nl) hipLaunchKernelGGL((conv_line_batch_kernel<N, 2>), grid, block, 0, st.s, k);
+      else if (mean) hipLaunchKernelGGL((conv_line_batch_kernel<N, 1>), grid, block, 0, st.s, k);
       else hipLaunchKernelGGL(conv_line_batch_kernel<N>, grid, block, 0, st.s, k);
     }
   } else {
@@ -916,7 +920,7 @@ bool launch_dct_line(const DctLineArgs& a, Stream& st, long long* trace) {
   RPDE_HIP(hipGetLastError());
   return true;
 }
-template <int N, bool MEAN = false>
+template <int N, int MEAN = 0>
 __global__ __launch_bounds__(N / 16, RPDE_CONV_WPC) void conv_line_kernel(const ConvLineArgs c) {
 #ifdef RPDE_CONV4096_HALF              // (A/B build: the 4097-point term on the half-length core -- 155 registers with the guarded loads)
   __shared__ __attribute__((aligned(16))) double buf[HdctGeom<N>::LDS];
@@ -940,19 +944,22 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   if (c.nlines <= 0) return true;
   const dim3 grid(8 * ((c.nlines + 7) / 8));
   if (c.N == 2048) {   // two waves per line on the half-length core, one wave per SIMD (two lines per CU, like the line program, without its phases)
-    if (mean) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, true>), grid, dim3(128), 0, st.s, c);
+    if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 2>), grid, dim3(128), 0, st.s, c);
+    else if (mean) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 1>), grid, dim3(128), 0, st.s, c);
     else hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC>), grid, dim3(128), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   if (c.N == 1024) {   // one wave per line on the half-length core; a 1025^2 grid is four lines per CU: the whole register file per wave
-    if (mean) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, true>), grid, dim3(64), 0, st.s, c);
+    if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 2>), grid, dim3(64), 0, st.s, c);
+    else if (mean) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 1>), grid, dim3(64), 0, st.s, c);
     else hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC>), grid, dim3(64), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   // 4097-point lines: the full-length core (168 VGPRs, three workgroups per CU); on the half-length core the term spills
-  if (mean) hipLaunchKernelGGL((conv_line_kernel<4096, true>), grid, dim3(256), 0, st.s, c);
+  if (mean && c.nonlin) hipLaunchKernelGGL((conv_line_kernel<4096, 2>), grid, dim3(256), 0, st.s, c);
+  else if (mean) hipLaunchKernelGGL((conv_line_kernel<4096, 1>), grid, dim3(256), 0, st.s, c);
   else hipLaunchKernelGGL(conv_line_kernel<4096>, grid, dim3(256), 0, st.s, c);
   RPDE_HIP(hipGetLastError());
   return true;
@@ -1484,13 +1491,19 @@ bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   for (int line = 0; line < c.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
+    if (c.um && c.nonlin) {   // Navier2DNonLin: the mean velocities added to u, v
+      if (c.N == 1024) hconv_line<1024, 2>(blk, c);
+      else if (c.N == 2048) hconv_line<2048, 2>(blk, c);
+      else if (c.N == 4096) conv_line<4096, 2>(blk, c); else conv_line<256, 2>(blk, c);
+      continue;
+    }
     if (c.um) {   // the linearised term (Navier2DLnse)
-      if (c.N == 1024) hconv_line<1024, true>(blk, c);
-      else if (c.N == 2048) hconv_line<2048, true>(blk, c);
+      if (c.N == 1024) hconv_line<1024, 1>(blk, c);
+      else if (c.N == 2048) hconv_line<2048, 1>(blk, c);
 #ifdef RPDE_CONV4096_HALF
-      else if (c.N == 4096) hconv_line<4096, true>(blk, c); else conv_line<256, true>(blk, c);
+      else if (c.N == 4096) hconv_line<4096, 1>(blk, c); else conv_line<256, 1>(blk, c);
 #else
-      else if (c.N == 4096) conv_line<4096, true>(blk, c); else conv_line<256, true>(blk, c);
+      else if (c.N == 4096) conv_line<4096, 1>(blk, c); else conv_line<256, 1>(blk, c);
 #endif
       continue;
     }

@@ -665,6 +665,41 @@ def check_nonlin_parity(lib, nx, ny, periodic, steps, ra=1e4, dt=0.01, tol=1e-10
     print("nonlin", nx, ny, "periodic" if periodic else "confined", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("nx,ny,periodic", [(17, 257, False), (16, 257, True)])
+def test_emu_nonlin_step_on_the_fused_schedule(emu_lib, tmp_path, monkeypatch, nx, ny, periodic):
+    """Round 6: Navier2DNonLin::update (nonlin.rs:264-296) on Navier2DEngine's fused schedule where the whole-line convection kernel
+    covers the y-lines -- the classic term with the mean velocities added to u, v and the mean gradients in the lift's place
+    (conv_line<N, 2>), and what the mean fields add to the right-hand sides (their diffusion, the mean temperature in the buoyancy) as
+    H^-1 of constant rows added behind the Helmholtz solves.  Against the oracle through update_direct, the adjoint steps that read
+    the history, and grad_adjoint; and against the generic composition (RPDE_LNSE_FUSED=0): equal to round-off, not bit for bit."""
+    monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+    check_nonlin_parity(emu_lib, nx, ny, periodic, steps=3, max_time=0.05, tmp_path=tmp_path)
+    from oracle import lnse as L
+
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("RPDE_LNSE_FUSED", flag)
+        mk_e = R.Navier2DNonLin.new_periodic if periodic else R.Navier2DNonLin.new_confined
+        mk_o = L.Navier2DNonLin.new_periodic if periodic else L.Navier2DNonLin.new_confined
+        nav = mk_e(nx, ny, 1e4, 1.0, 0.01, 1.0, "rbc", library=emu_lib, mean_file="/nonexistent/mean.h5")
+        _roll_mean(mk_o(nx, ny, 1e4, 1.0, 0.01, 1.0, "rbc", eig_mode="parity"), nav)
+        nav.set_velocity(0.2, 2.0, 1.0)
+        nav.set_temperature(0.1, 1.0, 2.0)
+        nav.update(2)
+        nav.update(1)
+        return nav.spectral_fields()
+    fused, generic = run(None), run("0")
+    monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
+    differs = False
+    for k in generic:
+        e = rel(fused[k], generic[k])
+        assert e < (1e-8 if k in ("pres", "pseu") else 1e-11), (k, e)
+        differs = differs or e > 0.0
+    assert differs, "RPDE_LNSE_FUSED made no difference: the fused schedule did not run"
+
+
 @pytest.mark.parametrize("nx,ny,periodic", [(17, 17, False), (33, 17, False), (16, 17, True)])
 def test_emu_nonlin_parity(emu_lib, tmp_path, nx, ny, periodic):
     check_nonlin_parity(emu_lib, nx, ny, periodic, steps=3, max_time=0.05, tmp_path=tmp_path)
@@ -812,7 +847,8 @@ def test_gpu_lnse_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,ny,periodic,steps,max_time", [(65, 65, False, 4, 0.05), (128, 65, True, 3, 0.05), (513, 257, False, 2, None)])
+@pytest.mark.parametrize("nx,ny,periodic,steps,max_time", [(65, 65, False, 4, 0.05), (128, 65, True, 3, 0.05), (513, 257, False, 2, None),
+                                                           (129, 1025, False, 3, 0.03), (128, 1025, True, 2, None), (65, 4097, False, 2, None)])
 def test_gpu_nonlin_parity(hip_lib, tmp_path, nx, ny, periodic, steps, max_time):
     check_nonlin_parity(hip_lib, nx, ny, periodic, steps, max_time=max_time, tmp_path=tmp_path)
 
