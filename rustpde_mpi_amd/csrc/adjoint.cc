@@ -617,8 +617,11 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
   if (!hc_ && (!e || std::atoi(e) != 0)) {
     try {
       fwd_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/nonlin_ ? 2 : 1);
-    } catch (const std::exception&) {
+    } catch (const std::exception& ex) {
       fwd_.reset();   // a shape the fused schedule does not cover: the generic composition
+      // (said aloud when the shape IS one the whole-line convection kernel covers: then something else refused, e.g. a switch)
+      if (ny == 1025 || ny == 2049 || ny == 4097)
+        std::fprintf(stderr, "Navier2DLnse: the fused schedule is not used (%s); composition of generic operators\n", ex.what());
     }
   }
 }
