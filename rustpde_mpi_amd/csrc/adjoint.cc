@@ -623,6 +623,13 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
       if (ny == 1025 || ny == 2049 || ny == 4097)
         std::fprintf(stderr, "Navier2DLnse: the fused schedule is not used (%s); composition of generic operators\n", ex.what());
     }
+    if (fwd_ && !nonlin_ && !periodic) {
+      try {
+        adj_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/3);
+      } catch (const std::exception&) {
+        adj_.reset();
+      }
+    }
   }
 }
 
@@ -715,19 +722,29 @@ bool Navier2DLnseEngine::exit() { return std::isnan(div_norm()); }
 
 // update() on Navier2DEngine's schedule (adjoint.h fwd_): the mean velocities and the six physical mean gradients once per change of a
 // mean field, the state per call
+void Navier2DLnseEngine::push_mean(Navier2DEngine& e, bool negate_velocities) {
+  refresh_mean();
+  if (negate_velocities) {   // the adjoint term carries -(U d/dx + V d/dy) f (engine.h lnse = 3)
+    lincomb(cp_, -1.0, um_, 0.0, um_); dev_sync(st_); e.set_lnse_mean_device(0, cp_);
+    lincomb(cp_, -1.0, vm_, 0.0, vm_); dev_sync(st_); e.set_lnse_mean_device(1, cp_);
+  } else {
+    e.set_lnse_mean_device(0, um_);
+    e.set_lnse_mean_device(1, vm_);
+  }
+  const char* const names[3] = {"velx", "vely", "temp"};
+  for (int f = 0; f < 3; ++f)
+    for (int d = 0; d < 2; ++d) {
+      F& m = mean(names[f]);
+      m.sp->gradient_backward(m.vhat, d == 0 ? 1 : 0, d == 0 ? 0 : 1, sx_, sy_, cp_, st_);
+      dev_sync(st_);
+      e.set_lnse_mean_device(2 + 2 * f + d, cp_);
+    }
+}
+
 void Navier2DLnseEngine::update_fused(int nsteps) {
   if (fwd_mean_gen_ != const_gen_) {
-    refresh_mean();
-    fwd_->set_lnse_mean_device(0, um_);
-    fwd_->set_lnse_mean_device(1, vm_);
+    push_mean(*fwd_, false);
     const char* const names[3] = {"velx", "vely", "temp"};
-    for (int f = 0; f < 3; ++f)
-      for (int d = 0; d < 2; ++d) {
-        F& m = mean(names[f]);
-        m.sp->gradient_backward(m.vhat, d == 0 ? 1 : 0, d == 0 ? 0 : 1, sx_, sy_, cp_, st_);
-        dev_sync(st_);
-        fwd_->set_lnse_mean_device(2 + 2 * f + d, cp_);
-      }
     if (nonlin_) {
       // what the mean fields add to the right-hand sides of Navier2DNonLin (nonlin_eq.rs:193-240, nonlin.rs:266): dt nu lap(U);
       // dt nu lap(V) + dt mean.temp.to_ortho() (the buoyancy of the mean temperature); dt ka lap(T).  The Helmholtz solves are linear:
@@ -826,6 +843,28 @@ void Navier2DLnseEngine::conv_adj(F& f, int d0, int d1, bool mean_gradients, Arr
 void Navier2DLnseEngine::update_adjoint(int nsteps) {
   F &velx = field("velx"), &vely = field("vely"), &temp = field("temp"), &pres = field("pres"), &pseu = field("pseu");
   const double dt = dt_;
+  if (adj_ && nsteps > 0) {   // the linear solver, confined: the whole adjoint step on the fused schedule (adjoint.h adj_)
+    if (adj_mean_gen_ != const_gen_) { push_mean(*adj_, true); adj_mean_gen_ = const_gen_; }
+    // the physical arrays of the START of the last step are what grad_adjoint returns (lnse_adj_grad.rs:185-191): the state of the
+    // start of step n is the state after n - 1 fused steps
+    if (nsteps > 1) {
+      dev_sync(st_);
+      for (const char* name : {"velx", "vely", "temp", "pres"}) adj_->set_field_spectral_device(name, field(name).vhat);
+      adj_->update(nsteps - 1);
+      for (const char* name : {"velx", "vely", "temp", "pres", "pseu"}) adj_->get_field_spectral_device(name, field(name).vhat);
+      adj_->sync();
+    }
+    backward(velx, ux_);
+    backward(vely, uy_);
+    backward(temp, tp_);
+    dev_sync(st_);
+    for (const char* name : {"velx", "vely", "temp", "pres"}) adj_->set_field_spectral_device(name, field(name).vhat);
+    adj_->update(1);
+    for (const char* name : {"velx", "vely", "temp", "pres", "pseu"}) adj_->get_field_spectral_device(name, field(name).vhat);
+    adj_->sync();
+    time_ += nsteps * dt_;
+    return;
+  }
   for (int step = 0; step < nsteps; ++step) {
     std::unique_ptr<Hist> nlh;
     if (nonlin_) {                                         // nonlin_adj_grad.rs:190-193: the last forward state, removed from the history

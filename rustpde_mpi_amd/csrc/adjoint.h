@@ -175,6 +175,11 @@ class Navier2DLnseEngine : public GenericFlow2D {
   std::unique_ptr<Navier2DEngine> fwd_;
   unsigned long fwd_mean_gen_ = 0;                  // const_gen_ of the mean arrays fwd_ holds
   void update_fused(int nsteps);
+  // update_adjoint() of the linear solver, confined, on the same schedule (engine.h lnse = 3); the physical arrays ux_ / uy_ / tp_ the
+  // gradient is read from are refreshed by the generic backward transforms at the start of every step, as in the generic form
+  std::unique_ptr<Navier2DEngine> adj_;
+  unsigned long adj_mean_gen_ = 0;
+  void push_mean(Navier2DEngine& e, bool negate_velocities);
 };
 
 }  // namespace rpde

@@ -368,6 +368,10 @@ struct ConvLineArgs {
   // nonlin != 0 (Navier2DNonLin, nonlin_eq.rs:59-134): (um + up) (d/dx f + bx) + (vm + vp) (d/dy f + by) -- the classic term with the
   // mean velocities added to the perturbation's (conv_line<N, 2>)
   int nonlin = 0;
+  // The adjoint LNSE term (lnse_adj_eq.rs:16-94; conv_line<N, 3>): um, vm hold MINUS the mean velocities, up / vp / tp the physical adjoint
+  // fields u*, v*, T*, bx / by / cz the mean gradients d_j U, d_j V, d_j T of the equation's direction j (zero arrays for the temperature
+  // equation): out = DCT_y[ um d/dx f + vm d/dy f + up bx + vp by + tp cz ] = MINUS the reference's conv_*_adjoint (the step subtracts dt out)
+  const double* tp = nullptr; const double* cz = nullptr;
 };
 RPDE_HD inline long conv_lift_pitch(const ConvLineArgs& c) { return c.ldl >= 0 ? c.ldl : c.ld; }
 RPDE_HD inline bool conv_line_ok(const ConvLineArgs& c) {
@@ -394,6 +398,8 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   const RowBuf rup = row_buf(c.up + off, rowb), rvp = row_buf(c.vp + off, rowb);
   const RowBuf rbx = row_buf(lift ? c.bx + offl : c.up + off, rowb), rby = row_buf(lift ? c.by + offl : c.vp + off, rowb);
   const RowBuf rum = row_buf((MEAN ? c.um : c.up) + off, rowb), rvm = row_buf((MEAN ? c.vm : c.vp) + off, rowb);
+  cgmem_t tp = (cgmem_t)((MEAN == 3 ? c.tp : c.up) + off), cz = (cgmem_t)((MEAN == 3 ? c.cz : c.up) + off);
+  const RowBuf rtp = row_buf((MEAN == 3 ? c.tp : c.up) + off, rowb), rcz = row_buf((MEAN == 3 ? c.cz : c.up) + off, rowb);
   auto pick = [&](const RowBuf& r, cgmem_t flat, int tid, int slot, int k) {
     if (slot == 16) return flat[k];                          // k = N / 2, thread 0 only
     return (slot & 1) ? row_ld1(r, 8 * (T - tid), 8 * (15 - (slot >> 1)) * T) : row_ld1(r, 8 * tid, 8 * (slot >> 1) * T);
@@ -415,7 +421,7 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   DctLineArgs a1{c.fx, c.ld, c.n_in, nullptr, 0, c.nlines, N, 2, c.tw, c.tw2, 1.0};
   auto e1 = [&](int tid, int slot, int k, double v) {
     if constexpr (MEAN == 2) RPDE_T(acc)[slot] = lift ? (pick(rum, um, tid, slot, k) + pick(rup, up, tid, slot, k)) * (v + pick(rbx, bx, tid, slot, k)) : v;
-    else if constexpr (MEAN == 1) RPDE_T(acc)[slot] = lift ? pick(rum, um, tid, slot, k) * v + pick(rup, up, tid, slot, k) * pick(rbx, bx, tid, slot, k) : v;
+    else if constexpr (MEAN == 1 || MEAN == 3) RPDE_T(acc)[slot] = lift ? pick(rum, um, tid, slot, k) * v + pick(rup, up, tid, slot, k) * pick(rbx, bx, tid, slot, k) : v;
     else RPDE_T(acc)[slot] = on ? pick(rup, up, tid, slot, k) * (lift ? v + pick(rbx, bx, tid, slot, k) : v) : v;
   };
   dct_line_core<N, decltype(e1), 0>(blk, a1, false, e1);
@@ -424,6 +430,7 @@ RPDE_DEV void conv_line(Blk& blk, const ConvLineArgs& c) {
   a2.in = c.f0; a2.deriv = 1; a2.dscale = c.dscale;
   auto e2 = [&](int tid, int slot, int k, double v) {
     if constexpr (MEAN == 2) RPDE_T(acc)[slot] += lift ? (pick(rvm, vm, tid, slot, k) + pick(rvp, vp, tid, slot, k)) * (v + pick(rby, by, tid, slot, k)) : v;
+    else if constexpr (MEAN == 3) RPDE_T(acc)[slot] += lift ? pick(rvm, vm, tid, slot, k) * v + pick(rvp, vp, tid, slot, k) * pick(rby, by, tid, slot, k) + pick(rtp, tp, tid, slot, k) * pick(rcz, cz, tid, slot, k) : v;
     else if constexpr (MEAN == 1) RPDE_T(acc)[slot] += lift ? pick(rvm, vm, tid, slot, k) * v + pick(rvp, vp, tid, slot, k) * pick(rby, by, tid, slot, k) : v;
     else RPDE_T(acc)[slot] += on ? pick(rvp, vp, tid, slot, k) * (lift ? v + pick(rby, by, tid, slot, k) : v) : v;
   };

@@ -56,6 +56,7 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");   // navier.rs:251 / 372
   hc_ = bc == "hc";
   RPDE_REQUIRE(!lnse_ || (comm_.size == 1 && !hc_), "the Navier2DLnse step on the fused schedule: one rank, bc = \"rbc\"");
+  RPDE_REQUIRE(lnse_ != 3 || !periodic, "the adjoint Navier2DLnse step on the fused schedule: confined only");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   // everything that can throw comes after this block; the members below are released by
@@ -157,6 +158,7 @@ void Navier2DEngine::construct(int nx, int ny, double ra, double pr, double dt, 
   BX_.alloc(nxy); BY_.alloc(nxy); PS_.alloc(nxy); UP_.alloc(nxy); VP_.alloc(nxy);
   if (lnse_) for (auto& b : LM_) b.alloc(nxy);
   if (lnse_ == 2) for (auto& b : NLC_) b.alloc(nyx);
+  if (lnse_ == 3) { TP_.alloc(nxy); ZX_.alloc(nxy); ZY_.alloc(nyx); }
   red_.alloc(2);
   nanflag_.alloc(2);
   {   // column scans (colscan.h): block carries, tables of this rank's rows, summaries that travel between the ranks
@@ -2109,6 +2111,10 @@ void Navier2DEngine::build_confined() {
   for (int k = 0; k < 6; ++k) T(yx(Y_[k]), X_[k].p, k >= 4 ? tr : my, nx, true, "T1");
   // ---- S2: y-lines: physical products and forward y transform
   // physical velocities once per step (shared by the three convection programs)
+  if (lnse_ == 3) {   // the adjoint term multiplies the mean temperature gradient with the physical T*: a third transform (whole-line only)
+    const DctLineArgs dl{X_[4].p, ldy, my, TP_.p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
+    RPDE_REQUIRE(yD.fft_n == ny - 1 && add_dct_line(dl, "S2 y: temp -> phys"), "the adjoint Navier2DLnse step on the fused schedule needs whole-line y transforms");
+  }
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
@@ -2131,6 +2137,10 @@ void Navier2DEngine::build_confined() {
     if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
       const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
       cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1; cl.nonlin = lnse_ == 2;
+      if (lnse_ == 3) {   // equation f has direction j = f (velx: x, vely: y): d_j U, d_j V, d_j T; the temperature equation: no mean gradients
+        cl.tp = TP_.p;
+        cl.bx = f < 2 ? LM_[2 + f].p : ZX_.p; cl.by = f < 2 ? LM_[4 + f].p : ZX_.p; cl.cz = f < 2 ? LM_[6 + f].p : ZX_.p;
+      }
       RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
                    "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
       return;
@@ -2178,8 +2188,10 @@ void Navier2DEngine::build_confined() {
       r.lowy = yD.low.p; r.lowy2 = yD.low.p; r.stx = which == 2 ? 1 : 2; r.lowx = xN.low.p;
       r.tw = ax.tw.p; r.tw2 = ax.tw2.p;
       if (which == 0) r.grad = yx(GX_);
-      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(T_); r.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); r.tbc_cols = tbc_cols_; }
-      if (which == 2) { r.tbc = yx(TBC2_); r.tbc_cols = tbc2_cols_; }
+      // (lnse_ == 3, the adjoint step: no buoyancy in the vely equation -- a zero array in the temperature's place; the temperature
+      // equation takes dt vely.to_ortho() through the slot of the lift's Laplacian, TBC2_ = vely.to_ortho() / ka, rebuilt every step)
+      if (which == 1) { r.grad = yx(GY_); r.st2 = yx(lnse_ == 3 ? ZY_ : T_); r.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); r.tbc_cols = tbc_cols_; }
+      if (which == 2) { r.tbc = yx(TBC2_); r.tbc_cols = lnse_ == 3 ? -1 : tbc2_cols_; }
       if (add_rhs_line(r, which, tag)) return;
     }
     ProgramBuilder pb = ypb(2, my);
@@ -2197,7 +2209,7 @@ void Navier2DEngine::build_confined() {
       pb.load(0, pb.arr(yx(GX_), ldx), nx, -dt, true);           // d/dx p, kept from the pressure update
     } else if (which == 1) {
       if (hc) pb.load(1, pb.arr(yx(TO_), ldx), mx);
-      else pb.loadx(1, pb.arr(yx(T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
+      else pb.loadx(1, pb.arr(yx(lnse_ == 3 ? ZY_ : T_), ldx), mx, my, yD.low.p);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(GY_), ldx), nx, -dt, true);
       pb.pair_last_loads();
       pb.to_ortho_axpby(0, 1.0, 1, dt, xN);
@@ -2208,6 +2220,15 @@ void Navier2DEngine::build_confined() {
     pb.store(0, pb.arr(yx(Y_[3 + which]), ldx), mx);
     add_line(pb, tag);
   };
+  if (lnse_ == 3) {   // the adjoint buoyancy of the temperature equation: vely.to_ortho() of the step's start (lnse_adj_grad.rs:73), over ka
+    ProgramBuilder pb = ypb(2, my);
+    pb.set_fft(xD);
+    pb.load(0, pb.arr(yx(ZY_), ldx), nx);
+    pb.loadx(1, pb.arr(yx(V_), ldx), mx, my, yD.low.p);
+    pb.to_ortho_axpby(0, 1.0, 1, 1.0 / ka_, xD);
+    pb.store(0, pb.arr(yx(TBC2_), ldx), nx);
+    add_line(pb, "S3 x: vely.to_ortho() for the temperature equation");
+  }
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");

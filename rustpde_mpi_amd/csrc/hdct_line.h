@@ -588,7 +588,7 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
         RPDE_T(acc)[2 * u + 1] = (h.y + f.y) * (e1 + g.y);
         return;
       }
-      if constexpr (MEAN == 1) {   // um d/dx f + up bx (lnse_eq.rs:59-110)
+      if constexpr (MEAN == 1 || MEAN == 3) {   // um d/dx f + up bx (lnse_eq.rs:59-110; MEAN 3: um = -U, lnse_adj_eq.rs:16-94)
         if (u == 8) { RPDE_T(acc)[16] = um[m] * e0 + up[m] * bx[m]; return; }
         const dbl2 f = row_ld2(rup, 16 * tid, 16 * u * T), g = row_ld2(rbx, 16 * tid, 16 * u * T), h = row_ld2(rum, 16 * tid, 16 * u * T);
         RPDE_T(acc)[2 * u] = h.x * e0 + f.x * g.x;
@@ -618,6 +618,16 @@ RPDE_DEV void hconv_line(Blk& blk, const ConvLineArgs& c) {
         const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T), g = row_ld2(rby, 16 * tid, 16 * u * T), h = row_ld2(rvm, 16 * tid, 16 * u * T);
         RPDE_T(acc)[2 * u] += (h.x + f.x) * (e0 + g.x);
         RPDE_T(acc)[2 * u + 1] += (h.y + f.y) * (e1 + g.y);
+        return;
+      }
+      if constexpr (MEAN == 3) {   // + vm d/dy f + vp by + tp cz (the adjoint term's third mean-gradient product)
+        cgmem_t tp = (cgmem_t)(c.tp + off), cz = (cgmem_t)(c.cz + off);
+        const RowBuf rtp = row_buf(c.tp + off, rowb), rcz = row_buf(c.cz + off, rowb);
+        if (u == 8) { RPDE_T(acc)[16] += vm[m] * e0 + vp[m] * by[m] + tp[m] * cz[m]; return; }
+        const dbl2 f = row_ld2(rvp, 16 * tid, 16 * u * T), g = row_ld2(rby, 16 * tid, 16 * u * T), h = row_ld2(rvm, 16 * tid, 16 * u * T);
+        const dbl2 p = row_ld2(rtp, 16 * tid, 16 * u * T), q = row_ld2(rcz, 16 * tid, 16 * u * T);
+        RPDE_T(acc)[2 * u] += h.x * e0 + f.x * g.x + p.x * q.x;
+        RPDE_T(acc)[2 * u + 1] += h.y * e1 + f.y * g.y + p.y * q.y;
         return;
       }
       if constexpr (MEAN == 1) {   // + vm d/dy f + vp by

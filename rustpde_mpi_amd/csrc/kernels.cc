@@ -755,6 +755,14 @@ static void launch_line_batch_n(const LineBatch& b, int nl, Stream& st) {
     // against 0.080 ms at 1025^2 (profiles/r04_experiments, call 10); N = 4096: the full-length core like conv_line_kernel
     bool mean = b.c[0].um != nullptr;
     for (int i = 0; i < b.n; ++i) RPDE_REQUIRE((b.c[i].um != nullptr) == mean && (!mean || (b.c[i].vm && b.c[i].bx && b.c[i].by)), "line batch: convection terms of one kind");
+    const bool adj = mean && b.c[0].tp != nullptr;
+    for (int i = 0; i < b.n; ++i) RPDE_REQUIRE(!mean || ((b.c[i].tp != nullptr) == adj && (!adj || b.c[i].cz)), "line batch: convection terms of one kind");
+    if (adj) {
+      if constexpr (N == 1024) hipLaunchKernelGGL((hconv_line_batch_kernel<N, RPDE_HCONV_WPC, 3>), grid, block, 0, st.s, k);
+      else hipLaunchKernelGGL((conv_line_batch_kernel<N, 3>), grid, block, 0, st.s, k);
+      RPDE_HIP(hipGetLastError());
+      return;
+    }
     const bool nl = mean && b.c[0].nonlin != 0;
     for (int i = 0; i < b.n; ++i) RPDE_REQUIRE(!mean || (b.c[i].nonlin != 0) == nl, "line batch: convection terms of one kind");
     if constexpr (N == 1024) {
@@ -941,24 +949,28 @@ bool launch_conv_line(const ConvLineArgs& c, Stream& st) {
   if ((c.N != 4096 && c.N != 2048 && c.N != 1024) || !conv_line_ok(c)) return false;
   const bool mean = c.um != nullptr;   // the linearised term (Navier2DLnse): needs all four factor arrays
   if (mean && !(c.vm && c.bx && c.by)) return false;
+  if (c.tp && !(mean && c.cz)) return false;
   if (c.nlines <= 0) return true;
   const dim3 grid(8 * ((c.nlines + 7) / 8));
   if (c.N == 2048) {   // two waves per line on the half-length core, one wave per SIMD (two lines per CU, like the line program, without its phases)
-    if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 2>), grid, dim3(128), 0, st.s, c);
+    if (mean && c.tp) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 3>), grid, dim3(128), 0, st.s, c);
+    else if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 2>), grid, dim3(128), 0, st.s, c);
     else if (mean) hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC, 1>), grid, dim3(128), 0, st.s, c);
     else hipLaunchKernelGGL((hconv_line_kernel<2048, RPDE_HCONV_WPC>), grid, dim3(128), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   if (c.N == 1024) {   // one wave per line on the half-length core; a 1025^2 grid is four lines per CU: the whole register file per wave
-    if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 2>), grid, dim3(64), 0, st.s, c);
+    if (mean && c.tp) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 3>), grid, dim3(64), 0, st.s, c);
+    else if (mean && c.nonlin) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 2>), grid, dim3(64), 0, st.s, c);
     else if (mean) hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC, 1>), grid, dim3(64), 0, st.s, c);
     else hipLaunchKernelGGL((hconv_line_kernel<1024, RPDE_HCONV_WPC>), grid, dim3(64), 0, st.s, c);
     RPDE_HIP(hipGetLastError());
     return true;
   }
   // 4097-point lines: the full-length core (168 VGPRs, three workgroups per CU); on the half-length core the term spills
-  if (mean && c.nonlin) hipLaunchKernelGGL((conv_line_kernel<4096, 2>), grid, dim3(256), 0, st.s, c);
+  if (mean && c.tp) hipLaunchKernelGGL((conv_line_kernel<4096, 3>), grid, dim3(256), 0, st.s, c);
+  else if (mean && c.nonlin) hipLaunchKernelGGL((conv_line_kernel<4096, 2>), grid, dim3(256), 0, st.s, c);
   else if (mean) hipLaunchKernelGGL((conv_line_kernel<4096, 1>), grid, dim3(256), 0, st.s, c);
   else hipLaunchKernelGGL(conv_line_kernel<4096>, grid, dim3(256), 0, st.s, c);
   RPDE_HIP(hipGetLastError());
@@ -1486,11 +1498,18 @@ void launch_col_diff_phase(const ColDiffArgs& a, int phase, Stream&) {
 bool launch_conv_line(const ConvLineArgs& c, Stream&) {
   if (!conv_line_ok(c)) return false;
   if (c.um && !(c.vm && c.bx && c.by)) return false;
+  if (c.tp && !(c.um && c.cz)) return false;
   std::vector<double> lds(hdct_lds_doubles(c.N) + 2);
   double* base = lds.data() + (((size_t)lds.data() & 15) ? 1 : 0);
   for (int line = 0; line < c.nlines; ++line) {
     std::fill(lds.begin(), lds.end(), std::nan(""));
     Blk blk{line, 0, c.N / 16, base};
+    if (c.um && c.tp) {   // the adjoint LNSE term
+      if (c.N == 1024) hconv_line<1024, 3>(blk, c);
+      else if (c.N == 2048) hconv_line<2048, 3>(blk, c);
+      else if (c.N == 4096) conv_line<4096, 3>(blk, c); else conv_line<256, 3>(blk, c);
+      continue;
+    }
     if (c.um && c.nonlin) {   // Navier2DNonLin: the mean velocities added to u, v
       if (c.N == 1024) hconv_line<1024, 2>(blk, c);
       else if (c.N == 2048) hconv_line<2048, 2>(blk, c);

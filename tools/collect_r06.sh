@@ -3,7 +3,7 @@
 S=gpurun_out/r06_final; P=profiles
 set -e
 cp $S/commit.txt $P/r06_commit.txt
-for f in bench bench_profiled bench_1025 bench_periodic bench_config5_1gpu bench_hc bench_adjoint_1025 bench_lnse_1025 bench_lnse_adjoint_1025 bench_nonlin_1025 bench_adjoint_4097 bench_lnse_4097 bench_lnse_generic_1025 bench_lnse_generic_4097 bench_nonlin_4097 bench_nonlin_generic_1025 bench_nonlin_generic_4097 criterion schedule pmc_traffic; do
+for f in bench bench_profiled bench_1025 bench_periodic bench_config5_1gpu bench_hc bench_adjoint_1025 bench_lnse_1025 bench_lnse_adjoint_1025 bench_nonlin_1025 bench_adjoint_4097 bench_lnse_4097 bench_lnse_generic_1025 bench_lnse_generic_4097 bench_nonlin_4097 bench_nonlin_generic_1025 bench_nonlin_generic_4097 bench_lnse_adjoint_4097 bench_lnse_adjoint_generic_1025 bench_lnse_adjoint_generic_4097 criterion schedule pmc_traffic; do
   [ -s $S/$f.json ] && cp $S/$f.json $P/r06_$f.json
 done
 [ -s $S/bench_parity_detail.json ] && cp $S/bench_parity_detail.json $P/r06_bench_parity_detail.json

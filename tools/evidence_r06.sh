@@ -70,6 +70,9 @@ RPDE_LNSE_FUSED=0 timeout 300 python bench.py --solver lnse --nx 4097 --ny 4097 
 timeout 300 python bench.py --solver nonlin --nx 4097 --ny 4097 --ra 1e8 --dt 2e-4 --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_nonlin_4097.json
 RPDE_LNSE_FUSED=0 timeout 400 python bench.py --solver nonlin --nx 1025 --ny 1025 --ra 1e5 --dt 0.01 --steps 20 --warmup 3 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_nonlin_generic_1025.json
 RPDE_LNSE_FUSED=0 timeout 300 python bench.py --solver nonlin --nx 4097 --ny 4097 --ra 1e8 --dt 2e-4 --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_nonlin_generic_4097.json
+RPDE_LNSE_FUSED=0 timeout 400 python bench.py --solver lnse_adjoint --nx 1025 --ny 1025 --ra 1e5 --dt 0.01 --steps 20 --warmup 3 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_lnse_adjoint_generic_1025.json
+timeout 300 python bench.py --solver lnse_adjoint --nx 4097 --ny 4097 --ra 1e8 --dt 2e-4 --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_lnse_adjoint_4097.json
+RPDE_LNSE_FUSED=0 timeout 300 python bench.py --solver lnse_adjoint --nx 4097 --ny 4097 --ra 1e8 --dt 2e-4 --steps 5 --warmup 1 --no-cpu-baseline 2>> $O/bench_f4.err | grep '^{' > $O/bench_lnse_adjoint_generic_4097.json
 timeout 600 python tools/bench_criterion.py --out $O/criterion.json > $O/criterion.txt 2>&1
 lap "other solvers, criterion"
 rm -f $O/*/*.db $O/*/*/*.db
