@@ -72,7 +72,7 @@ ENV_SWITCHES = {
     "RPDE_COL_ONEPASS", "RPDE_COL1_W", "RPDE_COL1_FORCE",   # column scans: one pass / three kernels, blocks per workgroup, skip the residency test (test_column_scans_in_one_pass*)
     "RPDE_ADJOINT_FUSED",                           # Navier2DAdjoint: forward step on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_adjoint_fused_forward_step)
     "RPDE_FORK",                                    # the two independent chains behind G2 on two streams / graph branches (test_gpu_parity.test_round6_forked_tail_bit_identical)
-    "RPDE_LNSE_FUSED",                              # Navier2DLnse::update on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_lnse_step_on_the_fused_schedule)
+    "RPDE_LNSE_FUSED",                              # Navier2DLnse::update / update_adjoint, Navier2DNonLin::update on Navier2DEngine's fused schedule / generic operators (tests/test_adjoint.py test_emu_*_on_the_fused_schedule)
     "RPDE_PER_ROWS",                                # periodic S5 / S8 / S9: element-wise kernels / line programs (test_periodic_elementwise_stages_equal_line_programs)
     "RPDE_GEMM_WAVES",                              # A/B of round 6: the GEMM's 128-tile by eight waves (test_gpu_parity.test_round6_gemm_eight_waves_bit_identical)
     "RPDE_S6_DERIVE",                               # A/B of round 6 (=1; not the default): S6 reads one factor row per line and derives the other three (test_emu_parity.test_s6_poisson_rows_as_one_kernel, test_gpu_parity.test_round6_s6_derived_factors)
