@@ -623,7 +623,7 @@ Navier2DLnseEngine::Navier2DLnseEngine(int nx, int ny, double ra, double pr, dou
       if (ny == 1025 || ny == 2049 || ny == 4097)
         std::fprintf(stderr, "Navier2DLnse: the fused schedule is not used (%s); composition of generic operators\n", ex.what());
     }
-    if (fwd_ && !nonlin_ && !periodic) {
+    if (fwd_ && !nonlin_) {
       try {
         adj_ = std::make_unique<Navier2DEngine>(nx, ny, ra, pr, dt, aspect, bc, periodic, nullptr, /*buoyancy_lift=*/false, /*lnse=*/3);
       } catch (const std::exception&) {

@@ -56,7 +56,6 @@ Navier2DEngine::Navier2DEngine(int nx, int ny, double ra, double pr, double dt, 
   RPDE_REQUIRE(bc == "rbc" || bc == "hc", "Boundary condition type \"" + bc + "\" not recognized!");   // navier.rs:251 / 372
   hc_ = bc == "hc";
   RPDE_REQUIRE(!lnse_ || (comm_.size == 1 && !hc_), "the Navier2DLnse step on the fused schedule: one rank, bc = \"rbc\"");
-  RPDE_REQUIRE(lnse_ != 3 || !periodic, "the adjoint Navier2DLnse step on the fused schedule: confined only");
   RPDE_REQUIRE(dt > 0 && ra > 0 && pr > 0 && aspect > 0, "ra, pr, dt, aspect must be positive");
 #ifndef RPDE_EMU
   // everything that can throw comes after this block; the members below are released by
@@ -2440,6 +2439,10 @@ void Navier2DEngine::build_periodic() {
   for (int k = 0; k < 6; ++k) Tr(yx(Y_[k]), X_[k].p, k >= 4 ? tr : my, nx, true, "T1");
   // ---- S2: identical to the confined case (real y-lines at physical x)
   // physical velocities once per step (shared by the three convection programs)
+  if (lnse_ == 3) {   // the physical T* of the adjoint convection terms (as in the confined step)
+    const DctLineArgs dl{X_[4].p, ldy, my, TP_.p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
+    RPDE_REQUIRE(yD.fft_n == ny - 1 && add_dct_line(dl, "S2 y: temp -> phys"), "the adjoint Navier2DLnse step on the fused schedule needs whole-line y transforms");
+  }
   for (int w = 0; w < 2; ++w) {
     // the whole-line kernel (four workgroups per CU, dct_line.h) where it covers the shape, the line program otherwise
     const DctLineArgs dl{X_[2 * w].p, ldy, my, (w ? VP_ : UP_).p, ldy, xlines(nx, false), ny - 1, 2, yD.tw.p, yD.tw2.p, 1.0};
@@ -2460,6 +2463,10 @@ void Navier2DEngine::build_periodic() {
     if (lnse_) {   // linearised about the mean fields (lnse_eq.rs:59-110): the whole-line kernel only (conv_line<N, true>)
       const int f = &out == &X_[6] ? 0 : &out == &X_[7] ? 1 : 2;
       cl.um = LM_[0].p; cl.vm = LM_[1].p; cl.bx = LM_[2 + 2 * f].p; cl.by = LM_[3 + 2 * f].p; cl.ldl = -1; cl.nonlin = lnse_ == 2;
+      if (lnse_ == 3) {   // equation f has direction j = f (velx: x, vely: y): d_j U, d_j V, d_j T; the temperature equation: no mean gradients
+        cl.tp = TP_.p;
+        cl.bx = f < 2 ? LM_[2 + f].p : ZX_.p; cl.by = f < 2 ? LM_[4 + f].p : ZX_.p; cl.cz = f < 2 ? LM_[6 + f].p : ZX_.p;
+      }
       RPDE_REQUIRE(&ys == &yD && yD.fft_n == ny - 1 && add_conv_line(cl, tag),
                    "the Navier2DLnse step on the fused schedule needs y-lines of 1025, 2049 or 4097 points (whole-line convection kernel)");
       return;
@@ -2505,10 +2512,10 @@ void Navier2DEngine::build_periodic() {
       if (which == 0) { a.p = yx(P_); a.pk = -dt / sx_; }
       if (which == 1) {
         a.gy = yx(GY_);
-        a.tsrc = hc ? yx(TO_) : yx(T_); a.tlow = hc ? nullptr : yD.low.p;
+        a.tsrc = hc ? yx(TO_) : yx(lnse_ == 3 ? ZY_ : T_); a.tlow = hc ? nullptr : yD.low.p;   // (lnse_ == 3: no buoyancy in the adjoint vely equation)
         a.tbc = yx(buoyancy_lift_ ? TBC_ : TBC0_); a.ctbc = dt; a.tbc_cols = tbc_cols_;
       }
-      if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; a.tbc_cols = tbc2_cols_; }
+      if (which == 2) { a.tbc = yx(TBC2_); a.ctbc = dt * ka_; a.tbc_cols = lnse_ == 3 ? -1 : tbc2_cols_; }
       a.diag = hh.diag0.p;
       if (xF.fft_n * 2 == nx && add_four_rhs(a, tag)) return;
     }
@@ -2528,7 +2535,7 @@ void Navier2DEngine::build_periodic() {
       pb.load(0, pb.arr(yx(GY_), ldx), nc, -dt, true);
       pb.pair_last_loads();                                             // with the state rows
       if (hc) pb.load(0, pb.arr(yx(TO_), ldx), nc, dt, true);
-      else pb.loadx(0, pb.arr(yx(T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
+      else pb.loadx(0, pb.arr(yx(lnse_ == 3 ? ZY_ : T_), ldx), nc, my, yD.low.p, dt, true);     // buoyancy: temp.to_ortho() + tempbc
       pb.load(0, pb.arr(yx(buoyancy_lift_ ? TBC_ : TBC0_), ldx), nc, dt, true);
       pb.pair_last_loads();
     } else {
@@ -2539,6 +2546,13 @@ void Navier2DEngine::build_periodic() {
     pb.store(0, pb.arr(yx(Y_[3 + which]), ldx), nc);
     add_line(pb, tag);
   };
+  if (lnse_ == 3) {   // the adjoint buoyancy of the temperature equation: S_y vely of the step's start (x is Fourier: no x stencil), over ka
+    ProgramBuilder pb = ypb(1, my);
+    pb.set_fft(xF);
+    pb.loadx(0, pb.arr(yx(V_), ldx), nc, my, yD.low.p, 1.0 / ka_);
+    pb.store(0, pb.arr(yx(TBC2_), ldx), nc);
+    add_line(pb, "S3 x: vely.to_ortho() for the temperature equation");
+  }
   rhs(0, "S3 x: rhs + hholtz-x velx");
   rhs(1, "S3 x: rhs + hholtz-x vely");
   rhs(2, "S3 x: rhs + hholtz-x temp");

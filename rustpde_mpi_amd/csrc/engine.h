@@ -48,7 +48,7 @@ class Navier2DEngine {
   // with the mean velocities added to u, v and the mean gradients in the lift's place, for all three fields), and what the mean fields
   // add to the right-hand sides (their diffusion, the mean temperature in the buoyancy) as three time-independent composite arrays
   // H^-1 c added behind the Helmholtz solves (the solve is linear): fields "nl_velx", "nl_vely", "nl_temp" (set_field_spectral_device).
-  // lnse = 3: Navier2DLnse::update_adjoint (lnse_adj_grad.rs:71-99, lnse_adj_eq.rs), confined: the convection terms
+  // lnse = 3: Navier2DLnse::update_adjoint (lnse_adj_grad.rs:71-99, lnse_adj_eq.rs): the convection terms
   // -(U d/dx f + V d/dy f) + u* d_j U + v* d_j V + T* d_j T (conv_line<N, 3>; the caller hands over MINUS the mean velocities as arrays
   // 0 / 1), no buoyancy in the vely equation, dt vely.to_ortho() of the step's start in the temperature equation.
   ~Navier2DEngine();
@@ -330,7 +330,7 @@ class Navier2DEngine {
   int tbc_cols_ = -1, tbc2_cols_ = -1;   // leading coefficients of a row of TBC_ (TBC0_) / TBC2_ that can be non-zero (-1: not analysed)
   void analyse_lift();
   bool buoyancy_lift_ = true;
-  int lnse_ = 0;                      // 1: Navier2DLnse, 2: Navier2DNonLin, 3: the adjoint step of Navier2DLnse (confined)
+  int lnse_ = 0;                      // 1: Navier2DLnse, 2: Navier2DNonLin, 3: the adjoint step of Navier2DLnse
   DBuf TP_, ZX_, ZY_;                // lnse_ == 3: the physical adjoint temperature (XY), zero arrays in the XY and the YX layout
   DBuf NLC_[3];                      // lnse_ == 2: H^-1 of the constant right-hand sides of velx, vely, temp (state layout)
   DBuf LM_[8];                       // lnse_: U, V, then d/dx, d/dy of the mean velx, vely, temp -- physical, XY layout (pitch ldy_)

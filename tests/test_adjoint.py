@@ -442,22 +442,22 @@ def test_emu_lnse_step_on_the_fused_schedule(emu_lib, monkeypatch, nx, ny, perio
     assert differs, "RPDE_LNSE_FUSED made no difference: the fused schedule did not run"
 
 
-def test_emu_lnse_adjoint_step_on_the_fused_schedule(emu_lib, tmp_path, monkeypatch):
-    """Round 6: Navier2DLnse::update_adjoint (lnse_adj_grad.rs:71-99, lnse_adj_eq.rs), confined, on Navier2DEngine's fused schedule:
+@pytest.mark.parametrize("nx,ny,periodic", [(17, 257, False), (16, 257, True)])
+def test_emu_lnse_adjoint_step_on_the_fused_schedule(emu_lib, tmp_path, monkeypatch, nx, ny, periodic):
+    """Round 6: Navier2DLnse::update_adjoint (lnse_adj_grad.rs:71-99, lnse_adj_eq.rs), confined and periodic, on Navier2DEngine's fused schedule:
     the convection terms -(U d/dx f + V d/dy f) + u* d_j U + v* d_j V + T* d_j T in the whole-line kernel (conv_line<N, 3>, the physical
     T* from a third y transform), no buoyancy in the vely equation, dt vely.to_ortho() of the step's start in the temperature equation.
     Against the oracle after every adjoint step, against the generic composition (round-off, not bit for bit), and through
     grad_adjoint (forward loop and adjoint loop fused, the gradient read from the physical arrays of the start of the last step)."""
-    nx, ny = 17, 257
     monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
-    check_lnse_parity(emu_lib, nx, ny, False, steps=3, adjoint=True)
+    check_lnse_parity(emu_lib, nx, ny, periodic, steps=3, adjoint=True)
 
     def run(flag):
         if flag is None:
             monkeypatch.delenv("RPDE_LNSE_FUSED", raising=False)
         else:
             monkeypatch.setenv("RPDE_LNSE_FUSED", flag)
-        nav, _ = lnse_pair(emu_lib, nx, ny, False, 1e5, 1.0, 0.01, mean_flow=True)
+        nav, _ = lnse_pair(emu_lib, nx, ny, periodic, 1e5, 1.0, 0.01, mean_flow=True)
         nav.update_adjoint(2)                  # several steps in one call: the last one starts from the state after the others
         nav.update_adjoint(1)
         return nav.spectral_fields(), {k: getattr(nav, k).v.copy() for k in ("velx", "vely", "temp")}
@@ -471,7 +471,7 @@ def test_emu_lnse_adjoint_step_on_the_fused_schedule(emu_lib, tmp_path, monkeypa
     assert differs, "RPDE_LNSE_FUSED made no difference: the fused schedule did not run"
     for k in gphys:                            # the physical arrays the state holds: those of the start of the last step, in both forms
         assert rel(fphys[k], gphys[k]) < 1e-11, k
-    check_lnse_gradient(emu_lib, nx, ny, False, max_time=0.05, with_target=True, fd_points=2, tmp_path=tmp_path)
+    check_lnse_gradient(emu_lib, nx, ny, periodic, max_time=0.05, with_target=True, fd_points=2, tmp_path=tmp_path)
 
 
 def test_emu_lnse_fused_schedule_follows_a_changed_mean(emu_lib, monkeypatch):
@@ -870,7 +870,7 @@ def test_emu_lnse_mean_from_a_snapshot_and_errors(emu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2), (129, 2049, False, 2), (65, 4097, False, 2)])
+@pytest.mark.parametrize("nx,ny,periodic,steps", [(129, 129, False, 5), (256, 129, True, 4), (1025, 1025, False, 2), (129, 2049, False, 2), (65, 4097, False, 2), (256, 1025, True, 3)])
 def test_gpu_lnse_adjoint_step_parity(hip_lib, nx, ny, periodic, steps):
     if nx >= 1025:
         check_lnse_parity(hip_lib, nx, ny, periodic, steps, ra=1e7, dt=1e-3, adjoint=True)
